@@ -1,0 +1,357 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+LIB_PATH = ORACLE_DIR / "liborb_oracle.so"
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_f32p = C.POINTER(C.c_float)
+_u16p = C.POINTER(C.c_uint16)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def build():
+    srcs = [ORACLE_DIR / n for n in ("orb_oracle.cpp", "match_oracle.cpp", "orb_oracle.h", "brief_pattern_data.inc")]
+    if LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
+        return
+    subprocess.check_call(["make", "-C", str(ORACLE_DIR)], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(str(LIB_PATH))
+        L.or_create.restype = C.c_void_p
+        L.or_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.or_destroy.argtypes = [C.c_void_p]
+        L.or_set_blur_taps.argtypes = [C.c_void_p, _u16p]
+        L.or_get_tables.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _i32p, _i32p]
+        L.or_extract.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p,
+                                 C.c_int, _i32p]
+        L.or_level_size.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p]
+        L.or_get_pyramid_level.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int, C.c_int]
+        L.or_get_blurred_level.argtypes = [C.c_void_p, C.c_int, _u8p, C.c_int]
+        L.or_get_candidates.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _i32p, C.c_int]
+        L.or_get_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.or_cv_round_f.argtypes = [C.c_float]
+        L.or_cv_round_d.argtypes = [C.c_double]
+        L.or_fast_atan2.restype = C.c_float
+        L.or_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.or_resize_linear_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int]
+        L.or_copy_make_border101.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
+        L.or_gaussian_blur7_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _u16p]
+        L.or_fast9_16.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int]
+        L.or_distribute_octree.argtypes = [_i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, _i32p, C.c_int]
+        L.or_ic_angle.restype = C.c_float
+        L.or_ic_angle.argtypes = [_u8p, C.c_int, C.c_int, C.c_int]
+        L.or_orb_descriptor.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_float, _u8p]
+        L.or_descriptor_distance.argtypes = [_u8p, _u8p]
+        L.or_three_maxima.argtypes = [_i32p, C.c_int, _i32p, _i32p, _i32p]
+        L.or_grid_build.restype = C.c_void_p
+        L.or_grid_build.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.or_grid_destroy.argtypes = [C.c_void_p]
+        L.or_grid_query.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, _i32p, C.c_int]
+        L.or_search_by_bow_kf_f.argtypes = [_u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                            _u8p, _f32p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                            C.c_float, C.c_int, _i32p]
+        L.or_search_by_bow_kf_kf.argtypes = [_u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                             _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                             C.c_float, C.c_int, _i32p]
+        L.or_search_by_projection_last.argtypes = [_u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _u8p, _f32p, _u8p,
+                                                   C.c_int, C.c_int, C.c_int, _i32p]
+        L.or_search_by_projection_local.argtypes = [_u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _i32p, _u8p,
+                                                    C.c_int, C.c_float, _i32p]
+        L.or_search_for_initialization.argtypes = [_u8p, _f32p, _i32p, C.c_int, _i32p, _i32p, _u8p, _f32p, C.c_int,
+                                                   C.c_float, C.c_int, _i32p]
+        L.or_block_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
+        _lib = L
+    return _lib
+
+
+def _u8c(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+def _i32c(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class OracleExtractor:
+    """Mirror of VS_GRAPHS::ORBextractor over the oracle (ORBextractor.h:51-93)."""
+
+    def __init__(self, nfeatures=1000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.L = lib()
+        self.h = self.L.or_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        assert self.h
+        self.nfeatures, self.nlevels = nfeatures, nlevels
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.or_destroy(self.h)
+            self.h = None
+
+    def set_blur_taps(self, taps):
+        t = np.ascontiguousarray(taps, dtype=np.uint16)
+        assert t.shape == (7,)
+        self.L.or_set_blur_taps(self.h, _ptr(t, _u16p))
+
+    def tables(self):
+        n = self.nlevels
+        sc, inv, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        fpl = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.L.or_get_tables(self.h, _ptr(sc, _f32p), _ptr(inv, _f32p), _ptr(s2, _f32p), _ptr(is2, _f32p),
+                             _ptr(fpl, _i32p), _ptr(umax, _i32p))
+        return dict(scale=sc, inv_scale=inv, sigma2=s2, inv_sigma2=is2, features_per_level=fpl, umax=umax)
+
+    def __call__(self, image, lapping=(0, 0)):
+        """Returns (monoIndex, keypoints[KP_DTYPE], descriptors[n,32])."""
+        if image is None or image.size == 0:
+            return -1, np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        img = _u8c(image)
+        rows, cols = img.shape
+        cap = self.nfeatures + 3 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int32(0)
+        mono = self.L.or_extract(self.h, _ptr(img, _u8p), rows, cols, img.strides[0], int(lapping[0]),
+                                 int(lapping[1]), kps.ctypes.data_as(C.c_void_p), _ptr(desc, _u8p), cap,
+                                 C.byref(n))
+        assert mono != -2, "oracle capacity too small"
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def level_size(self, level):
+        w, h = C.c_int32(), C.c_int32()
+        assert self.L.or_level_size(self.h, level, C.byref(w), C.byref(h)) == 0
+        return w.value, h.value
+
+    def pyramid_level(self, level, with_border=False):
+        w, h = self.level_size(level)
+        if with_border:
+            w, h = w + 38, h + 38
+        out = np.zeros((h, w), np.uint8)
+        assert self.L.or_get_pyramid_level(self.h, level, _ptr(out, _u8p), w, int(with_border)) == 0
+        return out
+
+    def blurred_level(self, level):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        rc = self.L.or_get_blurred_level(self.h, level, _ptr(out, _u8p), w)
+        return out if rc == 0 else None
+
+    def candidates(self, level):
+        cap = 1 << 18
+        x, y, r = (np.zeros(cap, np.int32) for _ in range(3))
+        n = self.L.or_get_candidates(self.h, level, _ptr(x, _i32p), _ptr(y, _i32p), _ptr(r, _i32p), cap)
+        assert 0 <= n <= cap
+        return x[:n].copy(), y[:n].copy(), r[:n].copy()
+
+    def level_keypoints(self, level):
+        cap = self.nfeatures + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        n = self.L.or_get_level_keypoints(self.h, level, kps.ctypes.data_as(C.c_void_p), cap)
+        assert 0 <= n <= cap
+        return kps[:n].copy()
+
+
+def cv_round_f(v):
+    return lib().or_cv_round_f(float(np.float32(v)))
+
+
+def fast_atan2(y, x):
+    return np.float32(lib().or_fast_atan2(float(np.float32(y)), float(np.float32(x))))
+
+
+def resize_linear(src, dw, dh):
+    src = _u8c(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().or_resize_linear_u8(_ptr(src, _u8p), src.shape[1], src.shape[0], src.strides[0], _ptr(dst, _u8p), dw, dh, dw)
+    return dst
+
+
+def copy_make_border101(src, b):
+    src = _u8c(src)
+    h, w = src.shape
+    dst = np.zeros((h + 2 * b, w + 2 * b), np.uint8)
+    lib().or_copy_make_border101(_ptr(src, _u8p), w, h, src.strides[0], _ptr(dst, _u8p), w + 2 * b, b)
+    return dst
+
+
+DEFAULT_TAPS = (18, 34, 49, 55, 49, 34, 18)
+
+
+def gaussian_blur7(src, taps=DEFAULT_TAPS):
+    src = _u8c(src)
+    h, w = src.shape
+    dst = np.zeros((h, w), np.uint8)
+    t = np.asarray(taps, np.uint16)
+    lib().or_gaussian_blur7_u8(_ptr(src, _u8p), w, h, src.strides[0], _ptr(dst, _u8p), w, _ptr(t, _u16p))
+    return dst
+
+
+def fast9_16(img, threshold, nonmax=True):
+    img = _u8c(img)
+    h, w = img.shape
+    cap = max(16, w * h)
+    x, y, s = (np.zeros(cap, np.int32) for _ in range(3))
+    n = lib().or_fast9_16(_ptr(img, _u8p), w, h, img.strides[0], threshold, int(nonmax), _ptr(x, _i32p),
+                          _ptr(y, _i32p), _ptr(s, _i32p), cap)
+    return x[:n].copy(), y[:n].copy(), s[:n].copy()
+
+
+def distribute_octree(x, y, response, min_x, max_x, min_y, max_y, n_target):
+    x, y, r = _i32c(x), _i32c(y), _i32c(response)
+    cap = len(x) + 8
+    out = np.zeros(cap, np.int32)
+    n = lib().or_distribute_octree(_ptr(x, _i32p), _ptr(y, _i32p), _ptr(r, _i32p), len(x), min_x, max_x, min_y,
+                                   max_y, n_target, _ptr(out, _i32p), cap)
+    return out[:n].copy()
+
+
+def ic_angle(img, cx, cy):
+    img = _u8c(img)
+    return np.float32(lib().or_ic_angle(_ptr(img, _u8p), img.strides[0], cx, cy))
+
+
+def orb_descriptor(blurred, cx, cy, angle_deg):
+    img = _u8c(blurred)
+    d = np.zeros(32, np.uint8)
+    lib().or_orb_descriptor(_ptr(img, _u8p), img.strides[0], cx, cy, float(np.float32(angle_deg)), _ptr(d, _u8p))
+    return d
+
+
+def descriptor_distance(a, b):
+    a, b = _u8c(a), _u8c(b)
+    return lib().or_descriptor_distance(_ptr(a, _u8p), _ptr(b, _u8p))
+
+
+def three_maxima(sizes):
+    s = _i32c(sizes)
+    a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+    lib().or_three_maxima(_ptr(s, _i32p), len(s), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+class OracleGrid:
+    def __init__(self, kps, min_x, min_y, max_x, max_y):
+        self.kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+        self.L = lib()
+        self.h = self.L.or_grid_build(self.kps.ctypes.data_as(C.c_void_p), len(self.kps), min_x, min_y, max_x, max_y)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.or_grid_destroy(self.h)
+            self.h = None
+
+    def query(self, x, y, r, min_level=-1, max_level=-1):
+        cap = len(self.kps) + 1
+        out = np.zeros(cap, np.int32)
+        n = self.L.or_grid_query(self.h, float(np.float32(x)), float(np.float32(y)), float(np.float32(r)),
+                                 min_level, max_level, _ptr(out, _i32p), cap)
+        return out[:n].copy()
+
+
+def search_by_bow_kf_f(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv, nnratio, check_ori):
+    """fv = (node_ids, offsets, indices) CSR. Returns (nmatches, matchF)."""
+    kd, fd = _u8c(kf_desc), _u8c(f_desc)
+    ka, fa = _f32c(kf_angle), _f32c(f_angle)
+    kv = _u8c(kf_valid)
+    kn, ko, ki = (_i32c(a) for a in kf_fv)
+    fn, fo, fi = (_i32c(a) for a in f_fv)
+    out = np.zeros(len(fd), np.int32)
+    n = lib().or_search_by_bow_kf_f(_ptr(kd, _u8p), _ptr(ka, _f32p), _ptr(kv, _u8p), len(kd), _ptr(kn, _i32p),
+                                    _ptr(ko, _i32p), _ptr(ki, _i32p), len(kn), _ptr(fd, _u8p), _ptr(fa, _f32p),
+                                    len(fd), _ptr(fn, _i32p), _ptr(fo, _i32p), _ptr(fi, _i32p), len(fn),
+                                    float(nnratio), int(check_ori), _ptr(out, _i32p))
+    return n, out
+
+
+def search_by_bow_kf_kf(d1, a1, v1, fv1, d2, a2, v2, fv2, nnratio, check_ori):
+    d1, d2 = _u8c(d1), _u8c(d2)
+    a1, a2 = _f32c(a1), _f32c(a2)
+    v1, v2 = _u8c(v1), _u8c(v2)
+    n1, o1, i1 = (_i32c(a) for a in fv1)
+    n2, o2, i2 = (_i32c(a) for a in fv2)
+    out = np.zeros(len(d1), np.int32)
+    n = lib().or_search_by_bow_kf_kf(_ptr(d1, _u8p), _ptr(a1, _f32p), _ptr(v1, _u8p), len(d1), _ptr(n1, _i32p),
+                                     _ptr(o1, _i32p), _ptr(i1, _i32p), len(n1), _ptr(d2, _u8p), _ptr(a2, _f32p),
+                                     _ptr(v2, _u8p), len(d2), _ptr(n2, _i32p), _ptr(o2, _i32p), _ptr(i2, _i32p),
+                                     len(n2), float(nnratio), int(check_ori), _ptr(out, _i32p))
+    return n, out
+
+
+def search_by_projection_last(q_desc, q_angle, q_blocks, cand_off, cand_idx, t_desc, t_angle, t_blocked, th_high,
+                              check_ori):
+    qd, td = _u8c(q_desc), _u8c(t_desc)
+    qa, ta = _f32c(q_angle), _f32c(t_angle)
+    qb = _u8c(q_blocks)
+    co, ci = _i32c(cand_off), _i32c(cand_idx)
+    if len(ci) == 0:
+        ci = np.zeros(1, np.int32)
+    tb = _u8c(t_blocked).copy()
+    tm = np.full(len(td), -1, np.int32)
+    n = lib().or_search_by_projection_last(_ptr(qd, _u8p), _ptr(qa, _f32p), _ptr(qb, _u8p), len(qd), _ptr(co, _i32p),
+                                           _ptr(ci, _i32p), _ptr(td, _u8p), _ptr(ta, _f32p), _ptr(tb, _u8p), len(td),
+                                           int(th_high), int(check_ori), _ptr(tm, _i32p))
+    return n, tm, tb
+
+
+def search_by_projection_local(q_desc, q_blocks, cand_off, cand_idx, t_desc, t_octave, t_blocked, nnratio):
+    qd, td = _u8c(q_desc), _u8c(t_desc)
+    qb = _u8c(q_blocks)
+    co, ci = _i32c(cand_off), _i32c(cand_idx)
+    if len(ci) == 0:
+        ci = np.zeros(1, np.int32)
+    to = _i32c(t_octave)
+    tb = _u8c(t_blocked).copy()
+    tm = np.full(len(td), -1, np.int32)
+    n = lib().or_search_by_projection_local(_ptr(qd, _u8p), _ptr(qb, _u8p), len(qd), _ptr(co, _i32p), _ptr(ci, _i32p),
+                                            _ptr(td, _u8p), _ptr(to, _i32p), _ptr(tb, _u8p), len(td), float(nnratio),
+                                            _ptr(tm, _i32p))
+    return n, tm, tb
+
+
+def search_for_initialization(d1, a1, oct1, cand_off, cand_idx, d2, a2, nnratio, check_ori):
+    d1, d2 = _u8c(d1), _u8c(d2)
+    a1, a2 = _f32c(a1), _f32c(a2)
+    o1 = _i32c(oct1)
+    co, ci = _i32c(cand_off), _i32c(cand_idx)
+    if len(ci) == 0:
+        ci = np.zeros(1, np.int32)
+    out = np.zeros(len(d1), np.int32)
+    n = lib().or_search_for_initialization(_ptr(d1, _u8p), _ptr(a1, _f32p), _ptr(o1, _i32p), len(d1), _ptr(co, _i32p),
+                                           _ptr(ci, _i32p), _ptr(d2, _u8p), _ptr(a2, _f32p), len(d2), float(nnratio),
+                                           int(check_ori), _ptr(out, _i32p))
+    return n, out
+
+
+def block_best2(a, b):
+    a, b = _u8c(a), _u8c(b)
+    best, second, arg = (np.zeros(len(a), np.int32) for _ in range(3))
+    lib().or_block_best2(_ptr(a, _u8p), len(a), _ptr(b, _u8p), len(b), _ptr(best, _i32p), _ptr(second, _i32p),
+                         _ptr(arg, _i32p))
+    return best, second, arg

@@ -1,0 +1,70 @@
+"""Seeded, integer-only synthetic gray frames.
+
+Corner-rich rectangles + uniform noise so that every pyramid level fills its
+quota, most FAST cells pass iniThFAST and some fall back to minThFAST.  The
+generator is pure integer arithmetic on a SplitMix64 stream, so host, tests
+and bench agree byte for byte.
+"""
+import numpy as np
+
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_C1 = np.uint64(0xBF58476D1CE4E5B9)
+_C2 = np.uint64(0x94D049BB133111EB)
+SEED_BASE = 0x5EED0000
+_MARGIN = 64
+
+
+def splitmix64(seed, n, offset=0):
+    """n outputs of SplitMix64 seeded with `seed`, skipping `offset` outputs."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(offset + 1, offset + n + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * _GAMMA
+        z = (z ^ (z >> np.uint64(30))) * _C1
+        z = (z ^ (z >> np.uint64(27))) * _C2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _scene(w, h, seed):
+    cw, ch = w + 2 * _MARGIN, h + 2 * _MARGIN
+    k = max(1, (400 * cw * ch) // 307200)
+    r = splitmix64(seed, 5 * k).reshape(k, 5)
+    canvas = np.full((ch, cw), 128, dtype=np.uint8)
+    xs = (r[:, 0] % np.uint64(cw)).astype(np.int64)
+    ys = (r[:, 1] % np.uint64(ch)).astype(np.int64)
+    ws = (r[:, 2] % np.uint64(57)).astype(np.int64) + 4
+    hs = (r[:, 3] % np.uint64(57)).astype(np.int64) + 4
+    gs = (r[:, 4] % np.uint64(256)).astype(np.uint8)
+    for i in range(k):
+        canvas[ys[i]:ys[i] + hs[i], xs[i]:xs[i] + ws[i]] = gs[i]
+    return canvas
+
+
+def sequence_frame(w, h, seq, t, amplitude_div=1, noise=6):
+    """Frame t of sequence `seq`: the scene translated by (3,2) px per step, fresh noise per frame."""
+    seed = SEED_BASE + seq
+    canvas = _scene(w, h, seed)
+    ox = _MARGIN + (3 * t) % _MARGIN
+    oy = _MARGIN + (2 * t) % _MARGIN
+    img = canvas[oy:oy + h, ox:ox + w].astype(np.int32)
+    if noise:
+        nz = splitmix64(seed ^ (0xA5A5 << 32) ^ (t + 1), w * h).reshape(h, w)
+        img = img + (nz % np.uint64(2 * noise + 1)).astype(np.int32) - noise
+    if amplitude_div != 1:
+        img = 128 + (img - 128) // amplitude_div
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def frame(w, h, index, amplitude_div=1, noise=6):
+    """Independent frame number `index` (seed 0x5EED0000 + index)."""
+    return sequence_frame(w, h, index, 0, amplitude_div=amplitude_div, noise=noise)
+
+
+def constant_frame(w, h, value=128):
+    return np.full((h, w), value, dtype=np.uint8)
+
+
+def random_descriptors(n, seed):
+    """n x 32 uint8 pseudo-random descriptors."""
+    r = splitmix64(SEED_BASE ^ (seed << 8) ^ 0xD35C, n * 4)
+    return r.view(np.uint8).reshape(n, 32).copy()
