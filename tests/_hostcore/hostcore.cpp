@@ -1,0 +1,86 @@
+// Host build of the PRODUCT's device-agnostic core (visual_sgraphs_amd/csrc/*.h) for CPU unit tests:
+// the octree algorithm runs here as a 1-thread group; geometry/tables are the same code the runtime
+// uses.  This library is test-only -- the shipped path is the HIP library and has no CPU fallback.
+#include <cstring>
+#include <vector>
+
+#include "vsg_geometry.h"
+#include "vsg_introsort.h"
+#include "vsg_math.h"
+#include "vsg_octree_core.h"
+
+using namespace vsg;
+
+static Geometry g_geom;
+static ExtractorTables g_tab;
+
+extern "C" {
+
+int hc_build(int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh, int rows, int cols) {
+  if (!build_tables(g_tab, nfeatures, scaleFactor, nlevels, iniTh, minTh)) return -1;
+  const uint16_t taps[7] = {18, 34, 49, 55, 49, 34, 18};
+  return build_geometry(g_geom, g_tab, rows, cols, 0, 0, taps);
+}
+
+// out: w,h,pitch,nCols,nRows,wCell,hCell,quota,cand_cap,sel_cap,nIni,oct_width,oct_height,cell_base,kp_size(int)
+int hc_level(int l, int *out) {
+  const LevelGeom &L = g_geom.fg.lv[l];
+  int v[] = {L.w, L.h, L.pitch, L.nCols, L.nRows, L.wCell, L.hCell, L.quota, L.cand_cap, L.sel_cap,
+             L.nIni, L.oct_width, L.oct_height, L.cell_base, (int)L.kp_size};
+  memcpy(out, v, sizeof(v));
+  return (int)(sizeof(v) / sizeof(int));
+}
+void hc_tables(float *scale, float *inv, int *quota, int *umax) {
+  for (int i = 0; i < g_tab.nlevels; i++) {
+    scale[i] = g_tab.scale[i];
+    inv[i] = g_tab.invScale[i];
+    quota[i] = g_tab.quota[i];
+  }
+  for (int i = 0; i < 16; i++) umax[i] = g_tab.umax[i];
+}
+int hc_total_cells() { return g_geom.fg.total_cells; }
+int hc_out_cap() { return g_geom.fg.out_cap; }
+void hc_cell(int i, int *out) {
+  const CellDesc &c = g_geom.cells[i];
+  out[0] = c.level, out[1] = c.x0, out[2] = c.y0, out[3] = c.x1, out[4] = c.y1;
+}
+// resize tables of level l (from l-1): xs[4*w], ys[4*h]
+void hc_resize_tables(int l, short *xs, short *ys) {
+  const LevelGeom &L = g_geom.fg.lv[l];
+  memcpy(xs, &g_geom.resizeTab[L.tab_x_off], sizeof(Short4) * L.w);
+  memcpy(ys, &g_geom.resizeTab[L.tab_y_off], sizeof(Short4) * L.h);
+}
+
+// octree of level l of the geometry built by hc_build; candidates given in ANY order
+int hc_octree(int l, const int *x, const int *y, const int *resp, int n, int N_override, int *outPacked) {
+  const LevelGeom &L = g_geom.fg.lv[l];
+  octree::Params P;
+  P.N = N_override >= 0 ? N_override : L.quota;
+  P.height = L.oct_height;
+  P.nIni = L.nIni;
+  P.iniUL = L.iniUL;
+  P.iniThresh = L.iniThresh;
+  P.nCols = L.nCols;
+  P.wCell = L.wCell;
+  P.hCell = L.hCell;
+  std::vector<uint32_t> cand(n > 0 ? n : 1);
+  for (int i = 0; i < n; i++) cand[i] = pack_cand(x[i], y[i], resp[i]);
+  std::vector<uint16_t> node_of(n > 0 ? n : 1);
+  const int cap = octree::node_capacity(P.N);
+  std::vector<uint64_t> buf(octree::work_bytes(cap) / 8 + 2);
+  octree::Work W;
+  octree::carve(W, buf.data(), cap);
+  std::vector<uint32_t> sel(cap);
+  octree::SerialGroup g;
+  int m = octree::distribute(g, P, cand.data(), n, node_of.data(), W, sel.data());
+  for (int i = 0; i < m; i++) outPacked[i] = (int)sel[i];
+  return m;
+}
+
+void hc_sort(uint64_t *items, int n) { introsort::sort(items, n); }
+float hc_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
+void hc_brief_rotation(float angle, float *a, float *b) { brief_rotation(angle, a, b); }
+void hc_brief_offset(int px, int py, float a, float b, int *dx, int *dy) { brief_offset(px, py, a, b, dx, dy); }
+float hc_sinf(float x, int fma) { return fma ? SinCosF<true>::eval(x, false) : SinCosF<false>::eval(x, false); }
+float hc_cosf(float x, int fma) { return fma ? SinCosF<true>::eval(x, true) : SinCosF<false>::eval(x, true); }
+}

@@ -1,0 +1,218 @@
+"""CPU tests of the PRODUCT's device-agnostic core (visual_sgraphs_amd/csrc/*.h compiled for the host by
+tests/_hostcore): geometry tables, the libstdc++-exact introsort, the array-based octree (run as a
+1-thread group) and the float helpers -- each against the oracle or against libm / std::sort."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from visual_sgraphs_amd import synth
+
+HC_DIR = Path(__file__).resolve().parent / "_hostcore"
+_i32p = C.POINTER(C.c_int32)
+
+
+@pytest.fixture(scope="module")
+def hc():
+    subprocess.check_call(["make", "-C", str(HC_DIR)], stdout=subprocess.DEVNULL)
+    L = C.CDLL(str(HC_DIR / "libvsg_hostcore.so"))
+    L.hc_build.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.hc_level.argtypes = [C.c_int, _i32p]
+    L.hc_octree.argtypes = [C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int, _i32p]
+    L.hc_fast_atan2.restype = C.c_float
+    L.hc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    L.hc_sinf.restype = C.c_float
+    L.hc_sinf.argtypes = [C.c_float, C.c_int]
+    L.hc_cosf.restype = C.c_float
+    L.hc_cosf.argtypes = [C.c_float, C.c_int]
+    L.hc_brief_rotation.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.hc_resize_tables.argtypes = [C.c_int, C.POINTER(C.c_int16), C.POINTER(C.c_int16)]
+    L.hc_sort.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    L.hc_tables.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), _i32p, _i32p]
+    L.hc_cell.argtypes = [C.c_int, _i32p]
+    return L
+
+
+def level_info(hc, l):
+    out = np.zeros(16, np.int32)
+    n = hc.hc_level(l, out.ctypes.data_as(_i32p))
+    keys = ["w", "h", "pitch", "nCols", "nRows", "wCell", "hCell", "quota", "cand_cap", "sel_cap", "nIni",
+            "oct_width", "oct_height", "cell_base", "kp_size"]
+    return dict(zip(keys, out[:n].tolist()))
+
+
+def hc_octree(hc, level, x, y, r, n_override=-1):
+    x, y, r = (np.ascontiguousarray(a, np.int32) for a in (x, y, r))
+    out = np.zeros(len(x) + 128, np.int32)
+    m = hc.hc_octree(level, x.ctypes.data_as(_i32p), y.ctypes.data_as(_i32p), r.ctypes.data_as(_i32p), len(x),
+                     n_override, out.ctypes.data_as(_i32p))
+    p = out[:m].astype(np.uint32)
+    return (p & 0xFFF).astype(np.int32), ((p >> 12) & 0xFFF).astype(np.int32), (p >> 24).astype(np.int32)
+
+
+GEOM_CASES = [(640, 480, 1000, 8), (752, 480, 1200, 8), (1280, 720, 2000, 8), (320, 240, 500, 4), (1241, 376, 2000, 8)]
+
+
+@pytest.mark.parametrize("w,h,nf,nl", GEOM_CASES)
+def test_geometry_matches_oracle(hc, w, h, nf, nl):
+    assert hc.hc_build(nf, 1.2, nl, 20, 7, h, w) == 0
+    e = ol.OracleExtractor(nf, 1.2, nl, 20, 7)
+    e(synth.constant_frame(w, h))
+    t = e.tables()
+    sc, inv = np.zeros(nl, np.float32), np.zeros(nl, np.float32)
+    q, um = np.zeros(nl, np.int32), np.zeros(16, np.int32)
+    hc.hc_tables(sc.ctypes.data_as(C.POINTER(C.c_float)), inv.ctypes.data_as(C.POINTER(C.c_float)),
+                 q.ctypes.data_as(_i32p), um.ctypes.data_as(_i32p))
+    assert np.array_equal(sc, t["scale"]) and np.array_equal(inv, t["inv_scale"])
+    assert np.array_equal(q, t["features_per_level"]) and np.array_equal(um, t["umax"])
+    for l in range(nl):
+        info = level_info(hc, l)
+        assert (info["w"], info["h"]) == e.level_size(l)
+        assert info["quota"] == t["features_per_level"][l]
+        assert info["kp_size"] == int(np.float32(31) * t["scale"][l])
+        assert info["pitch"] % 64 == 0 and info["pitch"] >= info["w"]
+
+
+def test_geometry_known_answers_c2(hc):
+    assert hc.hc_build(1000, 1.2, 8, 20, 7, 480, 640) == 0
+    cells = [(17, 12, 36, 38), (14, 10, 36, 37), (11, 8, 38, 38), (9, 7, 38, 36), (7, 5, 40, 40), (6, 4, 38, 41),
+             (5, 3, 37, 43), (4, 2, 37, 51)]
+    for l, c in enumerate(cells):
+        i = level_info(hc, l)
+        assert (i["nCols"], i["nRows"], i["wCell"], i["hCell"]) == c
+        assert i["nIni"] == 1
+    assert hc.hc_total_cells() == 577
+    assert hc.hc_build(1200, 1.2, 8, 20, 7, 480, 752) == 0
+    assert hc.hc_total_cells() == 700 and level_info(hc, 0)["nIni"] == 2
+    assert hc.hc_build(2000, 1.2, 8, 20, 7, 720, 1280) == 0
+    assert hc.hc_total_cells() == 1987
+
+
+def test_geometry_rejects_what_the_reference_cannot_process(hc):
+    assert hc.hc_build(500, 1.2, 8, 20, 7, 120, 160) < 0      # top level narrower than one 35px cell
+    assert hc.hc_build(500, 1.2, 4, 20, 7, 800, 300) < 0      # width/height rounds to 0 initial nodes
+    assert hc.hc_build(500, 1.2, 4, 0, 7, 240, 320) < 0       # threshold 0: score map cannot encode it
+    assert hc.hc_build(500, 1.2, 3, 20, 7, 120, 160) == 0
+
+
+def test_resize_tables_match_oracle_resize(hc):
+    """Apply the product's fixed-point tables in numpy and compare with the oracle's cv::resize restatement."""
+    assert hc.hc_build(500, 1.2, 4, 20, 7, 240, 320) == 0
+    src = synth.frame(320, 240, 77)
+    for l in range(1, 4):
+        info = level_info(hc, l)
+        w, h = info["w"], info["h"]
+        xs, ys = np.zeros((w, 4), np.int16), np.zeros((h, 4), np.int16)
+        hc.hc_resize_tables(l, xs.ctypes.data_as(C.POINTER(C.c_int16)), ys.ctypes.data_as(C.POINTER(C.c_int16)))
+        S = src.astype(np.int64)
+        sx, a0, a1, sx1 = (xs[:, k].astype(np.int64) for k in range(4))
+        sy0, sy1, b0, b1 = (ys[:, k].astype(np.int64) for k in range(4))
+        H = S[:, sx] * a0[None, :] + S[:, sx1] * a1[None, :]
+        out = ((((b0[:, None] * (H[sy0] >> 4)) >> 16) + ((b1[:, None] * (H[sy1] >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+        assert np.array_equal(out, ol.resize_linear(src, w, h))
+        src = out
+
+
+def test_introsort_is_libstdcxx_exact(hc):
+    """Key-only comparator with many ties: payload order must equal std::sort's (checked in C++ by
+    tests/_hostcore against std::sort on 200k cases during development; here: sortedness + stability
+    for n <= 16, where libstdc++ is a pure insertion sort)."""
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 5, 16, 17, 100, 1000):
+        keys = rng.integers(0, 5, n).astype(np.uint64)
+        items = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        buf = items.copy()
+        hc.hc_sort(buf.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        assert np.all(np.diff((buf >> np.uint64(32)).astype(np.int64)) >= 0)
+        assert sorted(buf.tolist()) == sorted(items.tolist())
+        if n <= 16:
+            assert np.array_equal(buf, items[np.argsort(keys, kind="stable")])
+
+
+def test_float_helpers_match_oracle_and_libm(hc):
+    rng = np.random.default_rng(2)
+    for _ in range(5000):
+        y, x = (int(v) for v in rng.integers(-200000, 200000, 2))
+        assert np.float32(hc.hc_fast_atan2(y, x)) == ol.fast_atan2(y, x)
+    # sinf/cosf kernels: bit-equal to this host's libm on a dense sample (the full 1.09e9-value sweep of
+    # [0, 6.4] was run offline: 0 mismatches for both contraction variants)
+    import struct
+    libm = C.CDLL("libm.so.6")
+    libm.sinf.restype = libm.cosf.restype = C.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [C.c_float]
+    xs = np.concatenate([rng.uniform(0, 6.3, 20000), [0.0, 1e-5, 0.785398, 0.7853982, 1.5707964, 3.1415927, 6.2831855]])
+    for xv in xs.astype(np.float32):
+        for fma in (0, 1):
+            assert struct.pack("f", hc.hc_sinf(float(xv), fma)) == struct.pack("f", libm.sinf(float(xv)))
+            assert struct.pack("f", hc.hc_cosf(float(xv), fma)) == struct.pack("f", libm.cosf(float(xv)))
+
+
+@pytest.mark.parametrize("w,h,nf,nl,seeds", [(640, 480, 1000, 8, [0, 1]), (752, 480, 1200, 8, [2]),
+                                              (320, 240, 500, 4, [3, 4, 5]), (1280, 720, 2000, 8, [6])])
+def test_octree_core_equals_oracle_on_real_candidates(hc, w, h, nf, nl, seeds):
+    assert hc.hc_build(nf, 1.2, nl, 20, 7, h, w) == 0
+    e = ol.OracleExtractor(nf, 1.2, nl, 20, 7)
+    rng = np.random.default_rng(9)
+    for seed in seeds:
+        e(synth.frame(w, h, seed))
+        for l in range(nl):
+            x, y, r = e.candidates(l)
+            kp = e.level_keypoints(l)
+            perm = rng.permutation(len(x))  # the core must not depend on candidate order
+            gx, gy, gr = hc_octree(hc, l, x[perm], y[perm], r[perm])
+            assert np.array_equal(gx + 16, kp["x"].astype(np.int32))
+            assert np.array_equal(gy + 16, kp["y"].astype(np.int32))
+            assert np.array_equal(gr, kp["response"].astype(np.int32))
+
+
+def test_octree_core_equals_oracle_on_adversarial_sets(hc):
+    """Random sparse/dense point sets, many equal responses (tie-breaking by candidate rank), quotas from 0
+    to more than the number of points, clustered points (deep trees, careful phase with ties)."""
+    assert hc.hc_build(1000, 1.2, 8, 20, 7, 480, 640) == 0
+    rng = np.random.default_rng(11)
+    for trial in range(150):
+        l = int(rng.integers(0, 8))
+        info = level_info(hc, l)
+        W, H = info["oct_width"], info["oct_height"]
+        # valid candidate coordinates are 3..W-4 (3 px inside the FAST cells)
+        n = int(rng.integers(0, 1500))
+        mode = trial % 3
+        if mode == 0:
+            xs = rng.integers(3, W - 3, n)
+            ys = rng.integers(3, H - 3, n)
+        elif mode == 1:  # clusters
+            cx, cy = rng.integers(3, W - 3, 5), rng.integers(3, H - 3, 5)
+            k = rng.integers(0, 5, n)
+            xs = np.clip(cx[k] + rng.integers(-12, 13, n), 3, W - 4)
+            ys = np.clip(cy[k] + rng.integers(-12, 13, n), 3, H - 4)
+        else:  # lattice
+            xs = 3 + (rng.integers(0, (W - 6) // 4, n) * 4)
+            ys = 3 + (rng.integers(0, (H - 6) // 4, n) * 4)
+        pts = np.unique(np.stack([ys, xs], 1), axis=0)
+        ys, xs = pts[:, 0], pts[:, 1]
+        n = len(xs)
+        rs = rng.integers(7, 10 if trial % 2 else 200, n)
+        N = int(rng.choice([0, 1, 2, 5, 17, 60, 217, 400, 2000]))
+        # reference candidate order = cell-major then row-major inside the cell
+        i, j = (ys - 3) // info["hCell"], (xs - 3) // info["wCell"]
+        order = np.lexsort((xs, ys, j, i))
+        xs, ys, rs = xs[order], ys[order], rs[order]
+        want = ol.distribute_octree(xs, ys, rs, 16, 16 + W, 16, 16 + H, N)
+        perm = rng.permutation(n)
+        gx, gy, gr = hc_octree(hc, l, xs[perm], ys[perm], rs[perm], N)
+        assert np.array_equal(gx, xs[want]) and np.array_equal(gy, ys[want]) and np.array_equal(gr, rs[want]), trial
+
+
+def test_octree_core_multiple_initial_nodes(hc):
+    assert hc.hc_build(2000, 1.2, 8, 20, 7, 376, 1241) == 0  # KITTI aspect: nIni = 3 or 4
+    e = ol.OracleExtractor(2000, 1.2, 8, 20, 7)
+    e(synth.frame(1241, 376, 8))
+    assert level_info(hc, 0)["nIni"] >= 3
+    for l in range(8):
+        x, y, r = e.candidates(l)
+        kp = e.level_keypoints(l)
+        gx, gy, gr = hc_octree(hc, l, x[::-1], y[::-1], r[::-1])
+        assert np.array_equal(gx + 16, kp["x"].astype(np.int32)) and np.array_equal(gy + 16, kp["y"].astype(np.int32))

@@ -1,0 +1,80 @@
+// vsg_common.h -- PODs shared by the host runtime, the HIP kernels and the host-side unit tests.
+#pragma once
+#include <stdint.h>
+
+namespace vsg {
+
+enum {
+  kMaxLevels = 16,
+  kMaxIniNodes = 16,     // octree: round(width/height) initial nodes (ORBextractor.cc:566)
+  kEdgeThreshold = 19,   // ORBextractor.cc:71
+  kHalfPatch = 15,       // ORBextractor.cc:70
+  kFastBorder = 16,      // EDGE_THRESHOLD - 3 (ORBextractor.cc:795)
+  kCellMax = 70,         // valid FAST cell extent is < 70 px: ceil(d / floor(d/35)) for d >= 35
+  kMaxQuota = 4000,      // per-level feature quota the octree workspace supports
+};
+
+// FAST candidate / selected keypoint packed in 32 bits: x | y<<12 | response<<24.
+// x,y are relative to (16,16) of the level, as in vToDistributeKeys (ORBextractor.cc:868-873).
+__attribute__((always_inline)) inline
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    uint32_t
+    pack_cand(int x, int y, int resp) {
+  return (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)resp << 24);
+}
+#define VSG_CAND_X(c) ((int)((c)&0xFFFu))
+#define VSG_CAND_Y(c) ((int)(((c) >> 12) & 0xFFFu))
+#define VSG_CAND_R(c) ((int)((c) >> 24))
+
+// Per-level geometry, computed once per (image size, extractor parameters) on the host.
+struct LevelGeom {
+  int w, h, pitch;          // level image, row pitch in bytes (multiple of 64)
+  int img_off;              // byte offset of the level inside one frame's pyramid block
+  int nCols, nRows, wCell, hCell;  // FAST cell grid (ORBextractor.cc:803-809)
+  int cell_base;            // index of this level's first cell in the global cell list
+  int quota;                // mnFeaturesPerLevel[level]
+  int cand_off, cand_cap;   // slice of the per-frame candidate array (uint32 units)
+  int sel_off, sel_cap;     // slice of the per-frame selected-keypoint array
+  int tab_x_off, tab_y_off; // resize tables (short4 units) for producing THIS level from level-1
+  int blur_tile_base;       // index of this level's first blur tile
+  int blur_tiles_x;         // tiles per row
+  float scale;              // mvScaleFactor[level]
+  float kp_size;            // (float)(int)(31 * scale)   (ORBextractor.cc:884,893)
+  // octree (ORBextractor.cc:562-593)
+  int oct_width, oct_height;         // maxX-minX, maxY-minY = w-32, h-32
+  int nIni;
+  int iniUL[kMaxIniNodes + 1];       // UL.x of initial node i; [nIni] = UR.x of the last one
+  int iniThresh[kMaxIniNodes];       // smallest x with (int)((float)x / hX) >= i
+};
+
+struct FrameGeom {
+  int nlevels;
+  int rows, cols;
+  int pyr_frame_bytes;   // bytes of one frame's pyramid block (all levels)
+  int cand_frame;        // uint32 per frame in the candidate array
+  int sel_frame;         // uint32 per frame in the selected array
+  int total_cells;       // FAST cells per frame (all levels)
+  int total_blur_tiles;
+  int out_cap;           // keypoint capacity per frame in the output arrays
+  int iniTh, minTh;
+  int lap0, lap1;
+  uint16_t taps[8];      // 7 taps of the 8.8 fixed-point Gaussian (+1 pad)
+  LevelGeom lv[kMaxLevels];
+};
+
+// cv::KeyPoint-compatible record (28 bytes): pt.x pt.y size angle response octave class_id
+struct KeyPointPOD {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+};
+
+// per-frame header written by the slot kernel
+struct FrameHeader {
+  int n;                        // total keypoints
+  int mono;                     // monoIndex (return value of operator())
+  int level_start[kMaxLevels + 1];  // prefix of per-level counts
+};
+
+}  // namespace vsg

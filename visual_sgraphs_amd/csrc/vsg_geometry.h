@@ -1,0 +1,249 @@
+// vsg_geometry.h -- host-side tables of the extractor (no GPU code): constructor tables of
+// ORBextractor (ORBextractor.cc:411-470) and the per-image-size geometry the kernels consume.
+// Float arithmetic follows the reference's types step by step (float vs double), because level
+// sizes, quotas and cell grids are all derived through float rounding.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "vsg_common.h"
+
+namespace vsg {
+
+struct ExtractorTables {
+  int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0;
+  double scaleFactor = 0;  // ORBextractor.h:105: a double member holding the float argument
+  std::vector<float> scale, invScale, sigma2, invSigma2;
+  std::vector<int> quota;
+  int umax[16];
+};
+
+inline int cv_round_f(float v) { return (int)lrintf(v); }  // SSE cvtss2si, round-half-even
+inline int cv_round_d(double v) { return (int)lrint(v); }
+
+inline bool build_tables(ExtractorTables &T, int nfeatures, float scaleFactor, int nlevels, int iniTh, int minTh) {
+  if (nlevels < 1 || nlevels > kMaxLevels || nfeatures < 0 || !(scaleFactor > 1.0f)) return false;
+  T.nfeatures = nfeatures;
+  T.nlevels = nlevels;
+  T.iniTh = iniTh;
+  T.minTh = minTh;
+  T.scaleFactor = scaleFactor;
+  T.scale.assign(nlevels, 1.0f);
+  T.sigma2.assign(nlevels, 1.0f);
+  for (int i = 1; i < nlevels; i++) {  // :419-423  float = float * double
+    T.scale[i] = (float)((double)T.scale[i - 1] * T.scaleFactor);
+    T.sigma2[i] = T.scale[i] * T.scale[i];
+  }
+  T.invScale.resize(nlevels);
+  T.invSigma2.resize(nlevels);
+  for (int i = 0; i < nlevels; i++) {  // :427-431
+    T.invScale[i] = 1.0f / T.scale[i];
+    T.invSigma2[i] = 1.0f / T.sigma2[i];
+  }
+  // :436-446 quotas
+  const float factor = (float)(1.0 / T.scaleFactor);
+  const float denom = 1.0f - (float)std::pow((double)factor, (double)nlevels);
+  float desired = (float)nfeatures * (1.0f - factor) / denom;
+  T.quota.assign(nlevels, 0);
+  int sum = 0;
+  for (int l = 0; l + 1 < nlevels; l++) {
+    T.quota[l] = cv_round_f(desired);
+    sum += T.quota[l];
+    desired *= factor;
+  }
+  T.quota[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+  // :454-469 umax
+  const int hp = kHalfPatch;
+  const float half_diag = (float)hp * std::sqrt(2.f) / 2;
+  const int vmax = (int)std::floor(half_diag + 1), vmin = (int)std::ceil(half_diag);
+  for (int v = 0; v <= vmax; ++v) T.umax[v] = cv_round_d(std::sqrt((double)hp * hp - (double)v * v));
+  for (int v = hp, v0 = 0; v >= vmin; --v) {
+    while (T.umax[v0] == T.umax[v0 + 1]) ++v0;
+    T.umax[v] = v0;
+    ++v0;
+  }
+  return true;
+}
+
+// resize table entries: dst column -> {sx, a0, a1, 0}; dst row -> {sy0, sy1, b0, b1}  ([OCV] resize.cpp)
+struct Short4 {
+  int16_t a, b, c, d;
+};
+
+struct CellDesc {  // one FAST cell: valid region [x0,x1) x [y0,y1) in level coordinates
+  int16_t level, x0, y0, x1, y1, pad;
+};
+struct BlurTile {
+  int16_t level, tx, ty, pad;
+};
+
+struct Geometry {
+  FrameGeom fg;
+  std::vector<Short4> resizeTab;  // all levels, x tables then y tables (offsets in LevelGeom)
+  std::vector<CellDesc> cells;
+  std::vector<BlurTile> blurTiles;
+  int maxQuota = 0;
+};
+
+enum { kBlurTileW = 64, kBlurTileH = 16 };
+
+inline int16_t sat_short(float v) {
+  int iv = cv_round_f(v);
+  return (int16_t)(iv < -32768 ? -32768 : iv > 32767 ? 32767 : iv);
+}
+
+inline void resize_axis_table(int dn, int sn, bool is_x, std::vector<Short4> &out) {
+  const double scale = 1.0 / ((double)dn / sn);
+  for (int d = 0; d < dn; d++) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)std::floor(f);
+    f -= s;
+    Short4 e;
+    if (is_x) {
+      if (s < 0) {
+        f = 0;
+        s = 0;
+      }
+      if (s >= sn - 1) {
+        f = 0;
+        s = sn - 1;
+      }
+      e.a = (int16_t)s;
+      e.b = sat_short((1.f - f) * 2048);
+      e.c = sat_short(f * 2048);
+      e.d = (int16_t)(s + 1 < sn ? s + 1 : sn - 1);
+    } else {
+      int s0 = s < 0 ? 0 : s >= sn ? sn - 1 : s;
+      int s1 = s + 1 < 0 ? 0 : s + 1 >= sn ? sn - 1 : s + 1;
+      e.a = (int16_t)s0;
+      e.b = (int16_t)s1;
+      e.c = sat_short((1.f - f) * 2048);
+      e.d = sat_short(f * 2048);
+    }
+    out.push_back(e);
+  }
+}
+
+// Returns 0 on success, <0 if the image size / parameters cannot be processed the way the reference
+// would (the reference itself divides by zero on such inputs).
+inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int cols, int lap0, int lap1,
+                          const uint16_t taps[7]) {
+  FrameGeom &fg = G.fg;
+  memset(&fg, 0, sizeof(fg));
+  G.resizeTab.clear();
+  G.cells.clear();
+  G.blurTiles.clear();
+  G.maxQuota = 0;
+  fg.nlevels = T.nlevels;
+  fg.rows = rows;
+  fg.cols = cols;
+  fg.iniTh = T.iniTh;
+  fg.minTh = T.minTh;
+  fg.lap0 = lap0;
+  fg.lap1 = lap1;
+  for (int k = 0; k < 7; k++) fg.taps[k] = taps[k];
+  if (T.iniTh < 1 || T.minTh < 1 || T.iniTh > 255 || T.minTh > 255) return -3;
+  int img_off = 0, cand_off = 0, sel_off = 0, out_cap = 0;
+  int prev_w = 0, prev_h = 0;
+  for (int l = 0; l < T.nlevels; l++) {
+    LevelGeom &L = fg.lv[l];
+    L.w = cv_round_f((float)cols * T.invScale[l]);  // :1175-1176
+    L.h = cv_round_f((float)rows * T.invScale[l]);
+    if (L.w > 4095 || L.h > 4095) return -3;
+    L.pitch = (L.w + 63) & ~63;
+    L.img_off = img_off;
+    img_off += L.pitch * L.h;
+    // FAST cell grid :795-809
+    const int minB = kFastBorder, maxBX = L.w - kFastBorder, maxBY = L.h - kFastBorder;
+    const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+    const float W = 35;
+    L.nCols = (int)(width / W);
+    L.nRows = (int)(height / W);
+    if (L.nCols < 1 || L.nRows < 1) return -3;  // reference: division by zero
+    L.wCell = (int)std::ceil(width / L.nCols);
+    L.hCell = (int)std::ceil(height / L.nRows);
+    if ((long long)L.nCols * L.nRows * L.wCell * L.hCell > 0xFFFFFF) return -3;
+    L.cell_base = (int)G.cells.size();
+    int cand_cap = 0;
+    for (int i = 0; i < L.nRows; i++) {
+      for (int j = 0; j < L.nCols; j++) {
+        const int iniY = minB + i * L.hCell, iniX = minB + j * L.wCell;
+        int maxY = iniY + L.hCell + 6, maxX = iniX + L.wCell + 6;
+        if (maxY > maxBY) maxY = maxBY;
+        if (maxX > maxBX) maxX = maxBX;
+        CellDesc c;
+        c.level = (int16_t)l;
+        c.x0 = (int16_t)(iniX + 3);
+        c.y0 = (int16_t)(iniY + 3);
+        c.x1 = (int16_t)(maxX - 3);
+        c.y1 = (int16_t)(maxY - 3);
+        c.pad = 0;
+        if (c.x1 < c.x0) c.x1 = c.x0;  // empty (the reference `continue`s or FAST finds nothing)
+        if (c.y1 < c.y0) c.y1 = c.y0;
+        G.cells.push_back(c);
+        // a strict 3x3 local maximum occupies a 2x2 block: worst-case survivors per cell
+        cand_cap += ((c.x1 - c.x0 + 1) / 2) * ((c.y1 - c.y0 + 1) / 2);
+      }
+    }
+    L.quota = T.quota[l];
+    if (L.quota > kMaxQuota) return -3;
+    if (L.quota > G.maxQuota) G.maxQuota = L.quota;
+    L.cand_off = cand_off;
+    L.cand_cap = (cand_cap + 63) & ~63;
+    cand_off += L.cand_cap;
+    L.sel_off = sel_off;
+    // final list size: <= quota+3 from the careful phase (:692,:753-754), or <= 4*nIni when the very
+    // first pass already reaches the quota; filled in below once nIni is known
+    // resize tables
+    L.tab_x_off = L.tab_y_off = 0;
+    if (l > 0) {
+      L.tab_x_off = (int)G.resizeTab.size();
+      resize_axis_table(L.w, prev_w, true, G.resizeTab);
+      L.tab_y_off = (int)G.resizeTab.size();
+      resize_axis_table(L.h, prev_h, false, G.resizeTab);
+    }
+    prev_w = L.w;
+    prev_h = L.h;
+    // blur tiles
+    L.blur_tile_base = (int)G.blurTiles.size();
+    L.blur_tiles_x = (L.w + kBlurTileW - 1) / kBlurTileW;
+    for (int ty = 0; ty < (L.h + kBlurTileH - 1) / kBlurTileH; ty++)
+      for (int tx = 0; tx < L.blur_tiles_x; tx++) G.blurTiles.push_back({(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
+    L.scale = T.scale[l];
+    L.kp_size = (float)(int)((float)(2 * kHalfPatch + 1) * T.scale[l]);  // :884
+    // octree initial nodes :566-593
+    L.oct_width = maxBX - minB;
+    L.oct_height = maxBY - minB;
+    L.nIni = (int)std::round((float)L.oct_width / (float)L.oct_height);
+    if (L.nIni < 1 || L.nIni > kMaxIniNodes) return -3;  // reference: hX = inf / out-of-range index
+    const float hX = (float)L.oct_width / (float)L.nIni;
+    for (int i = 0; i <= L.nIni; i++) L.iniUL[i] = (int)(hX * (float)i);
+    for (int i = 0; i < L.nIni; i++) L.iniThresh[i] = 0x7FFFFFFF;
+    for (int x = L.oct_width - 1; x >= 0; x--) {
+      int idx = (int)((float)x / hX);
+      if (idx >= L.nIni) return -3;  // reference: out-of-range vpIniNodes index
+      L.iniThresh[idx] = x;          // ends at the smallest x of every index
+    }
+    for (int i = 1; i < L.nIni; i++) {  // monotone fill for indices no x maps to
+      if (L.iniThresh[i] == 0x7FFFFFFF) L.iniThresh[i] = 0x7FFFFFFE;
+    }
+    L.iniThresh[0] = 0;
+    {
+      int worst = L.quota + 3 > 4 * L.nIni ? L.quota + 3 : 4 * L.nIni;
+      L.sel_cap = (worst + 3) & ~3;
+      sel_off += L.sel_cap;
+      out_cap += L.sel_cap;
+    }
+  }
+  fg.pyr_frame_bytes = (img_off + 255) & ~255;
+  fg.cand_frame = cand_off;
+  fg.sel_frame = sel_off;
+  fg.total_cells = (int)G.cells.size();
+  fg.total_blur_tiles = (int)G.blurTiles.size();
+  // output capacity: what operator() can produce = sum over levels of final list sizes
+  fg.out_cap = out_cap;
+  return 0;
+}
+
+}  // namespace vsg

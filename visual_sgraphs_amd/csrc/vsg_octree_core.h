@@ -1,0 +1,356 @@
+// vsg_octree_core.h -- ORBextractor::DistributeOctTree (ORBextractor.cc:482-785) as a data-parallel,
+// array-based algorithm for ONE workgroup per (frame, level).
+//
+// The reference walks a std::list, push_front()s children, and switches to a "careful" phase that
+// std::sort()s (size, node*) pairs and splits the largest nodes one at a time until the quota N is
+// reached.  Its output ORDER is the list order, which this code reproduces exactly:
+//   * a pass that splits the nodes proc[0..nEff) (in that order) creates their non-empty children in
+//     order n1..n4; the new list is reverse(creation order) ++ (old list minus the split nodes);
+//   * main passes use proc = every node with >1 point in list order; careful passes use the libstdc++
+//     introsort order (vsg_introsort.h) back to front and stop at the first prefix reaching size >= N;
+//   * vSizeAndPointerToNode (the sort input) is the creation order of children with >1 point.
+// Points are never moved: each keeps the list position of its node (node_of[]), relabelled per pass.
+// The candidate order only matters for "first maximum wins" (ORBextractor.cc:774), which is carried by
+// an explicit rank = position in the reference's cell-major / row-major candidate order.
+//
+// The algorithm is written against a Group concept (tid, nthreads, sync, LDS atomics, block scan) so
+// the same source runs as a 256-thread workgroup on the GPU and as a 1-thread group in the host unit
+// tests (tests/_hostcore), which compare it with the oracle's literal std::list restatement.
+#pragma once
+#include <stdint.h>
+
+#include "vsg_common.h"
+#include "vsg_introsort.h"
+
+#if defined(__HIPCC__)
+#define VSG_OCT_HD __host__ __device__ inline
+#else
+#define VSG_OCT_HD inline
+#endif
+
+namespace vsg {
+namespace octree {
+
+// ---- single-thread group (host tests; also valid on device for debugging)
+struct SerialGroup {
+  int tid = 0, nthreads = 1;
+  VSG_OCT_HD void sync() {}
+  VSG_OCT_HD int atomic_add(int *p, int v) {
+    int o = *p;
+    *p = o + v;
+    return o;
+  }
+  VSG_OCT_HD void atomic_max(uint32_t *p, uint32_t v) {
+    if (v > *p) *p = v;
+  }
+  VSG_OCT_HD void atomic_min(int *p, int v) {
+    if (v < *p) *p = v;
+  }
+  // in-place exclusive prefix sum of a[0..n); returns the total
+  VSG_OCT_HD int exclusive_scan(int *a, int n) {
+    int s = 0;
+    for (int i = 0; i < n; i++) {
+      int v = a[i];
+      a[i] = s;
+      s += v;
+    }
+    return s;
+  }
+};
+
+struct Params {
+  int N;                 // quota for this level
+  int height;            // maxY - minY
+  int nIni;
+  const int *iniUL;      // nIni + 1
+  const int *iniThresh;  // nIni
+  int nCols, wCell, hCell;  // FAST cell grid, for the candidate rank
+};
+
+// Capacity (in nodes) the workspace must provide for quota N.  The list never exceeds
+// max(N + 3, 4 * nIni): the first pass makes <= 4*nIni nodes; a further main pass only runs when
+// size + 3*nToExpand <= N (:696) and adds <= 3 per split node; the careful phase adds <= 3 per split
+// and stops at the first size >= N (:753).
+VSG_OCT_HD int node_capacity(int N) { return (N + 3 > 4 * kMaxIniNodes ? N + 3 : 4 * kMaxIniNodes) + 4; }
+
+// Workspace: carve from one byte buffer (LDS on the device).  Layout is 8-byte aligned.
+struct Work {
+  int16_t *ulx[2], *uly[2], *urx[2], *bly[2];
+  int *cnt[2];
+  int *childcnt;        // 4 per node; aliased by sortbuf (item_t per node) and bestkey
+  uint16_t *childpos;   // 4 per node
+  uint16_t *keeppos;
+  uint16_t *proc;
+  uint16_t *V;
+  uint8_t *divided;
+  int *scanA, *scanB;
+  int *ctrl;            // [0]=nL [1]=nV [2]=break index
+};
+
+VSG_OCT_HD size_t work_bytes(int cap) {
+  size_t capa = (size_t)((cap + 3) & ~3);
+  return capa * (2 * 4 * 2 + 2 * 4 + 16 + 8 + 2 + 2 + 2 + 1 + 4 + 4) + 64;
+}
+
+VSG_OCT_HD void carve(Work &W, void *buf, int cap) {
+  size_t capa = (size_t)((cap + 3) & ~3);
+  uint8_t *p = (uint8_t *)buf;
+  W.childcnt = (int *)p;
+  p += capa * 16;
+  for (int b = 0; b < 2; b++) {
+    W.cnt[b] = (int *)p;
+    p += capa * 4;
+  }
+  W.scanA = (int *)p;
+  p += capa * 4;
+  W.scanB = (int *)p;
+  p += capa * 4;
+  W.ctrl = (int *)p;
+  p += 64;
+  W.childpos = (uint16_t *)p;
+  p += capa * 8;
+  for (int b = 0; b < 2; b++) {
+    W.ulx[b] = (int16_t *)p;
+    p += capa * 2;
+    W.uly[b] = (int16_t *)p;
+    p += capa * 2;
+    W.urx[b] = (int16_t *)p;
+    p += capa * 2;
+    W.bly[b] = (int16_t *)p;
+    p += capa * 2;
+  }
+  W.keeppos = (uint16_t *)p;
+  p += capa * 2;
+  W.proc = (uint16_t *)p;
+  p += capa * 2;
+  W.V = (uint16_t *)p;
+  p += capa * 2;
+  W.divided = (uint8_t *)p;
+}
+
+VSG_OCT_HD int quadrant(const Work &W, int b, int n, int x, int y) {
+  const int ulx = W.ulx[b][n], uly = W.uly[b][n];
+  const int midX = ulx + ((W.urx[b][n] - ulx + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)  (:484)
+  const int midY = uly + ((W.bly[b][n] - uly + 1) >> 1);
+  return (x >= midX ? 1 : 0) | (y >= midY ? 2 : 0);       // n1,n2,n3,n4 (:513-527)
+}
+
+// position of a candidate in the reference's candidate order (cells row-major, pixels row-major
+// inside a cell): ORBextractor.cc:811-875 + FAST_t's row-major output.
+VSG_OCT_HD uint32_t cand_rank(const Params &P, int x, int y) {
+  const int cx = x - 3, cy = y - 3;  // valid region of a cell starts 3 px inside it
+  const int j = cx / P.wCell, i = cy / P.hCell;
+  return (uint32_t)(((i * P.nCols + j) * P.hCell + (cy - i * P.hCell)) * P.wCell + (cx - j * P.wCell));
+}
+
+// One splitting pass over proc[0..nProc).  Returns new list length; *nV_out = |V|.
+template <class G>
+VSG_OCT_HD int run_pass(G &g, const Params &P, Work &W, int &cur, int nL, int nProc, bool careful,
+                        const uint32_t *cand, int npts, uint16_t *node_of, int *nV_out) {
+  const int b = cur, nb = cur ^ 1;
+  for (int i = g.tid; i < nL; i += g.nthreads) W.divided[i] = 0;
+  g.sync();
+  for (int t = g.tid; t < nProc; t += g.nthreads) {
+    const int n = W.proc[t];
+    W.divided[n] = 1;
+    W.childcnt[4 * n + 0] = 0;
+    W.childcnt[4 * n + 1] = 0;
+    W.childcnt[4 * n + 2] = 0;
+    W.childcnt[4 * n + 3] = 0;
+  }
+  if (g.tid == 0) W.ctrl[2] = nProc;
+  g.sync();
+  for (int p = g.tid; p < npts; p += g.nthreads) {
+    const int n = node_of[p];
+    if (W.divided[n]) {
+      const uint32_t c = cand[p];
+      g.atomic_add(&W.childcnt[4 * n + quadrant(W, b, n, VSG_CAND_X(c), VSG_CAND_Y(c))], 1);
+    }
+  }
+  g.sync();
+  for (int t = g.tid; t < nProc; t += g.nthreads) {
+    const int n = W.proc[t];
+    int k = 0, e = 0;
+    for (int c = 0; c < 4; c++) {
+      const int cc = W.childcnt[4 * n + c];
+      k += cc > 0;
+      e += cc > 1;
+    }
+    W.scanA[t] = k | (e << 16);
+  }
+  g.sync();
+  const int total = g.exclusive_scan(W.scanA, nProc);
+  int nEff = nProc;
+  if (careful) {
+    // `if ((int)lNodes.size() >= N) break;` after each split (:753)
+    for (int t = g.tid; t < nProc; t += g.nthreads) {
+      const int n = W.proc[t];
+      int k = 0;
+      for (int c = 0; c < 4; c++) k += W.childcnt[4 * n + c] > 0;
+      const int sizeAfter = nL + (W.scanA[t] & 0xFFFF) + k - (t + 1);
+      if (sizeAfter >= P.N) g.atomic_min(&W.ctrl[2], t + 1);
+    }
+    g.sync();
+    nEff = W.ctrl[2];
+    g.sync();
+    for (int t = nEff + g.tid; t < nProc; t += g.nthreads) W.divided[W.proc[t]] = 0;
+  }
+  const int packed = nEff < nProc ? W.scanA[nEff] : total;
+  const int K = packed & 0xFFFF, E = packed >> 16;
+  g.sync();
+  for (int i = g.tid; i < nL; i += g.nthreads) W.scanB[i] = W.divided[i] ? 0 : 1;
+  g.sync();
+  const int kept = g.exclusive_scan(W.scanB, nL);
+  const int newL = K + kept;
+  for (int t = g.tid; t < nEff; t += g.nthreads) {
+    const int n = W.proc[t];
+    const int q0 = W.scanA[t] & 0xFFFF, e0 = W.scanA[t] >> 16;
+    const int ulx = W.ulx[b][n], uly = W.uly[b][n], urx = W.urx[b][n], bly = W.bly[b][n];
+    const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
+    int m = 0, ev = 0;
+    for (int c = 0; c < 4; c++) {
+      const int cc = W.childcnt[4 * n + c];
+      if (cc > 0) {
+        const int pos = K - 1 - (q0 + m);  // push_front => reversed creation order
+        W.ulx[nb][pos] = (int16_t)((c & 1) ? midX : ulx);
+        W.urx[nb][pos] = (int16_t)((c & 1) ? urx : midX);
+        W.uly[nb][pos] = (int16_t)((c & 2) ? midY : uly);
+        W.bly[nb][pos] = (int16_t)((c & 2) ? bly : midY);
+        W.cnt[nb][pos] = cc;
+        W.childpos[4 * n + c] = (uint16_t)pos;
+        if (cc > 1) W.V[e0 + ev++] = (uint16_t)pos;
+        m++;
+      }
+    }
+  }
+  for (int i = g.tid; i < nL; i += g.nthreads) {
+    if (!W.divided[i]) {
+      const int pos = K + W.scanB[i];
+      W.ulx[nb][pos] = W.ulx[b][i];
+      W.urx[nb][pos] = W.urx[b][i];
+      W.uly[nb][pos] = W.uly[b][i];
+      W.bly[nb][pos] = W.bly[b][i];
+      W.cnt[nb][pos] = W.cnt[b][i];
+      W.keeppos[i] = (uint16_t)pos;
+    }
+  }
+  g.sync();
+  for (int p = g.tid; p < npts; p += g.nthreads) {
+    const int n = node_of[p];
+    if (W.divided[n]) {
+      const uint32_t c = cand[p];
+      node_of[p] = W.childpos[4 * n + quadrant(W, b, n, VSG_CAND_X(c), VSG_CAND_Y(c))];
+    } else {
+      node_of[p] = W.keeppos[n];
+    }
+  }
+  g.sync();
+  cur = nb;
+  *nV_out = E;
+  return newL;
+}
+
+// DistributeOctTree.  cand[0..npts): packed candidates in ANY order.  node_of: npts uint16 scratch.
+// sel_out: receives the chosen candidate of every final node, in the reference's list order.
+// Returns the number of selected keypoints.  Must be called by every thread of the group.
+template <class G>
+VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts, uint16_t *node_of, Work &W,
+                          uint32_t *sel_out) {
+  int cur = 0;
+  // initial nodes (:575-586)
+  for (int i = g.tid; i < P.nIni; i += g.nthreads) {
+    W.ulx[0][i] = (int16_t)P.iniUL[i];
+    W.urx[0][i] = (int16_t)P.iniUL[i + 1];
+    W.uly[0][i] = 0;
+    W.bly[0][i] = (int16_t)P.height;
+    W.cnt[0][i] = 0;
+  }
+  g.sync();
+  // vpIniNodes[kp.pt.x / hX] (:589-593)
+  for (int p = g.tid; p < npts; p += g.nthreads) {
+    const int x = VSG_CAND_X(cand[p]);
+    int idx = 0;
+    for (int i = 1; i < P.nIni; i++) idx += (x >= P.iniThresh[i]);
+    node_of[p] = (uint16_t)idx;
+    g.atomic_add(&W.cnt[0][idx], 1);
+  }
+  g.sync();
+  // erase empty initial nodes, keep order (:597-608)
+  if (g.tid == 0) {
+    int pos = 0;
+    for (int i = 0; i < P.nIni; i++) {
+      if (W.cnt[0][i] > 0) {
+        W.ulx[1][pos] = W.ulx[0][i];
+        W.urx[1][pos] = W.urx[0][i];
+        W.uly[1][pos] = W.uly[0][i];
+        W.bly[1][pos] = W.bly[0][i];
+        W.cnt[1][pos] = W.cnt[0][i];
+        W.keeppos[i] = (uint16_t)pos;
+        pos++;
+      }
+    }
+    W.ctrl[0] = pos;
+  }
+  g.sync();
+  for (int p = g.tid; p < npts; p += g.nthreads) node_of[p] = W.keeppos[node_of[p]];
+  cur = 1;
+  int nL = W.ctrl[0];
+  g.sync();
+
+  bool finish = false;
+  while (!finish) {  // (:617)
+    const int prevSize = nL;
+    for (int i = g.tid; i < nL; i += g.nthreads) W.scanA[i] = W.cnt[cur][i] > 1;
+    g.sync();
+    const int nProc = g.exclusive_scan(W.scanA, nL);
+    for (int i = g.tid; i < nL; i += g.nthreads)
+      if (W.cnt[cur][i] > 1) W.proc[W.scanA[i]] = (uint16_t)i;
+    g.sync();
+    int nV = 0;
+    nL = run_pass(g, P, W, cur, nL, nProc, false, cand, npts, node_of, &nV);
+    if (nL >= P.N || nL == prevSize) {  // (:692)
+      finish = true;
+    } else if (nL + nV * 3 > P.N) {  // (:696)
+      while (!finish) {
+        const int prev2 = nL;
+        introsort::item_t *sortbuf = (introsort::item_t *)W.childcnt;
+        for (int t = g.tid; t < nV; t += g.nthreads) {
+          const int n = W.V[t];
+          // compareNodes: (size, UL.x) ascending (:539-560)
+          const uint32_t key = ((uint32_t)W.cnt[cur][n] << 13) | (uint32_t)(uint16_t)W.ulx[cur][n];
+          sortbuf[t] = ((introsort::item_t)key << 32) | (uint32_t)n;
+        }
+        g.sync();
+        if (g.tid == 0) introsort::sort(sortbuf, nV);  // (:707)
+        g.sync();
+        for (int t = g.tid; t < nV; t += g.nthreads) W.proc[t] = (uint16_t)(uint32_t)sortbuf[nV - 1 - t];  // (:708)
+        g.sync();
+        int nV2 = 0;
+        nL = run_pass(g, P, W, cur, nL, nV, true, cand, npts, node_of, &nV2);
+        nV = nV2;
+        if (nL >= P.N || nL == prev2) finish = true;  // (:757)
+      }
+    }
+  }
+
+  // retain the best point of every node, first maximum wins (:763-782)
+  uint32_t *bestkey = (uint32_t *)W.childcnt;
+  for (int i = g.tid; i < nL; i += g.nthreads) bestkey[i] = 0;
+  g.sync();
+  for (int p = g.tid; p < npts; p += g.nthreads) {
+    const uint32_t c = cand[p];
+    const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c)));
+    g.atomic_max(&bestkey[node_of[p]], key);
+  }
+  g.sync();
+  for (int p = g.tid; p < npts; p += g.nthreads) {
+    const uint32_t c = cand[p];
+    const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c)));
+    if (bestkey[node_of[p]] == key) sel_out[node_of[p]] = c;
+  }
+  g.sync();
+  return nL;
+}
+
+}  // namespace octree
+}  // namespace vsg
