@@ -1,0 +1,177 @@
+/*
+ * vsg_orb.h -- C ABI of the MI355X-native ORB front-end (libvsg_orb.so).
+ *
+ * Drop-in boundary for the per-frame hot path of snt-arg/visual_sgraphs (vS-Graphs on
+ * ORB-SLAM3).  Each entry point names the reference interface it replaces (paths relative to
+ * the reference tree).  Plain pointers and sizes only; nothing throws across this boundary;
+ * every function returns a negative VSG_ERR_* code on failure.  There is NO CPU fallback:
+ * without a HIP device every compute entry point fails with VSG_ERR_NO_DEVICE.
+ *
+ * Threading: a handle is not re-entrant (like one ORBextractor instance, which mutates
+ * mvImagePyramid); distinct handles may be used concurrently from different host threads,
+ * on the same or different GPUs (the stereo Frame ctor does exactly that, Frame.cc:129-132).
+ * Matcher entry points are stateless and thread-safe.
+ */
+#ifndef VSG_ORB_H
+#define VSG_ORB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSG_OK 0
+#define VSG_ERR_EMPTY_IMAGE (-1)   /* operator() returns -1 on an empty image (ORBextractor.cc:1087-1088) */
+#define VSG_ERR_CAPACITY (-2)      /* caller's keypoint/descriptor capacity is too small */
+#define VSG_ERR_UNSUPPORTED (-3)   /* parameters/image size the reference itself cannot process, or over a limit */
+#define VSG_ERR_NO_DEVICE (-4)     /* no usable HIP device / HIP runtime error at start-up */
+#define VSG_ERR_HIP (-5)           /* a HIP call failed; see vsg_last_error() */
+#define VSG_ERR_INVALID (-6)       /* bad argument */
+
+/* cv::KeyPoint-compatible record: pt.x pt.y size angle response octave class_id (28 bytes),
+ * so a C++ adaptor can memcpy into std::vector<cv::KeyPoint>. */
+typedef struct vsg_keypoint {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} vsg_keypoint;
+
+typedef struct vsg_orb vsg_orb; /* one ORBextractor instance + its device buffers and streams */
+
+const char *vsg_last_error(void);   /* thread-local description of the last failure */
+int vsg_device_count(void);         /* number of HIP devices, or VSG_ERR_NO_DEVICE */
+
+/* ---- ORBextractor ------------------------------------------------------------------------- */
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * (ORBextractor.h:51-52, ORBextractor.cc:411-470).  `device` = HIP device ordinal;
+ * `max_batch` = frames processed per launch by the batch entry points (>= 1). */
+int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device,
+                   int max_batch, vsg_orb **out);
+void vsg_orb_destroy(vsg_orb *h);
+
+/* GetLevels/GetScaleFactors/GetInverseScaleFactors/GetScaleSigmaSquares/GetInverseScaleSigmaSquares
+ * (ORBextractor.h:63-91) plus mnFeaturesPerLevel and umax[16]; any pointer may be NULL.
+ * Returns nlevels.  No device needed. */
+int vsg_orb_get_tables(const vsg_orb *h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                       int *features_per_level, int *umax16);
+
+/* The 7 taps of cv::GaussianBlur(7x7, sigma 2)'s 8.8 fixed-point kernel (ORBextractor.cc:1130).
+ * Default {18,34,49,55,49,34,18} (OpenCV 4.2.0 independent rounding); OpenCV >= 4.3 normalises to
+ * {18,34,48,56,48,34,18}.  Version-sensitive, hence data. */
+int vsg_orb_set_blur_taps(vsg_orb *h, const uint16_t taps[7]);
+
+/* Keypoint capacity a caller must provide per frame for images of this size (>= nfeatures + 3*nlevels,
+ * ORBextractor.cc:692,753-754), or a VSG_ERR_* code. */
+int vsg_orb_capacity(vsg_orb *h, int rows, int cols);
+
+/* int ORBextractor::operator()(image, mask, keypoints, descriptors, vLappingArea)
+ * (ORBextractor.h:59-61, ORBextractor.cc:1083-1169).  gray: CV_8UC1 host image, `stride` bytes per row.
+ * lap0/lap1 = vLappingArea.  kps[capacity], desc[capacity*32] are host buffers owned by the caller.
+ * Returns monoIndex (>= 0) like the reference, VSG_ERR_EMPTY_IMAGE (-1) for an empty image, or another
+ * VSG_ERR_*.  *n = number of keypoints (rows of the descriptor Mat; 0 => the reference release()s it). */
+int vsg_orb_extract(vsg_orb *h, const uint8_t *gray, int rows, int cols, int stride, int lap0, int lap1,
+                    vsg_keypoint *kps, uint8_t *desc, int capacity, int *n);
+
+/* Batched operator(): nframes (<= max_batch) images of equal size at gray + i*frame_stride.
+ * Outputs are [nframes][capacity] records; n[i], mono_index[i] per frame.  Host pointers. */
+int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t frame_stride, int rows, int cols,
+                          int stride, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc, int capacity, int *n,
+                          int *mono_index);
+
+/* Device-resident batched operator() for throughput pipelines and multi-GPU sharding:
+ * d_gray, d_kps ([nframes][capacity]), d_desc ([nframes][capacity][32]) and d_counts ([nframes][2] =
+ * {n, monoIndex}) are DEVICE pointers on the handle's device.  Work is enqueued asynchronously behind
+ * `stream` (a hipStream_t, may be NULL = the handle's own stream) and completes in stream order.
+ * Descriptors stay resident for the matcher entry points. */
+int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes, size_t frame_stride, int rows,
+                                 int cols, int stride, int lap0, int lap1, vsg_keypoint *d_kps, uint8_t *d_desc,
+                                 int *d_counts, int capacity, void *stream);
+
+/* mvImagePyramid[level] (public member, ORBextractor.h:93; read by Frame::ComputeStereoMatches,
+ * Frame.cc:964,1054-1069) of frame `frame` of the last call.  with_border != 0 copies the
+ * (w+38)x(h+38) buffer including the 19 px BORDER_REFLECT_101 frame (ORBextractor.cc:1186-1192). */
+int vsg_orb_level_size(vsg_orb *h, int level, int *w, int *ht);
+int vsg_orb_copy_pyramid_level(vsg_orb *h, int frame, int level, int with_border, uint8_t *dst, int dst_stride);
+
+/* Stage read-back of the last call, for stage-by-stage parity tests: the blurred level
+ * (ORBextractor.cc:1129-1130), the FAST candidates (vToDistributeKeys, :868-873; unordered,
+ * packed x | y<<12 | response<<24 relative to (16,16)) and the octree selection in list order. */
+int vsg_orb_copy_blurred_level(vsg_orb *h, int frame, int level, uint8_t *dst, int dst_stride);
+int vsg_orb_copy_candidates(vsg_orb *h, int frame, int level, uint32_t *dst, int cap);
+int vsg_orb_copy_selected(vsg_orb *h, int frame, int level, uint32_t *dst, int cap);
+
+/* Average device time per stage of the last N timed calls (HIP events on the handle's streams).
+ * names: "pyramid","fast","octree","blur","slots","orient_desc","total".  Returns number of stages. */
+int vsg_orb_enable_timing(vsg_orb *h, int enable);
+int vsg_orb_get_timing(vsg_orb *h, float *ms_out, int cap);
+
+/* ---- ORBmatcher (flattened POD views; pointer-graph walking and geometry stay in the C++ adaptor) ---- */
+
+/* static int ORBmatcher::DescriptorDistance(a, b) (ORBmatcher.h:40, ORBmatcher.cc:2047-2063)
+ * for npairs row pairs: dist[i] = hamming(a[ia[i]], b[ib[i]]).  Host pointers. */
+int vsg_hamming_pairs(int device, const uint8_t *a, int na, const uint8_t *b, int nb, const int32_t *ia,
+                      const int32_t *ib, int npairs, int32_t *dist);
+
+/* Brute-force best / second-best of every row of A against all rows of B: the inner loop of
+ * SearchByBoW (ORBmatcher.cc:276-299, 810-841) for one vocabulary node without greedy state.
+ * Ties resolve to the lowest B index (strict '<' scan).  Host pointers. */
+int vsg_hamming_block_best2(int device, const uint8_t *a, int na, const uint8_t *b, int nb, int32_t *best,
+                            int32_t *second, int32_t *argbest);
+/* Same on device pointers, batched over `nblocks` independent (A_i, B_i) blocks laid out with fixed
+ * strides (rows per block: na[i], nb[i] from d_counts[i*count_stride]); asynchronous on `stream`. */
+int vsg_hamming_block_best2_device(int device, const uint8_t *d_a, const uint8_t *d_b, size_t block_stride_bytes,
+                                   const int32_t *d_counts_a, const int32_t *d_counts_b, int count_stride,
+                                   int nblocks, int max_rows, int32_t *d_best, int32_t *d_second,
+                                   int32_t *d_argbest, void *stream);
+
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vpMapPointMatches) (ORBmatcher.h:64,
+ * ORBmatcher.cc:226-428), F.Nleft == -1.  FeatureVectors (DBoW2 std::map<NodeId, vector<unsigned>>)
+ * are CSR: node ids ascending, offsets[nodes+1], indices.  kf_valid[i] = (pMP && !pMP->isBad()).
+ * match_f[i] = KF feature index whose MapPoint F feature i received, or -1.  Returns nmatches. */
+int vsg_search_by_bow_kf_f(int device, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid,
+                           int n_kf, const int32_t *kf_node_id, const int32_t *kf_off, const int32_t *kf_idx,
+                           int kf_nodes, const uint8_t *f_desc, const float *f_angle, int n_f,
+                           const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
+                           float nnratio, int check_orientation, int32_t *match_f);
+
+/* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (ORBmatcher.h:65,
+ * ORBmatcher.cc:758-900), NLeft == -1.  matches12[idx1] = idx2 or -1. */
+int vsg_search_by_bow_kf_kf(int device, const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
+                            const int32_t *node_id1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                            const uint8_t *desc2, const float *angle2, const uint8_t *valid2, int n2,
+                            const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                            float nnratio, int check_orientation, int32_t *matches12);
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
+ * (ORBmatcher.h:50, ORBmatcher.cc:1667-1878), Nleft == -1.  The adaptor projects the map points and
+ * runs Frame::GetFeaturesInArea; query q brings its descriptor, keypoint angle and candidate list
+ * cand_idx[cand_off[q] .. cand_off[q+1]) in GetFeaturesInArea order.  train_blocked[i] =
+ * (CurrentFrame.mvpMapPoints[i] && Observations() > 0) on entry, updated in place; query_blocks[q] =
+ * (pMP_q->Observations() > 0).  train_match[i] = q or left untouched (caller initialises to -1).
+ * th_high = TH_HIGH (100).  Returns nmatches. */
+int vsg_search_by_projection_last(int device, const uint8_t *q_desc, const float *q_angle,
+                                  const uint8_t *query_blocks, int n_q, const int32_t *cand_off,
+                                  const int32_t *cand_idx, const uint8_t *t_desc, const float *t_angle,
+                                  uint8_t *train_blocked, int n_t, int th_high, int check_orientation,
+                                  int32_t *train_match);
+
+/* int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &, th, ...) (ORBmatcher.h:46,
+ * ORBmatcher.cc:42-216), left block, Nleft == -1: best + second best with octave-aware ratio test. */
+int vsg_search_by_projection_local(int device, const uint8_t *q_desc, const uint8_t *query_blocks, int n_q,
+                                   const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *t_desc,
+                                   const int32_t *t_octave, uint8_t *train_blocked, int n_t, float nnratio,
+                                   int32_t *train_match);
+
+/* int ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
+ * (ORBmatcher.h:68, ORBmatcher.cc:643-756); candidate lists from F2.GetFeaturesInArea per F1 keypoint. */
+int vsg_search_for_initialization(int device, const uint8_t *desc1, const float *angle1, const int32_t *octave1,
+                                  int n1, const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *desc2,
+                                  const float *angle2, int n2, float nnratio, int check_orientation,
+                                  int32_t *matches12);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSG_ORB_H */

@@ -1,0 +1,194 @@
+"""GPU parity tests of the extractor: every stage and the final operator() output of the HIP path, called
+through the C ABI, must equal the CPU oracle bit for bit (integer/byte/index work: exact; the only float
+fields -- angle, scaled coordinates -- are compared as raw bytes too)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from visual_sgraphs_amd import orb, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = np.load(Path(__file__).parent / "golden" / "orb_golden_v1.npz")
+
+
+def assert_same_output(got, want, what=""):
+    gm, gk, gd = got
+    wm, wk, wd = want
+    assert len(gk) == len(wk), f"{what}: keypoint count {len(gk)} != {len(wk)}"
+    assert gm == wm, f"{what}: monoIndex {gm} != {wm}"
+    for f in ("octave", "x", "y", "response", "size", "class_id", "angle"):
+        bad = np.nonzero(gk[f].view(np.uint32) != wk[f].view(np.uint32))[0]
+        assert len(bad) == 0, f"{what}: field {f} differs at {bad[:5]}: {gk[f][bad[:5]]} vs {wk[f][bad[:5]]}"
+    assert gk.tobytes() == wk.tobytes()
+    bad = np.nonzero((gd != wd).any(axis=1))[0]
+    assert len(bad) == 0, f"{what}: descriptors differ at rows {bad[:5]}"
+
+
+CASES = [
+    # w, h, nfeatures, nlevels, seed, amplitude_div
+    (640, 480, 1000, 8, 0, 1),     # C2
+    (640, 480, 1000, 8, 1, 8),     # low contrast: minThFAST fallback cells
+    (752, 480, 1200, 8, 2, 1),     # C3 geometry, two initial octree nodes
+    (320, 240, 500, 4, 3, 1),
+    (640, 480, 1250, 8, 4, 1),     # C5 parameters
+]
+
+
+@pytest.mark.parametrize("w,h,nf,nl,seed,div", CASES)
+def test_stage_by_stage_parity(w, h, nf, nl, seed, div):
+    img = synth.frame(w, h, seed, amplitude_div=div)
+    ref = ol.OracleExtractor(nf, 1.2, nl, 20, 7)
+    want = ref(img)
+    ex = orb.ORBextractor(nf, 1.2, nl, 20, 7)
+    got = ex(img)
+    for l in range(nl):
+        assert ex.level_size(l) == ref.level_size(l)
+        assert np.array_equal(ex.image_pyramid(l), ref.pyramid_level(l)), f"pyramid level {l}"
+        # FAST candidates: same multiset (the GPU list is unordered by design)
+        gx, gy, gr = ex.candidates(l)
+        rx, ry, rr = ref.candidates(l)
+        assert len(gx) == len(rx), f"candidate count level {l}: {len(gx)} vs {len(rx)}"
+        go, ro = np.lexsort((gx, gy)), np.lexsort((rx, ry))
+        assert np.array_equal(gx[go], rx[ro]) and np.array_equal(gy[go], ry[ro]) and np.array_equal(gr[go], rr[ro])
+        # octree selection: same keypoints in the same (list) order
+        sx, sy, sr = ex.selected(l)
+        lk = ref.level_keypoints(l)
+        assert np.array_equal(sx + 16, lk["x"].astype(np.int32)) and np.array_equal(sy + 16, lk["y"].astype(np.int32))
+        assert np.array_equal(sr, lk["response"].astype(np.int32))
+        rb = ref.blurred_level(l)
+        if rb is not None:
+            assert np.array_equal(ex.blurred_level(l), rb), f"blurred level {l}"
+    assert_same_output(got, want, f"{w}x{h}")
+    if div == 8:
+        assert np.any(want[1]["response"] < 20)  # the fallback branch really ran
+
+
+def test_pyramid_with_border_matches_mvImagePyramid():
+    img = synth.frame(320, 240, 12)
+    ref = ol.OracleExtractor(500, 1.2, 4, 20, 7)
+    ref(img)
+    ex = orb.ORBextractor(500, 1.2, 4, 20, 7)
+    ex(img)
+    for l in range(4):
+        assert np.array_equal(ex.image_pyramid(l, with_border=True), ref.pyramid_level(l, with_border=True))
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[0] for k in GOLDEN.files if k.endswith("/params")}))
+def test_golden_fixtures(name):
+    w, h, seed, div, nf, nl, lap0, lap1 = GOLDEN[name + "/params"].tolist()
+    ex = orb.ORBextractor(nf, 1.2, nl, 20, 7)
+    mono, kps, desc = ex(synth.frame(w, h, seed, amplitude_div=div), None, (lap0, lap1))
+    assert mono == int(GOLDEN[name + "/mono"][0])
+    assert kps.tobytes() == GOLDEN[name + "/kps"].tobytes()
+    assert np.array_equal(desc, GOLDEN[name + "/desc"])
+
+
+def test_empty_constant_and_lapping_slots():
+    ex = orb.ORBextractor(500, 1.2, 4, 20, 7)
+    ref = ol.OracleExtractor(500, 1.2, 4, 20, 7)
+    assert ex(None)[0] == -1 and ex(np.zeros((0, 0), np.uint8))[0] == -1
+    mono, kps, desc = ex(synth.constant_frame(320, 240))
+    assert (mono, len(kps), desc.shape) == (0, 0, (0, 32))  # _descriptors.release() path
+    img = synth.frame(320, 240, 2)
+    for lap in [(0, 0), (0, 1000), (100, 200), (150, 150), (-5, 40)]:
+        assert_same_output(ex(img, None, lap), ref(img, lap), f"lapping {lap}")
+
+
+def test_same_handle_different_sizes_and_reuse():
+    ex = orb.ORBextractor(800, 1.2, 6, 20, 7)
+    ref = ol.OracleExtractor(800, 1.2, 6, 20, 7)
+    for (w, h, seed) in [(480, 360, 1), (640, 480, 2), (480, 360, 3), (400, 300, 4)]:
+        img = synth.frame(w, h, seed)
+        assert_same_output(ex(img), ref(img), f"{w}x{h}")
+
+
+def test_strided_input_and_unusual_thresholds():
+    big = synth.frame(700, 500, 9)
+    view = big[10:490, 30:670]  # non-contiguous rows
+    ref = ol.OracleExtractor(1000, 1.2, 8, 12, 5)
+    ex = orb.ORBextractor(1000, 1.2, 8, 12, 5)
+    assert_same_output(ex(view), ref(np.ascontiguousarray(view)), "strided")
+    ref2, ex2 = ol.OracleExtractor(300, 1.5, 3, 40, 10), orb.ORBextractor(300, 1.5, 3, 40, 10)
+    img = synth.frame(512, 384, 10)
+    assert_same_output(ex2(img), ref2(img), "scale 1.5")
+
+
+def test_batch_equals_single_and_oracle():
+    B = 6
+    imgs = np.stack([synth.sequence_frame(640, 480, 5, t) for t in range(B)])
+    ex = orb.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    ref = ol.OracleExtractor(1000, 1.2, 8, 20, 7)
+    outs = ex.extract_batch(imgs)
+    single = orb.ORBextractor(1000, 1.2, 8, 20, 7)
+    for t in range(B):
+        want = ref(imgs[t])
+        assert_same_output(outs[t], want, f"batch frame {t}")
+        assert_same_output(single(imgs[t]), want, f"single frame {t}")
+    # a partial batch after a full one must not see stale state
+    outs2 = ex.extract_batch(imgs[3:5])
+    assert_same_output(outs2[0], ref(imgs[3]), "partial batch 0")
+    assert_same_output(outs2[1], ref(imgs[4]), "partial batch 1")
+
+
+def test_full_size_c4_and_kitti_aspect():
+    img = synth.frame(1280, 720, 21)
+    ref = ol.OracleExtractor(2000, 1.2, 8, 20, 7)
+    ex = orb.ORBextractor(2000, 1.2, 8, 20, 7)
+    assert_same_output(ex(img), ref(img), "C4 1280x720")
+    img = synth.frame(1241, 376, 22)  # 3-4 initial octree nodes
+    assert_same_output(ex(img), ref(img), "1241x376")
+
+
+def test_blur_taps_are_data():
+    ed = (18, 34, 48, 56, 48, 34, 18)
+    img = synth.frame(320, 240, 30)
+    ref = ol.OracleExtractor(500, 1.2, 4, 20, 7)
+    ref.set_blur_taps(ed)
+    ex = orb.ORBextractor(500, 1.2, 4, 20, 7)
+    ex.set_blur_taps(ed)
+    assert_same_output(ex(img), ref(img), "ED taps")
+    assert np.array_equal(ex.blurred_level(0), ol.gaussian_blur7(img, ed))
+
+
+def test_unsupported_inputs_return_codes():
+    ex = orb.ORBextractor(500, 1.2, 8, 20, 7)
+    with pytest.raises(orb.VsgError) as ei:
+        ex(synth.frame(160, 120, 1))  # top level narrower than one FAST cell: the reference divides by zero
+    assert ei.value.code == -3
+
+
+def test_two_handles_two_threads_like_stereo_ctor():
+    """Frame.cc:129-132: left/right extractors run concurrently on two host threads."""
+    import threading
+    L, R = synth.sequence_frame(752, 480, 8, 0), synth.sequence_frame(752, 480, 8, 1)
+    ref = ol.OracleExtractor(1200, 1.2, 8, 20, 7)
+    want = [ref(L), ref(R)]
+    exs = [orb.ORBextractor(1200, 1.2, 8, 20, 7), orb.ORBextractor(1200, 1.2, 8, 20, 7)]
+    got = [None, None]
+
+    def run(i, img):
+        for _ in range(3):
+            got[i] = exs[i](img)
+
+    ts = [threading.Thread(target=run, args=(0, L)), threading.Thread(target=run, args=(1, R))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert_same_output(got[0], want[0], "left")
+    assert_same_output(got[1], want[1], "right")
+
+
+def test_roundtrip_properties_at_full_size():
+    """Size-independent properties on the bench workload: determinism across repeated calls, quotas, ordering."""
+    ex = orb.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=8)
+    imgs = np.stack([synth.frame(640, 480, 100 + i) for i in range(8)])
+    a = ex.extract_batch(imgs)
+    b = ex.extract_batch(imgs)
+    q = ex.features_per_level()
+    for (m1, k1, d1), (m2, k2, d2) in zip(a, b):
+        assert m1 == m2 and k1.tobytes() == k2.tobytes() and np.array_equal(d1, d2)
+        assert np.all(np.diff(k1["octave"]) >= 0)
+        cnt = np.bincount(k1["octave"], minlength=8)
+        assert np.all(cnt <= q + 3) and cnt.sum() == len(k1) >= 900

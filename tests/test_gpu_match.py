@@ -1,0 +1,207 @@
+"""GPU parity tests of the Hamming searches (ORBmatcher) through the C ABI against the CPU oracle:
+index pairs and distances identical, including tie-breaking and the greedy, order-dependent state."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from visual_sgraphs_amd import orb, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = np.load(Path(__file__).parent / "golden" / "orb_golden_v1.npz")
+
+
+@pytest.fixture(scope="module")
+def frames():
+    """Two consecutive synthetic frames extracted by the oracle (matcher inputs)."""
+    e = ol.OracleExtractor(1000, 1.2, 8, 20, 7)
+    _, k0, d0 = e(synth.sequence_frame(640, 480, 3, 0))
+    _, k1, d1 = e(synth.sequence_frame(640, 480, 3, 1))
+    return (k0, d0), (k1, d1)
+
+
+def make_fv(n, n_nodes, rng, drop=0.0):
+    """Synthetic DBoW2 FeatureVector: node id per feature -> CSR with ascending node ids and, inside a node,
+    ascending feature indices (FeatureVector::addFeature appends in feature order)."""
+    node = rng.integers(0, n_nodes, n) * 7 + 3
+    keep = rng.random(n) >= drop
+    ids = np.unique(node[keep])
+    off = [0]
+    idx = []
+    for i in ids:
+        m = np.nonzero((node == i) & keep)[0]
+        idx += m.tolist()
+        off.append(len(idx))
+    return ids.astype(np.int32), np.array(off, np.int32), np.array(idx, np.int32)
+
+
+def near_duplicates(desc, rng, flips):
+    """Descriptors at small Hamming distance from `desc` (so ratio tests and ties actually trigger)."""
+    out = desc.copy()
+    for r in range(len(out)):
+        for b in rng.integers(0, 256, flips):
+            out[r, b >> 3] ^= np.uint8(1 << (b & 7))
+    return out
+
+
+def test_descriptor_distance_kats_and_random():
+    m = orb.ORBmatcher()
+    z = np.zeros(32, np.uint8)
+    assert m.DescriptorDistance(z, z) == 0 and m.DescriptorDistance(z, ~z) == 256
+    rng = np.random.default_rng(0)
+    a, b = rng.integers(0, 256, (2, 500, 32), dtype=np.uint8)
+    want = np.unpackbits(a ^ b, axis=1).sum(axis=1)
+    assert np.array_equal(m.DescriptorDistance(a, b), want)
+    ia, ib = rng.integers(0, 500, (2, 3000))
+    got = m.hamming_pairs(a, b, ia, ib)
+    assert np.array_equal(got, np.unpackbits(a[ia] ^ b[ib], axis=1).sum(axis=1))
+    assert got.tolist()[:50] == [ol.descriptor_distance(a[i], b[j]) for i, j in zip(ia[:50], ib[:50])]
+
+
+def test_block_best2_real_frames_and_golden(frames):
+    (k0, d0), (k1, d1) = frames
+    m = orb.ORBmatcher()
+    got = m.block_best2(d0, d1)
+    want = ol.block_best2(d0, d1)
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    g = m.block_best2(GOLDEN["match/desc0"], GOLDEN["match/desc1"])
+    assert np.array_equal(g[0], GOLDEN["match/best"]) and np.array_equal(g[1], GOLDEN["match/second"])
+    assert np.array_equal(g[2], GOLDEN["match/arg"])
+
+
+def test_block_best2_ties_and_ragged_sizes():
+    rng = np.random.default_rng(1)
+    m = orb.ORBmatcher()
+    for na, nb in [(1, 1), (3, 700), (257, 256), (256, 257), (1000, 3), (513, 1025)]:
+        # few distinct rows => many exact ties; first index must win
+        base = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+        a = base[rng.integers(0, 5, na)]
+        b = near_duplicates(base[rng.integers(0, 5, nb)], rng, 1)
+        for g, w in zip(m.block_best2(a, b), ol.block_best2(a, b)):
+            assert np.array_equal(g, w), (na, nb)
+    best, second, arg = m.block_best2(np.zeros((4, 32), np.uint8), np.zeros((0, 32), np.uint8))
+    assert best.tolist() == [256] * 4 and second.tolist() == [256] * 4 and arg.tolist() == [-1] * 4
+
+
+@pytest.mark.parametrize("seed,n_nodes,ratio,ori", [(0, 60, 0.7, True), (1, 8, 0.75, True), (2, 300, 0.9, False),
+                                                    (3, 1, 0.6, True)])
+def test_search_by_bow_kf_f(frames, seed, n_nodes, ratio, ori):
+    (k0, d0), (k1, d1) = frames
+    rng = np.random.default_rng(seed)
+    # F descriptors = KF descriptors with a few bit flips + shuffled, so many candidates pass TH_LOW / the ratio test
+    perm = rng.permutation(len(d0))
+    f_desc = near_duplicates(d0[perm], rng, 6)
+    f_angle = (k0["angle"][perm] + rng.choice([0, 0, 0, 45, 200], len(perm))).astype(np.float32) % np.float32(360)
+    kf_valid = (rng.random(len(d0)) > 0.2).astype(np.uint8)
+    # same vocabulary node for a feature and its perturbed copy (most of the time)
+    node_of_kf = rng.integers(0, n_nodes, len(d0))
+    node_of_f = node_of_kf[perm].copy()
+    flip = rng.random(len(perm)) < 0.1
+    node_of_f[flip] = rng.integers(0, n_nodes, flip.sum())
+
+    def csr(node):
+        ids = np.unique(node)
+        idx = np.concatenate([np.nonzero(node == i)[0] for i in ids])
+        off = np.concatenate([[0], np.cumsum([np.sum(node == i) for i in ids])])
+        return ids.astype(np.int32), off.astype(np.int32), idx.astype(np.int32)
+
+    kf_fv, f_fv = csr(node_of_kf), csr(node_of_f)
+    m = orb.ORBmatcher(ratio, ori)
+    n_got, got = m.SearchByBoW_KF_F(d0, k0["angle"], kf_valid, kf_fv, f_desc, f_angle, f_fv)
+    n_want, want = ol.search_by_bow_kf_f(d0, k0["angle"], kf_valid, kf_fv, f_desc, f_angle, f_fv, ratio, ori)
+    assert n_got == n_want and np.array_equal(got, want)
+    assert n_want > 50
+
+
+@pytest.mark.parametrize("seed,n_nodes", [(0, 40), (1, 5), (2, 200)])
+def test_search_by_bow_kf_kf(frames, seed, n_nodes):
+    (k0, d0), (k1, d1) = frames
+    rng = np.random.default_rng(100 + seed)
+    perm = rng.permutation(len(d0))
+    d2 = near_duplicates(d0[perm], rng, 5)
+    a2 = k0["angle"][perm]
+    v1 = (rng.random(len(d0)) > 0.15).astype(np.uint8)
+    v2 = (rng.random(len(d2)) > 0.15).astype(np.uint8)
+    fv1 = make_fv(len(d0), n_nodes, rng, drop=0.05)
+    node2 = rng.integers(0, n_nodes, len(d2))
+    fv2 = make_fv(len(d2), n_nodes, rng)
+    m = orb.ORBmatcher(0.8, True)
+    n_got, got = m.SearchByBoW_KF_KF(d0, k0["angle"], v1, fv1, d2, a2, v2, fv2)
+    n_want, want = ol.search_by_bow_kf_kf(d0, k0["angle"], v1, fv1, d2, a2, v2, fv2, 0.8, True)
+    assert n_got == n_want and np.array_equal(got, want)
+
+
+def window_candidates(kps_q, kps_t, radius, rng, level_window=True):
+    """Candidate lists exactly as the C++ adaptor would build them: Frame::GetFeaturesInArea on the grid."""
+    grid = ol.OracleGrid(kps_t, 0.0, 0.0, 640.0, 480.0)
+    off, idx = [0], []
+    for kp in kps_q:
+        lo, hi = (int(kp["octave"]) - 1, int(kp["octave"]) + 1) if level_window else (-1, -1)
+        c = grid.query(kp["x"] + 3.0, kp["y"] + 2.0, radius * (1.2 ** int(kp["octave"])), lo, hi)
+        idx += c.tolist()
+        off.append(len(idx))
+    return np.array(off, np.int32), np.array(idx, np.int32)
+
+
+@pytest.mark.parametrize("seed,ori,th", [(0, True, 100), (1, False, 100), (2, True, 60)])
+def test_search_by_projection_last(frames, seed, ori, th):
+    (k0, d0), (k1, d1) = frames
+    rng = np.random.default_rng(seed)
+    nq = 700
+    q = rng.choice(len(d0), nq, replace=False)
+    q.sort()
+    cand_off, cand_idx = window_candidates(k0[q], k1, 15.0, rng)
+    q_blocks = (rng.random(nq) > 0.3).astype(np.uint8)       # some temporal points with 0 observations
+    t_blocked = (rng.random(len(d1)) < 0.05).astype(np.uint8)
+    m = orb.ORBmatcher(0.9, ori)
+    n_got, tm_got, tb_got = m.SearchByProjection_Last(d0[q], k0["angle"][q], q_blocks, cand_off, cand_idx, d1,
+                                                      k1["angle"], t_blocked, th)
+    n_want, tm_want, tb_want = ol.search_by_projection_last(d0[q], k0["angle"][q], q_blocks, cand_off, cand_idx, d1,
+                                                            k1["angle"], t_blocked, th, ori)
+    assert n_got == n_want and np.array_equal(tm_got, tm_want) and np.array_equal(tb_got, tb_want)
+    assert n_want > 100
+
+
+@pytest.mark.parametrize("seed,ratio", [(0, 0.8), (1, 0.6)])
+def test_search_by_projection_local(frames, seed, ratio):
+    (k0, d0), (k1, d1) = frames
+    rng = np.random.default_rng(10 + seed)
+    q = np.sort(rng.choice(len(d0), 800, replace=False))
+    cand_off, cand_idx = window_candidates(k0[q], k1, 12.0, rng)
+    q_blocks = (rng.random(len(q)) > 0.2).astype(np.uint8)
+    t_blocked = (rng.random(len(d1)) < 0.1).astype(np.uint8)
+    m = orb.ORBmatcher(ratio, True)
+    n_got, tm_got, tb_got = m.SearchByProjection_Local(d0[q], q_blocks, cand_off, cand_idx, d1, k1["octave"], t_blocked)
+    n_want, tm_want, tb_want = ol.search_by_projection_local(d0[q], q_blocks, cand_off, cand_idx, d1, k1["octave"],
+                                                             t_blocked, ratio)
+    assert n_got == n_want and np.array_equal(tm_got, tm_want) and np.array_equal(tb_got, tb_want)
+    assert n_want > 100
+
+
+@pytest.mark.parametrize("seed,ori", [(0, True), (1, False)])
+def test_search_for_initialization(frames, seed, ori):
+    (k0, d0), (k1, d1) = frames
+    rng = np.random.default_rng(20 + seed)
+    grid = ol.OracleGrid(k1, 0.0, 0.0, 640.0, 480.0)
+    off, idx = [0], []
+    for kp in k0:
+        if kp["octave"] == 0:
+            idx += grid.query(kp["x"] + 3.0, kp["y"] + 2.0, 30.0, 0, 0).tolist()  # windowSize, level1, level1
+        off.append(len(idx))
+    m = orb.ORBmatcher(0.9, ori)
+    n_got, got = m.SearchForInitialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"])
+    n_want, want = ol.search_for_initialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"], 0.9, ori)
+    assert n_got == n_want and np.array_equal(got, want)
+    assert n_want > 30
+
+
+def test_matchers_on_empty_inputs():
+    m = orb.ORBmatcher(0.7, True)
+    e32 = np.zeros((0, 32), np.uint8)
+    fv0 = (np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+    assert m.SearchByBoW_KF_F(e32, [], [], fv0, e32, [], fv0)[0] == 0
+    n, tm, tb = m.SearchByProjection_Last(e32, [], [], [0], [], np.zeros((5, 32), np.uint8), np.zeros(5), np.zeros(5))
+    assert n == 0 and tm.tolist() == [-1] * 5

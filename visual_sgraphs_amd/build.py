@@ -1,0 +1,44 @@
+"""In-tree build of the HIP C-ABI library (libvsg_orb.so) for gfx950.
+
+`python -m visual_sgraphs_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU.
+"""
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libvsg_orb.so"
+SOURCES = ["vsg_kernels.hip", "vsg_orb.hip", "vsg_match.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wno-unused-value"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (needed to build libvsg_orb.so; there is no CPU fallback)")
+
+
+def needs_build():
+    if not LIB.exists():
+        return True
+    deps = list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + \
+        [PKG.parent / "include" / "vsg_orb.h"]
+    return any(d.stat().st_mtime > LIB.stat().st_mtime for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc()] + FLAGS + ["-o", str(LIB)] + [str(CSRC / s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=str(CSRC))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,601 @@
+// vsg_match.hip -- Hamming searches of ORBmatcher (orb_slam3/src/ORBmatcher.cc) on flattened POD views.
+//
+// Integer XOR + popcount work (v_xor_b32 / v_bcnt_u32_b32), no MFMA.  Distances are evaluated lane-parallel;
+// every greedy "already matched" decision of the reference stays ordered:
+//   * SearchByBoW: vocabulary nodes are independent (an F feature belongs to one node), so one wavefront per
+//     shared node walks that node's KF features in order, lanes over the node's F features;
+//   * SearchByProjection / SearchForInitialization: one wavefront walks the queries in order, lanes over the
+//     query's candidate list; the mutable state lives in global memory behind a wave-level fence.
+// best / second-best follow the reference's strict '<' scan: packed keys (dist << 20 | scan position) make
+// "earliest candidate wins ties" a plain integer minimum.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vsg_orb.h"
+#include "vsg_math.h"
+
+namespace {
+
+const int TH_HIGH = 100;      // ORBmatcher.cc:34
+const int TH_LOW = 50;        // ORBmatcher.cc:35
+const int HISTO_LENGTH = 30;  // ORBmatcher.cc:36
+const uint32_t KEY_NONE = (256u << 20) | 0xFFFFFu;
+
+__device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+__device__ __forceinline__ void load_desc(const uint8_t *base, int row, uint4 &lo, uint4 &hi) {
+  const uint4 *p = (const uint4 *)(base + (size_t)row * 32);
+  lo = p[0];
+  hi = p[1];
+}
+
+// two smallest of {k1,k2} U {o1,o2}, each pair already ordered
+__device__ __forceinline__ void merge2(uint32_t &k1, uint32_t &k2, uint32_t o1, uint32_t o2) {
+  if (o1 < k1) {
+    k2 = min(k1, o2);
+    k1 = o1;
+  } else {
+    k2 = min(k2, o1);
+  }
+}
+__device__ __forceinline__ void wave_best2(uint32_t &k1, uint32_t &k2) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o1 = __shfl_xor(k1, d), o2 = __shfl_xor(k2, d);
+    merge2(k1, k2, o1, o2);
+  }
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t k) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) k = min(k, __shfl_xor(k, d));
+  return k;
+}
+
+// ---- DescriptorDistance over index pairs
+__global__ void k_hamming_pairs(const uint8_t *a, const uint8_t *b, const int *ia, const int *ib, int n, int *dist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint4 a0, a1, b0, b1;
+  load_desc(a, ia[i], a0, a1);
+  load_desc(b, ib[i], b0, b1);
+  dist[i] = hamming256(a0, a1, b0, b1);
+}
+
+// ---- brute-force best / second best: thread = one row of A, B streamed through LDS in 256-row tiles.
+// The sequential strict-'<' scan of the reference is reproduced literally per thread.
+__global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, const uint8_t *b_base, size_t block_stride,
+                                                     const int *counts_a, const int *counts_b, int count_stride,
+                                                     int fixed_na, int fixed_nb, int max_rows, int *best, int *second,
+                                                     int *argbest) {
+  __shared__ uint4 tile[256 * 2];
+  const int blk = blockIdx.y;
+  const int na = counts_a ? min(counts_a[blk * count_stride], max_rows) : fixed_na;
+  const int nb = counts_b ? min(counts_b[blk * count_stride], max_rows) : fixed_nb;
+  const uint8_t *A = a_base + (size_t)blk * block_stride, *B = b_base + (size_t)blk * block_stride;
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x * 256 >= na) return;
+  uint4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+  if (row < na) load_desc(A, row, a0, a1);
+  int bestDist1 = 256, bestIdx = -1, bestDist2 = 256;
+  for (int t0 = 0; t0 < nb; t0 += 256) {
+    const int nt = min(256, nb - t0);
+    __syncthreads();
+    if ((int)threadIdx.x < nt) {
+      uint4 lo, hi;
+      load_desc(B, t0 + threadIdx.x, lo, hi);
+      tile[threadIdx.x * 2] = lo;
+      tile[threadIdx.x * 2 + 1] = hi;
+    }
+    __syncthreads();
+    for (int j = 0; j < nt; j++) {
+      const int dist = hamming256(a0, a1, tile[2 * j], tile[2 * j + 1]);
+      if (dist < bestDist1) {
+        bestDist2 = bestDist1;
+        bestDist1 = dist;
+        bestIdx = t0 + j;
+      } else if (dist < bestDist2) {
+        bestDist2 = dist;
+      }
+    }
+  }
+  if (row < na) {
+    const size_t o = (size_t)blk * max_rows + row;
+    best[o] = bestDist1;
+    second[o] = bestDist2;
+    argbest[o] = bestIdx;
+  }
+}
+
+// ---- SearchByBoW: one wavefront per shared vocabulary node (node pairs merged on the host).
+// mode 0: KF -> Frame  (ORBmatcher.cc:254-392): skip F features already in match_f; accept bestDist1 <= TH_LOW
+// mode 1: KF -> KF     (ORBmatcher.cc:790-864): skip vbMatched2 / invalid; accept bestDist1 <  TH_LOW
+struct NodePair {
+  int a_begin, a_end, b_begin, b_end;
+};
+
+__global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, int npairs, const uint8_t *descA,
+                                                       const uint8_t *validA, const int *idxA, const uint8_t *descB,
+                                                       const uint8_t *validB, const int *idxB, float nnratio, int mode,
+                                                       int *matchA /*mode1: matches12*/, int *matchB /*mode0: match_f; mode1: matched2 flags*/) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= npairs) return;
+  const NodePair np = pairs[wave];
+  const int nb = np.b_end - np.b_begin;
+  for (int ia = np.a_begin; ia < np.a_end; ia++) {
+    const int ra = idxA[ia];
+    if (!validA[ra]) continue;  // !pMP || pMP->isBad()
+    uint4 a0, a1;
+    load_desc(descA, ra, a0, a1);
+    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+    for (int j = lane; j < nb; j += 64) {
+      const int rb = idxB[np.b_begin + j];
+      const bool skip = mode == 0 ? (matchB[rb] >= 0) : (matchB[rb] != 0 || !validB[rb]);
+      if (skip) continue;
+      uint4 b0, b1;
+      load_desc(descB, rb, b0, b1);
+      const uint32_t key = ((uint32_t)hamming256(a0, a1, b0, b1) << 20) | (uint32_t)j;
+      merge2(k1, k2, key, KEY_NONE);
+    }
+    wave_best2(k1, k2);
+    const int bestDist1 = (int)(k1 >> 20), bestDist2 = (int)(k2 >> 20);
+    const bool pass = mode == 0 ? bestDist1 <= TH_LOW : bestDist1 < TH_LOW;
+    if (pass && (float)bestDist1 < nnratio * (float)bestDist2) {  // :335-337 / :843-845
+      const int rb = idxB[np.b_begin + (int)(k1 & 0xFFFFF)];
+      if (lane == 0) {
+        if (mode == 0) {
+          matchB[rb] = ra;  // vpMapPointMatches[bestIdxF] = pMP
+        } else {
+          matchA[ra] = rb;  // vpMatches12[idx1] = vpMapPoints2[bestIdx2]
+          matchB[rb] = 1;   // vbMatched2[bestIdx2] = true
+        }
+      }
+      __threadfence_block();
+    }
+  }
+}
+
+// ---- windowed searches: one wavefront walks the queries in order (greedy state), lanes over candidates.
+// mode 0: SearchByProjection(Cur, Last)   (:1686-1784)  best only, accept <= thHigh, events for the rot. histogram
+// mode 1: SearchByProjection(F, MapPoints)(:48-144)     best+second with octave-aware ratio test
+__global__ __launch_bounds__(64) void k_search_window(const uint8_t *qDesc, const uint8_t *queryBlocks, int nQ,
+                                                      const int *candOff, const int *candIdx, const uint8_t *tDesc,
+                                                      const int *tOctave, uint8_t *trainBlocked, int thHigh,
+                                                      float nnratio, int mode, int *trainMatch, int *events,
+                                                      int *result /*[0]=nmatches [1]=nevents*/) {
+  const int lane = threadIdx.x;
+  int nmatches = 0, nev = 0;
+  for (int q = 0; q < nQ; q++) {
+    const int c0 = candOff[q], c1 = candOff[q + 1];
+    if (c0 == c1) continue;
+    uint4 a0, a1;
+    load_desc(qDesc, q, a0, a1);
+    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+    for (int c = c0 + lane; c < c1; c += 64) {
+      const int i2 = candIdx[c];
+      if (trainBlocked[i2]) continue;
+      uint4 b0, b1;
+      load_desc(tDesc, i2, b0, b1);
+      const uint32_t key = ((uint32_t)hamming256(a0, a1, b0, b1) << 20) | (uint32_t)(c - c0);
+      merge2(k1, k2, key, KEY_NONE);
+    }
+    wave_best2(k1, k2);
+    const int bestDist = (int)(k1 >> 20);
+    if (bestDist > thHigh || k1 == KEY_NONE) continue;
+    const int bestIdx = candIdx[c0 + (int)(k1 & 0xFFFFF)];
+    bool accept = true;
+    if (mode == 1) {
+      const int bestDist2 = (int)(k2 >> 20);
+      const int bestLevel = tOctave[bestIdx];
+      const int bestLevel2 = k2 == KEY_NONE ? -1 : tOctave[candIdx[c0 + (int)(k2 & 0xFFFFF)]];
+      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) accept = false;       // :125-126
+      else if (!(bestLevel != bestLevel2 || (float)bestDist <= nnratio * (float)bestDist2)) accept = false;  // :128
+    }
+    if (!accept) continue;
+    if (lane == 0) {
+      trainMatch[bestIdx] = q;
+      trainBlocked[bestIdx] = queryBlocks[q];
+      if (events) {
+        events[2 * nev] = q;
+        events[2 * nev + 1] = bestIdx;
+      }
+    }
+    nmatches++;
+    nev++;
+    __threadfence_block();
+  }
+  if (lane == 0) {
+    result[0] = nmatches;
+    result[1] = nev;
+  }
+}
+
+// ---- SearchForInitialization (:656-724): state = vMatchedDistance / vnMatches21 / vnMatches12
+__global__ __launch_bounds__(64) void k_search_init(const uint8_t *desc1, const int *octave1, int n1, const int *candOff,
+                                                    const int *candIdx, const uint8_t *desc2, float nnratio,
+                                                    int *matchedDistance, int *matches21, int *matches12, int *partner,
+                                                    int *result) {
+  const int lane = threadIdx.x;
+  int nmatches = 0;
+  for (int i1 = 0; i1 < n1; i1++) {
+    if (octave1[i1] > 0) continue;
+    const int c0 = candOff[i1], c1 = candOff[i1 + 1];
+    if (c0 == c1) continue;
+    uint4 a0, a1;
+    load_desc(desc1, i1, a0, a1);
+    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+    for (int c = c0 + lane; c < c1; c += 64) {
+      const int i2 = candIdx[c];
+      uint4 b0, b1;
+      load_desc(desc2, i2, b0, b1);
+      const int dist = hamming256(a0, a1, b0, b1);
+      if (matchedDistance[i2] <= dist) continue;  // :682
+      merge2(k1, k2, ((uint32_t)dist << 20) | (uint32_t)(c - c0), KEY_NONE);
+    }
+    wave_best2(k1, k2);
+    if (k1 == KEY_NONE) continue;  // bestDist stays INT_MAX
+    const int bestDist = (int)(k1 >> 20);
+    // bestDist2 stays INT_MAX when there is no second candidate: (float)INT_MAX * ratio is still > bestDist
+    const float second = k2 == KEY_NONE ? (float)2147483647 : (float)(int)(k2 >> 20);
+    if (bestDist <= TH_LOW && (float)bestDist < second * nnratio) {  // :697-699
+      const int bestIdx2 = candIdx[c0 + (int)(k1 & 0xFFFFF)];
+      const int prev = matches21[bestIdx2];
+      if (prev >= 0) nmatches--;
+      if (lane == 0) {
+        if (prev >= 0) matches12[prev] = -1;
+        matches12[i1] = bestIdx2;
+        matches21[bestIdx2] = i1;
+        matchedDistance[bestIdx2] = bestDist;
+        partner[i1] = bestIdx2;
+      }
+      nmatches++;
+      __threadfence_block();
+    }
+  }
+  if (lane == 0) result[0] = nmatches;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+thread_local std::string g_merr;
+
+struct DevBuf {  // tiny RAII wrapper: device allocation + optional upload
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
+  hipError_t upload(const void *src, size_t bytes) {
+    hipError_t e = alloc(bytes);
+    if (e != hipSuccess || !bytes) return e;
+    return hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+  }
+  template <class T>
+  T *as() {
+    return (T *)p;
+  }
+};
+
+#define M_TRY(expr)                      \
+  do {                                   \
+    hipError_t _e = (expr);              \
+    if (_e != hipSuccess) return VSG_ERR_HIP; \
+  } while (0)
+
+int use_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return VSG_ERR_NO_DEVICE;
+  return hipSetDevice(device) == hipSuccess ? VSG_OK : VSG_ERR_NO_DEVICE;
+}
+
+// rotation-consistency bin (e.g. ORBmatcher.cc:351-356)
+inline int rot_bin(float angle1, float angle2) {
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = angle1 - angle2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)std::round(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+// ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2002-2043)
+void three_maxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) {
+      max3 = max2, max2 = max1, max1 = s;
+      ind3 = ind2, ind2 = ind1, ind1 = i;
+    } else if (s > max2) {
+      max3 = max2, max2 = s;
+      ind3 = ind2, ind2 = i;
+    } else if (s > max3) {
+      max3 = s, ind3 = i;
+    }
+  }
+  if (max2 < 0.1f * (float)max1) {
+    ind2 = -1;
+    ind3 = -1;
+  } else if (max3 < 0.1f * (float)max1) {
+    ind3 = -1;
+  }
+}
+
+// merge-join of two FeatureVectors (ORBmatcher.cc:247-405 loop skeleton incl. lower_bound jumps)
+void join_nodes(const int *idA, const int *offA, int nA, const int *idB, const int *offB, int nB,
+                std::vector<NodePair> &out) {
+  int i = 0, j = 0;
+  while (i != nA && j != nB) {
+    if (idA[i] == idB[j]) {
+      out.push_back({offA[i], offA[i + 1], offB[j], offB[j + 1]});
+      i++, j++;
+    } else if (idA[i] < idB[j]) {
+      i = (int)(std::lower_bound(idA, idA + nA, idB[j]) - idA);
+    } else {
+      j = (int)(std::lower_bound(idB, idB + nB, idA[i]) - idB);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vsg_hamming_pairs(int device, const uint8_t *a, int na, const uint8_t *b, int nb, const int32_t *ia,
+                      const int32_t *ib, int npairs, int32_t *dist) {
+  if (!a || !b || !ia || !ib || !dist || npairs < 0) return VSG_ERR_INVALID;
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  if (npairs == 0) return VSG_OK;
+  DevBuf da, db, dia, dib, dd;
+  M_TRY(da.upload(a, (size_t)na * 32));
+  M_TRY(db.upload(b, (size_t)nb * 32));
+  M_TRY(dia.upload(ia, (size_t)npairs * 4));
+  M_TRY(dib.upload(ib, (size_t)npairs * 4));
+  M_TRY(dd.alloc((size_t)npairs * 4));
+  hipLaunchKernelGGL(k_hamming_pairs, dim3((npairs + 255) / 256), dim3(256), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(),
+                     dia.as<int>(), dib.as<int>(), npairs, dd.as<int>());
+  M_TRY(hipMemcpy(dist, dd.p, (size_t)npairs * 4, hipMemcpyDeviceToHost));
+  return VSG_OK;
+}
+
+int vsg_hamming_block_best2_device(int device, const uint8_t *d_a, const uint8_t *d_b, size_t block_stride_bytes,
+                                   const int32_t *d_counts_a, const int32_t *d_counts_b, int count_stride,
+                                   int nblocks, int max_rows, int32_t *d_best, int32_t *d_second,
+                                   int32_t *d_argbest, void *stream) {
+  if (!d_a || !d_b || !d_best || !d_second || !d_argbest || nblocks < 1 || max_rows < 1) return VSG_ERR_INVALID;
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  dim3 grid((max_rows + 255) / 256, nblocks);
+  hipLaunchKernelGGL(k_block_best2, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes, d_counts_a,
+                     d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
+  M_TRY(hipGetLastError());
+  return VSG_OK;
+}
+
+int vsg_hamming_block_best2(int device, const uint8_t *a, int na, const uint8_t *b, int nb, int32_t *best,
+                            int32_t *second, int32_t *argbest) {
+  if (!a || !b || !best || !second || !argbest || na < 0 || nb < 0) return VSG_ERR_INVALID;
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  if (na == 0) return VSG_OK;
+  DevBuf da, db, d1, d2, d3;
+  M_TRY(da.upload(a, (size_t)na * 32));
+  M_TRY(db.upload(b, (size_t)nb * 32));
+  M_TRY(d1.alloc((size_t)na * 4));
+  M_TRY(d2.alloc((size_t)na * 4));
+  M_TRY(d3.alloc((size_t)na * 4));
+  hipLaunchKernelGGL(k_block_best2, dim3((na + 255) / 256, 1), dim3(256), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(),
+                     (size_t)0, (const int *)nullptr, (const int *)nullptr, 0, na, nb, na, d1.as<int>(), d2.as<int>(),
+                     d3.as<int>());
+  M_TRY(hipMemcpy(best, d1.p, (size_t)na * 4, hipMemcpyDeviceToHost));
+  M_TRY(hipMemcpy(second, d2.p, (size_t)na * 4, hipMemcpyDeviceToHost));
+  M_TRY(hipMemcpy(argbest, d3.p, (size_t)na * 4, hipMemcpyDeviceToHost));
+  return VSG_OK;
+}
+
+static int search_by_bow(int device, int mode, const uint8_t *descA, const float *angleA, const uint8_t *validA, int nA,
+                         const int *idA, const int *offA, const int *idxA, int nodesA, const uint8_t *descB,
+                         const float *angleB, const uint8_t *validB, int nB, const int *idB, const int *offB,
+                         const int *idxB, int nodesB, float nnratio, int checkOri, int *out) {
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  const int nOut = mode == 0 ? nB : nA;
+  for (int i = 0; i < nOut; i++) out[i] = -1;
+  std::vector<NodePair> pairs;
+  join_nodes(idA, offA, nodesA, idB, offB, nodesB, pairs);
+  if (pairs.empty() || nA == 0 || nB == 0) return 0;
+  const int nIdxA = offA[nodesA], nIdxB = offB[nodesB];
+  DevBuf dPairs, dDescA, dValidA, dIdxA, dDescB, dValidB, dIdxB, dMatchA, dMatchB;
+  M_TRY(dPairs.upload(pairs.data(), pairs.size() * sizeof(NodePair)));
+  M_TRY(dDescA.upload(descA, (size_t)nA * 32));
+  M_TRY(dValidA.upload(validA, (size_t)nA));
+  M_TRY(dIdxA.upload(idxA, (size_t)nIdxA * 4));
+  M_TRY(dDescB.upload(descB, (size_t)nB * 32));
+  M_TRY(dIdxB.upload(idxB, (size_t)nIdxB * 4));
+  if (mode == 0) {
+    M_TRY(dMatchB.alloc((size_t)nB * 4));
+    M_TRY(hipMemset(dMatchB.p, 0xFF, (size_t)nB * 4));  // -1
+    M_TRY(dValidB.alloc(4));
+    M_TRY(dMatchA.alloc(4));
+  } else {
+    M_TRY(dValidB.upload(validB, (size_t)nB));
+    M_TRY(dMatchA.alloc((size_t)nA * 4));
+    M_TRY(hipMemset(dMatchA.p, 0xFF, (size_t)nA * 4));
+    M_TRY(dMatchB.alloc((size_t)nB * 4));
+    M_TRY(hipMemset(dMatchB.p, 0, (size_t)nB * 4));
+  }
+  const int npairs = (int)pairs.size();
+  hipLaunchKernelGGL(k_search_by_bow, dim3((npairs + 3) / 4), dim3(256), 0, 0, dPairs.as<NodePair>(), npairs,
+                     dDescA.as<uint8_t>(), dValidA.as<uint8_t>(), dIdxA.as<int>(), dDescB.as<uint8_t>(),
+                     dValidB.as<uint8_t>(), dIdxB.as<int>(), nnratio, mode, dMatchA.as<int>(), dMatchB.as<int>());
+  M_TRY(hipMemcpy(out, mode == 0 ? dMatchB.p : dMatchA.p, (size_t)nOut * 4, hipMemcpyDeviceToHost));
+  // rotation consistency (:407-425 / :879-897): every match sits in exactly one bin
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < nOut; i++) {
+    if (out[i] < 0) continue;
+    nmatches++;
+    if (checkOri) {
+      const int bin = mode == 0 ? rot_bin(angleA[out[i]], angleB[i]) : rot_bin(angleA[i], angleB[out[i]]);
+      rotHist[bin].push_back(i);
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) {
+        out[rotHist[i][j]] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
+int vsg_search_by_bow_kf_f(int device, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid,
+                           int n_kf, const int32_t *kf_node_id, const int32_t *kf_off, const int32_t *kf_idx,
+                           int kf_nodes, const uint8_t *f_desc, const float *f_angle, int n_f,
+                           const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
+                           float nnratio, int check_orientation, int32_t *match_f) {
+  if (!match_f || n_kf < 0 || n_f < 0) return VSG_ERR_INVALID;
+  return search_by_bow(device, 0, kf_desc, kf_angle, kf_valid, n_kf, kf_node_id, kf_off, kf_idx, kf_nodes, f_desc,
+                       f_angle, nullptr, n_f, f_node_id, f_off, f_idx, f_nodes, nnratio, check_orientation, match_f);
+}
+
+int vsg_search_by_bow_kf_kf(int device, const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
+                            const int32_t *node_id1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                            const uint8_t *desc2, const float *angle2, const uint8_t *valid2, int n2,
+                            const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                            float nnratio, int check_orientation, int32_t *matches12) {
+  if (!matches12 || n1 < 0 || n2 < 0) return VSG_ERR_INVALID;
+  return search_by_bow(device, 1, desc1, angle1, valid1, n1, node_id1, off1, idx1, nodes1, desc2, angle2, valid2, n2,
+                       node_id2, off2, idx2, nodes2, nnratio, check_orientation, matches12);
+}
+
+static int search_window(int device, int mode, const uint8_t *q_desc, const float *q_angle,
+                         const uint8_t *query_blocks, int n_q, const int32_t *cand_off, const int32_t *cand_idx,
+                         const uint8_t *t_desc, const float *t_angle, const int32_t *t_octave, uint8_t *train_blocked,
+                         int n_t, int th_high, float nnratio, int check_orientation, int32_t *train_match) {
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  if (n_q == 0 || n_t == 0) return 0;
+  const int ncand = cand_off[n_q];
+  DevBuf dQ, dQB, dOff, dIdx, dT, dOct, dBlocked, dMatch, dEvents, dResult;
+  M_TRY(dQ.upload(q_desc, (size_t)n_q * 32));
+  M_TRY(dQB.upload(query_blocks, (size_t)n_q));
+  M_TRY(dOff.upload(cand_off, (size_t)(n_q + 1) * 4));
+  M_TRY(dIdx.upload(cand_idx, (size_t)ncand * 4));
+  M_TRY(dT.upload(t_desc, (size_t)n_t * 32));
+  if (t_octave) M_TRY(dOct.upload(t_octave, (size_t)n_t * 4));
+  M_TRY(dBlocked.upload(train_blocked, (size_t)n_t));
+  M_TRY(dMatch.upload(train_match, (size_t)n_t * 4));
+  M_TRY(dEvents.alloc((size_t)n_q * 8));
+  M_TRY(dResult.alloc(8));
+  hipLaunchKernelGGL(k_search_window, dim3(1), dim3(64), 0, 0, dQ.as<uint8_t>(), dQB.as<uint8_t>(), n_q, dOff.as<int>(),
+                     dIdx.as<int>(), dT.as<uint8_t>(), dOct.as<int>(), dBlocked.as<uint8_t>(), th_high, nnratio, mode,
+                     dMatch.as<int>(), mode == 0 ? dEvents.as<int>() : (int *)nullptr, dResult.as<int>());
+  int result[2] = {0, 0};
+  M_TRY(hipMemcpy(result, dResult.p, 8, hipMemcpyDeviceToHost));
+  M_TRY(hipMemcpy(train_match, dMatch.p, (size_t)n_t * 4, hipMemcpyDeviceToHost));
+  M_TRY(hipMemcpy(train_blocked, dBlocked.p, (size_t)n_t, hipMemcpyDeviceToHost));
+  int nmatches = result[0];
+  if (mode == 0 && check_orientation) {  // :1855-1875
+    std::vector<int> ev((size_t)result[1] * 2);
+    if (result[1] > 0) M_TRY(hipMemcpy(ev.data(), dEvents.p, ev.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for (int e = 0; e < result[1]; e++) rotHist[rot_bin(q_angle[ev[2 * e]], t_angle[ev[2 * e + 1]])].push_back(ev[2 * e + 1]);
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (size_t j = 0; j < rotHist[i].size(); j++) {
+          train_match[rotHist[i][j]] = -1;
+          nmatches--;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
+int vsg_search_by_projection_last(int device, const uint8_t *q_desc, const float *q_angle,
+                                  const uint8_t *query_blocks, int n_q, const int32_t *cand_off,
+                                  const int32_t *cand_idx, const uint8_t *t_desc, const float *t_angle,
+                                  uint8_t *train_blocked, int n_t, int th_high, int check_orientation,
+                                  int32_t *train_match) {
+  if (!cand_off || !train_blocked || !train_match || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
+  return search_window(device, 0, q_desc, q_angle, query_blocks, n_q, cand_off, cand_idx, t_desc, t_angle, nullptr,
+                       train_blocked, n_t, th_high, 0.f, check_orientation, train_match);
+}
+
+int vsg_search_by_projection_local(int device, const uint8_t *q_desc, const uint8_t *query_blocks, int n_q,
+                                   const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *t_desc,
+                                   const int32_t *t_octave, uint8_t *train_blocked, int n_t, float nnratio,
+                                   int32_t *train_match) {
+  if (!cand_off || !train_blocked || !train_match || !t_octave || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
+  return search_window(device, 1, q_desc, nullptr, query_blocks, n_q, cand_off, cand_idx, t_desc, nullptr, t_octave,
+                       train_blocked, n_t, TH_HIGH, nnratio, 0, train_match);
+}
+
+int vsg_search_for_initialization(int device, const uint8_t *desc1, const float *angle1, const int32_t *octave1,
+                                  int n1, const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *desc2,
+                                  const float *angle2, int n2, float nnratio, int check_orientation,
+                                  int32_t *matches12) {
+  if (!cand_off || !matches12 || n1 < 0 || n2 < 0) return VSG_ERR_INVALID;
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n1 == 0 || n2 == 0) return 0;
+  const int ncand = cand_off[n1];
+  DevBuf d1, dOct, dOff, dIdx, d2, dDist, d21, d12, dPartner, dResult;
+  M_TRY(d1.upload(desc1, (size_t)n1 * 32));
+  M_TRY(dOct.upload(octave1, (size_t)n1 * 4));
+  M_TRY(dOff.upload(cand_off, (size_t)(n1 + 1) * 4));
+  M_TRY(dIdx.upload(cand_idx, (size_t)ncand * 4));
+  M_TRY(d2.upload(desc2, (size_t)n2 * 32));
+  std::vector<int> init((size_t)n2, 0x7FFFFFFF);
+  M_TRY(dDist.upload(init.data(), (size_t)n2 * 4));  // vMatchedDistance = INT_MAX (:653)
+  M_TRY(d21.alloc((size_t)n2 * 4));
+  M_TRY(hipMemset(d21.p, 0xFF, (size_t)n2 * 4));
+  M_TRY(d12.alloc((size_t)n1 * 4));
+  M_TRY(hipMemset(d12.p, 0xFF, (size_t)n1 * 4));
+  M_TRY(dPartner.alloc((size_t)n1 * 4));
+  M_TRY(hipMemset(dPartner.p, 0xFF, (size_t)n1 * 4));
+  M_TRY(dResult.alloc(8));
+  hipLaunchKernelGGL(k_search_init, dim3(1), dim3(64), 0, 0, d1.as<uint8_t>(), dOct.as<int>(), n1, dOff.as<int>(),
+                     dIdx.as<int>(), d2.as<uint8_t>(), nnratio, dDist.as<int>(), d21.as<int>(), d12.as<int>(),
+                     dPartner.as<int>(), dResult.as<int>());
+  int nmatches = 0;
+  M_TRY(hipMemcpy(&nmatches, dResult.p, 4, hipMemcpyDeviceToHost));
+  M_TRY(hipMemcpy(matches12, d12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  if (check_orientation) {  // :726-748
+    std::vector<int> partner((size_t)n1);
+    M_TRY(hipMemcpy(partner.data(), dPartner.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for (int i1 = 0; i1 < n1; i1++)
+      if (partner[i1] >= 0) rotHist[rot_bin(angle1[i1], angle2[partner[i1]])].push_back(i1);
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) {
+        const int idx1 = rotHist[i][j];
+        if (matches12[idx1] >= 0) {
+          matches12[idx1] = -1;
+          nmatches--;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
+}  // extern "C"

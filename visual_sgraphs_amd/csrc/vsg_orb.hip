@@ -1,0 +1,442 @@
+// vsg_orb.hip -- host runtime + C ABI of the extractor (include/vsg_orb.h).
+//
+// A handle owns: the constructor tables, the geometry of the current image size, device buffers
+// for `max_batch` frames (pyramid, blurred pyramid, candidates, selection, outputs), pinned host
+// staging, two HIP streams (main chain + blur) and events.  One call enqueues
+//   [H2D] -> resize x (L-1) -> { blur  ||  FAST -> octree -> slots } -> orient+desc -> [D2H]
+// with the blur on its own stream so it overlaps the FAST/octree chain (both only read the pyramid).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vsg_orb.h"
+#include "vsg_common.h"
+#include "vsg_geometry.h"
+#include "vsg_kernels.h"
+
+using namespace vsg;
+
+static thread_local std::string g_err;
+static void set_err(const std::string &s) { g_err = s; }
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      set_err(std::string(#expr) + ": " + hipGetErrorString(_e));                                  \
+      return VSG_ERR_HIP;                                                                          \
+    }                                                                                              \
+  } while (0)
+
+static const int8_t kPattern[1024] = {
+#include "brief_pattern_data.inc"
+};
+
+static_assert(sizeof(KeyPointPOD) == 28 && sizeof(vsg_keypoint) == 28, "cv::KeyPoint layout");
+
+enum { kStages = 7, kEv = 10 };
+
+struct vsg_orb {
+  ExtractorTables T;
+  Geometry G;
+  int device = 0, max_batch = 1;
+  int rows = 0, cols = 0;  // geometry currently built for
+  uint16_t taps[7] = {18, 34, 49, 55, 49, 34, 18};
+  int last_frames = 0;
+  // device
+  FrameGeom *d_fg = nullptr;
+  Short4 *d_tab = nullptr;
+  CellDesc *d_cells = nullptr;
+  BlurTile *d_tiles = nullptr;
+  int8_t *d_pattern = nullptr;
+  uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+  uint32_t *d_cand = nullptr, *d_sel = nullptr;
+  uint16_t *d_nodeof = nullptr;
+  int *d_counts2 = nullptr;  // [2][B][kMaxLevels]: cand_count then sel_count
+  int *d_flags = nullptr, *d_slots = nullptr;
+  FrameHeader *d_hdr = nullptr;
+  KeyPointPOD *d_kps = nullptr;
+  uint8_t *d_desc = nullptr;
+  int *d_out_counts = nullptr;
+  // pinned host staging
+  uint8_t *h_in = nullptr;
+  KeyPointPOD *h_kps = nullptr;
+  uint8_t *h_desc = nullptr;
+  int *h_out_counts = nullptr;
+  hipStream_t s_main = nullptr, s_blur = nullptr;
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+  // timing
+  bool timing = false;
+  hipEvent_t ev[kEv] = {};
+  double acc_ms[kStages] = {};
+  int acc_n = 0;
+  bool ev_pending = false;
+};
+
+static void free_image_buffers(vsg_orb *h) {
+  hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_tiles);
+  hipFree(h->d_pyr), hipFree(h->d_blur), hipFree(h->d_cand), hipFree(h->d_sel), hipFree(h->d_nodeof);
+  hipFree(h->d_counts2), hipFree(h->d_flags), hipFree(h->d_slots), hipFree(h->d_hdr);
+  hipFree(h->d_kps), hipFree(h->d_desc), hipFree(h->d_out_counts);
+  hipHostFree(h->h_in), hipHostFree(h->h_kps), hipHostFree(h->h_desc), hipHostFree(h->h_out_counts);
+  h->d_fg = nullptr, h->d_tab = nullptr, h->d_cells = nullptr, h->d_tiles = nullptr;
+  h->d_pyr = h->d_blur = nullptr;
+  h->d_cand = h->d_sel = nullptr;
+  h->d_nodeof = nullptr;
+  h->d_counts2 = h->d_flags = h->d_slots = nullptr;
+  h->d_hdr = nullptr;
+  h->d_kps = nullptr, h->d_desc = nullptr, h->d_out_counts = nullptr;
+  h->h_in = nullptr, h->h_kps = nullptr, h->h_desc = nullptr, h->h_out_counts = nullptr;
+  h->rows = h->cols = 0;
+}
+
+// (re)build geometry + buffers for an image size
+static int ensure_geometry(vsg_orb *h, int rows, int cols) {
+  if (h->rows == rows && h->cols == cols) return VSG_OK;
+  Geometry G;
+  int rc = build_geometry(G, h->T, rows, cols, 0, 0, h->taps);
+  if (rc != 0) {
+    set_err("image size / parameters not processable (see vsg_geometry.h build_geometry)");
+    return VSG_ERR_UNSUPPORTED;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->s_main));
+  HIP_TRY(hipStreamSynchronize(h->s_blur));
+  free_image_buffers(h);
+  h->G = G;
+  const FrameGeom &fg = h->G.fg;
+  const size_t B = (size_t)h->max_batch;
+  HIP_TRY(hipMalloc(&h->d_fg, sizeof(FrameGeom)));
+  HIP_TRY(hipMalloc(&h->d_tab, sizeof(Short4) * (h->G.resizeTab.size() + 1)));
+  HIP_TRY(hipMalloc(&h->d_cells, sizeof(CellDesc) * h->G.cells.size()));
+  HIP_TRY(hipMalloc(&h->d_tiles, sizeof(BlurTile) * h->G.blurTiles.size()));
+  HIP_TRY(hipMemcpy(h->d_fg, &fg, sizeof(FrameGeom), hipMemcpyHostToDevice));
+  if (!h->G.resizeTab.empty())
+    HIP_TRY(hipMemcpy(h->d_tab, h->G.resizeTab.data(), sizeof(Short4) * h->G.resizeTab.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_cells, h->G.cells.data(), sizeof(CellDesc) * h->G.cells.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_tiles, h->G.blurTiles.data(), sizeof(BlurTile) * h->G.blurTiles.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&h->d_pyr, B * fg.pyr_frame_bytes));
+  HIP_TRY(hipMalloc(&h->d_blur, B * fg.pyr_frame_bytes));
+  HIP_TRY(hipMemset(h->d_pyr, 0, B * fg.pyr_frame_bytes));
+  HIP_TRY(hipMemset(h->d_blur, 0, B * fg.pyr_frame_bytes));
+  HIP_TRY(hipMalloc(&h->d_cand, B * fg.cand_frame * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&h->d_nodeof, B * fg.cand_frame * sizeof(uint16_t)));
+  HIP_TRY(hipMalloc(&h->d_sel, B * fg.sel_frame * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&h->d_counts2, 2 * B * kMaxLevels * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_flags, B * fg.out_cap * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_slots, B * fg.out_cap * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_hdr, B * sizeof(FrameHeader)));
+  HIP_TRY(hipMalloc(&h->d_kps, B * fg.out_cap * sizeof(KeyPointPOD)));
+  HIP_TRY(hipMalloc(&h->d_desc, B * fg.out_cap * 32));
+  HIP_TRY(hipMalloc(&h->d_out_counts, B * 2 * sizeof(int)));
+  HIP_TRY(hipHostMalloc(&h->h_in, B * (size_t)rows * cols));
+  HIP_TRY(hipHostMalloc(&h->h_kps, B * fg.out_cap * sizeof(KeyPointPOD)));
+  HIP_TRY(hipHostMalloc(&h->h_desc, B * fg.out_cap * 32));
+  HIP_TRY(hipHostMalloc(&h->h_out_counts, B * 2 * sizeof(int)));
+  h->rows = rows;
+  h->cols = cols;
+  return VSG_OK;
+}
+
+static void harvest_timing(vsg_orb *h) {
+  if (!h->ev_pending) return;
+  h->ev_pending = false;
+  if (hipEventSynchronize(h->ev[5]) != hipSuccess || hipEventSynchronize(h->ev[7]) != hipSuccess) return;
+  float ms;
+  // main chain: 0 start, 1 pyramid, 2 fast, 3 octree, 4 slots, 5 orient_desc ; blur: 6,7
+  const int pairs[kStages][2] = {{0, 1}, {1, 2}, {2, 3}, {6, 7}, {3, 4}, {4, 5}, {0, 5}};
+  for (int i = 0; i < kStages; i++)
+    if (hipEventElapsedTime(&ms, h->ev[pairs[i][0]], h->ev[pairs[i][1]]) == hipSuccess) h->acc_ms[i] += ms;
+  h->acc_n++;
+}
+
+// Enqueue the whole pipeline for `nframes` frames whose level-0 images already sit in d_pyr.
+static int enqueue_pipeline(vsg_orb *h, int nframes, int lap0, int lap1, KeyPointPOD *d_kps, uint8_t *d_desc,
+                            int *d_counts, int capacity, hipStream_t s) {
+  const FrameGeom &fg = h->G.fg;
+  const bool tm = h->timing;
+  if (tm) harvest_timing(h);
+  int *cand_count = h->d_counts2, *sel_count = h->d_counts2 + (size_t)h->max_batch * kMaxLevels;
+  HIP_TRY(hipMemsetAsync(h->d_counts2, 0, 2 * (size_t)h->max_batch * kMaxLevels * sizeof(int), s));
+  if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
+  for (int l = 1; l < fg.nlevels; l++) launch_resize(s, h->d_pyr, h->d_fg, h->d_tab, fg, l, nframes);
+  HIP_TRY(hipEventRecord(h->ev_pyr, s));
+  if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
+  // blur branch
+  HIP_TRY(hipStreamWaitEvent(h->s_blur, h->ev_pyr, 0));
+  if (tm) HIP_TRY(hipEventRecord(h->ev[6], h->s_blur));
+  launch_blur(h->s_blur, h->d_pyr, h->d_blur, h->d_fg, h->d_tiles, fg, nframes);
+  if (tm) HIP_TRY(hipEventRecord(h->ev[7], h->s_blur));
+  HIP_TRY(hipEventRecord(h->ev_blur, h->s_blur));
+  // detection chain
+  launch_fast(s, h->d_pyr, h->d_fg, h->d_cells, h->d_cand, cand_count, fg, nframes);
+  if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
+  launch_octree(s, h->d_fg, h->d_cand, cand_count, h->d_nodeof, h->d_sel, sel_count, fg, h->G.maxQuota, nframes);
+  if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
+  launch_slots(s, h->d_fg, h->d_sel, sel_count, h->d_flags, h->d_slots, h->d_hdr, lap0, lap1, nframes);
+  if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
+  HIP_TRY(hipStreamWaitEvent(s, h->ev_blur, 0));
+  launch_orient_desc(s, h->d_pyr, h->d_blur, h->d_fg, h->d_sel, h->d_slots, h->d_hdr, h->d_pattern, d_kps, d_desc,
+                     d_counts, capacity, fg, nframes);
+  if (tm) {
+    HIP_TRY(hipEventRecord(h->ev[5], s));
+    h->ev_pending = true;
+  }
+  HIP_TRY(hipGetLastError());
+  h->last_frames = nframes;
+  return VSG_OK;
+}
+
+extern "C" {
+
+const char *vsg_last_error(void) { return g_err.c_str(); }
+
+int vsg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_err("no HIP device");
+    return VSG_ERR_NO_DEVICE;
+  }
+  return n;
+}
+
+int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device,
+                   int max_batch, vsg_orb **out) {
+  if (!out || max_batch < 1) return VSG_ERR_INVALID;
+  *out = nullptr;
+  vsg_orb *h = new vsg_orb();
+  if (!build_tables(h->T, nfeatures, scale_factor, nlevels, ini_th_fast, min_th_fast)) {
+    delete h;
+    set_err("invalid extractor parameters");
+    return VSG_ERR_INVALID;
+  }
+  h->device = device;
+  h->max_batch = max_batch;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    delete h;
+    set_err("no usable HIP device (the extractor has no CPU fallback)");
+    return VSG_ERR_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->s_blur, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
+      hipMalloc(&h->d_pattern, 1024) != hipSuccess ||
+      hipMemcpy(h->d_pattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess) {
+    set_err("HIP initialisation failed");
+    vsg_orb_destroy(h);
+    return VSG_ERR_NO_DEVICE;
+  }
+  for (int i = 0; i < kEv; i++) hipEventCreate(&h->ev[i]);
+  *out = h;
+  return VSG_OK;
+}
+
+void vsg_orb_destroy(vsg_orb *h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  if (h->s_main) hipStreamSynchronize(h->s_main);
+  if (h->s_blur) hipStreamSynchronize(h->s_blur);
+  free_image_buffers(h);
+  hipFree(h->d_pattern);
+  for (int i = 0; i < kEv; i++)
+    if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  if (h->ev_pyr) hipEventDestroy(h->ev_pyr);
+  if (h->ev_blur) hipEventDestroy(h->ev_blur);
+  if (h->s_main) hipStreamDestroy(h->s_main);
+  if (h->s_blur) hipStreamDestroy(h->s_blur);
+  delete h;
+}
+
+int vsg_orb_get_tables(const vsg_orb *h, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                       int *features_per_level, int *umax16) {
+  if (!h) return VSG_ERR_INVALID;
+  for (int i = 0; i < h->T.nlevels; i++) {
+    if (scale) scale[i] = h->T.scale[i];
+    if (inv_scale) inv_scale[i] = h->T.invScale[i];
+    if (sigma2) sigma2[i] = h->T.sigma2[i];
+    if (inv_sigma2) inv_sigma2[i] = h->T.invSigma2[i];
+    if (features_per_level) features_per_level[i] = h->T.quota[i];
+  }
+  if (umax16)
+    for (int i = 0; i < 16; i++) umax16[i] = h->T.umax[i];
+  return h->T.nlevels;
+}
+
+int vsg_orb_set_blur_taps(vsg_orb *h, const uint16_t taps[7]) {
+  if (!h || !taps) return VSG_ERR_INVALID;
+  memcpy(h->taps, taps, sizeof(h->taps));
+  if (h->rows) {  // refresh the device copy of the geometry
+    for (int k = 0; k < 7; k++) h->G.fg.taps[k] = taps[k];
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->s_main));
+    HIP_TRY(hipMemcpy(h->d_fg, &h->G.fg, sizeof(FrameGeom), hipMemcpyHostToDevice));
+  }
+  return VSG_OK;
+}
+
+int vsg_orb_capacity(vsg_orb *h, int rows, int cols) {
+  if (!h) return VSG_ERR_INVALID;
+  if (rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
+  int rc = ensure_geometry(h, rows, cols);
+  if (rc != VSG_OK) return rc;
+  return h->G.fg.out_cap;
+}
+
+int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes, size_t frame_stride, int rows,
+                                 int cols, int stride, int lap0, int lap1, vsg_keypoint *d_kps, uint8_t *d_desc,
+                                 int *d_counts, int capacity, void *stream) {
+  if (!h || !d_kps || !d_desc || !d_counts || nframes < 1 || nframes > h->max_batch) return VSG_ERR_INVALID;
+  if (!d_gray || rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_geometry(h, rows, cols);
+  if (rc != VSG_OK) return rc;
+  const FrameGeom &fg = h->G.fg;
+  if (capacity < fg.out_cap) {
+    set_err("capacity below vsg_orb_capacity()");
+    return VSG_ERR_CAPACITY;
+  }
+  hipStream_t s = stream ? (hipStream_t)stream : h->s_main;
+  // level 0 <- caller's images (2D copy into the pitched pyramid block of every frame)
+  for (int f = 0; f < nframes; f++)
+    HIP_TRY(hipMemcpy2DAsync(h->d_pyr + (size_t)f * fg.pyr_frame_bytes + fg.lv[0].img_off, fg.lv[0].pitch,
+                             d_gray + (size_t)f * frame_stride, stride, cols, rows, hipMemcpyDeviceToDevice, s));
+  return enqueue_pipeline(h, nframes, lap0, lap1, (KeyPointPOD *)d_kps, d_desc, d_counts, capacity, s);
+}
+
+int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t frame_stride, int rows, int cols,
+                          int stride, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc, int capacity, int *n,
+                          int *mono_index) {
+  if (!h || nframes < 1 || nframes > h->max_batch || !n || !mono_index) return VSG_ERR_INVALID;
+  if (!gray || rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_geometry(h, rows, cols);
+  if (rc != VSG_OK) return rc;
+  const FrameGeom &fg = h->G.fg;
+  hipStream_t s = h->s_main;
+  for (int f = 0; f < nframes; f++) {
+    uint8_t *dst = h->h_in + (size_t)f * rows * cols;
+    const uint8_t *src = gray + (size_t)f * frame_stride;
+    for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * cols, src + (size_t)y * stride, (size_t)cols);
+    HIP_TRY(hipMemcpy2DAsync(h->d_pyr + (size_t)f * fg.pyr_frame_bytes + fg.lv[0].img_off, fg.lv[0].pitch, dst, cols,
+                             cols, rows, hipMemcpyHostToDevice, s));
+  }
+  rc = enqueue_pipeline(h, nframes, lap0, lap1, h->d_kps, h->d_desc, h->d_out_counts, fg.out_cap, s);
+  if (rc != VSG_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(h->h_out_counts, h->d_out_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)nframes * fg.out_cap * 32, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int status = VSG_OK;
+  for (int f = 0; f < nframes; f++) {
+    const int nf = h->h_out_counts[2 * f];
+    n[f] = nf;
+    mono_index[f] = h->h_out_counts[2 * f + 1];
+    if (nf > capacity) {
+      set_err("caller capacity too small for the extracted keypoints");
+      status = VSG_ERR_CAPACITY;
+      continue;
+    }
+    if (nf > 0 && kps) memcpy(kps + (size_t)f * capacity, h->h_kps + (size_t)f * fg.out_cap, (size_t)nf * sizeof(KeyPointPOD));
+    if (nf > 0 && desc) memcpy(desc + (size_t)f * capacity * 32, h->h_desc + (size_t)f * fg.out_cap * 32, (size_t)nf * 32);
+  }
+  return status;
+}
+
+int vsg_orb_extract(vsg_orb *h, const uint8_t *gray, int rows, int cols, int stride, int lap0, int lap1,
+                    vsg_keypoint *kps, uint8_t *desc, int capacity, int *n) {
+  if (n) *n = 0;
+  if (!h) return VSG_ERR_INVALID;
+  if (!gray || rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
+  int nn = 0, mono = 0;
+  int rc = vsg_orb_extract_batch(h, gray, 1, 0, rows, cols, stride, lap0, lap1, kps, desc, capacity, &nn, &mono);
+  if (n) *n = nn;
+  if (rc != VSG_OK) return rc;
+  return mono;
+}
+
+int vsg_orb_level_size(vsg_orb *h, int level, int *w, int *ht) {
+  if (!h || !h->rows || level < 0 || level >= h->T.nlevels) return VSG_ERR_INVALID;
+  if (w) *w = h->G.fg.lv[level].w;
+  if (ht) *ht = h->G.fg.lv[level].h;
+  return VSG_OK;
+}
+
+static int copy_level(vsg_orb *h, const uint8_t *base, int frame, int level, int with_border, uint8_t *dst,
+                      int dst_stride) {
+  if (!h || !h->rows || !dst || level < 0 || level >= h->T.nlevels || frame < 0 || frame >= h->max_batch)
+    return VSG_ERR_INVALID;
+  HIP_TRY(hipSetDevice(h->device));
+  const FrameGeom &fg = h->G.fg;
+  const LevelGeom &L = fg.lv[level];
+  const uint8_t *img = base + (size_t)frame * fg.pyr_frame_bytes + L.img_off;
+  HIP_TRY(hipStreamSynchronize(h->s_main));
+  HIP_TRY(hipStreamSynchronize(h->s_blur));
+  if (!with_border) {
+    HIP_TRY(hipMemcpy2D(dst, dst_stride, img, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return VSG_OK;
+  }
+  const int b = kEdgeThreshold, bw = L.w + 2 * b, bh = L.h + 2 * b;
+  uint8_t *tmp = nullptr;
+  HIP_TRY(hipMalloc(&tmp, (size_t)bw * bh));
+  launch_border_copy(h->s_main, img, L.w, L.h, L.pitch, tmp, bw, b);
+  hipError_t e = hipStreamSynchronize(h->s_main);
+  if (e == hipSuccess) e = hipMemcpy2D(dst, dst_stride, tmp, bw, bw, bh, hipMemcpyDeviceToHost);
+  hipFree(tmp);
+  HIP_TRY(e);
+  return VSG_OK;
+}
+
+int vsg_orb_copy_pyramid_level(vsg_orb *h, int frame, int level, int with_border, uint8_t *dst, int dst_stride) {
+  return copy_level(h, h ? h->d_pyr : nullptr, frame, level, with_border, dst, dst_stride);
+}
+int vsg_orb_copy_blurred_level(vsg_orb *h, int frame, int level, uint8_t *dst, int dst_stride) {
+  return copy_level(h, h ? h->d_blur : nullptr, frame, level, 0, dst, dst_stride);
+}
+
+static int copy_list(vsg_orb *h, const uint32_t *list, size_t frame_elems, int off, int lcap, const int *counts,
+                     int frame, int level, uint32_t *dst, int cap) {
+  if (!h || !h->rows || level < 0 || level >= h->T.nlevels || frame < 0 || frame >= h->max_batch) return VSG_ERR_INVALID;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->s_main));
+  int n = 0;
+  HIP_TRY(hipMemcpy(&n, counts + frame * kMaxLevels + level, sizeof(int), hipMemcpyDeviceToHost));
+  if (n > lcap) n = lcap;
+  const int m = n < cap ? n : cap;
+  if (m > 0 && dst) HIP_TRY(hipMemcpy(dst, list + (size_t)frame * frame_elems + off, (size_t)m * 4, hipMemcpyDeviceToHost));
+  return n;
+}
+
+int vsg_orb_copy_candidates(vsg_orb *h, int frame, int level, uint32_t *dst, int cap) {
+  if (!h || !h->rows || level < 0 || level >= h->T.nlevels) return VSG_ERR_INVALID;
+  const LevelGeom &L = h->G.fg.lv[level];
+  return copy_list(h, h->d_cand, h->G.fg.cand_frame, L.cand_off, L.cand_cap, h->d_counts2, frame, level, dst, cap);
+}
+int vsg_orb_copy_selected(vsg_orb *h, int frame, int level, uint32_t *dst, int cap) {
+  if (!h || !h->rows || level < 0 || level >= h->T.nlevels) return VSG_ERR_INVALID;
+  const LevelGeom &L = h->G.fg.lv[level];
+  return copy_list(h, h->d_sel, h->G.fg.sel_frame, L.sel_off, L.sel_cap,
+                   h->d_counts2 + (size_t)h->max_batch * kMaxLevels, frame, level, dst, cap);
+}
+
+int vsg_orb_enable_timing(vsg_orb *h, int enable) {
+  if (!h) return VSG_ERR_INVALID;
+  h->timing = enable != 0;
+  h->ev_pending = false;
+  memset(h->acc_ms, 0, sizeof(h->acc_ms));
+  h->acc_n = 0;
+  return VSG_OK;
+}
+
+int vsg_orb_get_timing(vsg_orb *h, float *ms_out, int cap) {
+  if (!h) return VSG_ERR_INVALID;
+  harvest_timing(h);
+  for (int i = 0; i < kStages && i < cap; i++) ms_out[i] = h->acc_n ? (float)(h->acc_ms[i] / h->acc_n) : 0.f;
+  return kStages;
+}
+
+}  // extern "C"
