@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of ORB extract+match on MI355X (BASELINE.json metric, config C2).
+
+One STEP = one pass of the hot path over one batch of `--batch` synthetic 640x480 gray frames that are
+already resident in HBM: ORBextractor::operator() for every frame (pyramid, per-cell FAST, octree,
+orientation, 7x7 blur, rBRIEF-256; nFeatures=1000, 8 levels) + the brute-force Hamming best/second-best
+match of every frame against its predecessor (the inner search of ORBmatcher::SearchByBoW with one node).
+With N > 1 ranks (torchrun) every rank processes its own `--batch` frames per step (frame sharding, weak
+scaling) and the keypoint/descriptor records are exchanged with one RCCL all-gather per step.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel by ALGORITHMIC bytes over
+its HIP-event duration; `cpu_baseline` is the CPU oracle (a port of the reference algorithm, not the
+reference binary) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (W, H, nfeatures)
+    "C2": (640, 480, 1000),
+    "C3": (752, 480, 1200),
+    "C4": (1280, 720, 2000),
+    "C5": (640, 480, 1250),
+}
+
+
+def algorithmic_bytes(ex, n_kp):
+    """Per-frame algorithmic bytes per stage: one read/write per unavoidable stage boundary."""
+    sizes = [ex.level_size(l) for l in range(ex.nlevels)]
+    P = sum(w * h for w, h in sizes)
+    wh0 = sizes[0][0] * sizes[0][1]
+    whl = sizes[-1][0] * sizes[-1][1]
+    stages = {
+        "ingest": wh0,
+        "pyramid": (P - whl) + (P - wh0),
+        "fast": P,
+        "blur": 2 * P,
+        "orient_desc": 60 * n_kp,
+    }
+    return stages, sum(stages.values())
+
+
+def cpu_baseline(w, h, nfeatures, frames, budget_s, threads):
+    """Time the CPU oracle (kind 'port') on `threads` host threads for about budget_s seconds."""
+    import oracle_lib as ol
+    from concurrent.futures import ThreadPoolExecutor
+    ol.lib()
+
+    def worker(tid):
+        e = ol.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
+        n = 0
+        t_end = time.perf_counter() + budget_s
+        i = tid
+        prev = None
+        while time.perf_counter() < t_end:
+            _, kps, desc = e(frames[i % len(frames)])
+            if prev is not None:
+                ol.block_best2(desc, prev)
+            prev = desc
+            n += 1
+            i += threads
+        return n
+
+    t0 = time.perf_counter()
+    if threads == 1:
+        total = worker(0)
+    else:
+        with ThreadPoolExecutor(threads) as pool:
+            total = sum(pool.map(worker, range(threads)))
+    dt = time.perf_counter() - t0
+    return total / dt, total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget per CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from visual_sgraphs_amd import orb, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the ORB front-end has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, nfeat = WORKLOADS[args.workload]
+    B, K, Wu = args.batch, args.steps, args.warmup
+    ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, device=local_rank, max_batch=B)
+    cap = ex.capacity(H, W)
+
+    # synthetic frames: every rank gets its own sequence; consecutive frames are translated copies (matchable)
+    frames = np.stack([synth.sequence_frame(W, H, 1000 + rank, t) for t in range(B)])
+    d_gray = torch.from_numpy(frames).to(dev)
+    # output records: slot 0 keeps the previous batch's last frame so every frame has a predecessor to match
+    d_kps = torch.zeros((B + 1, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros((B + 1, 2), dtype=torch.int32, device=dev)
+    d_best = torch.zeros((B, cap), dtype=torch.int32, device=dev)
+    d_second = torch.zeros_like(d_best)
+    d_arg = torch.zeros_like(d_best)
+    from visual_sgraphs_amd import sharding
+    if distributed and not args.no_gather:
+        # one fixed-capacity record block per frame: {n, monoIndex} + keypoints + descriptors
+        rec_bytes = sharding.record_bytes(cap)
+        send = torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev)
+        recv = torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev)
+    L = orb.load_library()
+    import ctypes as C
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        # carry the last frame of the previous batch into slot 0
+        d_desc[0].copy_(d_desc[B])
+        d_counts[0].copy_(d_counts[B])
+        ex.extract_batch_device(d_gray.data_ptr(), B, H * W, H, W, W, d_kps[1].data_ptr(), d_desc[1].data_ptr(),
+                                d_counts[1].data_ptr(), cap, (0, 0), stream)
+        if not args.no_match:
+            rc = L.vsg_hamming_block_best2_device(local_rank, C.c_void_p(d_desc[1].data_ptr()),
+                                                  C.c_void_p(d_desc[0].data_ptr()), cap * 32,
+                                                  C.c_void_p(d_counts[1].data_ptr()), C.c_void_p(d_counts[0].data_ptr()),
+                                                  2, B, cap, C.c_void_p(d_best.data_ptr()),
+                                                  C.c_void_p(d_second.data_ptr()), C.c_void_p(d_arg.data_ptr()),
+                                                  C.c_void_p(stream))
+            assert rc == 0, rc
+        if distributed and not args.no_gather:
+            sharding.pack_records(send, d_counts[1:], d_kps[1:], d_desc[1:])
+            sharding.all_gather_records(recv, send)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(Wu):
+        step()
+    barrier()
+    if not args.no_stage_timing:
+        ex.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stage_ms = ex.timing_ms() if not args.no_stage_timing else {}
+
+    # parity gate on this rank: first and last frame of the batch vs the CPU oracle, bit for bit
+    counts = d_counts.cpu().numpy()
+    kps_h = d_kps.cpu().numpy()
+    desc_h = d_desc.cpu().numpy()
+    parity = None
+    n_kp = float(counts[1:, 0].mean())
+    if rank == 0:
+        import oracle_lib as ol
+        ref = ol.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+        ok = True
+        for f in (0, B - 1):
+            mono, rk, rd = ref(frames[f])
+            n = int(counts[f + 1, 0])
+            ok &= n == len(rk) and int(counts[f + 1, 1]) == mono
+            ok &= kps_h[f + 1, :n].tobytes() == rk.tobytes() and np.array_equal(desc_h[f + 1, :n], rd)
+        if not args.no_match:
+            rb, rs, ra = ol.block_best2(desc_h[B, :int(counts[B, 0])], desc_h[B - 1, :int(counts[B - 1, 0])])
+            n = int(counts[B, 0])
+            ok &= np.array_equal(d_best[B - 1, :n].cpu().numpy(), rb) and np.array_equal(d_arg[B - 1, :n].cpu().numpy(), ra)
+            ok &= np.array_equal(d_second[B - 1, :n].cpu().numpy(), rs)
+        parity = bool(ok)
+
+    if rank != 0:
+        if distributed:
+            dist.destroy_process_group()
+        return
+
+    total_frames = world * B * K
+    fps = total_frames / dt
+    stages, bytes_per_frame = algorithmic_bytes(ex, n_kp)
+    roofline = None
+    if stage_ms:
+        timed = {k: stage_ms[k] for k in ("pyramid", "fast", "blur", "orient_desc", "octree") if stage_ms.get(k, 0) > 0}
+        dom = max(timed, key=timed.get)
+        dom_bytes = stages.get(dom, 0) * B  # algorithmic bytes one launch (batch of B frames) moves
+        ach = dom_bytes / (timed[dom] * 1e-3) / 1e9 if timed[dom] > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "launch_ms": round(timed[dom], 4), "bytes_per_launch": int(dom_bytes),
+                    "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                    "pipeline_achieved_GBs": round(bytes_per_frame * fps / world / 1e9, 2),
+                    "bytes_per_frame": int(bytes_per_frame)}
+
+    cpu = None
+    extra = {}
+    if args.cpu_seconds > 0 and world == 1:
+        sample = [frames[i] for i in range(min(B, 16))]
+        v1, n1 = cpu_baseline(W, H, nfeat, sample, args.cpu_seconds, 1)
+        cpu = {"value": round(v1, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{n1} frames of the same {W}x{H}/{nfeat} workload, extract + brute-force match, "
+                         f"{args.cpu_seconds:.0f} s, CPU oracle (port of the reference algorithm)"}
+        ncores = os.cpu_count() or 1
+        va, na = cpu_baseline(W, H, nfeat, sample, args.cpu_seconds, ncores)
+        extra["cpu_baseline_all_cores"] = {"value": round(va, 2), "unit": "frames/s", "cores": ncores, "kind": "port",
+                                           "sample": f"{na} frames, one independent extractor per host thread"}
+
+    out = {
+        "metric": "frames/sec ORB extract+match @640x480, 1000 feats; bit-exact vs CPU",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wu,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {W}x{H} gray, nFeatures={nfeat}, 8 levels, scale 1.2, FAST 20/7, "
+                               f"extract{'' if args.no_match else ' + brute-force Hamming best2 match vs previous frame'}",
+                   "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded x{world}"
+                   + (", RCCL all-gather of keypoint/descriptor records per step" if distributed and not args.no_gather else ""),
+                   "keypoints_per_frame": round(n_kp, 1), "inputs": "resident in HBM"},
+        "parity": {"bit_exact_vs_oracle": parity, "checked_frames": [0, B - 1]},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    out.update(extra)
+    print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""Frame sharding across ranks and the keypoint/descriptor record exchange.
+
+Extraction has no cross-frame state, so frames (or cameras) are partitioned over ranks with no data-path
+collective.  Matching frame t against t-1 (or a keyframe) needs the neighbour's descriptors, so the ranks
+exchange fixed-capacity per-frame records with ONE all-gather per batch (RCCL over xGMI on GPUs, gloo in
+the CPU tests).  Record layout per frame, `record_bytes(cap)` bytes:
+    int32 n, int32 monoIndex, KeyPoint[cap] (28 B each), uint8 desc[cap][32]
+"""
+import torch
+import torch.distributed as dist
+
+
+def record_bytes(cap):
+    return 8 + cap * 60
+
+
+def shard_frames(n_frames, rank, world):
+    """Round-robin frame -> rank map (frame f goes to rank f % world); returns this rank's frame indices."""
+    return list(range(rank, n_frames, world))
+
+
+def stream_to_rank(stream, n_streams, world):
+    """Multi-camera pinning (config C5): stream s -> rank s % world; with world > n_streams a stream's frames
+    are further split round-robin over the world // n_streams ranks that share it."""
+    return stream % world
+
+
+def pack_records(send, counts, kps, desc):
+    """counts [B,2] int32, kps [B,cap,28] uint8, desc [B,cap,32] uint8 -> send [B, record_bytes(cap)] uint8."""
+    B, cap = kps.shape[0], kps.shape[1]
+    send[:, :8].copy_(counts.contiguous().view(torch.uint8).view(B, 8))
+    send[:, 8:8 + cap * 28].copy_(kps.reshape(B, cap * 28))
+    send[:, 8 + cap * 28:].copy_(desc.reshape(B, cap * 32))
+    return send
+
+
+def unpack_records(recv, cap):
+    """recv [R, record_bytes(cap)] -> (counts [R,2] int32, kps [R,cap,28] uint8, desc [R,cap,32] uint8)."""
+    R = recv.shape[0]
+    counts = recv[:, :8].contiguous().view(torch.int32).view(R, 2)
+    kps = recv[:, 8:8 + cap * 28].reshape(R, cap, 28)
+    desc = recv[:, 8 + cap * 28:].reshape(R, cap, 32)
+    return counts, kps, desc
+
+
+def all_gather_records(recv, send):
+    """One collective per batch: recv [world*B, rec] <- every rank's send [B, rec] (rank-major)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_gather_into_tensor(recv, send)
+    else:
+        recv.copy_(send)
+    return recv
+
+
+def global_frame_index(rank, local_index, world):
+    """Inverse of shard_frames: the original frame number of a gathered record."""
+    return local_index * world + rank
