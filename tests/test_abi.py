@@ -52,3 +52,24 @@ def test_product_does_not_reference_the_oracle():
     for f in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")) + [ROOT / "include/vsg_orb.h"]:
         txt = f.read_text()
         assert "orb_oracle" not in txt and "oracle_lib" not in txt and "liborb_oracle" not in txt, f
+
+
+def test_cpp_adaptor_compiles_and_fails_loudly_without_device(lib, tmp_path):
+    """include/vsg_orb_adaptor.hpp is plain C++ over the C ABI: compile it with g++, link the HIP library and
+    check that constructing the extractor without a GPU throws (no silent fallback)."""
+    import subprocess
+    from visual_sgraphs_amd import orb
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "vsg_orb_adaptor.hpp"\n#include <cstdio>\n'
+                   'int main(){ try { vsg::ORBextractor e(1000,1.2f,8,20,7); std::vector<vsg_keypoint> k; '
+                   'std::vector<uint8_t> d; std::vector<int> lap{0,0}; std::vector<uint8_t> img(640*480,128);'
+                   'int m = e(img.data(),480,640,640,k,d,lap); printf("OK %d %zu\\n", m, k.size()); return 0; }'
+                   ' catch (const std::exception& ex) { printf("THROW %s\\n", ex.what()); return 3; } }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-I", str(ROOT / "include"), str(src), "-o", str(exe),
+                           str(orb.LIB_PATH), "-Wl,-rpath," + str(orb.LIB_PATH.parent), "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if lib.vsg_device_count() > 0:
+        assert r.returncode == 0 and r.stdout.startswith("OK 0 0")  # constant image: 0 keypoints
+    else:
+        assert r.returncode == 3 and "THROW" in r.stdout
