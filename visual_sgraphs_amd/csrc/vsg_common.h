@@ -38,8 +38,8 @@ struct LevelGeom {
   int cand_off, cand_cap;   // slice of the per-frame candidate array (uint32 units)
   int sel_off, sel_cap;     // slice of the per-frame selected-keypoint array
   int tab_x_off, tab_y_off; // resize tables (short4 units) for producing THIS level from level-1
-  int blur_tile_base;       // index of this level's first blur tile
-  int blur_tiles_x;         // tiles per row
+  int blur_block_base;      // first workgroup of this level in the blur launch
+  int blur_nxg, blur_nys;   // 4-pixel column groups per row / row strips of kBlurStrip rows
   float scale;              // mvScaleFactor[level]
   float kp_size;            // (float)(int)(31 * scale)   (ORBextractor.cc:884,893)
   // octree (ORBextractor.cc:562-593)
@@ -56,13 +56,22 @@ struct FrameGeom {
   int cand_frame;        // uint32 per frame in the candidate array
   int sel_frame;         // uint32 per frame in the selected array
   int total_cells;       // FAST cells per frame (all levels)
-  int total_blur_tiles;
+  int total_blur_blocks;
   int out_cap;           // keypoint capacity per frame in the output arrays
   int iniTh, minTh;
   int lap0, lap1;
   uint16_t taps[8];      // 7 taps of the 8.8 fixed-point Gaussian (+1 pad)
   LevelGeom lv[kMaxLevels];
 };
+
+// Level 0 is read in place from the caller's (or the staging) buffer: no ingest copy.
+struct Src0 {
+  const uint8_t *base;   // frame 0, 4-byte aligned
+  size_t frame_stride;   // bytes between frames, multiple of 4
+  int pitch;             // bytes per row, multiple of 4
+};
+
+enum { kBlurStrip = 36 };  // output rows per thread in k_blur (36 + 6 halo rows = 6 x 7-row window turns)
 
 // cv::KeyPoint-compatible record (28 bytes): pt.x pt.y size angle response octave class_id
 struct KeyPointPOD {

@@ -74,19 +74,14 @@ struct Short4 {
 struct CellDesc {  // one FAST cell: valid region [x0,x1) x [y0,y1) in level coordinates
   int16_t level, x0, y0, x1, y1, pad;
 };
-struct BlurTile {
-  int16_t level, tx, ty, pad;
-};
 
 struct Geometry {
   FrameGeom fg;
   std::vector<Short4> resizeTab;  // all levels, x tables then y tables (offsets in LevelGeom)
   std::vector<CellDesc> cells;
-  std::vector<BlurTile> blurTiles;
   int maxQuota = 0;
 };
 
-enum { kBlurTileW = 64, kBlurTileH = 16 };
 
 inline int16_t sat_short(float v) {
   int iv = cv_round_f(v);
@@ -133,7 +128,6 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   memset(&fg, 0, sizeof(fg));
   G.resizeTab.clear();
   G.cells.clear();
-  G.blurTiles.clear();
   G.maxQuota = 0;
   fg.nlevels = T.nlevels;
   fg.rows = rows;
@@ -144,7 +138,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   fg.lap1 = lap1;
   for (int k = 0; k < 7; k++) fg.taps[k] = taps[k];
   if (T.iniTh < 1 || T.minTh < 1 || T.iniTh > 255 || T.minTh > 255) return -3;
-  int img_off = 0, cand_off = 0, sel_off = 0, out_cap = 0;
+  int img_off = 0, cand_off = 0, sel_off = 0, out_cap = 0, blur_blocks = 0;
   int prev_w = 0, prev_h = 0;
   for (int l = 0; l < T.nlevels; l++) {
     LevelGeom &L = fg.lv[l];
@@ -205,11 +199,11 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
     }
     prev_w = L.w;
     prev_h = L.h;
-    // blur tiles
-    L.blur_tile_base = (int)G.blurTiles.size();
-    L.blur_tiles_x = (L.w + kBlurTileW - 1) / kBlurTileW;
-    for (int ty = 0; ty < (L.h + kBlurTileH - 1) / kBlurTileH; ty++)
-      for (int tx = 0; tx < L.blur_tiles_x; tx++) G.blurTiles.push_back({(int16_t)l, (int16_t)tx, (int16_t)ty, 0});
+    // blur launch: thread = 4 px x kBlurStrip rows, 256 threads per workgroup, workgroups never straddle levels
+    L.blur_block_base = blur_blocks;
+    L.blur_nxg = (L.w + 3) / 4;
+    L.blur_nys = (L.h + kBlurStrip - 1) / kBlurStrip;
+    blur_blocks += (L.blur_nxg * L.blur_nys + 255) / 256;
     L.scale = T.scale[l];
     L.kp_size = (float)(int)((float)(2 * kHalfPatch + 1) * T.scale[l]);  // :884
     // octree initial nodes :566-593
@@ -240,7 +234,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   fg.cand_frame = cand_off;
   fg.sel_frame = sel_off;
   fg.total_cells = (int)G.cells.size();
-  fg.total_blur_tiles = (int)G.blurTiles.size();
+  fg.total_blur_blocks = blur_blocks;
   // output capacity: what operator() can produce = sum over levels of final list sizes
   fg.out_cap = out_cap;
   return 0;

@@ -21,19 +21,31 @@
 namespace vsg {
 
 // ------------------------------------------------------------------------------------------------
+// Level l of frame f: level 0 is read in place from the caller's buffer (Src0), levels >= 1 from the pyramid.
+__device__ __forceinline__ const uint8_t *level_ptr(const FrameGeom *fg, const Src0 &s0, const uint8_t *pyr, int frame,
+                                                    int level, int &pitch) {
+  if (level == 0) {
+    pitch = s0.pitch;
+    return s0.base + (size_t)frame * s0.frame_stride;
+  }
+  pitch = fg->lv[level].pitch;
+  return pyr + (size_t)frame * fg->pyr_frame_bytes + fg->lv[level].img_off;
+}
+
 // Pyramid: level `level` from level-1, chained like the reference (resize of the previous LEVEL).
 // Thread = 4 horizontally adjacent destination pixels -> one aligned 32-bit store.
 __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
-                                                const Short4 *__restrict__ tab, int level) {
+                                                const Short4 *__restrict__ tab, Src0 s0, int level) {
   const LevelGeom &D = fg->lv[level];
-  const LevelGeom &S = fg->lv[level - 1];
   const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
   const int y = blockIdx.y * 4 + threadIdx.y;
   if (x4 >= D.w || y >= D.h) return;
   uint8_t *frame = pyr + (size_t)blockIdx.z * fg->pyr_frame_bytes;
+  int spitch;
+  const uint8_t *S = level_ptr(fg, s0, pyr, blockIdx.z, level - 1, spitch);
   const Short4 ty = tab[D.tab_y_off + y];
-  const uint8_t *S0 = frame + S.img_off + (size_t)ty.a * S.pitch;
-  const uint8_t *S1 = frame + S.img_off + (size_t)ty.b * S.pitch;
+  const uint8_t *S0 = S + (size_t)ty.a * spitch;
+  const uint8_t *S1 = S + (size_t)ty.b * spitch;
   const int b0 = ty.c, b1 = ty.d;
   uint32_t out = 0;
 #pragma unroll
@@ -51,15 +63,25 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// FAST-9-16 score of the pixel at `c` in an LDS tile of row pitch `P`:
-//   score = max over the 16 contiguous 9-arcs of min(+-(v - ring)) - 1, or 0 if below `floor_t`.
-// corner-at-t <=> score >= t, and the score does not depend on t ([OCV] cornerScore<16>).
-enum { kTileP = 80, kScoreP = 72 };
+// FAST-9-16 ([OCV] fast.cpp FAST_t<16>, fast_score.cpp cornerScore<16>) on an LDS tile of row pitch kTileP.
+//   score = max over the 16 contiguous 9-arcs of min(+-(v - ring)) - 1;  corner-at-t <=> score >= t, and the
+//   score does not depend on t.  fast_quick() is a necessary condition on two opposing ring pairs (same idea as
+//   the tab[] pre-test of FAST_t); fast_score() is exact and returns 0 below `floor_t`.
+enum { kTileP = 84, kScoreP = 72 };
+
+__device__ __forceinline__ bool fast_quick(const uint8_t *c, int floor_t) {
+  const int P = kTileP;
+  const int v = c[0];
+  const int r0 = c[3 * P], r8 = c[-3 * P], r4 = c[3], r12 = c[-3];
+  const int lo = v - floor_t, hi = v + floor_t;
+  const bool dark = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
+  const bool bright = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
+  return dark | bright;
+}
 
 __device__ __forceinline__ int fast_score(const uint8_t *c, int floor_t) {
   const int P = kTileP;
   const int v = c[0];
-  // cheap necessary test on 4 opposing pairs (same idea as the tab[] pre-test in FAST_t)
   const int r0 = c[3 * P], r8 = c[-3 * P], r4 = c[3], r12 = c[-3];
   const int r2 = c[2 * P + 2], r10 = c[-2 * P - 2], r6 = c[-2 * P + 2], r14 = c[2 * P - 2];
   const int lo = v - floor_t, hi = v + floor_t;
@@ -106,16 +128,18 @@ __device__ __forceinline__ int fast_score(const uint8_t *c, int floor_t) {
   return s >= floor_t ? s : 0;
 }
 
-// One workgroup per FAST cell.  The cell's valid region (3 px inside the reference's sub-image) is
-// scored into LDS, non-max suppressed against neighbours INSIDE the region only (outside counts as 0,
-// exactly like the zeroed row buffers of FAST_t), then emitted with the threshold fallback:
-// survivors >= iniTh if any, else survivors >= minTh.  Order is irrelevant (the octree ranks candidates).
+// One workgroup per FAST cell.  The cell's valid region (3 px inside the reference's sub-image) is staged in LDS
+// with aligned 32-bit loads; a cheap necessary test runs on every pixel and the few that pass are COMPACTED into an
+// LDS queue, so the exact (expensive) score and the non-max suppression run on dense wavefronts.  NMS only looks at
+// neighbours INSIDE the valid region (outside counts as 0, exactly like the zeroed row buffers of FAST_t); the cell
+// emits survivors >= iniTh if any, else survivors >= minTh.  Order is irrelevant (the octree ranks candidates).
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
-                                                    const CellDesc *__restrict__ cells, uint32_t *__restrict__ cand,
-                                                    int *__restrict__ cand_count) {
-  __shared__ uint8_t tile[(kCellMax + 6) * kTileP];
-  __shared__ uint8_t score[(kCellMax + 2) * kScoreP];
-  __shared__ int s_cnt[4];  // [0]=survivors>=iniTh [1]=survivors>=floor [2]=emit cursor [3]=global base
+                                                    const CellDesc *__restrict__ cells, Src0 s0,
+                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[(kCellMax + 6) * kTileP];
+  __shared__ __attribute__((aligned(16))) uint8_t score[(kCellMax + 2) * kScoreP];
+  __shared__ uint16_t queue[kCellMax * kCellMax];
+  __shared__ int s_cnt[5];  // [0]=survivors>=iniTh [1]=survivors>=floor [2]=emit cursor [3]=global base [4]=queue length
   const CellDesc cell = cells[blockIdx.x];
   const int frame = blockIdx.y;
   const LevelGeom &L = fg->lv[cell.level];
@@ -123,26 +147,51 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   if (vw <= 0 || vh <= 0) return;
   const int iniTh = fg->iniTh, minTh = fg->minTh;
   const int floor_t = min(iniTh, minTh);
-  const int tid = threadIdx.x;
-  const uint8_t *img = pyr + (size_t)frame * fg->pyr_frame_bytes + L.img_off;
-  const int tw = vw + 6, th = vh + 6;
-  for (int i = tid; i < tw * th; i += 256) {
-    const int r = i / tw, c = i - r * tw;
-    tile[r * kTileP + c] = img[(size_t)(cell.y0 - 3 + r) * L.pitch + (cell.x0 - 3 + c)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  int pitch;
+  const uint8_t *img = level_ptr(fg, s0, pyr, frame, cell.level, pitch);
+  // tile column 0 <-> image column ax (4-byte aligned); the valid region starts at tile column ox + 3
+  const int ax = (cell.x0 - 3) & ~3, ox = (cell.x0 - 3) - ax;
+  const int tdw = (ox + vw + 6 + 3) >> 2, th = vh + 6;  // dwords per tile row (<= 21)
+  for (int i = tid; i < tdw * th; i += 256) {
+    const int r = i / tdw, c = i - r * tdw;
+    *(uint32_t *)&tile[r * kTileP + 4 * c] = *(const uint32_t *)(img + (size_t)(cell.y0 - 3 + r) * pitch + ax + 4 * c);
   }
-  for (int i = tid; i < (vh + 2) * kScoreP; i += 256) score[i] = 0;
-  if (tid < 4) s_cnt[tid] = 0;
+  for (int i = tid; i < (vh + 2) * (kScoreP / 4); i += 256) ((uint32_t *)score)[i] = 0;
+  if (tid < 5) s_cnt[tid] = 0;
   __syncthreads();
+  // ---- phase 1: necessary test on every pixel, compaction of the passers
   const int npx = vw * vh;
-  for (int i = tid; i < npx; i += 256) {
+  for (int i0 = 0; i0 < npx; i0 += 256) {
+    const int i = i0 + tid;
+    bool pass = false;
+    if (i < npx) {
+      const int r = i / vw, c = i - r * vw;
+      pass = fast_quick(&tile[(r + 3) * kTileP + (c + 3 + ox)], floor_t);
+    }
+    const uint64_t m = __ballot(pass);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&s_cnt[4], __popcll(m));
+      base = __shfl(base, 0);
+      if (pass) queue[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+    }
+  }
+  __syncthreads();
+  const int nq = s_cnt[4];
+  // ---- phase 2: exact score of the queued pixels
+  for (int q = tid; q < nq; q += 256) {
+    const int i = queue[q];
     const int r = i / vw, c = i - r * vw;
-    const int s = fast_score(&tile[(r + 3) * kTileP + (c + 3)], floor_t);
+    const int s = fast_score(&tile[(r + 3) * kTileP + (c + 3 + ox)], floor_t);
     if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
   }
   __syncthreads();
-  uint32_t keep = 0;  // bit per loop iteration: pixel survives NMS
+  // ---- phase 3: non-max suppression inside the cell
+  uint32_t keep = 0;  // bit per loop iteration: queued pixel survives NMS
   int it = 0;
-  for (int i = tid; i < npx; i += 256, it++) {
+  for (int q = tid; q < nq; q += 256, it++) {
+    const int i = queue[q];
     const int r = i / vw, c = i - r * vw;
     const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
     const int s = sp[0];
@@ -159,15 +208,15 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   const int nHi = s_cnt[0], nLo = s_cnt[1];
   const int thr = nHi > 0 ? iniTh : minTh;  // vKeysCell.empty() -> retry with minThFAST (:848-851)
   const int nEmit = nHi > 0 ? nHi : nLo;
-  // with iniTh < minTh (unusual) the second pass of the reference still only runs when the first is empty
   if (nEmit == 0) return;
   if (tid == 0) s_cnt[3] = atomicAdd(&cand_count[frame * kMaxLevels + cell.level], nEmit);
   __syncthreads();
   const int base = s_cnt[3];
   uint32_t *out = cand + (size_t)frame * fg->cand_frame + L.cand_off;
   it = 0;
-  for (int i = tid; i < npx; i += 256, it++) {
+  for (int q = tid; q < nq; q += 256, it++) {
     if (!(keep & (1u << it))) continue;
+    const int i = queue[q];
     const int r = i / vw, c = i - r * vw;
     const int s = score[(r + 1) * kScoreP + (c + 1)];
     if (s < thr) continue;
@@ -247,53 +296,80 @@ __global__ __launch_bounds__(256) void k_octree(const FrameGeom *__restrict__ fg
 }
 
 // ------------------------------------------------------------------------------------------------
-// 7x7 Gaussian, sigma 2, 8.8 fixed point, BORDER_REFLECT_101 at the level's own edges (the reference
-// blurs a border-less clone).  64x16 output tile per workgroup, separable through LDS.
+// 7x7 Gaussian, sigma 2, 8.8 fixed point, BORDER_REFLECT_101 at the level's own edges (the reference blurs a
+// border-less clone, ORBextractor.cc:1129-1130).  No LDS: a thread owns 4 adjacent columns and walks down
+// kBlurStrip + 6 rows with a 7-row register window.  Per row it loads 3 aligned dwords (12 px), forms the 4
+// horizontal 8.8 sums with v_alignbyte + v_dot4_u32_u8, and once the window is full emits 4 output bytes
+// (one 32-bit store) from 7 v_mad_u32_u24 per pixel.  Adjacent lanes own adjacent column groups, so every
+// wave-level load/store is one contiguous 256-byte row segment.
 __device__ __forceinline__ int reflect101(int p, int len) {
   while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
   return p;
 }
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
-                                              const FrameGeom *__restrict__ fg, const BlurTile *__restrict__ tiles) {
-  __shared__ uint8_t src[(kBlurTileH + 6) * 72];
-  __shared__ uint16_t hb[(kBlurTileH + 6) * kBlurTileW];
-  const BlurTile t = tiles[blockIdx.x];
-  const LevelGeom &L = fg->lv[t.level];
-  const size_t foff = (size_t)blockIdx.y * fg->pyr_frame_bytes + L.img_off;
-  const uint8_t *img = pyr + foff;
-  const int x0 = t.tx * kBlurTileW, y0 = t.ty * kBlurTileH;
-  const int tid = threadIdx.x;
-  int taps[7];
+                                              const FrameGeom *__restrict__ fg, Src0 s0) {
+  int level = 0;
+  while (level + 1 < fg->nlevels && (int)blockIdx.x >= fg->lv[level + 1].blur_block_base) level++;
+  const LevelGeom &L = fg->lv[level];
+  const int t = ((int)blockIdx.x - L.blur_block_base) * 256 + (int)threadIdx.x;
+  if (t >= L.blur_nxg * L.blur_nys) return;
+  const int gx = t % L.blur_nxg, sy = t / L.blur_nxg;
+  const int x0 = gx * 4, y0 = sy * kBlurStrip;
+  const int w = L.w, h = L.h;
+  int spitch;
+  const uint8_t *img = level_ptr(fg, s0, pyr, blockIdx.y, level, spitch);
+  uint8_t *dst = blur + (size_t)blockIdx.y * fg->pyr_frame_bytes + L.img_off;
+  const uint32_t T0 = fg->taps[0] | (fg->taps[1] << 8) | (fg->taps[2] << 16) | ((uint32_t)fg->taps[3] << 24);
+  const uint32_t T1 = fg->taps[4] | (fg->taps[5] << 8) | (fg->taps[6] << 16);
+  uint32_t k[7];
 #pragma unroll
-  for (int k = 0; k < 7; k++) taps[k] = fg->taps[k];
-  for (int i = tid; i < (kBlurTileH + 6) * 70; i += 256) {
-    const int r = i / 70, c = i - r * 70;
-    const int sy = reflect101(y0 + r - 3, L.h), sx = reflect101(x0 + c - 3, L.w);
-    src[r * 72 + c] = img[(size_t)sy * L.pitch + sx];
-  }
-  __syncthreads();
-  for (int i = tid; i < (kBlurTileH + 6) * kBlurTileW; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    const uint8_t *s = &src[r * 72 + c];
-    uint32_t acc = 0;
+  for (int j = 0; j < 7; j++) k[j] = fg->taps[j];
+  const bool interior = x0 >= 4 && x0 + 8 <= w;  // all 12 source bytes exist: aligned dword loads
+  uint32_t win[7][4];
 #pragma unroll
-    for (int k = 0; k < 7; k++) acc += (uint32_t)taps[k] * s[k];
-    hb[i] = (uint16_t)min(acc, 65535u);  // ufixedpoint16 '+' saturates
-  }
-  __syncthreads();
-  const int r = tid >> 4, cg = (tid & 15) * 4;
-  if (y0 + r < L.h && x0 + cg < L.w) {
-    uint32_t out = 0;
+  for (int turn = 0; turn < (kBlurStrip + 6) / 7; turn++) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      uint32_t acc = 0;
+    for (int s = 0; s < 7; s++) {
+      const int rr = turn * 7 + s;           // 0 .. kBlurStrip+5 : source row y0 - 3 + rr
+      const int ysrc = reflect101(y0 - 3 + rr, h);
+      const uint8_t *row = img + (size_t)ysrc * spitch;
+      uint32_t d0, d1, d2;
+      if (interior) {
+        d0 = *(const uint32_t *)(row + x0 - 4);
+        d1 = *(const uint32_t *)(row + x0);
+        d2 = *(const uint32_t *)(row + x0 + 4);
+      } else {
+        uint32_t b[12];
 #pragma unroll
-      for (int k = 0; k < 7; k++) acc += (uint32_t)taps[k] * hb[(r + k) * kBlurTileW + cg + j];
-      const uint32_t v = min((acc + 32768u) >> 16, 255u);
-      out |= v << (8 * j);
+        for (int i = 0; i < 12; i++) b[i] = row[reflect101(x0 - 4 + i, w)];
+        d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+      }
+      // pixel j: taps over bytes j+1 .. j+7 of {d0,d1,d2}
+      win[s][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), T0,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), T1, 0u, false), false);
+      win[s][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), T0,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), T1, 0u, false), false);
+      win[s][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), T0,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), T1, 0u, false), false);
+      win[s][3] = __builtin_amdgcn_udot4(d1, T0, __builtin_amdgcn_udot4(d2, T1, 0u, false), false);
+      if (rr >= 6) {
+        const int yo = y0 + rr - 6;
+        if (yo < h) {
+          uint32_t out = 0;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            uint32_t acc = 32768u;
+#pragma unroll
+            for (int q = 0; q < 7; q++) acc += __umul24(k[q], win[(s + 1 + q) % 7][j]);  // oldest row first
+            out |= min(acc >> 16, 255u) << (8 * j);
+          }
+          *(uint32_t *)(dst + (size_t)yo * L.pitch + x0) = out;
+        }
+      }
     }
-    *(uint32_t *)(blur + foff + (size_t)(y0 + r) * L.pitch + x0 + cg) = out;
   }
 }
 
@@ -352,7 +428,8 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
-                                                     const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ sel,
+                                                     const FrameGeom *__restrict__ fg, Src0 s0,
+                                                     const uint32_t *__restrict__ sel,
                                                      const int *__restrict__ slots, const FrameHeader *__restrict__ hdr,
                                                      const int8_t *__restrict__ pattern, KeyPointPOD *__restrict__ kps,
                                                      uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity) {
@@ -375,12 +452,14 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   const uint32_t c = sel[(size_t)frame * fg->sel_frame + L.sel_off + (g - H.level_start[l])];
   const int cx = VSG_CAND_X(c) + kFastBorder, cy = VSG_CAND_Y(c) + kFastBorder;
   const size_t foff = (size_t)frame * fg->pyr_frame_bytes + L.img_off;
+  int upitch;
+  const uint8_t *unblurred = level_ptr(fg, s0, pyr, frame, l, upitch);
   // ---- IC_Angle: lanes 0..61 = 31 rows x {left half, right half}
   int m10 = 0, m01 = 0;
   if (lane < 62) {
     const int v = (lane >> 1) - kHalfPatch;
     const int dmax = c_umax[v < 0 ? -v : v];
-    const uint8_t *row = pyr + foff + (size_t)(cy + v) * L.pitch + cx;
+    const uint8_t *row = unblurred + (size_t)(cy + v) * upitch + cx;
     int u0, u1;
     if (lane & 1) {
       u0 = 0;
@@ -451,16 +530,16 @@ __global__ void k_border_copy(const uint8_t *__restrict__ img, int w, int h, int
 
 // ------------------------------------------------------------------------------------------------
 // launchers (host)
-void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const FrameGeom &fg,
-                   int level, int nframes) {
+void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
+                   const FrameGeom &fg, int level, int nframes) {
   const LevelGeom &D = fg.lv[level];
   dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nframes), block(64, 4);
-  hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, d_fg, d_tab, level);
+  hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, d_fg, d_tab, s0, level);
 }
-void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, uint32_t *cand,
-                 int *cand_count, const FrameGeom &fg, int nframes) {
+void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
+                 uint32_t *cand, int *cand_count, const FrameGeom &fg, int nframes) {
   dim3 grid(fg.total_cells, nframes), block(256);
-  hipLaunchKernelGGL(k_fast_cells, grid, block, 0, s, pyr, d_fg, d_cells, cand, cand_count);
+  hipLaunchKernelGGL(k_fast_cells, grid, block, 0, s, pyr, d_fg, d_cells, s0, cand, cand_count);
 }
 void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, const int *cand_count,
                    uint16_t *node_of, uint32_t *sel, int *sel_count, const FrameGeom &fg, int maxQuota, int nframes) {
@@ -469,21 +548,21 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   dim3 grid(fg.nlevels, nframes), block(256);
   hipLaunchKernelGGL(k_octree, grid, block, lds, s, d_fg, cand, cand_count, node_of, sel, sel_count, cap);
 }
-void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGeom *d_fg, const BlurTile *d_tiles,
+void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                  const FrameGeom &fg, int nframes) {
-  dim3 grid(fg.total_blur_tiles, nframes), block(256);
-  hipLaunchKernelGGL(k_blur, grid, block, 0, s, pyr, blur, d_fg, d_tiles);
+  dim3 grid(fg.total_blur_blocks, nframes), block(256);
+  hipLaunchKernelGGL(k_blur, grid, block, 0, s, pyr, blur, d_fg, s0);
 }
 void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, const int *sel_count, int *flags,
                   int *slots, FrameHeader *hdr, int lap0, int lap1, int nframes) {
   hipLaunchKernelGGL(k_slots, dim3(nframes), dim3(256), 0, s, d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1);
 }
-void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg,
+void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                         const uint32_t *sel, const int *slots, const FrameHeader *hdr, const int8_t *pattern,
                         KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes) {
   dim3 grid((fg.out_cap + 3) / 4, nframes), block(256);
-  hipLaunchKernelGGL(k_orient_desc, grid, block, 0, s, pyr, blur, d_fg, sel, slots, hdr, pattern, kps, desc, counts,
-                     capacity);
+  hipLaunchKernelGGL(k_orient_desc, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
+                     counts, capacity);
 }
 void launch_border_copy(hipStream_t s, const uint8_t *img, int w, int h, int pitch, uint8_t *dst, int dpitch, int b) {
   dim3 grid((w + 2 * b + 255) / 256, h + 2 * b), block(256);

@@ -50,7 +50,9 @@ struct vsg_orb {
   FrameGeom *d_fg = nullptr;
   Short4 *d_tab = nullptr;
   CellDesc *d_cells = nullptr;
-  BlurTile *d_tiles = nullptr;
+  uint8_t *d_in = nullptr;  // level-0 staging for host images / unaligned device images, pitch in_pitch
+  int in_pitch = 0;
+  Src0 last_src0 = {nullptr, 0, 0};
   int8_t *d_pattern = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
   uint32_t *d_cand = nullptr, *d_sel = nullptr;
@@ -77,12 +79,13 @@ struct vsg_orb {
 };
 
 static void free_image_buffers(vsg_orb *h) {
-  hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_tiles);
+  hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in);
   hipFree(h->d_pyr), hipFree(h->d_blur), hipFree(h->d_cand), hipFree(h->d_sel), hipFree(h->d_nodeof);
   hipFree(h->d_counts2), hipFree(h->d_flags), hipFree(h->d_slots), hipFree(h->d_hdr);
   hipFree(h->d_kps), hipFree(h->d_desc), hipFree(h->d_out_counts);
   hipHostFree(h->h_in), hipHostFree(h->h_kps), hipHostFree(h->h_desc), hipHostFree(h->h_out_counts);
-  h->d_fg = nullptr, h->d_tab = nullptr, h->d_cells = nullptr, h->d_tiles = nullptr;
+  h->d_fg = nullptr, h->d_tab = nullptr, h->d_cells = nullptr, h->d_in = nullptr;
+  h->last_src0 = {nullptr, 0, 0};
   h->d_pyr = h->d_blur = nullptr;
   h->d_cand = h->d_sel = nullptr;
   h->d_nodeof = nullptr;
@@ -112,12 +115,10 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   HIP_TRY(hipMalloc(&h->d_fg, sizeof(FrameGeom)));
   HIP_TRY(hipMalloc(&h->d_tab, sizeof(Short4) * (h->G.resizeTab.size() + 1)));
   HIP_TRY(hipMalloc(&h->d_cells, sizeof(CellDesc) * h->G.cells.size()));
-  HIP_TRY(hipMalloc(&h->d_tiles, sizeof(BlurTile) * h->G.blurTiles.size()));
   HIP_TRY(hipMemcpy(h->d_fg, &fg, sizeof(FrameGeom), hipMemcpyHostToDevice));
   if (!h->G.resizeTab.empty())
     HIP_TRY(hipMemcpy(h->d_tab, h->G.resizeTab.data(), sizeof(Short4) * h->G.resizeTab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_cells, h->G.cells.data(), sizeof(CellDesc) * h->G.cells.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->d_tiles, h->G.blurTiles.data(), sizeof(BlurTile) * h->G.blurTiles.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&h->d_pyr, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMalloc(&h->d_blur, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMemset(h->d_pyr, 0, B * fg.pyr_frame_bytes));
@@ -132,7 +133,9 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   HIP_TRY(hipMalloc(&h->d_kps, B * fg.out_cap * sizeof(KeyPointPOD)));
   HIP_TRY(hipMalloc(&h->d_desc, B * fg.out_cap * 32));
   HIP_TRY(hipMalloc(&h->d_out_counts, B * 2 * sizeof(int)));
-  HIP_TRY(hipHostMalloc(&h->h_in, B * (size_t)rows * cols));
+  h->in_pitch = (cols + 3) & ~3;
+  HIP_TRY(hipMalloc(&h->d_in, B * (size_t)rows * h->in_pitch + 64));
+  HIP_TRY(hipHostMalloc(&h->h_in, B * (size_t)rows * h->in_pitch));
   HIP_TRY(hipHostMalloc(&h->h_kps, B * fg.out_cap * sizeof(KeyPointPOD)));
   HIP_TRY(hipHostMalloc(&h->h_desc, B * fg.out_cap * 32));
   HIP_TRY(hipHostMalloc(&h->h_out_counts, B * 2 * sizeof(int)));
@@ -154,33 +157,34 @@ static void harvest_timing(vsg_orb *h) {
 }
 
 // Enqueue the whole pipeline for `nframes` frames whose level-0 images already sit in d_pyr.
-static int enqueue_pipeline(vsg_orb *h, int nframes, int lap0, int lap1, KeyPointPOD *d_kps, uint8_t *d_desc,
-                            int *d_counts, int capacity, hipStream_t s) {
+static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, int lap1, KeyPointPOD *d_kps,
+                            uint8_t *d_desc, int *d_counts, int capacity, hipStream_t s) {
+  h->last_src0 = s0;
   const FrameGeom &fg = h->G.fg;
   const bool tm = h->timing;
   if (tm) harvest_timing(h);
   int *cand_count = h->d_counts2, *sel_count = h->d_counts2 + (size_t)h->max_batch * kMaxLevels;
   HIP_TRY(hipMemsetAsync(h->d_counts2, 0, 2 * (size_t)h->max_batch * kMaxLevels * sizeof(int), s));
   if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
-  for (int l = 1; l < fg.nlevels; l++) launch_resize(s, h->d_pyr, h->d_fg, h->d_tab, fg, l, nframes);
+  for (int l = 1; l < fg.nlevels; l++) launch_resize(s, h->d_pyr, h->d_fg, h->d_tab, s0, fg, l, nframes);
   HIP_TRY(hipEventRecord(h->ev_pyr, s));
   if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
   // blur branch
   HIP_TRY(hipStreamWaitEvent(h->s_blur, h->ev_pyr, 0));
   if (tm) HIP_TRY(hipEventRecord(h->ev[6], h->s_blur));
-  launch_blur(h->s_blur, h->d_pyr, h->d_blur, h->d_fg, h->d_tiles, fg, nframes);
+  launch_blur(h->s_blur, h->d_pyr, h->d_blur, h->d_fg, s0, fg, nframes);
   if (tm) HIP_TRY(hipEventRecord(h->ev[7], h->s_blur));
   HIP_TRY(hipEventRecord(h->ev_blur, h->s_blur));
   // detection chain
-  launch_fast(s, h->d_pyr, h->d_fg, h->d_cells, h->d_cand, cand_count, fg, nframes);
+  launch_fast(s, h->d_pyr, h->d_fg, h->d_cells, s0, h->d_cand, cand_count, fg, nframes);
   if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   launch_octree(s, h->d_fg, h->d_cand, cand_count, h->d_nodeof, h->d_sel, sel_count, fg, h->G.maxQuota, nframes);
   if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
   launch_slots(s, h->d_fg, h->d_sel, sel_count, h->d_flags, h->d_slots, h->d_hdr, lap0, lap1, nframes);
   if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
   HIP_TRY(hipStreamWaitEvent(s, h->ev_blur, 0));
-  launch_orient_desc(s, h->d_pyr, h->d_blur, h->d_fg, h->d_sel, h->d_slots, h->d_hdr, h->d_pattern, d_kps, d_desc,
-                     d_counts, capacity, fg, nframes);
+  launch_orient_desc(s, h->d_pyr, h->d_blur, h->d_fg, s0, h->d_sel, h->d_slots, h->d_hdr, h->d_pattern, d_kps,
+                     d_desc, d_counts, capacity, fg, nframes);
   if (tm) {
     HIP_TRY(hipEventRecord(h->ev[5], s));
     h->ev_pending = true;
@@ -269,6 +273,12 @@ int vsg_orb_get_tables(const vsg_orb *h, float *scale, float *inv_scale, float *
 
 int vsg_orb_set_blur_taps(vsg_orb *h, const uint16_t taps[7]) {
   if (!h || !taps) return VSG_ERR_INVALID;
+  int tsum = 0;
+  for (int k = 0; k < 7; k++) {
+    if (taps[k] > 255) return VSG_ERR_UNSUPPORTED;  // 8-bit taps: the kernel uses v_dot4_u32_u8
+    tsum += taps[k];
+  }
+  if (tsum > 257) return VSG_ERR_UNSUPPORTED;  // keeps the 8.8 row sums within 16 bits (no saturation anywhere)
   memcpy(h->taps, taps, sizeof(h->taps));
   if (h->rows) {  // refresh the device copy of the geometry
     for (int k = 0; k < 7; k++) h->G.fg.taps[k] = taps[k];
@@ -301,11 +311,16 @@ int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes,
     return VSG_ERR_CAPACITY;
   }
   hipStream_t s = stream ? (hipStream_t)stream : h->s_main;
-  // level 0 <- caller's images (2D copy into the pitched pyramid block of every frame)
-  for (int f = 0; f < nframes; f++)
-    HIP_TRY(hipMemcpy2DAsync(h->d_pyr + (size_t)f * fg.pyr_frame_bytes + fg.lv[0].img_off, fg.lv[0].pitch,
-                             d_gray + (size_t)f * frame_stride, stride, cols, rows, hipMemcpyDeviceToDevice, s));
-  return enqueue_pipeline(h, nframes, lap0, lap1, (KeyPointPOD *)d_kps, d_desc, d_counts, capacity, s);
+  Src0 s0;
+  if (((uintptr_t)d_gray & 3) == 0 && (stride & 3) == 0 && (frame_stride & 3) == 0) {
+    s0 = {d_gray, frame_stride, stride};  // level 0 is read in place: no ingest copy
+  } else {                                 // unaligned layout: restage (rare)
+    for (int f = 0; f < nframes; f++)
+      HIP_TRY(hipMemcpy2DAsync(h->d_in + (size_t)f * rows * h->in_pitch, h->in_pitch, d_gray + (size_t)f * frame_stride,
+                               stride, cols, rows, hipMemcpyDeviceToDevice, s));
+    s0 = {h->d_in, (size_t)rows * h->in_pitch, h->in_pitch};
+  }
+  return enqueue_pipeline(h, s0, nframes, lap0, lap1, (KeyPointPOD *)d_kps, d_desc, d_counts, capacity, s);
 }
 
 int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t frame_stride, int rows, int cols,
@@ -318,14 +333,18 @@ int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t f
   if (rc != VSG_OK) return rc;
   const FrameGeom &fg = h->G.fg;
   hipStream_t s = h->s_main;
+  const int ip = h->in_pitch;
   for (int f = 0; f < nframes; f++) {
-    uint8_t *dst = h->h_in + (size_t)f * rows * cols;
+    uint8_t *dst = h->h_in + (size_t)f * rows * ip;
     const uint8_t *src = gray + (size_t)f * frame_stride;
-    for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * cols, src + (size_t)y * stride, (size_t)cols);
-    HIP_TRY(hipMemcpy2DAsync(h->d_pyr + (size_t)f * fg.pyr_frame_bytes + fg.lv[0].img_off, fg.lv[0].pitch, dst, cols,
-                             cols, rows, hipMemcpyHostToDevice, s));
+    if (stride == ip)
+      memcpy(dst, src, (size_t)rows * ip);
+    else
+      for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * ip, src + (size_t)y * stride, (size_t)cols);
   }
-  rc = enqueue_pipeline(h, nframes, lap0, lap1, h->d_kps, h->d_desc, h->d_out_counts, fg.out_cap, s);
+  HIP_TRY(hipMemcpyAsync(h->d_in, h->h_in, (size_t)nframes * rows * ip, hipMemcpyHostToDevice, s));  // one DMA
+  const Src0 s0 = {h->d_in, (size_t)rows * ip, ip};
+  rc = enqueue_pipeline(h, s0, nframes, lap0, lap1, h->d_kps, h->d_desc, h->d_out_counts, fg.out_cap, s);
   if (rc != VSG_OK) return rc;
   HIP_TRY(hipMemcpyAsync(h->h_out_counts, h->d_out_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, s));
@@ -374,16 +393,22 @@ static int copy_level(vsg_orb *h, const uint8_t *base, int frame, int level, int
   const FrameGeom &fg = h->G.fg;
   const LevelGeom &L = fg.lv[level];
   const uint8_t *img = base + (size_t)frame * fg.pyr_frame_bytes + L.img_off;
+  int ipitch = L.pitch;
+  if (level == 0 && base == h->d_pyr) {  // level 0 lives in the caller's / staging buffer of the last call
+    if (!h->last_src0.base) return VSG_ERR_INVALID;
+    img = h->last_src0.base + (size_t)frame * h->last_src0.frame_stride;
+    ipitch = h->last_src0.pitch;
+  }
   HIP_TRY(hipStreamSynchronize(h->s_main));
   HIP_TRY(hipStreamSynchronize(h->s_blur));
   if (!with_border) {
-    HIP_TRY(hipMemcpy2D(dst, dst_stride, img, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy2D(dst, dst_stride, img, ipitch, L.w, L.h, hipMemcpyDeviceToHost));
     return VSG_OK;
   }
   const int b = kEdgeThreshold, bw = L.w + 2 * b, bh = L.h + 2 * b;
   uint8_t *tmp = nullptr;
   HIP_TRY(hipMalloc(&tmp, (size_t)bw * bh));
-  launch_border_copy(h->s_main, img, L.w, L.h, L.pitch, tmp, bw, b);
+  launch_border_copy(h->s_main, img, L.w, L.h, ipitch, tmp, bw, b);
   hipError_t e = hipStreamSynchronize(h->s_main);
   if (e == hipSuccess) e = hipMemcpy2D(dst, dst_stride, tmp, bw, bw, bh, hipMemcpyDeviceToHost);
   hipFree(tmp);
