@@ -11,6 +11,7 @@
 // All image arithmetic is integer; the float pieces live in vsg_math.h with explicit non-contracting ops.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "vsg_common.h"
 #include "vsg_geometry.h"
@@ -65,161 +66,204 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
 // ------------------------------------------------------------------------------------------------
 // FAST-9-16 ([OCV] fast.cpp FAST_t<16>, fast_score.cpp cornerScore<16>) on an LDS tile of row pitch kTileP.
 //   score = max over the 16 contiguous 9-arcs of min(+-(v - ring)) - 1;  corner-at-t <=> score >= t, and the
-//   score does not depend on t.  fast_quick() is a necessary condition on two opposing ring pairs (same idea as
-//   the tab[] pre-test of FAST_t); fast_score() is exact and returns 0 below `floor_t`.
+//   score does not depend on t.
 enum { kTileP = 84, kScoreP = 72 };
 
-__device__ __forceinline__ bool fast_quick(const uint8_t *c, int floor_t) {
-  const int P = kTileP;
-  const int v = c[0];
-  const int r0 = c[3 * P], r8 = c[-3 * P], r4 = c[3], r12 = c[-3];
-  const int lo = v - floor_t, hi = v + floor_t;
-  const bool dark = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo));
-  const bool bright = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi));
-  return dark | bright;
-}
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s16x2 pk_swap(s16x2 a) { return a.yx; }
 
+// Exact score with packed 16-bit min/max: lane pair P[k] = (d[k], d[k+8]) so one v_pk_min/max_i16 advances the
+// sliding 9-arc minimum/maximum of two opposite arcs at once.  Returns 0 below `floor_t`.
 __device__ __forceinline__ int fast_score(const uint8_t *c, int floor_t) {
   const int P = kTileP;
-  const int v = c[0];
-  const int r0 = c[3 * P], r8 = c[-3 * P], r4 = c[3], r12 = c[-3];
-  const int r2 = c[2 * P + 2], r10 = c[-2 * P - 2], r6 = c[-2 * P + 2], r14 = c[2 * P - 2];
-  const int lo = v - floor_t, hi = v + floor_t;
-  const bool dark = ((r0 < lo) | (r8 < lo)) & ((r4 < lo) | (r12 < lo)) & ((r2 < lo) | (r10 < lo)) & ((r6 < lo) | (r14 < lo));
-  const bool bright = ((r0 > hi) | (r8 > hi)) & ((r4 > hi) | (r12 > hi)) & ((r2 > hi) | (r10 > hi)) & ((r6 > hi) | (r14 > hi));
-  if (!(dark | bright)) return 0;
-  int d[16];
-  d[0] = v - r0;
-  d[1] = v - c[3 * P + 1];
-  d[2] = v - r2;
-  d[3] = v - c[P + 3];
-  d[4] = v - r4;
-  d[5] = v - c[-P + 3];
-  d[6] = v - r6;
-  d[7] = v - c[-3 * P + 1];
-  d[8] = v - r8;
-  d[9] = v - c[-3 * P - 1];
-  d[10] = v - r10;
-  d[11] = v - c[-P - 3];
-  d[12] = v - r12;
-  d[13] = v - c[P - 3];
-  d[14] = v - r14;
-  d[15] = v - c[3 * P - 1];
-  int mn2[16], mx2[16], mn4[16], mx4[16];
+  const short v = c[0];
+  s16x2 D[8];
+  D[0] = (s16x2){(short)(v - c[3 * P]), (short)(v - c[-3 * P])};
+  D[1] = (s16x2){(short)(v - c[3 * P + 1]), (short)(v - c[-3 * P - 1])};
+  D[2] = (s16x2){(short)(v - c[2 * P + 2]), (short)(v - c[-2 * P - 2])};
+  D[3] = (s16x2){(short)(v - c[P + 3]), (short)(v - c[-P - 3])};
+  D[4] = (s16x2){(short)(v - c[3]), (short)(v - c[-3])};
+  D[5] = (s16x2){(short)(v - c[-P + 3]), (short)(v - c[P - 3])};
+  D[6] = (s16x2){(short)(v - c[-2 * P + 2]), (short)(v - c[2 * P - 2])};
+  D[7] = (s16x2){(short)(v - c[-3 * P + 1]), (short)(v - c[3 * P - 1])};
+  // X[k] for k = 0..15 with X[k+8] = swap(X[k])
+#define DX(k) ((k) < 8 ? D[(k)] : pk_swap(D[(k)-8]))
+  s16x2 mn2[8], mx2[8], mn4[8], mx4[8], mn8[8], mx8[8];
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn2[k] = min(d[k], d[(k + 1) & 15]);
-    mx2[k] = max(d[k], d[(k + 1) & 15]);
+  for (int k = 0; k < 8; k++) {
+    mn2[k] = pk_min(D[k], DX(k + 1));
+    mx2[k] = pk_max(D[k], DX(k + 1));
   }
+#define M2N(k) ((k) < 8 ? mn2[(k)] : pk_swap(mn2[(k)-8]))
+#define M2X(k) ((k) < 8 ? mx2[(k)] : pk_swap(mx2[(k)-8]))
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    mn4[k] = min(mn2[k], mn2[(k + 2) & 15]);
-    mx4[k] = max(mx2[k], mx2[(k + 2) & 15]);
+  for (int k = 0; k < 8; k++) {
+    mn4[k] = pk_min(mn2[k], M2N(k + 2));
+    mx4[k] = pk_max(mx2[k], M2X(k + 2));
   }
-  int A = -256, B = 256;
+#define M4N(k) ((k) < 8 ? mn4[(k)] : pk_swap(mn4[(k)-8]))
+#define M4X(k) ((k) < 8 ? mx4[(k)] : pk_swap(mx4[(k)-8]))
+  s16x2 A = (s16x2){-256, -256}, B = (s16x2){256, 256};
 #pragma unroll
-  for (int k = 0; k < 16; k++) {
-    const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-    const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-    A = max(A, mn9);
-    B = min(B, mx9);
+  for (int k = 0; k < 8; k++) {
+    mn8[k] = pk_min(mn4[k], M4N(k + 4));
+    mx8[k] = pk_max(mx4[k], M4X(k + 4));
+    A = pk_max(A, pk_min(mn8[k], pk_swap(D[k])));  // arcs k..k+8 and k+8..k+16
+    B = pk_min(B, pk_max(mx8[k], pk_swap(D[k])));
   }
-  const int s = max(A, -B) - 1;
+#undef DX
+#undef M2N
+#undef M2X
+#undef M4N
+#undef M4X
+  const int a = max((int)A.x, (int)A.y), bb = min((int)B.x, (int)B.y);
+  const int s = max(a, -bb) - 1;
   return s >= floor_t ? s : 0;
 }
 
+// Necessary condition on two opposing ring pairs for 4 horizontally adjacent pixels held in packed dwords:
+// C = centres, U/Dn = rows -3/+3 (same columns), W/E = columns -3/+3 (same row).  Bit j of the result is set
+// if pixel j may be a corner at threshold t (same idea as the tab[] pre-test of FAST_t).
+__device__ __forceinline__ uint32_t fast_quick4(uint32_t C, uint32_t U, uint32_t Dn, uint32_t W, uint32_t E, int t) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int v = (C >> (8 * j)) & 255, u = (U >> (8 * j)) & 255, d = (Dn >> (8 * j)) & 255;
+    const int w = (W >> (8 * j)) & 255, e = (E >> (8 * j)) & 255;
+    const int lo = v - t, hi = v + t;
+    const bool dark = ((u < lo) | (d < lo)) & ((w < lo) | (e < lo));
+    const bool bright = ((u > hi) | (d > hi)) & ((w > hi) | (e > hi));
+    m |= (uint32_t)(dark | bright) << j;
+  }
+  return m;
+}
+
+// floor(i / d) for 0 <= i < 2^16 and 1 <= d <= 128 with inv = 1.0f / d: (i + 0.5) / d stays >= 0.5/d away from
+// every integer, far more than the float rounding error, so the truncation is exact (3 VALU ops, no v_rcp chain).
+__device__ __forceinline__ int div_small(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
+
 // One workgroup per FAST cell.  The cell's valid region (3 px inside the reference's sub-image) is staged in LDS
-// with aligned 32-bit loads; a cheap necessary test runs on every pixel and the few that pass are COMPACTED into an
-// LDS queue, so the exact (expensive) score and the non-max suppression run on dense wavefronts.  NMS only looks at
-// neighbours INSIDE the valid region (outside counts as 0, exactly like the zeroed row buffers of FAST_t); the cell
-// emits survivors >= iniTh if any, else survivors >= minTh.  Order is irrelevant (the octree ranks candidates).
+// with aligned 32-bit loads; a cheap necessary test runs on 4 pixels per thread from packed dwords and the pixels
+// that pass are COMPACTED into an LDS queue, so the exact score (packed 16-bit min/max) and the non-max suppression
+// run on dense wavefronts.  Like the reference the cell is first searched at iniThFAST and only if that yields
+// nothing at minThFAST (ORBextractor.cc:832-851); NMS only looks at neighbours INSIDE the valid region (outside
+// counts as 0, exactly like the zeroed row buffers of FAST_t).  Emission order is irrelevant (the octree ranks
+// candidates).
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                     const CellDesc *__restrict__ cells, Src0 s0,
-                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count) {
+                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count,
+                                                    int dbg) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[(kCellMax + 6) * kTileP];
   __shared__ __attribute__((aligned(16))) uint8_t score[(kCellMax + 2) * kScoreP];
   __shared__ uint16_t queue[kCellMax * kCellMax];
-  __shared__ int s_cnt[5];  // [0]=survivors>=iniTh [1]=survivors>=floor [2]=emit cursor [3]=global base [4]=queue length
+  __shared__ int s_cnt[4];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base
   const CellDesc cell = cells[blockIdx.x];
   const int frame = blockIdx.y;
   const LevelGeom &L = fg->lv[cell.level];
   const int vw = cell.x1 - cell.x0, vh = cell.y1 - cell.y0;
   if (vw <= 0 || vh <= 0) return;
-  const int iniTh = fg->iniTh, minTh = fg->minTh;
-  const int floor_t = min(iniTh, minTh);
   const int tid = threadIdx.x, lane = tid & 63;
   int pitch;
   const uint8_t *img = level_ptr(fg, s0, pyr, frame, cell.level, pitch);
-  // tile column 0 <-> image column ax (4-byte aligned); the valid region starts at tile column ox + 3
+  // tile column 0 <-> image column ax (4-byte aligned); valid-region column c sits at tile column c + 3 + ox
   const int ax = (cell.x0 - 3) & ~3, ox = (cell.x0 - 3) - ax;
   const int tdw = (ox + vw + 6 + 3) >> 2, th = vh + 6;  // dwords per tile row (<= 21)
+  const float inv_tdw = 1.0f / (float)tdw;
   for (int i = tid; i < tdw * th; i += 256) {
-    const int r = i / tdw, c = i - r * tdw;
+    const int r = div_small(i, inv_tdw), c = i - r * tdw;
     *(uint32_t *)&tile[r * kTileP + 4 * c] = *(const uint32_t *)(img + (size_t)(cell.y0 - 3 + r) * pitch + ax + 4 * c);
   }
-  for (int i = tid; i < (vh + 2) * (kScoreP / 4); i += 256) ((uint32_t *)score)[i] = 0;
-  if (tid < 5) s_cnt[tid] = 0;
-  __syncthreads();
-  // ---- phase 1: necessary test on every pixel, compaction of the passers
-  const int npx = vw * vh;
-  for (int i0 = 0; i0 < npx; i0 += 256) {
-    const int i = i0 + tid;
-    bool pass = false;
-    if (i < npx) {
-      const int r = i / vw, c = i - r * vw;
-      pass = fast_quick(&tile[(r + 3) * kTileP + (c + 3 + ox)], floor_t);
+  if (dbg == 1) return;
+  // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1
+  const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0;
+  const int ngroups = ng * vh;
+  const float inv_ng = 1.0f / (float)ng, inv_vw = 1.0f / (float)vw;
+  uint32_t keep = 0;
+  int nq = 0, thr = fg->iniTh;
+  for (int pass = 0; pass < 2; pass++) {
+    for (int i = tid; i < (vh + 2) * (kScoreP / 4); i += 256) ((uint32_t *)score)[i] = 0;
+    if (tid < 4) s_cnt[tid] = 0;
+    __syncthreads();
+    // ---- phase 1: necessary test, 4 pixels per thread, compaction of the passers
+    for (int i0 = 0; i0 < ngroups; i0 += 256) {
+      const int i = i0 + tid;
+      uint32_t m = 0;
+      int r = 0, cb = 0;
+      if (i < ngroups) {
+        r = div_small(i, inv_ng);
+        const int g = g0 + (i - r * ng);
+        const uint8_t *t = &tile[(r + 3) * kTileP + 4 * g];
+        const uint32_t C = *(const uint32_t *)t, Lf = *(const uint32_t *)(t - 4), Rt = *(const uint32_t *)(t + 4);
+        const uint32_t U = *(const uint32_t *)(t - 3 * kTileP), Dn = *(const uint32_t *)(t + 3 * kTileP);
+        m = fast_quick4(C, U, Dn, __builtin_amdgcn_alignbyte(C, Lf, 1), __builtin_amdgcn_alignbyte(Rt, C, 3), thr);
+        cb = 4 * g - 3 - ox;  // valid-region column of byte 0 of this group
+        // mask pixels outside [0, vw)
+        if (cb < 0) m &= 0xFu << (-cb);
+        if (cb + 4 > vw) m &= 0xFu >> (cb + 4 - vw);
+      }
+      // compaction: wave-level exclusive prefix of popcount(m) (0..4) from three ballots, one LDS atomic per wave
+      const int cnt = __popc(m);
+      const uint64_t b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+      if (b0 | b1 | b2) {
+        const uint64_t lt = (1ull << lane) - 1;
+        const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+        int pos = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_cnt[1], total);
+        pos += __shfl(base, 0);
+        const int pix = r * vw + cb;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if ((m >> j) & 1) queue[pos++] = (uint16_t)(pix + j);
+      }
     }
-    const uint64_t m = __ballot(pass);
-    if (m) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&s_cnt[4], __popcll(m));
-      base = __shfl(base, 0);
-      if (pass) queue[base + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)i;
+    __syncthreads();
+    nq = s_cnt[1];
+    if (dbg == 2) return;
+    // ---- phase 2: exact score of the queued pixels
+    for (int q = tid; q < nq; q += 256) {
+      const int i = queue[q];
+      const int r = div_small(i, inv_vw), c = i - r * vw;
+      const int s = fast_score(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr);
+      if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
     }
-  }
-  __syncthreads();
-  const int nq = s_cnt[4];
-  // ---- phase 2: exact score of the queued pixels
-  for (int q = tid; q < nq; q += 256) {
-    const int i = queue[q];
-    const int r = i / vw, c = i - r * vw;
-    const int s = fast_score(&tile[(r + 3) * kTileP + (c + 3 + ox)], floor_t);
-    if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
-  }
-  __syncthreads();
-  // ---- phase 3: non-max suppression inside the cell
-  uint32_t keep = 0;  // bit per loop iteration: queued pixel survives NMS
-  int it = 0;
-  for (int q = tid; q < nq; q += 256, it++) {
-    const int i = queue[q];
-    const int r = i / vw, c = i - r * vw;
-    const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
-    const int s = sp[0];
-    if (s == 0) continue;
-    const bool is_max = s > sp[-1] && s > sp[1] && s > sp[-kScoreP - 1] && s > sp[-kScoreP] && s > sp[-kScoreP + 1] &&
-                        s > sp[kScoreP - 1] && s > sp[kScoreP] && s > sp[kScoreP + 1];
-    if (is_max) {
-      keep |= 1u << it;
-      atomicAdd(&s_cnt[1], 1);
-      if (s >= iniTh) atomicAdd(&s_cnt[0], 1);
+    __syncthreads();
+    if (dbg == 3) return;
+    // ---- phase 3: non-max suppression inside the cell
+    keep = 0;  // bit per loop iteration: queued pixel survives NMS
+    int it = 0;
+    for (int q = tid; q < nq; q += 256, it++) {
+      const int i = queue[q];
+      const int r = div_small(i, inv_vw), c = i - r * vw;
+      const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
+      const int s = sp[0];
+      if (s == 0) continue;
+      const bool is_max = s > sp[-1] && s > sp[1] && s > sp[-kScoreP - 1] && s > sp[-kScoreP] && s > sp[-kScoreP + 1] &&
+                          s > sp[kScoreP - 1] && s > sp[kScoreP] && s > sp[kScoreP + 1];
+      if (is_max) {
+        keep |= 1u << it;
+        atomicAdd(&s_cnt[0], 1);
+      }
     }
+    __syncthreads();
+    if (s_cnt[0] > 0 || pass == 1 || fg->minTh >= thr) break;
+    thr = fg->minTh;  // vKeysCell.empty() -> retry with minThFAST (:848-851)
+    __syncthreads();
   }
-  __syncthreads();
-  const int nHi = s_cnt[0], nLo = s_cnt[1];
-  const int thr = nHi > 0 ? iniTh : minTh;  // vKeysCell.empty() -> retry with minThFAST (:848-851)
-  const int nEmit = nHi > 0 ? nHi : nLo;
+  const int nEmit = s_cnt[0];
   if (nEmit == 0) return;
   if (tid == 0) s_cnt[3] = atomicAdd(&cand_count[frame * kMaxLevels + cell.level], nEmit);
   __syncthreads();
   const int base = s_cnt[3];
   uint32_t *out = cand + (size_t)frame * fg->cand_frame + L.cand_off;
-  it = 0;
+  int it = 0;
   for (int q = tid; q < nq; q += 256, it++) {
     if (!(keep & (1u << it))) continue;
     const int i = queue[q];
-    const int r = i / vw, c = i - r * vw;
+    const int r = div_small(i, inv_vw), c = i - r * vw;
     const int s = score[(r + 1) * kScoreP + (c + 1)];
-    if (s < thr) continue;
     const int slot = base + atomicAdd(&s_cnt[2], 1);
     if (slot < L.cand_cap) out[slot] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
   }
@@ -314,7 +358,19 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   const LevelGeom &L = fg->lv[level];
   const int t = ((int)blockIdx.x - L.blur_block_base) * 256 + (int)threadIdx.x;
   if (t >= L.blur_nxg * L.blur_nys) return;
-  const int gx = t % L.blur_nxg, sy = t / L.blur_nxg;
+  // Interior column groups first, the three edge groups (which need per-byte REFLECT_101 loads) last, so that
+  // whole wavefronts take either the fast or the slow load path instead of every wave diverging at a row end.
+  const int nI = L.blur_nxg - 3, nInt = nI * L.blur_nys;
+  int gx, sy;
+  if (t < nInt) {
+    sy = t / nI;
+    gx = 1 + (t - sy * nI);
+  } else {
+    const int e = t - nInt;
+    sy = e / 3;
+    const int k = e - sy * 3;
+    gx = k == 0 ? 0 : L.blur_nxg - 3 + k;
+  }
   const int x0 = gx * 4, y0 = sy * kBlurStrip;
   const int w = L.w, h = L.h;
   int spitch;
@@ -329,32 +385,36 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   uint32_t win[7][4];
 #pragma unroll
   for (int turn = 0; turn < (kBlurStrip + 6) / 7; turn++) {
+    // issue the loads of the next 7 rows together (the kernel is latency-, not issue-bound), then consume them
+    uint32_t d0[7], d1[7], d2[7];
 #pragma unroll
     for (int s = 0; s < 7; s++) {
-      const int rr = turn * 7 + s;           // 0 .. kBlurStrip+5 : source row y0 - 3 + rr
-      const int ysrc = reflect101(y0 - 3 + rr, h);
+      const int ysrc = reflect101(y0 - 3 + turn * 7 + s, h);
       const uint8_t *row = img + (size_t)ysrc * spitch;
-      uint32_t d0, d1, d2;
       if (interior) {
-        d0 = *(const uint32_t *)(row + x0 - 4);
-        d1 = *(const uint32_t *)(row + x0);
-        d2 = *(const uint32_t *)(row + x0 + 4);
+        d0[s] = *(const uint32_t *)(row + x0 - 4);
+        d1[s] = *(const uint32_t *)(row + x0);
+        d2[s] = *(const uint32_t *)(row + x0 + 4);
       } else {
         uint32_t b[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) b[i] = row[reflect101(x0 - 4 + i, w)];
-        d0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-        d1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-        d2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+        d0[s] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        d1[s] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        d2[s] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
       }
+    }
+#pragma unroll
+    for (int s = 0; s < 7; s++) {
+      const int rr = turn * 7 + s;  // 0 .. kBlurStrip+5 : source row y0 - 3 + rr
       // pixel j: taps over bytes j+1 .. j+7 of {d0,d1,d2}
-      win[s][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), T0,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), T1, 0u, false), false);
-      win[s][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), T0,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), T1, 0u, false), false);
-      win[s][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), T0,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), T1, 0u, false), false);
-      win[s][3] = __builtin_amdgcn_udot4(d1, T0, __builtin_amdgcn_udot4(d2, T1, 0u, false), false);
+      win[s][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 1), T0,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 1), T1, 0u, false), false);
+      win[s][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 2), T0,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 2), T1, 0u, false), false);
+      win[s][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 3), T0,
+                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 3), T1, 0u, false), false);
+      win[s][3] = __builtin_amdgcn_udot4(d1[s], T0, __builtin_amdgcn_udot4(d2[s], T1, 0u, false), false);
       if (rr >= 6) {
         const int yo = y0 + rr - 6;
         if (yo < h) {
@@ -426,55 +486,75 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
 // One wavefront per keypoint: intensity-centroid angle on the un-blurred level, steered rBRIEF-256 on
 // the blurred level, keypoint record + 32 descriptor bytes written to the keypoint's output slot.
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+enum { kPatchR = 18, kPatchW = 2 * kPatchR + 1, kPatchP = 40 };  // rBRIEF patch radius / width / LDS row pitch
 
 __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                      const FrameGeom *__restrict__ fg, Src0 s0,
                                                      const uint32_t *__restrict__ sel,
                                                      const int *__restrict__ slots, const FrameHeader *__restrict__ hdr,
                                                      const int8_t *__restrict__ pattern, KeyPointPOD *__restrict__ kps,
-                                                     uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity) {
+                                                     uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity,
+                                                     int dbg) {
   __shared__ int8_t pat[1024];
+  __shared__ int s_hdr[kMaxLevels + 3];  // n, mono, level_start[0..kMaxLevels]
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchW * kPatchP];
+  __shared__ uint32_t s_disc[64];
   const int frame = blockIdx.y, tid = threadIdx.x;
   ((uint32_t *)pat)[tid] = ((const uint32_t *)pattern)[tid];
-  const FrameHeader &H = hdr[frame];
-  const int n = H.n;
-  if (blockIdx.x == 0 && tid == 0) {
-    counts[frame * 2 + 0] = n;
-    counts[frame * 2 + 1] = H.mono;
+  if (tid < kMaxLevels + 3) s_hdr[tid] = ((const int *)&hdr[frame])[tid];
+  if (tid < 64) {  // disc membership of the IC_Angle patch for lane layout (u = (tid & 31) - 15, rows 2*it + (tid >> 5) - 15)
+    const int u = (tid & 31) - kHalfPatch, au = u < 0 ? -u : u, hh = tid >> 5;
+    uint32_t m = 0;
+    for (int it = 0; it < 16; it++) {
+      const int v = 2 * it + hh - kHalfPatch, av = v < 0 ? -v : v;
+      const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * (av & 15))) & 15);  // umax[|v|], ORBextractor.cc:454-469
+      if (u <= kHalfPatch && v <= kHalfPatch && au <= um) m |= 1u << it;
+    }
+    s_disc[tid] = m;
   }
   __syncthreads();
+  const int n = s_hdr[0];
+  if (blockIdx.x == 0 && tid == 0) {
+    counts[frame * 2 + 0] = n;
+    counts[frame * 2 + 1] = s_hdr[1];
+  }
   const int lane = tid & 63;
-  const int g = blockIdx.x * 4 + (tid >> 6);
+  // everything derived from the keypoint index is wave-uniform: keep it in SGPRs so the per-level geometry comes
+  // through the scalar cache in one round trip instead of a chain of dependent vector loads
+  const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));
   if (g >= n) return;
+  const int *level_start = &s_hdr[2];
   int l = 0;
-  while (g >= H.level_start[l + 1]) l++;
+  while (g >= level_start[l + 1]) l++;
+  l = __builtin_amdgcn_readfirstlane(l);
   const LevelGeom &L = fg->lv[l];
-  const uint32_t c = sel[(size_t)frame * fg->sel_frame + L.sel_off + (g - H.level_start[l])];
+  const int gi = __builtin_amdgcn_readfirstlane(g - level_start[l]);
+  const uint32_t c = __builtin_amdgcn_readfirstlane(sel[(size_t)frame * fg->sel_frame + L.sel_off + gi]);
+  const int slot = slots[(size_t)frame * fg->out_cap + g];  // issued early, consumed at the very end
   const int cx = VSG_CAND_X(c) + kFastBorder, cy = VSG_CAND_Y(c) + kFastBorder;
   const size_t foff = (size_t)frame * fg->pyr_frame_bytes + L.img_off;
   int upitch;
   const uint8_t *unblurred = level_ptr(fg, s0, pyr, frame, l, upitch);
-  // ---- IC_Angle: lanes 0..61 = 31 rows x {left half, right half}
+  // ---- IC_Angle: lanes run ALONG image rows (lane & 31 = column u + 15, lane >> 5 = one of two rows per
+  // instruction), so each of the 16 byte-load instructions touches 2 rows instead of 31 cache lines.
   int m10 = 0, m01 = 0;
-  if (lane < 62) {
-    const int v = (lane >> 1) - kHalfPatch;
-    const int dmax = c_umax[v < 0 ? -v : v];
-    const uint8_t *row = unblurred + (size_t)(cy + v) * upitch + cx;
-    int u0, u1;
-    if (lane & 1) {
-      u0 = 0;
-      u1 = dmax;
-    } else {
-      u0 = -dmax;
-      u1 = -1;
+  {
+    const int u = (lane & 31) - kHalfPatch, h = lane >> 5;
+    // bit `it` of the lane's disc mask: pixel (u, v = 2*it + h - 15) lies inside the 749-px patch
+    const uint32_t disc = s_disc[lane];
+    const uint8_t *ptr = unblurred + (ptrdiff_t)(cy + h - kHalfPatch) * upitch + cx + (u > kHalfPatch ? 0 : u);
+    const ptrdiff_t step2 = 2 * (ptrdiff_t)upitch;
+    int sum_u = 0;
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      // row v = 16 (h = 1, it = 15) is masked; read row 15 again so the address stays inside the image
+      const int pv = (it == 15) ? (int)ptr[-(ptrdiff_t)h * upitch] : (int)ptr[0];
+      ptr += step2;
+      const int p = ((disc >> it) & 1) ? pv : 0;
+      sum_u += p;
+      m01 += (2 * it + h - kHalfPatch) * p;
     }
-    int sum = 0;
-    for (int u = u0; u <= u1; u++) {
-      const int p = row[u];
-      m10 += u * p;
-      sum += p;
-    }
-    m01 = v * sum;
+    m10 = u * sum_u;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -483,19 +563,50 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   float a, b;
-  brief_rotation(angle, &a, &b);
-  // ---- descriptor: lane handles tests lane, lane+64, lane+128, lane+192
-  const uint8_t *center = blur + foff + (size_t)cy * L.pitch + cx;
-  const int pitch = L.pitch;
-  const int slot = slots[(size_t)frame * fg->out_cap + g];
+  if (dbg == 1) {
+    a = angle * 0.001f, b = 1.0f - a;  // ablation: no sincos
+  } else
+    brief_rotation(angle, &a, &b);
+  if (dbg == 2) {  // ablation: no descriptor
+    if (lane == 0 && slot < capacity) kps[(size_t)frame * capacity + slot].angle = a + b;
+    return;
+  }
+  // ---- descriptor.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38), so the 37x37 blurred
+  // patch is staged in LDS with row-major (coalesced) byte loads; the 8 samples per lane are then LDS reads.
+  uint8_t *patch = &s_patch[(tid >> 6) * (kPatchW * kPatchP)];
+  {
+    // 37 rows x 10 (unaligned) dwords; gfx950 global loads accept any byte alignment
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+    const uint8_t *corner = blur + foff + (size_t)(cy - kPatchR) * L.pitch + (cx - kPatchR);
+    const int pitch = L.pitch;
+    constexpr int kDw = kPatchP / 4, kN = kPatchW * kDw, kIt = (kN + 63) / 64;
+    uint32_t pv[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; it++) {
+      int i = it * 64 + lane;
+      i = i < kN ? i : kN - 1;
+      const int r = i / kDw, cc = i - r * kDw;
+      pv[it] = *(const u32_unaligned *)(corner + r * pitch + 4 * cc);
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; it++) {
+      int i = it * 64 + lane;
+      i = i < kN ? i : kN - 1;
+      *(uint32_t *)(patch + 4 * i) = pv[it];  // r * kPatchP + 4 * cc == 4 * i
+    }
+  }
+  // the patch is private to this wavefront: LDS writes complete in order before the reads below
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint8_t *center = patch + kPatchR * kPatchP + kPatchR;
   uint64_t word = 0;
 #pragma unroll
-  for (int r = 0; r < 4; r++) {
+  for (int r = 0; r < 4; r++) {  // lane handles tests lane, lane+64, lane+128, lane+192
     const int k = r * 64 + lane;
     int dx0, dy0, dx1, dy1;
     brief_offset(pat[4 * k + 0], pat[4 * k + 1], a, b, &dx0, &dy0);
     brief_offset(pat[4 * k + 2], pat[4 * k + 3], a, b, &dx1, &dy1);
-    const int t0 = center[dy0 * pitch + dx0], t1 = center[dy1 * pitch + dx1];
+    const int t0 = center[dy0 * kPatchP + dx0], t1 = center[dy1 * kPatchP + dx1];
     const uint64_t m = __ballot(t0 < t1);
     if (lane == r) word = m;
   }
@@ -539,7 +650,8 @@ void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sho
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
                  uint32_t *cand, int *cand_count, const FrameGeom &fg, int nframes) {
   dim3 grid(fg.total_cells, nframes), block(256);
-  hipLaunchKernelGGL(k_fast_cells, grid, block, 0, s, pyr, d_fg, d_cells, s0, cand, cand_count);
+  static const int dbg = getenv("VSG_FAST_DBG") ? atoi(getenv("VSG_FAST_DBG")) : 0;
+  hipLaunchKernelGGL(k_fast_cells, grid, block, 0, s, pyr, d_fg, d_cells, s0, cand, cand_count, dbg);
 }
 void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, const int *cand_count,
                    uint16_t *node_of, uint32_t *sel, int *sel_count, const FrameGeom &fg, int maxQuota, int nframes) {
@@ -561,8 +673,9 @@ void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, 
                         const uint32_t *sel, const int *slots, const FrameHeader *hdr, const int8_t *pattern,
                         KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes) {
   dim3 grid((fg.out_cap + 3) / 4, nframes), block(256);
+  static const int dbg = getenv("VSG_ORIENT_DBG") ? atoi(getenv("VSG_ORIENT_DBG")) : 0;
   hipLaunchKernelGGL(k_orient_desc, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
-                     counts, capacity);
+                     counts, capacity, dbg);
 }
 void launch_border_copy(hipStream_t s, const uint8_t *img, int w, int h, int pitch, uint8_t *dst, int dpitch, int b) {
   dim3 grid((w + 2 * b + 255) / 256, h + 2 * b), block(256);

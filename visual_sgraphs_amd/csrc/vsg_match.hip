@@ -68,8 +68,9 @@ __global__ void k_hamming_pairs(const uint8_t *a, const uint8_t *b, const int *i
   dist[i] = hamming256(a0, a1, b0, b1);
 }
 
-// ---- brute-force best / second best: thread = one row of A, B streamed through LDS in 256-row tiles.
-// The sequential strict-'<' scan of the reference is reproduced literally per thread.
+// ---- brute-force best / second best: 4 lanes share one row of A and scan interleaved quarters of B, which is
+// streamed through LDS in 256-row tiles.  Packed keys (dist << 20 | index) keep the reference's strict-'<' scan
+// semantics: the smallest key is the first minimum, the second smallest is "bestDist2".
 __global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, const uint8_t *b_base, size_t block_stride,
                                                      const int *counts_a, const int *counts_b, int count_stride,
                                                      int fixed_na, int fixed_nb, int max_rows, int *best, int *second,
@@ -79,11 +80,11 @@ __global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, cons
   const int na = counts_a ? min(counts_a[blk * count_stride], max_rows) : fixed_na;
   const int nb = counts_b ? min(counts_b[blk * count_stride], max_rows) : fixed_nb;
   const uint8_t *A = a_base + (size_t)blk * block_stride, *B = b_base + (size_t)blk * block_stride;
-  const int row = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= na) return;
+  if (blockIdx.x * 64 >= na) return;
+  const int row = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
   uint4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
   if (row < na) load_desc(A, row, a0, a1);
-  int bestDist1 = 256, bestIdx = -1, bestDist2 = 256;
+  uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
   for (int t0 = 0; t0 < nb; t0 += 256) {
     const int nt = min(256, nb - t0);
     __syncthreads();
@@ -94,22 +95,26 @@ __global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, cons
       tile[threadIdx.x * 2 + 1] = hi;
     }
     __syncthreads();
-    for (int j = 0; j < nt; j++) {
-      const int dist = hamming256(a0, a1, tile[2 * j], tile[2 * j + 1]);
-      if (dist < bestDist1) {
-        bestDist2 = bestDist1;
-        bestDist1 = dist;
-        bestIdx = t0 + j;
-      } else if (dist < bestDist2) {
-        bestDist2 = dist;
+    for (int j = sub; j < nt; j += 4) {
+      const uint32_t key = ((uint32_t)hamming256(a0, a1, tile[2 * j], tile[2 * j + 1]) << 20) | (uint32_t)(t0 + j);
+      if (key < k1) {
+        k2 = k1;
+        k1 = key;
+      } else {
+        k2 = min(k2, key);
       }
     }
   }
-  if (row < na) {
+#pragma unroll
+  for (int d = 1; d <= 2; d <<= 1) {
+    const uint32_t o1 = __shfl_xor(k1, d), o2 = __shfl_xor(k2, d);
+    merge2(k1, k2, o1, o2);
+  }
+  if (row < na && sub == 0) {
     const size_t o = (size_t)blk * max_rows + row;
-    best[o] = bestDist1;
-    second[o] = bestDist2;
-    argbest[o] = bestIdx;
+    best[o] = (int)(k1 >> 20);
+    second[o] = (int)(k2 >> 20);
+    argbest[o] = k1 == KEY_NONE ? -1 : (int)(k1 & 0xFFFFF);
   }
 }
 
@@ -371,7 +376,7 @@ int vsg_hamming_block_best2_device(int device, const uint8_t *d_a, const uint8_t
   if (!d_a || !d_b || !d_best || !d_second || !d_argbest || nblocks < 1 || max_rows < 1) return VSG_ERR_INVALID;
   int rc = use_device(device);
   if (rc != VSG_OK) return rc;
-  dim3 grid((max_rows + 255) / 256, nblocks);
+  dim3 grid((max_rows + 63) / 64, nblocks);
   hipLaunchKernelGGL(k_block_best2, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes, d_counts_a,
                      d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
   M_TRY(hipGetLastError());
@@ -390,7 +395,7 @@ int vsg_hamming_block_best2(int device, const uint8_t *a, int na, const uint8_t 
   M_TRY(d1.alloc((size_t)na * 4));
   M_TRY(d2.alloc((size_t)na * 4));
   M_TRY(d3.alloc((size_t)na * 4));
-  hipLaunchKernelGGL(k_block_best2, dim3((na + 255) / 256, 1), dim3(256), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(),
+  hipLaunchKernelGGL(k_block_best2, dim3((na + 63) / 64, 1), dim3(256), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(),
                      (size_t)0, (const int *)nullptr, (const int *)nullptr, 0, na, nb, na, d1.as<int>(), d2.as<int>(),
                      d3.as<int>());
   M_TRY(hipMemcpy(best, d1.p, (size_t)na * 4, hipMemcpyDeviceToHost));

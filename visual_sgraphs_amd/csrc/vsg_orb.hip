@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -37,7 +38,7 @@ static const int8_t kPattern[1024] = {
 
 static_assert(sizeof(KeyPointPOD) == 28 && sizeof(vsg_keypoint) == 28, "cv::KeyPoint layout");
 
-enum { kStages = 7, kEv = 10 };
+enum { kStages = 7, kEv = 10, kMaxSub = 8 };
 
 struct vsg_orb {
   ExtractorTables T;
@@ -69,7 +70,11 @@ struct vsg_orb {
   uint8_t *h_desc = nullptr;
   int *h_out_counts = nullptr;
   hipStream_t s_main = nullptr, s_blur = nullptr;
-  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+  hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_fork = nullptr;
+  // sub-batch pipelining
+  int nsub = 1;
+  hipStream_t sub_s[kMaxSub] = {}, sub_b[kMaxSub] = {};
+  hipEvent_t sub_ev_pyr[kMaxSub] = {}, sub_ev_blur[kMaxSub] = {}, sub_ev_done[kMaxSub] = {};
   // timing
   bool timing = false;
   hipEvent_t ev[kEv] = {};
@@ -156,38 +161,74 @@ static void harvest_timing(vsg_orb *h) {
   h->acc_n++;
 }
 
-// Enqueue the whole pipeline for `nframes` frames whose level-0 images already sit in d_pyr.
+// Enqueue the stage chain for frames [f0, f0 + nf) on stream `s` (blur on `sb`, joined before orient+desc).
+// Every buffer is frame-strided, so a sub-batch is just offset base pointers.
+static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, int lap1, KeyPointPOD *d_kps,
+                         uint8_t *d_desc, int *d_counts, int capacity, hipStream_t s, hipStream_t sb,
+                         hipEvent_t ev_pyr, hipEvent_t ev_blur, bool tm) {
+  const FrameGeom &fg = h->G.fg;
+  const size_t F = (size_t)f0;
+  const Src0 s0 = {src.base + F * src.frame_stride, src.frame_stride, src.pitch};
+  uint8_t *pyr = h->d_pyr + F * fg.pyr_frame_bytes, *blur = h->d_blur + F * fg.pyr_frame_bytes;
+  uint32_t *cand = h->d_cand + F * fg.cand_frame, *sel = h->d_sel + F * fg.sel_frame;
+  uint16_t *nodeof = h->d_nodeof + F * fg.cand_frame;
+  int *cand_count = h->d_counts2 + F * kMaxLevels;
+  int *sel_count = h->d_counts2 + ((size_t)h->max_batch + F) * kMaxLevels;
+  int *flags = h->d_flags + F * fg.out_cap, *slots = h->d_slots + F * fg.out_cap;
+  FrameHeader *hdr = h->d_hdr + F;
+  if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
+  for (int l = 1; l < fg.nlevels; l++) launch_resize(s, pyr, h->d_fg, h->d_tab, s0, fg, l, nf);
+  HIP_TRY(hipEventRecord(ev_pyr, s));
+  if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
+  HIP_TRY(hipStreamWaitEvent(sb, ev_pyr, 0));
+  if (tm) HIP_TRY(hipEventRecord(h->ev[6], sb));
+  launch_blur(sb, pyr, blur, h->d_fg, s0, fg, nf);
+  if (tm) HIP_TRY(hipEventRecord(h->ev[7], sb));
+  HIP_TRY(hipEventRecord(ev_blur, sb));
+  launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, fg, nf);
+  if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
+  launch_octree(s, h->d_fg, cand, cand_count, nodeof, sel, sel_count, fg, h->G.maxQuota, nf);
+  if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
+  launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
+  if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
+  HIP_TRY(hipStreamWaitEvent(s, ev_blur, 0));
+  launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, slots, hdr, h->d_pattern, d_kps + F * capacity,
+                     d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf);
+  if (tm) HIP_TRY(hipEventRecord(h->ev[5], s));
+  return VSG_OK;
+}
+
+// Enqueue the whole pipeline for `nframes` frames whose level-0 images are described by `s0`.
+// The batch is cut into `h->nsub` sub-batches that run on their own stream pairs: the latency-bound stages of
+// one sub-batch (octree, orient+desc, the small pyramid levels) then overlap the throughput-bound stages of
+// another (FAST, blur).  VSG_NO_OVERLAP=1 serialises everything on `s` (used to time kernels in isolation).
 static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, int lap1, KeyPointPOD *d_kps,
                             uint8_t *d_desc, int *d_counts, int capacity, hipStream_t s) {
   h->last_src0 = s0;
-  const FrameGeom &fg = h->G.fg;
-  const bool tm = h->timing;
+  static const bool no_overlap = getenv("VSG_NO_OVERLAP") != nullptr;
+  int nsub = no_overlap ? 1 : h->nsub;
+  if (nsub > nframes) nsub = nframes;
+  const bool tm = h->timing && nsub == 1;
   if (tm) harvest_timing(h);
-  int *cand_count = h->d_counts2, *sel_count = h->d_counts2 + (size_t)h->max_batch * kMaxLevels;
   HIP_TRY(hipMemsetAsync(h->d_counts2, 0, 2 * (size_t)h->max_batch * kMaxLevels * sizeof(int), s));
-  if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
-  for (int l = 1; l < fg.nlevels; l++) launch_resize(s, h->d_pyr, h->d_fg, h->d_tab, s0, fg, l, nframes);
-  HIP_TRY(hipEventRecord(h->ev_pyr, s));
-  if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
-  // blur branch
-  HIP_TRY(hipStreamWaitEvent(h->s_blur, h->ev_pyr, 0));
-  if (tm) HIP_TRY(hipEventRecord(h->ev[6], h->s_blur));
-  launch_blur(h->s_blur, h->d_pyr, h->d_blur, h->d_fg, s0, fg, nframes);
-  if (tm) HIP_TRY(hipEventRecord(h->ev[7], h->s_blur));
-  HIP_TRY(hipEventRecord(h->ev_blur, h->s_blur));
-  // detection chain
-  launch_fast(s, h->d_pyr, h->d_fg, h->d_cells, s0, h->d_cand, cand_count, fg, nframes);
-  if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
-  launch_octree(s, h->d_fg, h->d_cand, cand_count, h->d_nodeof, h->d_sel, sel_count, fg, h->G.maxQuota, nframes);
-  if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
-  launch_slots(s, h->d_fg, h->d_sel, sel_count, h->d_flags, h->d_slots, h->d_hdr, lap0, lap1, nframes);
-  if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
-  HIP_TRY(hipStreamWaitEvent(s, h->ev_blur, 0));
-  launch_orient_desc(s, h->d_pyr, h->d_blur, h->d_fg, s0, h->d_sel, h->d_slots, h->d_hdr, h->d_pattern, d_kps,
-                     d_desc, d_counts, capacity, fg, nframes);
-  if (tm) {
-    HIP_TRY(hipEventRecord(h->ev[5], s));
-    h->ev_pending = true;
+  if (nsub == 1) {
+    int rc = enqueue_range(h, s0, 0, nframes, lap0, lap1, d_kps, d_desc, d_counts, capacity, s,
+                           no_overlap ? s : h->s_blur, h->ev_pyr, h->ev_blur, tm);
+    if (rc != VSG_OK) return rc;
+    if (tm) h->ev_pending = true;
+  } else {
+    HIP_TRY(hipEventRecord(h->ev_fork, s));
+    const int per = (nframes + nsub - 1) / nsub;
+    for (int j = 0; j < nsub; j++) {
+      const int f0 = j * per, nf = nframes - f0 < per ? nframes - f0 : per;
+      if (nf <= 0) break;
+      HIP_TRY(hipStreamWaitEvent(h->sub_s[j], h->ev_fork, 0));
+      int rc = enqueue_range(h, s0, f0, nf, lap0, lap1, d_kps, d_desc, d_counts, capacity, h->sub_s[j], h->sub_b[j],
+                             h->sub_ev_pyr[j], h->sub_ev_blur[j], false);
+      if (rc != VSG_OK) return rc;
+      HIP_TRY(hipEventRecord(h->sub_ev_done[j], h->sub_s[j]));
+      HIP_TRY(hipStreamWaitEvent(s, h->sub_ev_done[j], 0));
+    }
   }
   HIP_TRY(hipGetLastError());
   h->last_frames = nframes;
@@ -236,6 +277,19 @@ int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fa
     return VSG_ERR_NO_DEVICE;
   }
   for (int i = 0; i < kEv; i++) hipEventCreate(&h->ev[i]);
+  hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  for (int j = 0; j < kMaxSub; j++) {
+    hipStreamCreateWithFlags(&h->sub_s[j], hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&h->sub_b[j], hipStreamNonBlocking);
+    hipEventCreateWithFlags(&h->sub_ev_pyr[j], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->sub_ev_blur[j], hipEventDisableTiming);
+    hipEventCreateWithFlags(&h->sub_ev_done[j], hipEventDisableTiming);
+  }
+  {
+    const char *e = getenv("VSG_SUBBATCH");
+    int k = e ? atoi(e) : 1;
+    h->nsub = k < 1 ? 1 : k > kMaxSub ? kMaxSub : k;
+  }
   *out = h;
   return VSG_OK;
 }
@@ -249,6 +303,14 @@ void vsg_orb_destroy(vsg_orb *h) {
   hipFree(h->d_pattern);
   for (int i = 0; i < kEv; i++)
     if (h->ev[i]) hipEventDestroy(h->ev[i]);
+  for (int j = 0; j < kMaxSub; j++) {
+    if (h->sub_s[j]) hipStreamSynchronize(h->sub_s[j]), hipStreamDestroy(h->sub_s[j]);
+    if (h->sub_b[j]) hipStreamSynchronize(h->sub_b[j]), hipStreamDestroy(h->sub_b[j]);
+    if (h->sub_ev_pyr[j]) hipEventDestroy(h->sub_ev_pyr[j]);
+    if (h->sub_ev_blur[j]) hipEventDestroy(h->sub_ev_blur[j]);
+    if (h->sub_ev_done[j]) hipEventDestroy(h->sub_ev_done[j]);
+  }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_pyr) hipEventDestroy(h->ev_pyr);
   if (h->ev_blur) hipEventDestroy(h->ev_blur);
   if (h->s_main) hipStreamDestroy(h->s_main);
