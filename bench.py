@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of ORB extract+match on MI355X (BASELINE.json metric, config C2).
 
-One STEP = one pass of the hot path over one batch of `--batch` synthetic 640x480 gray frames that are
+One STEP = one pass of the hot path over one batch of `--batch` (default 256) synthetic 640x480 gray frames that are
 already resident in HBM: ORBextractor::operator() for every frame (pyramid, per-cell FAST, octree,
 orientation, 7x7 blur, rBRIEF-256; nFeatures=1000, 8 levels) + the brute-force Hamming best/second-best
 match of every frame against its predecessor (the inner search of ORBmatcher::SearchByBoW with one node).
@@ -52,35 +52,28 @@ def algorithmic_bytes(ex, n_kp):
     return stages, sum(stages.values())
 
 
+def effective_cores():
+    """Host threads this process may really use: min(affinity, cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(w, h, nfeatures, frames, budget_s, threads):
-    """Time the CPU oracle (kind 'port') on `threads` host threads for about budget_s seconds."""
+    """Time the CPU oracle (kind 'port') on `threads` native host threads for about budget_s seconds."""
     import oracle_lib as ol
-    from concurrent.futures import ThreadPoolExecutor
-    ol.lib()
-
-    def worker(tid):
-        e = ol.OracleExtractor(nfeatures, 1.2, 8, 20, 7)
-        n = 0
-        t_end = time.perf_counter() + budget_s
-        i = tid
-        prev = None
-        while time.perf_counter() < t_end:
-            _, kps, desc = e(frames[i % len(frames)])
-            if prev is not None:
-                ol.block_best2(desc, prev)
-            prev = desc
-            n += 1
-            i += threads
-        return n
-
-    t0 = time.perf_counter()
-    if threads == 1:
-        total = worker(0)
-    else:
-        with ThreadPoolExecutor(threads) as pool:
-            total = sum(pool.map(worker, range(threads)))
-    dt = time.perf_counter() - t0
-    return total / dt, total
+    return ol.bench_throughput(np.stack(frames), nfeatures, threads, budget_s, do_match=True)
 
 
 def main():
@@ -88,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -175,7 +168,19 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    stage_ms = ex.timing_ms() if not args.no_stage_timing else {}
+    stage_ms_timed = ex.timing_ms() if not args.no_stage_timing else {}
+    # Per-kernel durations for the roofline: the same K steps once more with every kernel on ONE stream, so a
+    # kernel's HIP-event span is its own duration (in the timed region the blur runs beside FAST/octree and the
+    # spans stretch each other).  Not part of `value`.
+    stage_ms = {}
+    if not args.no_stage_timing:
+        ex.set_serialize(True)
+        ex.enable_timing(True)
+        for _ in range(K):
+            step()
+        barrier()
+        stage_ms = ex.timing_ms()
+        ex.set_serialize(False)
 
     # parity gate on this rank: first and last frame of the batch vs the CPU oracle, bit for bit
     counts = d_counts.cpu().numpy()
@@ -208,15 +213,25 @@ def main():
     fps = total_frames / dt
     stages, bytes_per_frame = algorithmic_bytes(ex, n_kp)
     roofline = None
-    if stage_ms:
-        timed = {k: stage_ms[k] for k in ("pyramid", "fast", "blur", "orient_desc", "octree") if stage_ms.get(k, 0) > 0}
+    timed = {k: stage_ms[k] for k in ("pyramid", "fast", "blur", "orient_desc", "octree") if stage_ms.get(k, 0) > 0}
+    if timed:
         dom = max(timed, key=timed.get)
         dom_bytes = stages.get(dom, 0) * B  # algorithmic bytes one launch (batch of B frames) moves
         ach = dom_bytes / (timed[dom] * 1e-3) / 1e9 if timed[dom] > 0 else 0.0
+        traffic = None
+        try:  # PMC-derived HBM bytes per launch of that kernel, collected offline (profiles/README.md)
+            tr = json.load(open(ROOT / "profiles" / "traffic_r01.json")).get(f"{args.workload}/{B}", {}).get(dom)
+            if tr:
+                traffic = tr["fetch_bytes"] + tr["write_bytes"]
+        except (OSError, ValueError):
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "launch_ms": round(timed[dom], 4), "bytes_per_launch": int(dom_bytes),
+                    "timing": "HIP events per kernel, serialized pass of the same steps (stage_ms); "
+                              "stage_ms_timed_region = spans inside the timed region (blur overlapped)",
                     "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                    "stage_ms_timed_region": {k: round(v, 4) for k, v in stage_ms_timed.items()},
                     "pipeline_achieved_GBs": round(bytes_per_frame * fps / world / 1e9, 2),
                     "bytes_per_frame": int(bytes_per_frame)}
 
@@ -228,10 +243,12 @@ def main():
         cpu = {"value": round(v1, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": f"{n1} frames of the same {W}x{H}/{nfeat} workload, extract + brute-force match, "
                          f"{args.cpu_seconds:.0f} s, CPU oracle (port of the reference algorithm)"}
-        ncores = os.cpu_count() or 1
+        ncores = effective_cores()  # the box advertises 256 hardware threads but the cgroup quota is what we get
         va, na = cpu_baseline(W, H, nfeat, sample, args.cpu_seconds, ncores)
         extra["cpu_baseline_all_cores"] = {"value": round(va, 2), "unit": "frames/s", "cores": ncores, "kind": "port",
-                                           "sample": f"{na} frames, one independent extractor per host thread"}
+                                           "sample": f"{na} frames in {args.cpu_seconds:.0f} s, one independent "
+                                                     "extractor per host thread (native std::thread); cores = "
+                                                     f"min(affinity, cgroup cpu quota) of {os.cpu_count()} hw threads"}
 
     out = {
         "metric": "frames/sec ORB extract+match @640x480, 1000 feats; bit-exact vs CPU",

@@ -105,6 +105,9 @@ int vsg_orb_copy_selected(vsg_orb *h, int frame, int level, uint32_t *dst, int c
 /* Average device time per stage of the last N timed calls (HIP events on the handle's streams).
  * names: "pyramid","fast","octree","blur","slots","orient_desc","total".  Returns number of stages. */
 int vsg_orb_enable_timing(vsg_orb *h, int enable);
+/* serialize != 0: enqueue every kernel on one stream (no blur overlap), so that stage timings and rocprof kernel
+ * durations are free of interference from concurrent kernels.  Results are identical either way. */
+int vsg_orb_set_serialize(vsg_orb *h, int serialize);
 int vsg_orb_get_timing(vsg_orb *h, float *ms_out, int cap);
 
 /* ---- ORBmatcher (flattened POD views; pointer-graph walking and geometry stay in the C++ adaptor) ---- */

@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <list>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -885,6 +888,40 @@ float or_ic_angle(const uint8_t *img, int stride, int cx, int cy) {
 
 void or_orb_descriptor(const uint8_t *blurred, int stride, int cx, int cy, float angleDeg, uint8_t desc[32]) {
   computeOrbDescriptor(angleDeg, blurred + (size_t)cy * stride + cx, stride, kBitPattern31, desc);
+}
+
+double or_bench_throughput(const uint8_t *frames, int nframes, int rows, int cols, int nfeatures, float scaleFactor,
+                           int nlevels, int iniThFAST, int minThFAST, int nthreads, double seconds, int do_match,
+                           long *frames_done) {
+  if (nthreads < 1) nthreads = 1;
+  std::atomic<long> total(0);
+  const auto t0 = std::chrono::steady_clock::now();
+  auto elapsed = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  auto worker = [&](int tid) {
+    OrExtractor *e = or_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
+    const int cap = nfeatures + 3 * nlevels + 64;
+    std::vector<OrKeyPoint> kps(cap);
+    std::vector<uint8_t> desc((size_t)cap * 32), prev((size_t)cap * 32);
+    std::vector<int> best(cap), second(cap), arg(cap);
+    int nprev = 0;
+    long done = 0;
+    for (int i = tid; elapsed() < seconds; i += nthreads) {
+      int n = 0;
+      or_extract(e, frames + (size_t)(i % nframes) * rows * cols, rows, cols, cols, 0, 0, kps.data(), desc.data(), cap, &n);
+      if (do_match && nprev > 0 && n > 0) or_block_best2(desc.data(), n, prev.data(), nprev, best.data(), second.data(), arg.data());
+      prev.swap(desc);
+      nprev = n;
+      done++;
+    }
+    total += done;
+    or_destroy(e);
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+  for (auto &t : th) t.join();
+  const double dt = elapsed();
+  if (frames_done) *frames_done = total.load();
+  return (double)total.load() / dt;
 }
 
 }  // extern "C"

@@ -84,6 +84,14 @@ float or_ic_angle(const uint8_t *img, int stride, int cx, int cy);
 /* computeOrbDescriptor (ORBextractor.cc:103-149) */
 void or_orb_descriptor(const uint8_t *blurred, int stride, int cx, int cy, float angleDeg, uint8_t desc[32]);
 
+/* ---- CPU baseline (bench.py cpu_baseline leg): `nthreads` independent extractors, each on its own host thread
+ * (the reference is single-threaded per ORBextractor, two threads for stereo: Frame.cc:129-132), looping over the
+ * given frames: operator() + brute-force best/second-best match against the thread's previous frame when
+ * do_match != 0.  Runs for about `seconds`; returns frames/s, *frames_done = frames processed. */
+double or_bench_throughput(const uint8_t *frames, int nframes, int rows, int cols, int nfeatures, float scaleFactor,
+                           int nlevels, int iniThFAST, int minThFAST, int nthreads, double seconds, int do_match,
+                           long *frames_done);
+
 /* ---- ORBmatcher ---- */
 /* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2047-2063) */
 int or_descriptor_distance(const uint8_t *a, const uint8_t *b);

@@ -83,6 +83,9 @@ def lib():
         L.or_search_for_initialization.argtypes = [_u8p, _f32p, _i32p, C.c_int, _i32p, _i32p, _u8p, _f32p, C.c_int,
                                                    C.c_float, C.c_int, _i32p]
         L.or_block_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
+        L.or_bench_throughput.restype = C.c_double
+        L.or_bench_throughput.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_long)]
         _lib = L
     return _lib
 
@@ -355,3 +358,13 @@ def block_best2(a, b):
     lib().or_block_best2(_ptr(a, _u8p), len(a), _ptr(b, _u8p), len(b), _ptr(best, _i32p), _ptr(second, _i32p),
                          _ptr(arg, _i32p))
     return best, second, arg
+
+
+def bench_throughput(frames, nfeatures, nthreads, seconds, do_match=True, scale=1.2, nlevels=8, ini_th=20, min_th=7):
+    """Native multi-threaded CPU baseline (frames/s, frames processed)."""
+    f = np.ascontiguousarray(frames, dtype=np.uint8)
+    n, rows, cols = f.shape
+    done = C.c_long(0)
+    fps = lib().or_bench_throughput(_ptr(f, _u8p), n, rows, cols, nfeatures, scale, nlevels, ini_th, min_th,
+                                    int(nthreads), float(seconds), int(do_match), C.byref(done))
+    return fps, done.value

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round profile: un-profiled bench line, rocprofv3 kernel stats of the SAME command (serialized so kernel
+# durations are interference-free), and two PMC passes (FETCH_SIZE / WRITE_SIZE) for HBM traffic.
+# Usage (on the GPU box): bash tools/profile_round.sh <tag>
+set -u
+TAG=${1:-rXX}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+VSG_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --cpu-seconds 0 --no-stage-timing > $OUT/bench_rocprof.json 2> $OUT/rocprof.err
+VSG_NO_OVERLAP=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --cpu-seconds 0 --no-stage-timing --steps 3 --warmup 1 > /dev/null 2>&1
+VSG_NO_OVERLAP=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --cpu-seconds 0 --no-stage-timing --steps 3 --warmup 1 > /dev/null 2>&1
+cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.txt 2>&1
+rm -rf $OUT/stats/*/*kernel_trace.csv
+cat $OUT/bench.json | cut -c1-2500
+cat $OUT/pmc_traffic.txt

@@ -75,8 +75,19 @@ struct CellDesc {  // one FAST cell: valid region [x0,x1) x [y0,y1) in level coo
   int16_t level, x0, y0, x1, y1, pad;
 };
 
+// Fused pyramid: one workgroup computes, for one tile of the TOP level, the regions of every lower level that
+// feed it ("need"), and writes the part of each level it owns ("own").  Rects are {x0, y0, x1, y1}, x1/y1 exclusive.
+struct PyrTile {
+  int16_t need[kMaxLevels][4];
+  int16_t own[kMaxLevels][4];
+};
+enum { kPyrTile = 32 };  // top-level tile edge
+
 struct Geometry {
   FrameGeom fg;
+  std::vector<PyrTile> pyrTiles;
+  int pyrLdsA = 0, pyrLdsB = 0;  // LDS bytes for even / odd levels of the ping-pong
+  int pyrTabMax = 0;             // max over tiles of staged table entries
   std::vector<Short4> resizeTab;  // all levels, x tables then y tables (offsets in LevelGeom)
   std::vector<CellDesc> cells;
   int maxQuota = 0;
@@ -229,6 +240,57 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
       sel_off += L.sel_cap;
       out_cap += L.sel_cap;
     }
+  }
+  // ---- fused-pyramid tiles
+  G.pyrTiles.clear();
+  G.pyrLdsA = G.pyrLdsB = 0;
+  G.pyrTabMax = 0;
+  if (T.nlevels > 1) {
+    const int top = T.nlevels - 1;
+    const int ntx = (fg.lv[top].w + kPyrTile - 1) / kPyrTile, nty = (fg.lv[top].h + kPyrTile - 1) / kPyrTile;
+    for (int ty = 0; ty < nty; ty++)
+      for (int tx = 0; tx < ntx; tx++) {
+        PyrTile t;
+        memset(&t, 0, sizeof(t));
+        int16_t *o = t.own[top];
+        o[0] = (int16_t)(tx * kPyrTile);
+        o[1] = (int16_t)(ty * kPyrTile);
+        o[2] = (int16_t)(tx + 1 == ntx ? fg.lv[top].w : (tx + 1) * kPyrTile);
+        o[3] = (int16_t)(ty + 1 == nty ? fg.lv[top].h : (ty + 1) * kPyrTile);
+        memcpy(t.need[top], o, sizeof(t.need[top]));
+        for (int l = top; l >= 1; l--) {
+          const LevelGeom &D = fg.lv[l], &S = fg.lv[l - 1];
+          const Short4 *tabx = &G.resizeTab[D.tab_x_off], *taby = &G.resizeTab[D.tab_y_off];
+          const int16_t *od = t.own[l], *nd = t.need[l];
+          int16_t *os = t.own[l - 1], *ns = t.need[l - 1];
+          // ownership boundaries follow the (monotone) source index of the destination boundary
+          os[0] = (int16_t)(tx == 0 ? 0 : tabx[od[0]].a);
+          os[2] = (int16_t)(tx + 1 == ntx ? S.w : tabx[od[2]].a);
+          os[1] = (int16_t)(ty == 0 ? 0 : taby[od[1]].a);
+          os[3] = (int16_t)(ty + 1 == nty ? S.h : taby[od[3]].a);
+          // needed source region = sources of the needed destination region, plus what this tile owns
+          int nx0 = tabx[nd[0]].a, nx1 = tabx[nd[2] - 1].d + 1, ny0 = taby[nd[1]].a, ny1 = taby[nd[3] - 1].b + 1;
+          ns[0] = (int16_t)(nx0 < os[0] ? nx0 : os[0]);
+          ns[2] = (int16_t)(nx1 > os[2] ? nx1 : os[2]);
+          ns[1] = (int16_t)(ny0 < os[1] ? ny0 : os[1]);
+          ns[3] = (int16_t)(ny1 > os[3] ? ny1 : os[3]);
+        }
+        int tabn = 0;
+        for (int l = 1; l <= top; l++) tabn += (t.need[l][2] - t.need[l][0]) + (t.need[l][3] - t.need[l][1]);
+        if (tabn > G.pyrTabMax) G.pyrTabMax = tabn;
+        for (int l = 0; l <= top; l++) {
+          // LDS image of a level: columns start at the 4-byte aligned column below need.x0, pitch multiple of 4
+          const int x0a = t.need[l][0] & ~3;
+          const int pitch = ((t.need[l][2] - x0a) + 3) & ~3;
+          const int bytes = pitch * (t.need[l][3] - t.need[l][1]);
+          if (l & 1) {
+            if (bytes > G.pyrLdsB) G.pyrLdsB = bytes;
+          } else {
+            if (bytes > G.pyrLdsA) G.pyrLdsA = bytes;
+          }
+        }
+        G.pyrTiles.push_back(t);
+      }
   }
   fg.pyr_frame_bytes = (img_off + 255) & ~255;
   fg.cand_frame = cand_off;

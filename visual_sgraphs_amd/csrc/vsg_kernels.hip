@@ -64,6 +64,129 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// floor(i / d) for 0 <= i < 2^16 and 1 <= d <= 128 with inv = 1.0f / d: (i + 0.5) / d stays >= 0.5/d away from
+// every integer, far more than the float rounding error, so the truncation is exact (3 VALU ops, no v_rcp chain).
+__device__ __forceinline__ int div_small(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
+
+// Fused pyramid: ONE launch builds levels 1..L-1 of every frame.  A workgroup owns one tile of the top level and
+// walks DOWN the dependency cone: it stages the level-0 region that feeds the tile in LDS, then produces level 1,
+// 2, ... in LDS ping-pong buffers (each level resized from the previous LEVEL, exactly like the reference's chain,
+// ORBextractor.cc:1184), writing to HBM only the part of each level it owns.  Ownership boundaries are the source
+// indices of the destination boundaries, so tiles partition every level without gaps or overlaps; the ~25 % halo
+// is recomputed instead of communicated.  HBM traffic: level 0 read once (+halo), levels 1.. written once.
+__global__ __launch_bounds__(256) void k_pyramid(uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
+                                                 const Short4 *__restrict__ tab, Src0 s0,
+                                                 const PyrTile *__restrict__ tiles, int ldsA, int ldsAB) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
+  __shared__ int s_tab_off[2 * kMaxLevels];  // [2l] = x slice of level l, [2l+1] = y slice
+  const PyrTile &T = tiles[blockIdx.x];
+  const int frame = blockIdx.y, tid = threadIdx.x;
+  uint8_t *buf0 = pyr_lds, *buf1 = pyr_lds + ldsA;
+  Short4 *s_tab = (Short4 *)(pyr_lds + ldsAB);  // the tile's slices of the resize tables, all levels
+  {  // stage the table slices once, already converted to LDS offsets of the source image:
+     //   x entry {sx - sx0a, a0, a1, sx1 - sx0a}     y entry {(sy0 - y0)*pitch, (sy1 - y0)*pitch, b0, b1}
+    int off = 0;
+    for (int l = 1; l < fg->nlevels; l++) {
+      const LevelGeom &D = fg->lv[l];
+      const int dw = T.need[l][2] - T.need[l][0], dh = T.need[l][3] - T.need[l][1];
+      const int sx0a = T.need[l - 1][0] & ~3, sy0 = T.need[l - 1][1];
+      const int spitch = ((T.need[l - 1][2] - sx0a) + 3) & ~3;
+      if (tid == 0) {
+        s_tab_off[2 * l] = off;
+        s_tab_off[2 * l + 1] = off + dw;
+      }
+      for (int i = tid; i < dw; i += 256) {
+        Short4 e = tab[D.tab_x_off + T.need[l][0] + i];
+        e.a = (int16_t)(e.a - sx0a);
+        e.d = (int16_t)(e.d - sx0a);
+        s_tab[off + i] = e;
+      }
+      for (int i = tid; i < dh; i += 256) {
+        Short4 e = tab[D.tab_y_off + T.need[l][1] + i];
+        e.a = (int16_t)((e.a - sy0) * spitch);
+        e.b = (int16_t)((e.b - sy0) * spitch);
+        s_tab[off + dw + i] = e;
+      }
+      off += dw + dh;
+    }
+  }
+  {  // level-0 region -> LDS, aligned dwords
+    const int x0a = T.need[0][0] & ~3, y0 = T.need[0][1];
+    const int w4 = ((T.need[0][2] - x0a) + 3) >> 2, hh = T.need[0][3] - y0, pitch = 4 * w4;
+    const uint8_t *src = s0.base + (size_t)frame * s0.frame_stride + (size_t)y0 * s0.pitch + x0a;
+    const float inv = 1.0f / (float)w4;
+    for (int i = tid; i < w4 * hh; i += 256) {
+      const int r = div_small(i, inv), c = i - r * w4;
+      *(uint32_t *)(buf0 + r * pitch + 4 * c) = *(const uint32_t *)(src + (size_t)r * s0.pitch + 4 * c);
+    }
+  }
+  __syncthreads();
+  uint8_t *frame_base = pyr + (size_t)frame * fg->pyr_frame_bytes;
+  for (int l = 1; l < fg->nlevels; l++) {
+    const LevelGeom &D = fg->lv[l];
+    const uint8_t *src = (l & 1) ? buf0 : buf1;
+    uint8_t *dst = (l & 1) ? buf1 : buf0;
+    const int dx0 = T.need[l][0], dy0 = T.need[l][1], dw = T.need[l][2] - dx0, dh = T.need[l][3] - dy0;
+    const int dx0a = dx0 & ~3, dpitch = ((T.need[l][2] - dx0a) + 3) & ~3;
+    // thread = one destination column, looping over rows; narrower levels use more row groups
+    const int shift = dw <= 32 ? 5 : dw <= 64 ? 6 : 7;
+    const int c = tid & ((1 << shift) - 1), rg = tid >> shift, nrg = 256 >> shift;
+    if (c < dw) {
+      const Short4 tx = s_tab[s_tab_off[2 * l] + c];
+      const Short4 *tyv = &s_tab[s_tab_off[2 * l + 1]];
+      const uint8_t *sa = src + tx.a, *sd = src + tx.d;
+      const int a0 = tx.b, a1 = tx.c;
+      uint8_t *dcol = dst + (dx0 - dx0a) + c;
+      // 4 independent rows per trip: 4 table reads, then 16 byte reads in flight, then the arithmetic
+      for (int r = rg; r < dh; r += 4 * nrg) {
+        Short4 ty[4];
+        int p[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int rr = r + k * nrg;
+          ty[k] = tyv[rr < dh ? rr : dh - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          p[k][0] = sa[ty[k].a];
+          p[k][1] = sd[ty[k].a];
+          p[k][2] = sa[ty[k].b];
+          p[k][3] = sd[ty[k].b];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int rr = r + k * nrg;
+          const int h0 = p[k][0] * a0 + p[k][1] * a1, h1 = p[k][2] * a0 + p[k][3] * a1;
+          const int v = (((((int)ty[k].c * (h0 >> 4)) >> 16) + (((int)ty[k].d * (h1 >> 4)) >> 16) + 2) >> 2);
+          if (rr < dh) dcol[rr * dpitch] = (uint8_t)v;
+        }
+      }
+    }
+    __syncthreads();
+    // write the owned part of this level: aligned dwords where all 4 bytes are owned, bytes at the seams
+    {
+      const int ox0 = T.own[l][0], oy0 = T.own[l][1], ox1 = T.own[l][2], oy1 = T.own[l][3];
+      const int g0 = ox0 >> 2, ng = ((ox1 + 3) >> 2) - g0, nrow = oy1 - oy0;
+      uint8_t *gl = frame_base + D.img_off;
+      const float inv = 1.0f / (float)ng;
+      for (int i = tid; i < ng * nrow; i += 256) {
+        const int r = div_small(i, inv), g = g0 + (i - r * ng);
+        const int y = oy0 + r, x = 4 * g;
+        const uint8_t *lp = dst + (y - dy0) * dpitch + (x - dx0a);
+        uint8_t *gp = gl + (size_t)y * D.pitch + x;
+        if (x >= ox0 && x + 4 <= ox1) {
+          *(uint32_t *)gp = *(const uint32_t *)lp;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (x + j >= ox0 && x + j < ox1) gp[j] = lp[j];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // FAST-9-16 ([OCV] fast.cpp FAST_t<16>, fast_score.cpp cornerScore<16>) on an LDS tile of row pitch kTileP.
 //   score = max over the 16 contiguous 9-arcs of min(+-(v - ring)) - 1;  corner-at-t <=> score >= t, and the
 //   score does not depend on t.
@@ -139,10 +262,6 @@ __device__ __forceinline__ uint32_t fast_quick4(uint32_t C, uint32_t U, uint32_t
   }
   return m;
 }
-
-// floor(i / d) for 0 <= i < 2^16 and 1 <= d <= 128 with inv = 1.0f / d: (i + 0.5) / d stays >= 0.5/d away from
-// every integer, far more than the float rounding error, so the truncation is exact (3 VALU ops, no v_rcp chain).
-__device__ __forceinline__ int div_small(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
 
 // One workgroup per FAST cell.  The cell's valid region (3 px inside the reference's sub-image) is staged in LDS
 // with aligned 32-bit loads; a cheap necessary test runs on 4 pixels per thread from packed dwords and the pixels
@@ -639,6 +758,16 @@ __global__ void k_border_copy(const uint8_t *__restrict__ img, int w, int h, int
   dst[(size_t)y * dpitch + x] = img[(size_t)reflect101(y - b, h) * pitch + reflect101(x - b, w)];
 }
 
+// per-call reset of the candidate / selection counters (a kernel rather than hipMemsetAsync so that it is
+// ordered like every other stage on the stream and the stage-timing events bracket real work)
+__global__ void k_zero(int *p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+void launch_zero(hipStream_t s, int *p, int n) {
+  hipLaunchKernelGGL(k_zero, dim3((n + 255) / 256), dim3(256), 0, s, p, n);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers (host)
 void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
@@ -646,6 +775,12 @@ void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sho
   const LevelGeom &D = fg.lv[level];
   dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nframes), block(64, 4);
   hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, d_fg, d_tab, s0, level);
+}
+void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
+                    const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes) {
+  const int a16 = (ldsA + 15) & ~15, ab16 = a16 + ((ldsB + 15) & ~15);
+  hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(256), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg, d_tab,
+                     s0, d_tiles, a16, ab16);
 }
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
                  uint32_t *cand, int *cand_count, const FrameGeom &fg, int nframes) {

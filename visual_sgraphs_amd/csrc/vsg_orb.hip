@@ -38,7 +38,7 @@ static const int8_t kPattern[1024] = {
 
 static_assert(sizeof(KeyPointPOD) == 28 && sizeof(vsg_keypoint) == 28, "cv::KeyPoint layout");
 
-enum { kStages = 7, kEv = 10, kMaxSub = 8 };
+enum { kStages = 7, kEv = 12, kMaxSub = 8 };
 
 struct vsg_orb {
   ExtractorTables T;
@@ -51,6 +51,7 @@ struct vsg_orb {
   FrameGeom *d_fg = nullptr;
   Short4 *d_tab = nullptr;
   CellDesc *d_cells = nullptr;
+  PyrTile *d_ptiles = nullptr;
   uint8_t *d_in = nullptr;  // level-0 staging for host images / unaligned device images, pitch in_pitch
   int in_pitch = 0;
   Src0 last_src0 = {nullptr, 0, 0};
@@ -73,6 +74,7 @@ struct vsg_orb {
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_fork = nullptr;
   // sub-batch pipelining
   int nsub = 1;
+  bool serialize = false;  // every kernel on one stream (per-kernel timing without interference)
   hipStream_t sub_s[kMaxSub] = {}, sub_b[kMaxSub] = {};
   hipEvent_t sub_ev_pyr[kMaxSub] = {}, sub_ev_blur[kMaxSub] = {}, sub_ev_done[kMaxSub] = {};
   // timing
@@ -84,7 +86,8 @@ struct vsg_orb {
 };
 
 static void free_image_buffers(vsg_orb *h) {
-  hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in);
+  hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in), hipFree(h->d_ptiles);
+  h->d_ptiles = nullptr;
   hipFree(h->d_pyr), hipFree(h->d_blur), hipFree(h->d_cand), hipFree(h->d_sel), hipFree(h->d_nodeof);
   hipFree(h->d_counts2), hipFree(h->d_flags), hipFree(h->d_slots), hipFree(h->d_hdr);
   hipFree(h->d_kps), hipFree(h->d_desc), hipFree(h->d_out_counts);
@@ -124,6 +127,9 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   if (!h->G.resizeTab.empty())
     HIP_TRY(hipMemcpy(h->d_tab, h->G.resizeTab.data(), sizeof(Short4) * h->G.resizeTab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_cells, h->G.cells.data(), sizeof(CellDesc) * h->G.cells.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&h->d_ptiles, sizeof(PyrTile) * (h->G.pyrTiles.size() + 1)));
+  if (!h->G.pyrTiles.empty())
+    HIP_TRY(hipMemcpy(h->d_ptiles, h->G.pyrTiles.data(), sizeof(PyrTile) * h->G.pyrTiles.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&h->d_pyr, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMalloc(&h->d_blur, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMemset(h->d_pyr, 0, B * fg.pyr_frame_bytes));
@@ -154,8 +160,9 @@ static void harvest_timing(vsg_orb *h) {
   h->ev_pending = false;
   if (hipEventSynchronize(h->ev[5]) != hipSuccess || hipEventSynchronize(h->ev[7]) != hipSuccess) return;
   float ms;
-  // main chain: 0 start, 1 pyramid, 2 fast, 3 octree, 4 slots, 5 orient_desc ; blur: 6,7
-  const int pairs[kStages][2] = {{0, 1}, {1, 2}, {2, 3}, {6, 7}, {3, 4}, {4, 5}, {0, 5}};
+  // main chain: 0 start, 1 pyramid end, 8 fast begin, 2 fast end, 3 octree end, 4 slots end, 9 orient begin,
+  // 5 orient end; blur (own stream unless serialised): 6 begin, 7 end
+  const int pairs[kStages][2] = {{0, 1}, {8, 2}, {2, 3}, {6, 7}, {3, 4}, {9, 5}, {0, 5}};
   for (int i = 0; i < kStages; i++)
     if (hipEventElapsedTime(&ms, h->ev[pairs[i][0]], h->ev[pairs[i][1]]) == hipSuccess) h->acc_ms[i] += ms;
   h->acc_n++;
@@ -177,21 +184,41 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   int *flags = h->d_flags + F * fg.out_cap, *slots = h->d_slots + F * fg.out_cap;
   FrameHeader *hdr = h->d_hdr + F;
   if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
-  for (int l = 1; l < fg.nlevels; l++) launch_resize(s, pyr, h->d_fg, h->d_tab, s0, fg, l, nf);
-  HIP_TRY(hipEventRecord(ev_pyr, s));
+  static const bool per_level = getenv("VSG_PYR_PER_LEVEL") != nullptr;  // A/B switch: 7 chained launches
+  if (per_level || h->G.pyrLdsA + h->G.pyrLdsB + 8 * h->G.pyrTabMax > 64000) {
+    for (int l = 1; l < fg.nlevels; l++) launch_resize(s, pyr, h->d_fg, h->d_tab, s0, fg, l, nf);
+  } else if (fg.nlevels > 1) {
+    launch_pyramid(s, pyr, h->d_fg, h->d_tab, s0, h->d_ptiles, (int)h->G.pyrTiles.size(), h->G.pyrLdsA, h->G.pyrLdsB,
+                   h->G.pyrTabMax, nf);
+  }
   if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
+  // The blur only needs the pyramid and runs on its own stream next to FAST -> octree -> slots.  Measured on
+  // MI355X the placement hardly matters (every kernel here is issue-bound, so concurrency just shares the CUs):
+  // released right after the pyramid 139.1k fps, after FAST (VSG_BLUR_LATE=1) 136.6k, fully serialised 134.4k
+  // (C2, 256-frame batches).
+  static const bool blur_early = getenv("VSG_BLUR_LATE") == nullptr;
+  if (!blur_early) {
+    if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
+    launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, fg, nf);
+    if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
+  }
+  HIP_TRY(hipEventRecord(ev_pyr, s));
   HIP_TRY(hipStreamWaitEvent(sb, ev_pyr, 0));
   if (tm) HIP_TRY(hipEventRecord(h->ev[6], sb));
   launch_blur(sb, pyr, blur, h->d_fg, s0, fg, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[7], sb));
   HIP_TRY(hipEventRecord(ev_blur, sb));
-  launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, fg, nf);
-  if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
+  if (blur_early) {
+    if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
+    launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, fg, nf);
+    if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
+  }
   launch_octree(s, h->d_fg, cand, cand_count, nodeof, sel, sel_count, fg, h->G.maxQuota, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
   launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
   HIP_TRY(hipStreamWaitEvent(s, ev_blur, 0));
+  if (tm) HIP_TRY(hipEventRecord(h->ev[9], s));
   launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, slots, hdr, h->d_pattern, d_kps + F * capacity,
                      d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[5], s));
@@ -205,12 +232,12 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
 static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, int lap1, KeyPointPOD *d_kps,
                             uint8_t *d_desc, int *d_counts, int capacity, hipStream_t s) {
   h->last_src0 = s0;
-  static const bool no_overlap = getenv("VSG_NO_OVERLAP") != nullptr;
+  const bool no_overlap = h->serialize;
   int nsub = no_overlap ? 1 : h->nsub;
   if (nsub > nframes) nsub = nframes;
   const bool tm = h->timing && nsub == 1;
   if (tm) harvest_timing(h);
-  HIP_TRY(hipMemsetAsync(h->d_counts2, 0, 2 * (size_t)h->max_batch * kMaxLevels * sizeof(int), s));
+  launch_zero(s, h->d_counts2, 2 * h->max_batch * kMaxLevels);
   if (nsub == 1) {
     int rc = enqueue_range(h, s0, 0, nframes, lap0, lap1, d_kps, d_desc, d_counts, capacity, s,
                            no_overlap ? s : h->s_blur, h->ev_pyr, h->ev_blur, tm);
@@ -289,6 +316,7 @@ int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fa
     const char *e = getenv("VSG_SUBBATCH");
     int k = e ? atoi(e) : 1;
     h->nsub = k < 1 ? 1 : k > kMaxSub ? kMaxSub : k;
+    h->serialize = getenv("VSG_NO_OVERLAP") != nullptr;
   }
   *out = h;
   return VSG_OK;
@@ -508,6 +536,12 @@ int vsg_orb_copy_selected(vsg_orb *h, int frame, int level, uint32_t *dst, int c
   const LevelGeom &L = h->G.fg.lv[level];
   return copy_list(h, h->d_sel, h->G.fg.sel_frame, L.sel_off, L.sel_cap,
                    h->d_counts2 + (size_t)h->max_batch * kMaxLevels, frame, level, dst, cap);
+}
+
+int vsg_orb_set_serialize(vsg_orb *h, int serialize) {
+  if (!h) return VSG_ERR_INVALID;
+  h->serialize = serialize != 0;
+  return VSG_OK;
 }
 
 int vsg_orb_enable_timing(vsg_orb *h, int enable) {

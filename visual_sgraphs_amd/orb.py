@@ -35,7 +35,7 @@ EXPORTS = [
     "vsg_orb_set_blur_taps", "vsg_orb_capacity", "vsg_orb_extract", "vsg_orb_extract_batch",
     "vsg_orb_extract_batch_device", "vsg_orb_level_size", "vsg_orb_copy_pyramid_level",
     "vsg_orb_copy_blurred_level", "vsg_orb_copy_candidates", "vsg_orb_copy_selected", "vsg_orb_enable_timing",
-    "vsg_orb_get_timing", "vsg_hamming_pairs", "vsg_hamming_block_best2", "vsg_hamming_block_best2_device",
+    "vsg_orb_get_timing", "vsg_orb_set_serialize", "vsg_hamming_pairs", "vsg_hamming_block_best2", "vsg_hamming_block_best2_device",
     "vsg_search_by_bow_kf_f", "vsg_search_by_bow_kf_kf", "vsg_search_by_projection_last",
     "vsg_search_by_projection_local", "vsg_search_for_initialization",
 ]
@@ -80,6 +80,7 @@ def load_library():
     L.vsg_orb_copy_selected.argtypes = [C.c_void_p, C.c_int, C.c_int, _u32p, C.c_int]
     L.vsg_orb_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.vsg_orb_get_timing.argtypes = [C.c_void_p, _f32p, C.c_int]
+    L.vsg_orb_set_serialize.argtypes = [C.c_void_p, C.c_int]
     L.vsg_hamming_pairs.argtypes = [C.c_int, _u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, C.c_int, _i32p]
     L.vsg_hamming_block_best2.argtypes = [C.c_int, _u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
     L.vsg_hamming_block_best2_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
@@ -282,6 +283,9 @@ class ORBextractor:
         buf = np.zeros(cap, np.uint32)
         n = _check(self._L.vsg_orb_copy_selected(self._h, frame, level, _p(buf, _u32p), cap), "vsg_orb_copy_selected")
         return self._unpack(buf[:n])
+
+    def set_serialize(self, on=True):
+        _check(self._L.vsg_orb_set_serialize(self._h, int(on)), "vsg_orb_set_serialize")
 
     def enable_timing(self, on=True):
         _check(self._L.vsg_orb_enable_timing(self._h, int(on)), "vsg_orb_enable_timing")
