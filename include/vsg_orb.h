@@ -167,6 +167,34 @@ int vsg_search_by_projection_local(int device, const uint8_t *q_desc, const uint
                                    const int32_t *t_octave, uint8_t *train_blocked, int n_t, float nnratio,
                                    int32_t *train_match);
 
+/* Common core of the searches that keep only the best candidate per projected MapPoint:
+ *   SearchByProjection(KeyFrame*, Sim3, vpPoints, vpMatched, th, ratioHamming)   (ORBmatcher.h:58, .cc:430-528)
+ *   SearchByProjection(KeyFrame*, Sim3, vpPoints, vpPointsKFs, ...)             (ORBmatcher.h:62, .cc:530-641)
+ *   SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)           (ORBmatcher.h:54, .cc:1880-2000; the
+ *                                                  rotation check is vsg_search_by_projection_last's check_orientation)
+ *   SearchBySim3's two directional passes (.cc:1500-1640) and Fuse's candidate loops (.cc:1148-1446), whose
+ *   geometric predicates (level window, chi2 of the reprojection) filter the candidate lists in the adaptor.
+ * For each query in order: best (strict '<', earliest wins) over the non-blocked candidates; q_best_idx/q_best_dist per
+ * query (-1 / 256 if none); if dist <= th_high the match is accepted: train_match[best] = q, train_blocked[best] =
+ * query_blocks[q] (NULL: never blocks).  train_blocked / train_match may be NULL.  Returns the number accepted. */
+int vsg_search_window(int device, const uint8_t *q_desc, const uint8_t *query_blocks, int n_q,
+                      const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *t_desc, uint8_t *train_blocked,
+                      int n_t, int th_high, int32_t *q_best_idx, int32_t *q_best_dist, int32_t *train_match);
+
+/* ---- Frame grid: Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:521-553, 870-880) and
+ * Frame::GetFeaturesInArea / KeyFrame::GetFeaturesInArea (Frame.cc:802-868, KeyFrame.cc:834-874) on the device.
+ * 64 x 48 cells (Frame.h:49-50).  kps = the (undistorted) keypoints the reference indexes (host pointer). */
+typedef struct vsg_grid vsg_grid;
+int vsg_grid_build(int device, const vsg_keypoint *kps, int n, float min_x, float min_y, float max_x, float max_y,
+                   vsg_grid **out);
+void vsg_grid_destroy(vsg_grid *g);
+/* nq queries (x, y, r, minLevel, maxLevel) -> CSR candidate lists in the reference's order (cells ix outer, iy
+ * inner, insertion order inside a cell): cand_off[nq+1], cand_idx[cap].  min_level/max_level may be NULL (= -1,
+ * KeyFrame::GetFeaturesInArea has no level filter).  Returns the total number of candidates (which may exceed
+ * cap: nothing beyond cap is written) or a VSG_ERR_* code. */
+int vsg_grid_query(vsg_grid *g, const float *x, const float *y, const float *r, const int32_t *min_level,
+                   const int32_t *max_level, int nq, int32_t *cand_off, int32_t *cand_idx, int cap);
+
 /* int ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
  * (ORBmatcher.h:68, ORBmatcher.cc:643-756); candidate lists from F2.GetFeaturesInArea per F1 keypoint. */
 int vsg_search_for_initialization(int device, const uint8_t *desc1, const float *angle1, const int32_t *octave1,

@@ -348,6 +348,34 @@ int or_search_by_projection_local(const uint8_t *qDesc, const uint8_t *queryBloc
   return nmatches;
 }
 
+int or_search_window(const uint8_t *qDesc, const uint8_t *queryBlocks, int nQ, const int *candOff, const int *candIdx,
+                     const uint8_t *tDesc, uint8_t *trainBlocked, int nT, int thHigh, int *qBestIdx, int *qBestDist,
+                     int *trainMatch) {
+  // e.g. ORBmatcher.cc:494-524: bestDist = 256; skip taken candidates; strict '<'; accept <= threshold
+  (void)nT;
+  int nmatches = 0;
+  for (int q = 0; q < nQ; q++) {
+    int bestDist = 256, bestIdx = -1;
+    for (int c = candOff[q]; c < candOff[q + 1]; c++) {
+      const int idx = candIdx[c];
+      if (trainBlocked && trainBlocked[idx]) continue;
+      const int dist = DescriptorDistance(qDesc + (size_t)q * 32, tDesc + (size_t)idx * 32);
+      if (dist < bestDist) {
+        bestDist = dist;
+        bestIdx = idx;
+      }
+    }
+    qBestIdx[q] = bestIdx;
+    qBestDist[q] = bestDist;
+    if (bestIdx >= 0 && bestDist <= thHigh) {
+      if (trainMatch) trainMatch[bestIdx] = q;
+      if (trainBlocked) trainBlocked[bestIdx] = queryBlocks ? queryBlocks[q] : 0;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
 int or_search_for_initialization(const uint8_t *desc1, const float *angle1, const int *octave1, int n1,
                                  const int *candOff, const int *candIdx, const uint8_t *desc2, const float *angle2,
                                  int n2, float mfNNratio, int checkOri, int *vnMatches12) {

@@ -134,6 +134,15 @@ int or_search_by_projection_local(const uint8_t *qDesc, const uint8_t *queryBloc
                                   const int *candIdx, const uint8_t *tDesc, const int *tOctave,
                                   uint8_t *trainBlocked, int nT, float nnratio, int *trainMatch);
 
+/* Common core of the projection searches that keep only the best candidate: SearchByProjection(KF, Scw, ...)
+ * (ORBmatcher.cc:430-528, :530-641), SearchByProjection(F, KF, ...) (:1880-2000) without the rotation check,
+ * SearchBySim3's two directional passes (:1500-1640) and Fuse's candidate loop (:1148-1446): for each query in
+ * order, best (strict '<') over the non-blocked candidates; qBestIdx/qBestDist per query (-1 / 256 if none);
+ * accepted when dist <= thHigh: trainMatch[best] = q, trainBlocked[best] = queryBlocks[q] (NULL = never blocks). */
+int or_search_window(const uint8_t *qDesc, const uint8_t *queryBlocks, int nQ, const int *candOff, const int *candIdx,
+                     const uint8_t *tDesc, uint8_t *trainBlocked, int nT, int thHigh, int *qBestIdx, int *qBestDist,
+                     int *trainMatch);
+
 /* SearchForInitialization (ORBmatcher.cc:643-756): octave-0 keypoints of F1, candidate lists per F1 kp
  * from F2.GetFeaturesInArea(prevMatched, windowSize, 0, 0).  candOff/candIdx as above (empty for octave>0). */
 int or_search_for_initialization(const uint8_t *desc1, const float *angle1, const int *octave1, int n1,

@@ -83,6 +83,8 @@ def lib():
         L.or_search_for_initialization.argtypes = [_u8p, _f32p, _i32p, C.c_int, _i32p, _i32p, _u8p, _f32p, C.c_int,
                                                    C.c_float, C.c_int, _i32p]
         L.or_block_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
+        L.or_search_window.argtypes = [_u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _u8p, C.c_int, C.c_int, _i32p, _i32p,
+                                       _i32p]
         L.or_bench_throughput.restype = C.c_double
         L.or_bench_throughput.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_long)]
@@ -368,3 +370,19 @@ def bench_throughput(frames, nfeatures, nthreads, seconds, do_match=True, scale=
     fps = lib().or_bench_throughput(_ptr(f, _u8p), n, rows, cols, nfeatures, scale, nlevels, ini_th, min_th,
                                     int(nthreads), float(seconds), int(do_match), C.byref(done))
     return fps, done.value
+
+
+def search_window(q_desc, q_blocks, cand_off, cand_idx, t_desc, t_blocked, th_high):
+    """Returns (nmatches, q_best_idx, q_best_dist, train_match, train_blocked)."""
+    qd, td = _u8c(q_desc), _u8c(t_desc)
+    co, ci = _i32c(cand_off), _i32c(cand_idx)
+    if len(ci) == 0:
+        ci = np.zeros(1, np.int32)
+    qb = _u8c(q_blocks) if q_blocks is not None else None
+    tb = _u8c(t_blocked).copy() if t_blocked is not None else None
+    qi, qdist = np.zeros(len(qd), np.int32), np.zeros(len(qd), np.int32)
+    tm = np.full(len(td), -1, np.int32)
+    n = lib().or_search_window(_ptr(qd, _u8p), _ptr(qb, _u8p) if qb is not None else None, len(qd), _ptr(co, _i32p),
+                               _ptr(ci, _i32p), _ptr(td, _u8p), _ptr(tb, _u8p) if tb is not None else None, len(td),
+                               int(th_high), _ptr(qi, _i32p), _ptr(qdist, _i32p), _ptr(tm, _i32p))
+    return n, qi, qdist, tm, tb

@@ -205,3 +205,63 @@ def test_matchers_on_empty_inputs():
     assert m.SearchByBoW_KF_F(e32, [], [], fv0, e32, [], fv0)[0] == 0
     n, tm, tb = m.SearchByProjection_Last(e32, [], [], [0], [], np.zeros((5, 32), np.uint8), np.zeros(5), np.zeros(5))
     assert n == 0 and tm.tolist() == [-1] * 5
+
+
+# ----------------------------------------------------------------------------- the Frame grid on the device
+@pytest.mark.parametrize("seed", [0, 1])
+def test_device_grid_query_equals_reference_order(frames, seed):
+    (k0, d0), (k1, d1) = frames
+    rng = np.random.default_rng(seed)
+    g_ref = ol.OracleGrid(k1, 0.0, 0.0, 640.0, 480.0)
+    g = orb.FrameGrid(k1, 0.0, 0.0, 640.0, 480.0)
+    nq = 400
+    x = rng.uniform(-20, 660, nq).astype(np.float32)
+    y = rng.uniform(-20, 500, nq).astype(np.float32)
+    r = rng.uniform(1, 60, nq).astype(np.float32)
+    lo = rng.integers(-1, 5, nq).astype(np.int32)
+    hi = rng.integers(-1, 8, nq).astype(np.int32)
+    off, idx = g.GetFeaturesInArea(x, y, r, lo, hi)
+    for q in range(nq):
+        want = g_ref.query(x[q], y[q], r[q], int(lo[q]), int(hi[q]))
+        assert np.array_equal(idx[off[q]:off[q + 1]], want), q  # same elements in the same ORDER
+    off2, idx2 = g.GetFeaturesInArea(x, y, r)  # KeyFrame::GetFeaturesInArea: no level filter
+    for q in range(0, nq, 7):
+        assert np.array_equal(idx2[off2[q]:off2[q + 1]], g_ref.query(x[q], y[q], r[q], -1, -1))
+    assert off[-1] > 1000
+
+
+def test_device_grid_edge_cases():
+    e32 = np.zeros(0, orb.KP_DTYPE)
+    g = orb.FrameGrid(e32, 0.0, 0.0, 640.0, 480.0)
+    off, idx = g.GetFeaturesInArea([10.0, 700.0], [10.0, 10.0], [5.0, 5.0])
+    assert off.tolist() == [0, 0, 0] and len(idx) == 0
+    kp = np.zeros(3, orb.KP_DTYPE)
+    kp["x"], kp["y"], kp["octave"] = [5.0, 5.0, 639.9], [5.0, 5.0, 479.9], [0, 3, 1]
+    g = orb.FrameGrid(kp, 0.0, 0.0, 640.0, 480.0)
+    ref = ol.OracleGrid(kp, 0.0, 0.0, 640.0, 480.0)
+    for q in [(5.0, 5.0, 1.0, -1, -1), (5.0, 5.0, 1.0, 2, 4), (639.0, 479.0, 3.0, -1, -1), (-50.0, 5.0, 10.0, -1, -1)]:
+        off, idx = g.GetFeaturesInArea([q[0]], [q[1]], [q[2]], [q[3]], [q[4]])
+        assert idx.tolist() == ref.query(*q).tolist()
+
+
+@pytest.mark.parametrize("seed,blocking", [(0, True), (1, False), (2, None)])
+def test_search_window_generic(frames, seed, blocking):
+    """Common core of the Sim3 / relocalisation projection searches, SearchBySim3 and Fuse (per-query best)."""
+    (k0, d0), (k1, d1) = frames
+    rng = np.random.default_rng(40 + seed)
+    q = np.sort(rng.choice(len(d0), 600, replace=False))
+    grid = orb.FrameGrid(k1, 0.0, 0.0, 640.0, 480.0)
+    cand_off, cand_idx = grid.GetFeaturesInArea(k0["x"][q] + 3.0, k0["y"][q] + 2.0, np.full(len(q), 14.0, np.float32))
+    if blocking is None:
+        q_blocks, t_blocked = None, None
+    else:
+        q_blocks = np.full(len(q), 1 if blocking else 0, np.uint8)
+        t_blocked = (rng.random(len(d1)) < 0.1).astype(np.uint8)
+    th = 50 if seed else 100
+    got = orb.search_window(d0[q], q_blocks, cand_off, cand_idx, d1, t_blocked, th)
+    want = ol.search_window(d0[q], q_blocks, cand_off, cand_idx, d1, t_blocked, th)
+    assert got[0] == want[0] > 50
+    for a, b in zip(got[1:4], want[1:4]):
+        assert np.array_equal(a, b)
+    if blocking is not None:
+        assert np.array_equal(got[4], want[4])

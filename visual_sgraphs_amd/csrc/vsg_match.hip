@@ -173,11 +173,16 @@ __global__ __launch_bounds__(64) void k_search_window(const uint8_t *qDesc, cons
                                                       const int *candOff, const int *candIdx, const uint8_t *tDesc,
                                                       const int *tOctave, uint8_t *trainBlocked, int thHigh,
                                                       float nnratio, int mode, int *trainMatch, int *events,
+                                                      int *qBest /*optional [nQ][2] = idx, dist*/,
                                                       int *result /*[0]=nmatches [1]=nevents*/) {
   const int lane = threadIdx.x;
   int nmatches = 0, nev = 0;
   for (int q = 0; q < nQ; q++) {
     const int c0 = candOff[q], c1 = candOff[q + 1];
+    if (qBest && lane == 0) {
+      qBest[2 * q] = -1;
+      qBest[2 * q + 1] = 256;
+    }
     if (c0 == c1) continue;
     uint4 a0, a1;
     load_desc(qDesc, q, a0, a1);
@@ -192,6 +197,10 @@ __global__ __launch_bounds__(64) void k_search_window(const uint8_t *qDesc, cons
     }
     wave_best2(k1, k2);
     const int bestDist = (int)(k1 >> 20);
+    if (qBest && lane == 0 && k1 != KEY_NONE) {
+      qBest[2 * q] = candIdx[c0 + (int)(k1 & 0xFFFFF)];
+      qBest[2 * q + 1] = bestDist;
+    }
     if (bestDist > thHigh || k1 == KEY_NONE) continue;
     const int bestIdx = candIdx[c0 + (int)(k1 & 0xFFFFF)];
     bool accept = true;
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(64) void k_search_window(const uint8_t *qDesc, cons
     if (!accept) continue;
     if (lane == 0) {
       trainMatch[bestIdx] = q;
-      trainBlocked[bestIdx] = queryBlocks[q];
+      trainBlocked[bestIdx] = queryBlocks ? queryBlocks[q] : 0;
       if (events) {
         events[2 * nev] = q;
         events[2 * nev + 1] = bestIdx;
@@ -506,7 +515,7 @@ static int search_window(int device, int mode, const uint8_t *q_desc, const floa
   M_TRY(dResult.alloc(8));
   hipLaunchKernelGGL(k_search_window, dim3(1), dim3(64), 0, 0, dQ.as<uint8_t>(), dQB.as<uint8_t>(), n_q, dOff.as<int>(),
                      dIdx.as<int>(), dT.as<uint8_t>(), dOct.as<int>(), dBlocked.as<uint8_t>(), th_high, nnratio, mode,
-                     dMatch.as<int>(), mode == 0 ? dEvents.as<int>() : (int *)nullptr, dResult.as<int>());
+                     dMatch.as<int>(), mode == 0 ? dEvents.as<int>() : (int *)nullptr, (int *)nullptr, dResult.as<int>());
   int result[2] = {0, 0};
   M_TRY(hipMemcpy(result, dResult.p, 8, hipMemcpyDeviceToHost));
   M_TRY(hipMemcpy(train_match, dMatch.p, (size_t)n_t * 4, hipMemcpyDeviceToHost));
@@ -548,6 +557,41 @@ int vsg_search_by_projection_local(int device, const uint8_t *q_desc, const uint
   if (!cand_off || !train_blocked || !train_match || !t_octave || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
   return search_window(device, 1, q_desc, nullptr, query_blocks, n_q, cand_off, cand_idx, t_desc, nullptr, t_octave,
                        train_blocked, n_t, TH_HIGH, nnratio, 0, train_match);
+}
+
+int vsg_search_window(int device, const uint8_t *q_desc, const uint8_t *query_blocks, int n_q,
+                      const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *t_desc, uint8_t *train_blocked,
+                      int n_t, int th_high, int32_t *q_best_idx, int32_t *q_best_dist, int32_t *train_match) {
+  if (!cand_off || !q_best_idx || !q_best_dist || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  for (int q = 0; q < n_q; q++) q_best_idx[q] = -1, q_best_dist[q] = 256;
+  if (n_q == 0 || n_t == 0) return 0;
+  const int ncand = cand_off[n_q];
+  DevBuf dQ, dQB, dOff, dIdx, dT, dBlocked, dMatch, dBest, dResult;
+  M_TRY(dQ.upload(q_desc, (size_t)n_q * 32));
+  if (query_blocks) M_TRY(dQB.upload(query_blocks, (size_t)n_q));
+  M_TRY(dOff.upload(cand_off, (size_t)(n_q + 1) * 4));
+  M_TRY(dIdx.upload(cand_idx, (size_t)ncand * 4));
+  M_TRY(dT.upload(t_desc, (size_t)n_t * 32));
+  std::vector<uint8_t> zeros((size_t)n_t, 0);
+  M_TRY(dBlocked.upload(train_blocked ? train_blocked : zeros.data(), (size_t)n_t));
+  std::vector<int> minus1((size_t)n_t, -1);
+  M_TRY(dMatch.upload(train_match ? train_match : minus1.data(), (size_t)n_t * 4));
+  M_TRY(dBest.alloc((size_t)n_q * 8));
+  M_TRY(dResult.alloc(8));
+  hipLaunchKernelGGL(k_search_window, dim3(1), dim3(64), 0, 0, dQ.as<uint8_t>(),
+                     query_blocks ? dQB.as<uint8_t>() : (uint8_t *)nullptr, n_q, dOff.as<int>(), dIdx.as<int>(),
+                     dT.as<uint8_t>(), (const int *)nullptr, dBlocked.as<uint8_t>(), th_high, 0.f, 0, dMatch.as<int>(),
+                     (int *)nullptr, dBest.as<int>(), dResult.as<int>());
+  int result[2] = {0, 0};
+  M_TRY(hipMemcpy(result, dResult.p, 8, hipMemcpyDeviceToHost));
+  std::vector<int> best((size_t)n_q * 2);
+  M_TRY(hipMemcpy(best.data(), dBest.p, (size_t)n_q * 8, hipMemcpyDeviceToHost));
+  for (int q = 0; q < n_q; q++) q_best_idx[q] = best[2 * q], q_best_dist[q] = best[2 * q + 1];
+  if (train_match) M_TRY(hipMemcpy(train_match, dMatch.p, (size_t)n_t * 4, hipMemcpyDeviceToHost));
+  if (train_blocked) M_TRY(hipMemcpy(train_blocked, dBlocked.p, (size_t)n_t, hipMemcpyDeviceToHost));
+  return result[0];
 }
 
 int vsg_search_for_initialization(int device, const uint8_t *desc1, const float *angle1, const int32_t *octave1,

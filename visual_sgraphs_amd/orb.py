@@ -37,7 +37,8 @@ EXPORTS = [
     "vsg_orb_copy_blurred_level", "vsg_orb_copy_candidates", "vsg_orb_copy_selected", "vsg_orb_enable_timing",
     "vsg_orb_get_timing", "vsg_orb_set_serialize", "vsg_hamming_pairs", "vsg_hamming_block_best2", "vsg_hamming_block_best2_device",
     "vsg_search_by_bow_kf_f", "vsg_search_by_bow_kf_kf", "vsg_search_by_projection_last",
-    "vsg_search_by_projection_local", "vsg_search_for_initialization",
+    "vsg_search_by_projection_local", "vsg_search_for_initialization", "vsg_search_window", "vsg_grid_build",
+    "vsg_grid_destroy", "vsg_grid_query",
 ]
 
 
@@ -97,6 +98,13 @@ def load_library():
                                                  C.c_int, C.c_float, _i32p]
     L.vsg_search_for_initialization.argtypes = [C.c_int, _u8p, _f32p, _i32p, C.c_int, _i32p, _i32p, _u8p, _f32p,
                                                 C.c_int, C.c_float, C.c_int, _i32p]
+    L.vsg_search_window.argtypes = [C.c_int, _u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _u8p, C.c_int, C.c_int, _i32p,
+                                    _i32p, _i32p]
+    L.vsg_grid_build.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.POINTER(C.c_void_p)]
+    L.vsg_grid_destroy.argtypes = [C.c_void_p]
+    L.vsg_grid_destroy.restype = None
+    L.vsg_grid_query.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _i32p, _i32p, C.c_int, _i32p, _i32p, C.c_int]
     _lib = L
     return L
 
@@ -405,3 +413,58 @@ class ORBmatcher:
                                                          int(self.mbCheckOrientation), _p(out, _i32p)),
                    "vsg_search_for_initialization")
         return n, out[:len(d1)]
+
+
+class FrameGrid:
+    """Frame::AssignFeaturesToGrid + GetFeaturesInArea on the device (Frame.cc:521-553, 802-880)."""
+
+    def __init__(self, kps, min_x, min_y, max_x, max_y, device=0):
+        self._L = load_library()
+        self._kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+        self._h = C.c_void_p()
+        _check(self._L.vsg_grid_build(int(device), self._kps.ctypes.data_as(C.c_void_p), len(self._kps), float(min_x),
+                                      float(min_y), float(max_x), float(max_y), C.byref(self._h)), "vsg_grid_build")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.vsg_grid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=None, maxLevel=None):
+        """Batched query.  Returns (cand_off[nq+1], cand_idx) in the reference's candidate order."""
+        x, y, r = _f32(np.atleast_1d(x)), _f32(np.atleast_1d(y)), _f32(np.atleast_1d(r))
+        nq = len(x)
+        lo = _i32(np.atleast_1d(minLevel)) if minLevel is not None else None
+        hi = _i32(np.atleast_1d(maxLevel)) if maxLevel is not None else None
+        off = np.zeros(nq + 1, np.int32)
+        cap = max(1, 64 * nq)
+        while True:
+            idx = np.zeros(cap, np.int32)
+            total = _check(self._L.vsg_grid_query(self._h, _p(x, _f32p), _p(y, _f32p), _p(r, _f32p),
+                                                  _p(lo, _i32p) if lo is not None else None,
+                                                  _p(hi, _i32p) if hi is not None else None, nq, _p(off, _i32p),
+                                                  _p(idx, _i32p), cap), "vsg_grid_query")
+            if total <= cap:
+                return off, idx[:total]
+            cap = total
+
+
+def search_window(q_desc, q_blocks, cand_off, cand_idx, t_desc, t_blocked, th_high, device=0):
+    """vsg_search_window.  Returns (nmatches, q_best_idx, q_best_dist, train_match, train_blocked)."""
+    qd, td = _u8(q_desc).reshape(-1, 32), _u8(t_desc).reshape(-1, 32)
+    co, ci = _i32(cand_off), _i32(cand_idx)
+    qb = _u8(q_blocks) if q_blocks is not None else None
+    tb = _u8(t_blocked).copy() if t_blocked is not None else None
+    qi, qdist = np.zeros(max(len(qd), 1), np.int32), np.zeros(max(len(qd), 1), np.int32)
+    tm = np.full(max(len(td), 1), -1, np.int32)
+    n = _check(load_library().vsg_search_window(int(device), _p(qd, _u8p), _p(qb, _u8p) if qb is not None else None,
+                                                len(qd), _p(co, _i32p), _p(ci, _i32p), _p(td, _u8p),
+                                                _p(tb, _u8p) if tb is not None else None, len(td), int(th_high),
+                                                _p(qi, _i32p), _p(qdist, _i32p), _p(tm, _i32p)), "vsg_search_window")
+    return n, qi[:len(qd)], qdist[:len(qd)], tm[:len(td)], tb
