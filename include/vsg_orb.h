@@ -110,6 +110,15 @@ int vsg_orb_enable_timing(vsg_orb *h, int enable);
 int vsg_orb_set_serialize(vsg_orb *h, int serialize);
 int vsg_orb_get_timing(vsg_orb *h, float *ms_out, int cap);
 
+/* void Frame::ComputeStereoMatches() (Frame.cc:957-1127) for a rectified pair.  hl/hr = the
+ * extractors that just processed the left/right image (their mvImagePyramid is read on the device; one handle
+ * with a 2-frame batch works too: frame_l/frame_r index the batch).  kps/desc = the operator() outputs (host).
+ * u_right[n_l], depth[n_l] receive mvuRight / mvDepth (-1 where no match); mb, mbf as in Frame.  Returns the
+ * number of stereo matches kept. */
+int vsg_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const vsg_keypoint *kps_l,
+                       const uint8_t *desc_l, int n_l, const vsg_keypoint *kps_r, const uint8_t *desc_r, int n_r,
+                       float mb, float mbf, float *u_right, float *depth);
+
 /* ---- ORBmatcher (flattened POD views; pointer-graph walking and geometry stay in the C++ adaptor) ---- */
 
 /* static int ORBmatcher::DescriptorDistance(a, b) (ORBmatcher.h:40, ORBmatcher.cc:2047-2063)

@@ -890,6 +890,125 @@ void or_orb_descriptor(const uint8_t *blurred, int stride, int cx, int cy, float
   computeOrbDescriptor(angleDeg, blurred + (size_t)cy * stride + cx, stride, kBitPattern31, desc);
 }
 
+void or_stereo_matches(const OrExtractor *left, const OrExtractor *right, const OrKeyPoint *mvKeys,
+                       const uint8_t *mDescriptors, int N, const OrKeyPoint *mvKeysRight,
+                       const uint8_t *mDescriptorsRight, int Nr, float mb, float mbf, float *mvuRight,
+                       float *mvDepth) {
+  // Frame.cc:957-1127
+  for (int i = 0; i < N; i++) mvuRight[i] = -1.0f, mvDepth[i] = -1.0f;
+  const int TH_HIGH = 100, TH_LOW = 50;
+  const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+  const std::vector<float> &mvScaleFactors = left->mvScaleFactor, &mvInvScaleFactors = left->mvInvScaleFactor;
+  const int nRows = left->mvImagePyramid[0].rows;
+  std::vector<std::vector<size_t>> vRowIndices(nRows, std::vector<size_t>());
+  for (int iR = 0; iR < Nr; iR++) {
+    const OrKeyPoint &kp = mvKeysRight[iR];
+    const float &kpY = kp.y;
+    const float r = 2.0f * mvScaleFactors[mvKeysRight[iR].octave];
+    const int maxr = (int)ceil(kpY + r);
+    const int minr = (int)floor(kpY - r);
+    for (int yi = minr; yi <= maxr; yi++)
+      if (yi >= 0 && yi < nRows) vRowIndices[yi].push_back(iR);  // (the reference indexes unchecked)
+  }
+  const float minZ = mb;
+  const float minD = 0;
+  const float maxD = mbf / minZ;
+  std::vector<std::pair<int, int>> vDistIdx;
+  auto descDist = [](const uint8_t *a, const uint8_t *b) {
+    int d = 0;
+    for (int k = 0; k < 32; k++) d += __builtin_popcount((unsigned)(a[k] ^ b[k]));
+    return d;
+  };
+  for (int iL = 0; iL < N; iL++) {
+    const OrKeyPoint &kpL = mvKeys[iL];
+    const int &levelL = kpL.octave;
+    const float &vL = kpL.y;
+    const float &uL = kpL.x;
+    if ((int)vL < 0 || (int)vL >= nRows) continue;
+    const std::vector<size_t> &vCandidates = vRowIndices[(size_t)vL];
+    if (vCandidates.empty()) continue;
+    const float minU = uL - maxD;
+    const float maxU = uL - minD;
+    if (maxU < 0) continue;
+    int bestDist = TH_HIGH;
+    size_t bestIdxR = 0;
+    const uint8_t *dL = mDescriptors + (size_t)iL * 32;
+    for (size_t iC = 0; iC < vCandidates.size(); iC++) {
+      const size_t iR = vCandidates[iC];
+      const OrKeyPoint &kpR = mvKeysRight[iR];
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      const float &uR = kpR.x;
+      if (uR >= minU && uR <= maxU) {
+        const int dist = descDist(dL, mDescriptorsRight + iR * 32);
+        if (dist < bestDist) {
+          bestDist = dist;
+          bestIdxR = iR;
+        }
+      }
+    }
+    if (bestDist < thOrbDist) {
+      const float uR0 = mvKeysRight[bestIdxR].x;
+      const float scaleFactor = mvInvScaleFactors[kpL.octave];
+      const float scaleduL = roundf(kpL.x * scaleFactor);
+      const float scaledvL = roundf(kpL.y * scaleFactor);
+      const float scaleduR0 = roundf(uR0 * scaleFactor);
+      const int w = 5;
+      const Img &pl = left->mvImagePyramid[kpL.octave], &pr = right->mvImagePyramid[kpL.octave];
+      // IL = pl.rowRange(scaledvL - w, scaledvL + w + 1).colRange(scaleduL - w, scaleduL + w + 1)
+      const int ily = (int)(scaledvL - w), ilx = (int)(scaleduL - w);
+      int bestDistS = INT_MAX;
+      int bestincR = 0;
+      const int L = 5;
+      std::vector<float> vDists(2 * L + 1);
+      const float iniu = scaleduR0 + L - w;
+      const float endu = scaleduR0 + L + w + 1;
+      if (iniu < 0 || endu >= pr.cols) continue;
+      for (int incR = -L; incR <= +L; incR++) {
+        const int irx = (int)(scaleduR0 + incR - w);
+        long sum = 0;  // cv::norm(IL, IR, cv::NORM_L1)
+        for (int yy = 0; yy < 2 * w + 1; yy++)
+          for (int xx = 0; xx < 2 * w + 1; xx++)
+            sum += std::abs((int)pl.ptr(ily + yy)[ilx + xx] - (int)pr.ptr(ily + yy)[irx + xx]);
+        float dist = (float)(double)sum;
+        if (dist < bestDistS) {
+          bestDistS = (int)dist;
+          bestincR = incR;
+        }
+        vDists[L + incR] = dist;
+      }
+      if (bestincR == -L || bestincR == L) continue;
+      const float dist1 = vDists[L + bestincR - 1];
+      const float dist2 = vDists[L + bestincR];
+      const float dist3 = vDists[L + bestincR + 1];
+      const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+      if (deltaR < -1 || deltaR > 1) continue;
+      float bestuR = mvScaleFactors[kpL.octave] * ((float)scaleduR0 + (float)bestincR + deltaR);
+      float disparity = (uL - bestuR);
+      if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) {
+          disparity = 0.01;
+          bestuR = uL - 0.01;
+        }
+        mvDepth[iL] = mbf / disparity;
+        mvuRight[iL] = bestuR;
+        vDistIdx.push_back(std::pair<int, int>(bestDistS, iL));
+      }
+    }
+  }
+  if (vDistIdx.empty()) return;  // (the reference reads vDistIdx[0] of an empty vector here)
+  std::sort(vDistIdx.begin(), vDistIdx.end());
+  const float median = vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+    if (vDistIdx[i].first < thDist)
+      break;
+    else {
+      mvuRight[vDistIdx[i].second] = -1;
+      mvDepth[vDistIdx[i].second] = -1;
+    }
+  }
+}
+
 double or_bench_throughput(const uint8_t *frames, int nframes, int rows, int cols, int nfeatures, float scaleFactor,
                            int nlevels, int iniThFAST, int minThFAST, int nthreads, double seconds, int do_match,
                            long *frames_done) {

@@ -84,6 +84,13 @@ float or_ic_angle(const uint8_t *img, int stride, int cx, int cy);
 /* computeOrbDescriptor (ORBextractor.cc:103-149) */
 void or_orb_descriptor(const uint8_t *blurred, int stride, int cx, int cy, float angleDeg, uint8_t desc[32]);
 
+/* Frame::ComputeStereoMatches (Frame.cc:957-1127) for a rectified pair whose two extractors have just run
+ * or_extract (their mvImagePyramid is read, Frame.cc:964,1054-1069).  kps/desc = the operator() outputs.
+ * uRight[nL], depth[nL] receive mvuRight / mvDepth (-1 where no match). */
+void or_stereo_matches(const OrExtractor *left, const OrExtractor *right, const OrKeyPoint *kpsL, const uint8_t *descL,
+                       int nL, const OrKeyPoint *kpsR, const uint8_t *descR, int nR, float mb, float mbf,
+                       float *uRight, float *depth);
+
 /* ---- CPU baseline (bench.py cpu_baseline leg): `nthreads` independent extractors, each on its own host thread
  * (the reference is single-threaded per ORBextractor, two threads for stereo: Frame.cc:129-132), looping over the
  * given frames: operator() + brute-force best/second-best match against the thread's previous frame when

@@ -85,6 +85,9 @@ def lib():
         L.or_block_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
         L.or_search_window.argtypes = [_u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _u8p, C.c_int, C.c_int, _i32p, _i32p,
                                        _i32p]
+        L.or_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _u8p, C.c_int, C.c_void_p, _u8p, C.c_int,
+                                        C.c_float, C.c_float, _f32p, _f32p]
+        L.or_stereo_matches.restype = None
         L.or_bench_throughput.restype = C.c_double
         L.or_bench_throughput.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_long)]
@@ -386,3 +389,14 @@ def search_window(q_desc, q_blocks, cand_off, cand_idx, t_desc, t_blocked, th_hi
                                _ptr(ci, _i32p), _ptr(td, _u8p), _ptr(tb, _u8p) if tb is not None else None, len(td),
                                int(th_high), _ptr(qi, _i32p), _ptr(qdist, _i32p), _ptr(tm, _i32p))
     return n, qi, qdist, tm, tb
+
+
+def stereo_matches(ex_left, ex_right, kps_l, desc_l, kps_r, desc_r, mb, mbf):
+    """Frame::ComputeStereoMatches on two OracleExtractors that have just run.  Returns (uRight, depth)."""
+    kl, kr = np.ascontiguousarray(kps_l, KP_DTYPE), np.ascontiguousarray(kps_r, KP_DTYPE)
+    dl, dr = _u8c(desc_l), _u8c(desc_r)
+    ur, dep = np.zeros(max(len(kl), 1), np.float32), np.zeros(max(len(kl), 1), np.float32)
+    lib().or_stereo_matches(ex_left.h, ex_right.h, kl.ctypes.data_as(C.c_void_p), _ptr(dl, _u8p), len(kl),
+                            kr.ctypes.data_as(C.c_void_p), _ptr(dr, _u8p), len(kr), float(mb), float(mbf),
+                            _ptr(ur, _f32p), _ptr(dep, _f32p))
+    return ur[:len(kl)], dep[:len(kl)]

@@ -71,6 +71,13 @@ struct Src0 {
   int pitch;             // bytes per row, multiple of 4
 };
 
+// pyramid of one frame as raw level pointers (level 0 may live in the caller's buffer)
+struct PyrView {
+  const uint8_t *lvl[kMaxLevels];
+  int pitch[kMaxLevels];
+  int w[kMaxLevels], h[kMaxLevels];
+};
+
 enum { kBlurStrip = 36 };  // output rows per thread in k_blur (36 + 6 halo rows = 6 x 7-row window turns)
 
 // cv::KeyPoint-compatible record (28 bytes): pt.x pt.y size angle response octave class_id

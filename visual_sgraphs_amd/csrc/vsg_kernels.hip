@@ -758,6 +758,146 @@ __global__ void k_border_copy(const uint8_t *__restrict__ img, int w, int h, int
   dst[(size_t)y * dpitch + x] = img[(size_t)reflect101(y - b, h) * pitch + reflect101(x - b, w)];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches (Frame.cc:957-1127), one wavefront per LEFT keypoint (no greedy state: left
+// keypoints are independent).  Row-band candidates are found by scanning the right keypoints in index order
+// (= the push order of vRowIndices), packed keys keep "first minimum wins"; the 11x11 L1 SAD over 11 shifts runs
+// on the un-blurred pyramid level of the left keypoint's octave; the sub-pixel parabola and the disparity/depth
+// arithmetic are plain non-contracted float ops.  The median-based outlier cut (:1113-1126) is done by the host.
+struct StereoParams {
+  float mb, mbf;
+  float scale[kMaxLevels], invScale[kMaxLevels];
+  int nRows;
+};
+
+__global__ __launch_bounds__(256) void k_stereo(PyrView pl, PyrView pr, StereoParams sp, const KeyPointPOD *kpsL,
+                                                const uint8_t *descL, int nL, const KeyPointPOD *kpsR,
+                                                const uint8_t *descR, int nR, float *uRight, float *depth,
+                                                int *sadBest) {
+  const int lane = threadIdx.x & 63;
+  const int iL = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (iL >= nL) return;
+  const KeyPointPOD kpL = kpsL[iL];
+  const int levelL = kpL.octave;
+  const float vL = kpL.y, uL = kpL.x;
+  float outU = -1.0f, outD = -1.0f;
+  int outS = -1;
+  const float minZ = sp.mb, minD = 0.f;
+  const float maxD = fdiv(sp.mbf, minZ);
+  const float minU = fsub(uL, maxD), maxU = fsub(uL, minD);
+  const int rowL = (int)vL;
+  uint32_t k = 0xFFFFFFFFu;
+  if (rowL >= 0 && rowL < sp.nRows && !(maxU < 0)) {
+    const uint4 *dl = (const uint4 *)(descL + (size_t)iL * 32);
+    const uint4 a0 = dl[0], a1 = dl[1];
+    for (int iR = lane; iR < nR; iR += 64) {
+      const KeyPointPOD kpR = kpsR[iR];
+      const float r = fmul(2.0f, sp.scale[kpR.octave]);
+      const int maxr = (int)ceilf(fadd(kpR.y, r)), minr = (int)floorf(fsub(kpR.y, r));
+      if (rowL < minr || rowL > maxr) continue;
+      if (kpR.octave < levelL - 1 || kpR.octave > levelL + 1) continue;
+      if (!(kpR.x >= minU && kpR.x <= maxU)) continue;
+      const uint4 *dr = (const uint4 *)(descR + (size_t)iR * 32);
+      const uint4 b0 = dr[0], b1 = dr[1];
+      const int dist = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                       __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+      if (dist < 100) k = min(k, ((uint32_t)dist << 20) | (uint32_t)iR);  // bestDist starts at TH_HIGH (:1013)
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) k = min(k, __shfl_xor(k, d));
+  const int thOrbDist = (100 + 50) / 2;
+  if (k != 0xFFFFFFFFu && (int)(k >> 20) < thOrbDist) {
+    const int bestIdxR = (int)(k & 0xFFFFF);
+    const float uR0 = kpsR[bestIdxR].x;
+    const float sf = sp.invScale[levelL];
+    const float scaleduL = roundf(fmul(kpL.x, sf)), scaledvL = roundf(fmul(kpL.y, sf)), scaleduR0 = roundf(fmul(uR0, sf));
+    const int w = 5, L = 5;
+    const int ily = (int)fsub(scaledvL, (float)w), ilx = (int)fsub(scaleduL, (float)w);
+    const float iniu = fsub(fadd(scaleduR0, (float)L), (float)w);
+    const float endu = fadd(fadd(fadd(scaleduR0, (float)L), (float)w), 1.0f);
+    if (!(iniu < 0 || endu >= (float)pr.w[levelL])) {
+      const uint8_t *PL = pl.lvl[levelL], *PR = pr.lvl[levelL];
+      const int pL = pl.pitch[levelL], pR = pr.pitch[levelL];
+      // this lane's pixels of the 11x11 window: p = lane and lane + 64
+      int py[2], px[2], lv[2];
+      bool ok[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int p = lane + 64 * t;
+        ok[t] = p < 121;
+        py[t] = ok[t] ? p / 11 : 0;
+        px[t] = ok[t] ? p - py[t] * 11 : 0;
+        lv[t] = PL[(size_t)(ily + py[t]) * pL + ilx + px[t]];
+      }
+      int bestDistS = 0x7FFFFFFF, bestincR = 0;
+      float vDists[11];
+#pragma unroll
+      for (int incR = -5; incR <= 5; incR++) {
+        const int irx = (int)fsub(fadd(scaleduR0, (float)incR), (float)w);
+        int s = 0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const int rv = PR[(size_t)(ily + py[t]) * pR + irx + px[t]];
+          const int dd = lv[t] - rv;
+          s += ok[t] ? (dd < 0 ? -dd : dd) : 0;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+        const float dist = (float)s;  // cv::norm(IL, IR, NORM_L1)
+        if (dist < (float)bestDistS) {
+          bestDistS = (int)dist;
+          bestincR = incR;
+        }
+        vDists[incR + 5] = dist;
+      }
+      if (!(bestincR == -L || bestincR == L)) {
+        float dist1 = 0, dist2 = 0, dist3 = 0;
+#pragma unroll
+        for (int j = 1; j < 10; j++)
+          if (j == bestincR + 5) {
+            dist1 = vDists[j - 1];
+            dist2 = vDists[j];
+            dist3 = vDists[j + 1];
+          }
+        const float deltaR = fdiv(fsub(dist1, dist3), fmul(2.0f, fsub(fadd(dist1, dist3), fmul(2.0f, dist2))));
+        if (!(deltaR < -1 || deltaR > 1)) {
+          float bestuR = fmul(sp.scale[levelL], fadd(fadd(scaleduR0, (float)bestincR), deltaR));
+          float disparity = fsub(uL, bestuR);
+          if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) {
+              disparity = 0.01f;                                   // disparity = 0.01 (double literal -> float)
+              bestuR = (float)((double)uL - 0.01);                 // bestuR = uL - 0.01
+            }
+            outD = fdiv(sp.mbf, disparity);
+            outU = bestuR;
+            outS = bestDistS;
+          }
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    uRight[iL] = outU;
+    depth[iL] = outD;
+    sadBest[iL] = outS;
+  }
+}
+void launch_stereo(hipStream_t s, const PyrView &pl, const PyrView &pr, float mb, float mbf, const float *scale,
+                   const float *invScale, int nlevels, const KeyPointPOD *kpsL, const uint8_t *descL, int nL,
+                   const KeyPointPOD *kpsR, const uint8_t *descR, int nR, float *uRight, float *depth, int *sadBest) {
+  StereoParams sp;
+  sp.mb = mb;
+  sp.mbf = mbf;
+  for (int l = 0; l < kMaxLevels; l++) {
+    sp.scale[l] = l < nlevels ? scale[l] : 1.f;
+    sp.invScale[l] = l < nlevels ? invScale[l] : 1.f;
+  }
+  sp.nRows = pl.h[0];
+  hipLaunchKernelGGL(k_stereo, dim3((nL + 3) / 4), dim3(256), 0, s, pl, pr, sp, kpsL, descL, nL, kpsR, descR, nR, uRight,
+                     depth, sadBest);
+}
+
 // per-call reset of the candidate / selection counters (a kernel rather than hipMemsetAsync so that it is
 // ordered like every other stage on the stream and the stage-timing events bracket real work)
 __global__ void k_zero(int *p, int n) {

@@ -9,8 +9,10 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/vsg_orb.h"
@@ -536,6 +538,81 @@ int vsg_orb_copy_selected(vsg_orb *h, int frame, int level, uint32_t *dst, int c
   const LevelGeom &L = h->G.fg.lv[level];
   return copy_list(h, h->d_sel, h->G.fg.sel_frame, L.sel_off, L.sel_cap,
                    h->d_counts2 + (size_t)h->max_batch * kMaxLevels, frame, level, dst, cap);
+}
+
+static int pyr_view(vsg_orb *h, int frame, PyrView &v) {
+  if (!h || !h->rows || frame < 0 || frame >= h->max_batch || !h->last_src0.base) return VSG_ERR_INVALID;
+  const FrameGeom &fg = h->G.fg;
+  memset(&v, 0, sizeof(v));
+  for (int l = 0; l < fg.nlevels; l++) {
+    v.w[l] = fg.lv[l].w;
+    v.h[l] = fg.lv[l].h;
+    if (l == 0) {
+      v.lvl[0] = h->last_src0.base + (size_t)frame * h->last_src0.frame_stride;
+      v.pitch[0] = h->last_src0.pitch;
+    } else {
+      v.lvl[l] = h->d_pyr + (size_t)frame * fg.pyr_frame_bytes + fg.lv[l].img_off;
+      v.pitch[l] = fg.lv[l].pitch;
+    }
+  }
+  return VSG_OK;
+}
+
+int vsg_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const vsg_keypoint *kps_l,
+                       const uint8_t *desc_l, int n_l, const vsg_keypoint *kps_r, const uint8_t *desc_r, int n_r,
+                       float mb, float mbf, float *u_right, float *depth) {
+  if (!hl || !hr || !u_right || !depth || n_l < 0 || n_r < 0 || hl->device != hr->device) return VSG_ERR_INVALID;
+  for (int i = 0; i < n_l; i++) u_right[i] = -1.0f, depth[i] = -1.0f;
+  if (n_l == 0 || n_r == 0) return 0;
+  PyrView pl, pr;
+  int rc = pyr_view(hl, frame_l, pl);
+  if (rc == VSG_OK) rc = pyr_view(hr, frame_r, pr);
+  if (rc != VSG_OK) return rc;
+  HIP_TRY(hipSetDevice(hl->device));
+  HIP_TRY(hipStreamSynchronize(hl->s_main));
+  HIP_TRY(hipStreamSynchronize(hr->s_main));
+  KeyPointPOD *dkl = nullptr, *dkr = nullptr;
+  uint8_t *ddl = nullptr, *ddr = nullptr;
+  float *du = nullptr, *dd = nullptr;
+  int *ds = nullptr;
+  hipError_t e = hipMalloc(&dkl, sizeof(KeyPointPOD) * n_l);
+  if (e == hipSuccess) e = hipMalloc(&dkr, sizeof(KeyPointPOD) * n_r);
+  if (e == hipSuccess) e = hipMalloc(&ddl, 32 * (size_t)n_l);
+  if (e == hipSuccess) e = hipMalloc(&ddr, 32 * (size_t)n_r);
+  if (e == hipSuccess) e = hipMalloc(&du, 4 * (size_t)n_l);
+  if (e == hipSuccess) e = hipMalloc(&dd, 4 * (size_t)n_l);
+  if (e == hipSuccess) e = hipMalloc(&ds, 4 * (size_t)n_l);
+  if (e == hipSuccess) e = hipMemcpy(dkl, kps_l, sizeof(KeyPointPOD) * n_l, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dkr, kps_r, sizeof(KeyPointPOD) * n_r, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ddl, desc_l, 32 * (size_t)n_l, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ddr, desc_r, 32 * (size_t)n_r, hipMemcpyHostToDevice);
+  std::vector<int> sad((size_t)n_l, -1);
+  if (e == hipSuccess) {
+    launch_stereo(hl->s_main, pl, pr, mb, mbf, hl->T.scale.data(), hl->T.invScale.data(), hl->T.nlevels, dkl, ddl, n_l,
+                  dkr, ddr, n_r, du, dd, ds);
+    e = hipStreamSynchronize(hl->s_main);
+  }
+  if (e == hipSuccess) e = hipMemcpy(u_right, du, 4 * (size_t)n_l, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(depth, dd, 4 * (size_t)n_l, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(sad.data(), ds, 4 * (size_t)n_l, hipMemcpyDeviceToHost);
+  hipFree(dkl), hipFree(dkr), hipFree(ddl), hipFree(ddr), hipFree(du), hipFree(dd), hipFree(ds);
+  HIP_TRY(e);
+  // median-based outlier cut (Frame.cc:1113-1126)
+  std::vector<std::pair<int, int>> vDistIdx;
+  for (int i = 0; i < n_l; i++)
+    if (sad[i] >= 0) vDistIdx.push_back(std::pair<int, int>(sad[i], i));
+  if (vDistIdx.empty()) return 0;
+  std::sort(vDistIdx.begin(), vDistIdx.end());
+  const float median = (float)vDistIdx[vDistIdx.size() / 2].first;
+  const float thDist = 1.5f * 1.4f * median;
+  int kept = (int)vDistIdx.size();
+  for (int i = (int)vDistIdx.size() - 1; i >= 0; i--) {
+    if ((float)vDistIdx[i].first < thDist) break;
+    u_right[vDistIdx[i].second] = -1;
+    depth[vDistIdx[i].second] = -1;
+    kept--;
+  }
+  return kept;
 }
 
 int vsg_orb_set_serialize(vsg_orb *h, int serialize) {

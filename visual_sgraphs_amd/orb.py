@@ -38,7 +38,7 @@ EXPORTS = [
     "vsg_orb_get_timing", "vsg_orb_set_serialize", "vsg_hamming_pairs", "vsg_hamming_block_best2", "vsg_hamming_block_best2_device",
     "vsg_search_by_bow_kf_f", "vsg_search_by_bow_kf_kf", "vsg_search_by_projection_last",
     "vsg_search_by_projection_local", "vsg_search_for_initialization", "vsg_search_window", "vsg_grid_build",
-    "vsg_grid_destroy", "vsg_grid_query",
+    "vsg_grid_destroy", "vsg_grid_query", "vsg_stereo_matches",
 ]
 
 
@@ -100,6 +100,8 @@ def load_library():
                                                 C.c_int, C.c_float, C.c_int, _i32p]
     L.vsg_search_window.argtypes = [C.c_int, _u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _u8p, C.c_int, C.c_int, _i32p,
                                     _i32p, _i32p]
+    L.vsg_stereo_matches.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, _u8p, C.c_int, C.c_void_p,
+                                     _u8p, C.c_int, C.c_float, C.c_float, _f32p, _f32p]
     L.vsg_grid_build.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.POINTER(C.c_void_p)]
     L.vsg_grid_destroy.argtypes = [C.c_void_p]
@@ -468,3 +470,15 @@ def search_window(q_desc, q_blocks, cand_off, cand_idx, t_desc, t_blocked, th_hi
                                                 _p(tb, _u8p) if tb is not None else None, len(td), int(th_high),
                                                 _p(qi, _i32p), _p(qdist, _i32p), _p(tm, _i32p)), "vsg_search_window")
     return n, qi[:len(qd)], qdist[:len(qd)], tm[:len(td)], tb
+
+
+def ComputeStereoMatches(ex_left, frame_l, ex_right, frame_r, kps_l, desc_l, kps_r, desc_r, mb, mbf):
+    """Frame::ComputeStereoMatches (Frame.cc:957-1127).  Returns (mvuRight, mvDepth)."""
+    kl, kr = np.ascontiguousarray(kps_l, KP_DTYPE), np.ascontiguousarray(kps_r, KP_DTYPE)
+    dl, dr = _u8(desc_l).reshape(-1, 32), _u8(desc_r).reshape(-1, 32)
+    ur, dep = np.zeros(max(len(kl), 1), np.float32), np.zeros(max(len(kl), 1), np.float32)
+    _check(load_library().vsg_stereo_matches(ex_left.handle, int(frame_l), ex_right.handle, int(frame_r),
+                                             kl.ctypes.data_as(C.c_void_p), _p(dl, _u8p), len(kl),
+                                             kr.ctypes.data_as(C.c_void_p), _p(dr, _u8p), len(kr), float(mb), float(mbf),
+                                             _p(ur, _f32p), _p(dep, _f32p)), "vsg_stereo_matches")
+    return ur[:len(kl)], dep[:len(kl)]
