@@ -89,6 +89,21 @@ int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes,
                                  int cols, int stride, int lap0, int lap1, vsg_keypoint *d_kps, uint8_t *d_desc,
                                  int *d_counts, int capacity, void *stream);
 
+/* Colour input: Tracking::GrabImage{Monocular,Stereo,RGBD} converts with cv::cvtColor(...,
+ * COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) before building the Frame (Tracking.cc:1526-1551, 1595-1608, 1643-1656).  This
+ * entry takes the interleaved 8-bit colour frames (channels = 3 or 4; rgb_order != 0 for RGB(A), 0 for BGR(A) =
+ * Tracking::mbRGB) on the device and fuses the conversion into the level-0 staging.  Coefficients are data
+ * (default = OpenCV 4.2: R2Y 4899, G2Y 9617, B2Y 1868, shift 14); they must sum to 1 << shift. */
+int vsg_orb_set_gray_coeffs(vsg_orb *h, const int coeffs[3], int shift);
+int vsg_orb_extract_batch_device_color(vsg_orb *h, const uint8_t *d_img, int channels, int rgb_order, int nframes,
+                                       size_t frame_stride, int rows, int cols, int stride, int lap0, int lap1,
+                                       vsg_keypoint *d_kps, uint8_t *d_desc, int *d_counts, int capacity,
+                                       void *stream);
+/* same with host pointers (colour cv::Mat frames in, keypoints/descriptors out) */
+int vsg_orb_extract_batch_color(vsg_orb *h, const uint8_t *img, int channels, int rgb_order, int nframes,
+                                size_t frame_stride, int rows, int cols, int stride, int lap0, int lap1,
+                                vsg_keypoint *kps, uint8_t *desc, int capacity, int *n, int *mono_index);
+
 /* mvImagePyramid[level] (public member, ORBextractor.h:93; read by Frame::ComputeStereoMatches,
  * Frame.cc:964,1054-1069) of frame `frame` of the last call.  with_border != 0 copies the
  * (w+38)x(h+38) buffer including the 19 px BORDER_REFLECT_101 frame (ORBextractor.cc:1186-1192). */

@@ -890,6 +890,18 @@ void or_orb_descriptor(const uint8_t *blurred, int stride, int cx, int cy, float
   computeOrbDescriptor(angleDeg, blurred + (size_t)cy * stride + cx, stride, kBitPattern31, desc);
 }
 
+void or_cvt_gray_u8(const uint8_t *src, int rows, int cols, int sstride, int channels, int rgb_order, uint8_t *dst,
+                    int dstride, const int coeffs[3], int shift) {
+  // [OCV] color_rgb.simd.hpp RGB2Gray<uchar>: CV_DESCALE(b*cb + g*cg + r*cr, shift)
+  const int ri = rgb_order ? 0 : 2, bi = rgb_order ? 2 : 0;
+  for (int y = 0; y < rows; y++) {
+    const uint8_t *s = src + (size_t)y * sstride;
+    uint8_t *d = dst + (size_t)y * dstride;
+    for (int x = 0; x < cols; x++, s += channels)
+      d[x] = (uint8_t)((s[ri] * coeffs[0] + s[1] * coeffs[1] + s[bi] * coeffs[2] + (1 << (shift - 1))) >> shift);
+  }
+}
+
 void or_stereo_matches(const OrExtractor *left, const OrExtractor *right, const OrKeyPoint *mvKeys,
                        const uint8_t *mDescriptors, int N, const OrKeyPoint *mvKeysRight,
                        const uint8_t *mDescriptorsRight, int Nr, float mb, float mbf, float *mvuRight,

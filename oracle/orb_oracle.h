@@ -84,6 +84,12 @@ float or_ic_angle(const uint8_t *img, int stride, int cx, int cy);
 /* computeOrbDescriptor (ORBextractor.cc:103-149) */
 void or_orb_descriptor(const uint8_t *blurred, int stride, int cx, int cy, float angleDeg, uint8_t desc[32]);
 
+/* cv::cvtColor(COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) for 8-bit images as called in Tracking::GrabImage*
+ * (Tracking.cc:1526-1551, 1595-1608, 1643-1656): gray = (R*cr + G*cg + B*cb + (1 << (shift-1))) >> shift.
+ * [OCV] 4.2 coefficients: cr,cg,cb = 4899, 9617, 1868, shift 14 (version-sensitive => data). */
+void or_cvt_gray_u8(const uint8_t *src, int rows, int cols, int sstride, int channels, int rgb_order, uint8_t *dst,
+                    int dstride, const int coeffs[3], int shift);
+
 /* Frame::ComputeStereoMatches (Frame.cc:957-1127) for a rectified pair whose two extractors have just run
  * or_extract (their mvImagePyramid is read, Frame.cc:964,1054-1069).  kps/desc = the operator() outputs.
  * uRight[nL], depth[nL] receive mvuRight / mvDepth (-1 where no match). */

@@ -85,6 +85,8 @@ def lib():
         L.or_block_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
         L.or_search_window.argtypes = [_u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _u8p, C.c_int, C.c_int, _i32p, _i32p,
                                        _i32p]
+        L.or_cvt_gray_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _i32p, C.c_int]
+        L.or_cvt_gray_u8.restype = None
         L.or_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _u8p, C.c_int, C.c_void_p, _u8p, C.c_int,
                                         C.c_float, C.c_float, _f32p, _f32p]
         L.or_stereo_matches.restype = None
@@ -400,3 +402,17 @@ def stereo_matches(ex_left, ex_right, kps_l, desc_l, kps_r, desc_r, mb, mbf):
                             kr.ctypes.data_as(C.c_void_p), _ptr(dr, _u8p), len(kr), float(mb), float(mbf),
                             _ptr(ur, _f32p), _ptr(dep, _f32p))
     return ur[:len(kl)], dep[:len(kl)]
+
+
+GRAY_COEFFS = (4899, 9617, 1868)
+GRAY_SHIFT = 14
+
+
+def cvt_gray(img, rgb_order=True, coeffs=GRAY_COEFFS, shift=GRAY_SHIFT):
+    img = _u8c(img)
+    rows, cols, ch = img.shape
+    out = np.zeros((rows, cols), np.uint8)
+    c = np.asarray(coeffs, np.int32)
+    lib().or_cvt_gray_u8(_ptr(img, _u8p), rows, cols, img.strides[0], ch, int(rgb_order), _ptr(out, _u8p), cols,
+                         _ptr(c, _i32p), int(shift))
+    return out

@@ -192,3 +192,24 @@ def test_roundtrip_properties_at_full_size():
         assert np.all(np.diff(k1["octave"]) >= 0)
         cnt = np.bincount(k1["octave"], minlength=8)
         assert np.all(cnt <= q + 3) and cnt.sum() == len(k1) >= 900
+
+
+@pytest.mark.parametrize("channels,rgb", [(3, True), (3, False), (4, True), (4, False)])
+def test_colour_input_cvtcolor_fused(channels, rgb):
+    """SURVEY 8f N4: Tracking::GrabImage* cvtColor(RGB/BGR/RGBA/BGRA -> GRAY) fused into the level-0 staging."""
+    rng = np.random.default_rng(7)
+    base = synth.frame(640, 480, 60)
+    col = np.stack([np.clip(base.astype(np.int32) + rng.integers(-20, 21, base.shape), 0, 255).astype(np.uint8)
+                    for _ in range(channels)], axis=-1)
+    gray = ol.cvt_gray(col, rgb)
+    # the oracle's conversion equals the definition
+    r, b = (col[..., 0], col[..., 2]) if rgb else (col[..., 2], col[..., 0])
+    assert np.array_equal(gray, ((r.astype(np.int64) * 4899 + col[..., 1].astype(np.int64) * 9617 +
+                                  b.astype(np.int64) * 1868 + 8192) >> 14).astype(np.uint8))
+    ref = ol.OracleExtractor(1000, 1.2, 8, 20, 7)
+    want = ref(gray)
+    ex = orb.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=2)
+    got = ex.extract_batch_color(np.stack([col, col]), rgb)
+    assert np.array_equal(ex.image_pyramid(0), gray)
+    assert_same_output(got[0], want, "colour frame 0")
+    assert_same_output(got[1], want, "colour frame 1")

@@ -9,6 +9,8 @@ namespace vsg {
 void launch_stereo(hipStream_t s, const PyrView &pl, const PyrView &pr, float mb, float mbf, const float *scale,
                    const float *invScale, int nlevels, const KeyPointPOD *kpsL, const uint8_t *descL, int nL,
                    const KeyPointPOD *kpsR, const uint8_t *descR, int nR, float *uRight, float *depth, int *sadBest);
+void launch_cvt_gray(hipStream_t s, const uint8_t *src, size_t sframe, int spitch, int channels, int rgb_order, int rows,
+                     int cols, uint8_t *dst, size_t dframe, int dpitch, const int coeffs[3], int shift, int nframes);
 void launch_zero(hipStream_t s, int *p, int n);
 void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
                    const FrameGeom &fg, int level, int nframes);

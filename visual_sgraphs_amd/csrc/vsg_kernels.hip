@@ -898,6 +898,35 @@ void launch_stereo(hipStream_t s, const PyrView &pl, const PyrView &pr, float mb
                      depth, sadBest);
 }
 
+// ------------------------------------------------------------------------------------------------
+// cv::cvtColor(..., COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) of Tracking::GrabImage* (Tracking.cc:1595-1608) fused into the
+// level-0 staging: thread = 4 output pixels -> one 32-bit store into the gray staging buffer.
+__global__ __launch_bounds__(256) void k_cvt_gray(const uint8_t *__restrict__ src, size_t sframe, int spitch,
+                                                  int channels, int ri, int bi, int rows, int cols,
+                                                  uint8_t *__restrict__ dst, size_t dframe, int dpitch, int cr, int cg,
+                                                  int cb, int shift) {
+  const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, y = blockIdx.y;
+  if (x4 >= cols) return;
+  const uint8_t *s = src + (size_t)blockIdx.z * sframe + (size_t)y * spitch + (size_t)x4 * channels;
+  uint32_t out = 0;
+  const int half = 1 << (shift - 1);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (x4 + k < cols) {
+      const uint8_t *p = s + k * channels;
+      const int v = ((int)p[ri] * cr + (int)p[1] * cg + (int)p[bi] * cb + half) >> shift;
+      out |= (uint32_t)(v & 0xFF) << (8 * k);
+    }
+  }
+  *(uint32_t *)(dst + (size_t)blockIdx.z * dframe + (size_t)y * dpitch + x4) = out;
+}
+void launch_cvt_gray(hipStream_t s, const uint8_t *src, size_t sframe, int spitch, int channels, int rgb_order, int rows,
+                     int cols, uint8_t *dst, size_t dframe, int dpitch, const int coeffs[3], int shift, int nframes) {
+  dim3 grid((cols + 1023) / 1024, rows, nframes), block(256);
+  hipLaunchKernelGGL(k_cvt_gray, grid, block, 0, s, src, sframe, spitch, channels, rgb_order ? 0 : 2, rgb_order ? 2 : 0,
+                     rows, cols, dst, dframe, dpitch, coeffs[0], coeffs[1], coeffs[2], shift);
+}
+
 // per-call reset of the candidate / selection counters (a kernel rather than hipMemsetAsync so that it is
 // ordered like every other stage on the stream and the stage-timing events bracket real work)
 __global__ void k_zero(int *p, int n) {

@@ -48,6 +48,8 @@ struct vsg_orb {
   int device = 0, max_batch = 1;
   int rows = 0, cols = 0;  // geometry currently built for
   uint16_t taps[7] = {18, 34, 49, 55, 49, 34, 18};
+  int gray_coeffs[3] = {4899, 9617, 1868};  // [OCV] 4.2 R2Y, G2Y, B2Y
+  int gray_shift = 14;                        // yuv_shift
   int last_frames = 0;
   // device
   FrameGeom *d_fg = nullptr;
@@ -389,6 +391,34 @@ int vsg_orb_capacity(vsg_orb *h, int rows, int cols) {
   return h->G.fg.out_cap;
 }
 
+}  // extern "C"
+
+// D2H of the handle's own output buffers + copy into the caller's [nframes][capacity] arrays
+static int fetch_outputs(vsg_orb *h, int nframes, vsg_keypoint *kps, uint8_t *desc, int capacity, int *n,
+                         int *mono_index, hipStream_t s) {
+  const FrameGeom &fg = h->G.fg;
+  HIP_TRY(hipMemcpyAsync(h->h_out_counts, h->d_out_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)nframes * fg.out_cap * 32, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int status = VSG_OK;
+  for (int f = 0; f < nframes; f++) {
+    const int nf = h->h_out_counts[2 * f];
+    n[f] = nf;
+    mono_index[f] = h->h_out_counts[2 * f + 1];
+    if (nf > capacity) {
+      set_err("caller capacity too small for the extracted keypoints");
+      status = VSG_ERR_CAPACITY;
+      continue;
+    }
+    if (nf > 0 && kps) memcpy(kps + (size_t)f * capacity, h->h_kps + (size_t)f * fg.out_cap, (size_t)nf * sizeof(KeyPointPOD));
+    if (nf > 0 && desc) memcpy(desc + (size_t)f * capacity * 32, h->h_desc + (size_t)f * fg.out_cap * 32, (size_t)nf * 32);
+  }
+  return status;
+}
+
+extern "C" {
+
 int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes, size_t frame_stride, int rows,
                                  int cols, int stride, int lap0, int lap1, vsg_keypoint *d_kps, uint8_t *d_desc,
                                  int *d_counts, int capacity, void *stream) {
@@ -415,6 +445,33 @@ int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes,
   return enqueue_pipeline(h, s0, nframes, lap0, lap1, (KeyPointPOD *)d_kps, d_desc, d_counts, capacity, s);
 }
 
+int vsg_orb_set_gray_coeffs(vsg_orb *h, const int coeffs[3], int shift) {
+  if (!h || !coeffs || shift < 1 || shift > 20) return VSG_ERR_INVALID;
+  if (coeffs[0] + coeffs[1] + coeffs[2] != (1 << shift)) return VSG_ERR_INVALID;  // CV_Assert in RGB2Gray<uchar>
+  memcpy(h->gray_coeffs, coeffs, sizeof(h->gray_coeffs));
+  h->gray_shift = shift;
+  return VSG_OK;
+}
+
+int vsg_orb_extract_batch_device_color(vsg_orb *h, const uint8_t *d_img, int channels, int rgb_order, int nframes,
+                                       size_t frame_stride, int rows, int cols, int stride, int lap0, int lap1,
+                                       vsg_keypoint *d_kps, uint8_t *d_desc, int *d_counts, int capacity,
+                                       void *stream) {
+  if (!h || !d_kps || !d_desc || !d_counts || nframes < 1 || nframes > h->max_batch) return VSG_ERR_INVALID;
+  if (channels != 3 && channels != 4) return VSG_ERR_INVALID;
+  if (!d_img || rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_geometry(h, rows, cols);
+  if (rc != VSG_OK) return rc;
+  if (capacity < h->G.fg.out_cap) return VSG_ERR_CAPACITY;
+  hipStream_t s = stream ? (hipStream_t)stream : h->s_main;
+  // cvtColor of Tracking::GrabImage* straight into the gray level-0 staging buffer
+  launch_cvt_gray(s, d_img, frame_stride, stride, channels, rgb_order, rows, cols, h->d_in,
+                  (size_t)rows * h->in_pitch, h->in_pitch, h->gray_coeffs, h->gray_shift, nframes);
+  const Src0 s0 = {h->d_in, (size_t)rows * h->in_pitch, h->in_pitch};
+  return enqueue_pipeline(h, s0, nframes, lap0, lap1, (KeyPointPOD *)d_kps, d_desc, d_counts, capacity, s);
+}
+
 int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t frame_stride, int rows, int cols,
                           int stride, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc, int capacity, int *n,
                           int *mono_index) {
@@ -438,24 +495,37 @@ int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t f
   const Src0 s0 = {h->d_in, (size_t)rows * ip, ip};
   rc = enqueue_pipeline(h, s0, nframes, lap0, lap1, h->d_kps, h->d_desc, h->d_out_counts, fg.out_cap, s);
   if (rc != VSG_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(h->h_out_counts, h->d_out_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)nframes * fg.out_cap * 32, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  int status = VSG_OK;
-  for (int f = 0; f < nframes; f++) {
-    const int nf = h->h_out_counts[2 * f];
-    n[f] = nf;
-    mono_index[f] = h->h_out_counts[2 * f + 1];
-    if (nf > capacity) {
-      set_err("caller capacity too small for the extracted keypoints");
-      status = VSG_ERR_CAPACITY;
-      continue;
-    }
-    if (nf > 0 && kps) memcpy(kps + (size_t)f * capacity, h->h_kps + (size_t)f * fg.out_cap, (size_t)nf * sizeof(KeyPointPOD));
-    if (nf > 0 && desc) memcpy(desc + (size_t)f * capacity * 32, h->h_desc + (size_t)f * fg.out_cap * 32, (size_t)nf * 32);
+  return fetch_outputs(h, nframes, kps, desc, capacity, n, mono_index, s);
+}
+
+int vsg_orb_extract_batch_color(vsg_orb *h, const uint8_t *img, int channels, int rgb_order, int nframes,
+                                size_t frame_stride, int rows, int cols, int stride, int lap0, int lap1,
+                                vsg_keypoint *kps, uint8_t *desc, int capacity, int *n, int *mono_index) {
+  if (!h || nframes < 1 || nframes > h->max_batch || !n || !mono_index) return VSG_ERR_INVALID;
+  if (channels != 3 && channels != 4) return VSG_ERR_INVALID;
+  if (!img || rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_geometry(h, rows, cols);
+  if (rc != VSG_OK) return rc;
+  const FrameGeom &fg = h->G.fg;
+  hipStream_t s = h->s_main;
+  const size_t row_bytes = (size_t)cols * channels, frame_bytes = row_bytes * rows;
+  uint8_t *d_color = nullptr;
+  HIP_TRY(hipMalloc(&d_color, frame_bytes * nframes));
+  hipError_t e = hipSuccess;
+  for (int f = 0; f < nframes && e == hipSuccess; f++)
+    e = hipMemcpy2DAsync(d_color + f * frame_bytes, row_bytes, img + (size_t)f * frame_stride, stride, row_bytes, rows,
+                         hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    rc = vsg_orb_extract_batch_device_color(h, d_color, channels, rgb_order, nframes, frame_bytes, rows, cols,
+                                            (int)row_bytes, lap0, lap1, (vsg_keypoint *)h->d_kps, h->d_desc,
+                                            h->d_out_counts, fg.out_cap, s);
+    if (rc == VSG_OK) rc = fetch_outputs(h, nframes, kps, desc, capacity, n, mono_index, s);
   }
-  return status;
+  hipStreamSynchronize(s);
+  hipFree(d_color);
+  HIP_TRY(e);
+  return rc;
 }
 
 int vsg_orb_extract(vsg_orb *h, const uint8_t *gray, int rows, int cols, int stride, int lap0, int lap1,

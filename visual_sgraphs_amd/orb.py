@@ -38,7 +38,8 @@ EXPORTS = [
     "vsg_orb_get_timing", "vsg_orb_set_serialize", "vsg_hamming_pairs", "vsg_hamming_block_best2", "vsg_hamming_block_best2_device",
     "vsg_search_by_bow_kf_f", "vsg_search_by_bow_kf_kf", "vsg_search_by_projection_last",
     "vsg_search_by_projection_local", "vsg_search_for_initialization", "vsg_search_window", "vsg_grid_build",
-    "vsg_grid_destroy", "vsg_grid_query", "vsg_stereo_matches",
+    "vsg_grid_destroy", "vsg_grid_query", "vsg_stereo_matches", "vsg_orb_set_gray_coeffs",
+    "vsg_orb_extract_batch_device_color", "vsg_orb_extract_batch_color",
 ]
 
 
@@ -102,6 +103,12 @@ def load_library():
                                     _i32p, _i32p]
     L.vsg_stereo_matches.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, _u8p, C.c_int, C.c_void_p,
                                      _u8p, C.c_int, C.c_float, C.c_float, _f32p, _f32p]
+    L.vsg_orb_set_gray_coeffs.argtypes = [C.c_void_p, _i32p, C.c_int]
+    L.vsg_orb_extract_batch_device_color.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t,
+                                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.vsg_orb_extract_batch_color.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p, C.c_int, _i32p, _i32p]
     L.vsg_grid_build.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.POINTER(C.c_void_p)]
     L.vsg_grid_destroy.argtypes = [C.c_void_p]
@@ -255,6 +262,37 @@ class ORBextractor:
                                                     C.c_void_p(d_counts), int(capacity),
                                                     C.c_void_p(stream) if stream else None),
                "vsg_orb_extract_batch_device")
+        self._shape = (rows, cols)
+
+    def set_gray_coeffs(self, coeffs, shift):
+        c = np.ascontiguousarray(coeffs, dtype=np.int32)
+        _check(self._L.vsg_orb_set_gray_coeffs(self._h, _p(c, _i32p), int(shift)), "vsg_orb_set_gray_coeffs")
+
+    def extract_batch_color(self, images, rgb_order=True, vLappingArea=(0, 0)):
+        """images: [B,H,W,3|4] uint8 colour frames (Tracking::mbRGB = rgb_order).  Returns [(mono, kps, desc)]."""
+        imgs = np.ascontiguousarray(images, dtype=np.uint8)
+        assert imgs.ndim == 4 and imgs.shape[3] in (3, 4) and imgs.shape[0] <= self.max_batch
+        B, rows, cols, ch = imgs.shape
+        cap = self.capacity(rows, cols)
+        kps = np.zeros((B, cap), KP_DTYPE)
+        desc = np.zeros((B, cap, 32), np.uint8)
+        n, mono = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        _check(self._L.vsg_orb_extract_batch_color(self._h, _p(imgs, _u8p), ch, int(rgb_order), B, imgs.strides[0],
+                                                   rows, cols, imgs.strides[1], int(vLappingArea[0]),
+                                                   int(vLappingArea[1]), kps.ctypes.data_as(C.c_void_p),
+                                                   _p(desc, _u8p), cap, _p(n, _i32p), _p(mono, _i32p)),
+               "vsg_orb_extract_batch_color")
+        self._shape = (rows, cols)
+        return [(int(mono[i]), kps[i, :n[i]].copy(), desc[i, :n[i]].copy()) for i in range(B)]
+
+    def extract_batch_device_color(self, d_img, channels, rgb_order, nframes, frame_stride, rows, cols, stride, d_kps,
+                                   d_desc, d_counts, capacity, vLappingArea=(0, 0), stream=None):
+        """Interleaved 8-bit RGB(A)/BGR(A) frames on the device: cvtColor fused into the level-0 staging."""
+        _check(self._L.vsg_orb_extract_batch_device_color(
+            self._h, C.c_void_p(d_img), int(channels), int(rgb_order), int(nframes), int(frame_stride), int(rows),
+            int(cols), int(stride), int(vLappingArea[0]), int(vLappingArea[1]), C.c_void_p(d_kps), C.c_void_p(d_desc),
+            C.c_void_p(d_counts), int(capacity), C.c_void_p(stream) if stream else None),
+            "vsg_orb_extract_batch_device_color")
         self._shape = (rows, cols)
 
     # ---- mvImagePyramid and stage read-back
