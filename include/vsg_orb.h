@@ -219,6 +219,20 @@ void vsg_grid_destroy(vsg_grid *g);
 int vsg_grid_query(vsg_grid *g, const float *x, const float *y, const float *r, const int32_t *min_level,
                    const int32_t *max_level, int nq, int32_t *cand_off, int32_t *cand_idx, int cap);
 
+/* ---- DBoW2 vocabulary: ORBVocabulary::loadFromBinFile (TemplatedVocabulary.h:1478-1552, called at
+ * System.cc:105-112) from an in-memory image of the .bin file, and transform(features, BowVector, FeatureVector,
+ * levelsup) (TemplatedVocabulary.h:1139-1212) as called by Frame::ComputeBoW / KeyFrame::ComputeBoW with
+ * levelsup = 4 (Frame.cc:882-889).  BowVector: ascending (word id, value) pairs; FeatureVector: CSR with ascending
+ * node ids (the form vsg_search_by_bow_* takes); fv_idx must hold n entries, fv_off fv_cap+1.  word_of / node_of /
+ * weight_of (optional) are the per-feature leaf word, node at level L - levelsup and word weight. */
+typedef struct vsg_vocab vsg_vocab;
+int vsg_vocab_load(int device, const uint8_t *blob, size_t size, vsg_vocab **out);
+void vsg_vocab_destroy(vsg_vocab *v);
+int vsg_vocab_info(const vsg_vocab *v, int *k, int *L, int *scoring, int *weighting, int *nnodes, int *nwords);
+int vsg_bow_transform(vsg_vocab *voc, const uint8_t *desc, int n, int levelsup, int32_t *bow_ids, double *bow_vals,
+                      int bow_cap, int *n_bow, int32_t *fv_node, int32_t *fv_off, int32_t *fv_idx, int fv_cap,
+                      int *n_fv, int32_t *word_of, int32_t *node_of, double *weight_of);
+
 /* int ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
  * (ORBmatcher.h:68, ORBmatcher.cc:643-756); candidate lists from F2.GetFeaturesInArea per F1 keypoint. */
 int vsg_search_for_initialization(int device, const uint8_t *desc1, const float *angle1, const int32_t *octave1,

@@ -24,6 +24,7 @@
 #ifndef ORB_ORACLE_H
 #define ORB_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -83,6 +84,17 @@ int or_distribute_octree(const int *x, const int *y, const int *response, int n,
 float or_ic_angle(const uint8_t *img, int stride, int cx, int cy);
 /* computeOrbDescriptor (ORBextractor.cc:103-149) */
 void or_orb_descriptor(const uint8_t *blurred, int stride, int cx, int cy, float angleDeg, uint8_t desc[32]);
+
+/* ---- DBoW2 (vendored): vocabulary in the reference's binary layout and transform() (bow_oracle.cpp) ---- */
+typedef struct OrVocab OrVocab;
+OrVocab *or_vocab_load(const uint8_t *blob, size_t size);
+void or_vocab_destroy(OrVocab *v);
+int or_vocab_info(const OrVocab *v, int *k, int *L, int *scoring, int *weighting, int *nnodes, int *nwords);
+/* transform(features, BowVector, FeatureVector, levelsup): BowVector as ascending (id, value) pairs, FeatureVector
+ * as CSR (ascending node ids); fv_idx must hold n ints; optional per-feature word / node / weight. */
+int or_vocab_transform(const OrVocab *voc, const uint8_t *desc, int n, int levelsup, int *bow_ids, double *bow_vals,
+                       int bow_cap, int *n_bow, int *fv_node, int *fv_off, int *fv_idx, int fv_cap, int *n_fv,
+                       int *word_of, int *node_of, double *weight_of);
 
 /* cv::cvtColor(COLOR_{RGB,BGR,RGBA,BGRA}2GRAY) for 8-bit images as called in Tracking::GrabImage*
  * (Tracking.cc:1526-1551, 1595-1608, 1643-1656): gray = (R*cr + G*cg + B*cb + (1 << (shift-1))) >> shift.

@@ -25,7 +25,8 @@ def _ptr(a, t):
 
 
 def build():
-    srcs = [ORACLE_DIR / n for n in ("orb_oracle.cpp", "match_oracle.cpp", "orb_oracle.h", "brief_pattern_data.inc")]
+    srcs = [ORACLE_DIR / n for n in ("orb_oracle.cpp", "match_oracle.cpp", "bow_oracle.cpp", "orb_oracle.h",
+                                     "brief_pattern_data.inc")]
     if LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return
     subprocess.check_call(["make", "-C", str(ORACLE_DIR)], stdout=subprocess.DEVNULL)
@@ -85,6 +86,13 @@ def lib():
         L.or_block_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
         L.or_search_window.argtypes = [_u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _u8p, C.c_int, C.c_int, _i32p, _i32p,
                                        _i32p]
+        L.or_vocab_load.restype = C.c_void_p
+        L.or_vocab_load.argtypes = [_u8p, C.c_size_t]
+        L.or_vocab_destroy.argtypes = [C.c_void_p]
+        L.or_vocab_info.argtypes = [C.c_void_p] + [_i32p] * 6
+        _f64p = C.POINTER(C.c_double)
+        L.or_vocab_transform.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, _i32p, _f64p, C.c_int, _i32p, _i32p, _i32p,
+                                         _i32p, C.c_int, _i32p, _i32p, _i32p, _f64p]
         L.or_cvt_gray_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, _i32p, C.c_int]
         L.or_cvt_gray_u8.restype = None
         L.or_stereo_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _u8p, C.c_int, C.c_void_p, _u8p, C.c_int,
@@ -416,3 +424,38 @@ def cvt_gray(img, rgb_order=True, coeffs=GRAY_COEFFS, shift=GRAY_SHIFT):
     lib().or_cvt_gray_u8(_ptr(img, _u8p), rows, cols, img.strides[0], ch, int(rgb_order), _ptr(out, _u8p), cols,
                          _ptr(c, _i32p), int(shift))
     return out
+
+
+class OracleVocabulary:
+    """DBoW2 TemplatedVocabulary restatement (loadFromBinFile image + transform)."""
+
+    def __init__(self, blob):
+        b = np.frombuffer(blob, dtype=np.uint8).copy()
+        self.L_ = lib()
+        self.h = self.L_.or_vocab_load(_ptr(b, _u8p), len(b))
+        assert self.h, "not a vocabulary image"
+        v = [C.c_int32() for _ in range(6)]
+        self.L_.or_vocab_info(self.h, *[C.byref(x) for x in v])
+        self.k, self.L, self.scoring, self.weighting, self.nnodes, self.nwords = [x.value for x in v]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L_.or_vocab_destroy(self.h)
+            self.h = None
+
+    def transform(self, desc, levelsup):
+        """Returns dict(bow_ids, bow_vals, fv=(node, off, idx), word, node, weight)."""
+        d = _u8c(desc).reshape(-1, 32)
+        n = len(d)
+        cap = n + 1
+        bi, bv = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        fn, fo, fi = np.zeros(cap, np.int32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+        w_of, n_of, wt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        nb, nf = C.c_int32(), C.c_int32()
+        f64p = C.POINTER(C.c_double)
+        self.L_.or_vocab_transform(self.h, _ptr(d, _u8p), n, int(levelsup), _ptr(bi, _i32p), _ptr(bv, f64p), cap,
+                                   C.byref(nb), _ptr(fn, _i32p), _ptr(fo, _i32p), _ptr(fi, _i32p), cap, C.byref(nf),
+                                   _ptr(w_of, _i32p), _ptr(n_of, _i32p), _ptr(wt, f64p))
+        return dict(bow_ids=bi[:nb.value].copy(), bow_vals=bv[:nb.value].copy(),
+                    fv=(fn[:nf.value].copy(), fo[:nf.value + 1].copy(), fi[:fo[nf.value]].copy()),
+                    word=w_of[:n].copy(), node=n_of[:n].copy(), weight=wt[:n].copy())

@@ -39,7 +39,8 @@ EXPORTS = [
     "vsg_search_by_bow_kf_f", "vsg_search_by_bow_kf_kf", "vsg_search_by_projection_last",
     "vsg_search_by_projection_local", "vsg_search_for_initialization", "vsg_search_window", "vsg_grid_build",
     "vsg_grid_destroy", "vsg_grid_query", "vsg_stereo_matches", "vsg_orb_set_gray_coeffs",
-    "vsg_orb_extract_batch_device_color", "vsg_orb_extract_batch_color",
+    "vsg_orb_extract_batch_device_color", "vsg_orb_extract_batch_color", "vsg_vocab_load", "vsg_vocab_destroy",
+    "vsg_vocab_info", "vsg_bow_transform",
 ]
 
 
@@ -109,6 +110,13 @@ def load_library():
                                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.vsg_orb_extract_batch_color.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int,
                                               C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p, C.c_int, _i32p, _i32p]
+    _f64p = C.POINTER(C.c_double)
+    L.vsg_vocab_load.argtypes = [C.c_int, _u8p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.vsg_vocab_destroy.argtypes = [C.c_void_p]
+    L.vsg_vocab_destroy.restype = None
+    L.vsg_vocab_info.argtypes = [C.c_void_p] + [_i32p] * 6
+    L.vsg_bow_transform.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, _i32p, _f64p, C.c_int, _i32p, _i32p, _i32p,
+                                    _i32p, C.c_int, _i32p, _i32p, _i32p, _f64p]
     L.vsg_grid_build.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.POINTER(C.c_void_p)]
     L.vsg_grid_destroy.argtypes = [C.c_void_p]
@@ -520,3 +528,44 @@ def ComputeStereoMatches(ex_left, frame_l, ex_right, frame_r, kps_l, desc_l, kps
                                              kr.ctypes.data_as(C.c_void_p), _p(dr, _u8p), len(kr), float(mb), float(mbf),
                                              _p(ur, _f32p), _p(dep, _f32p)), "vsg_stereo_matches")
     return ur[:len(kl)], dep[:len(kl)]
+
+
+class ORBVocabulary:
+    """DBoW2 ORBVocabulary on the device: loadFromBinFile image + transform (TemplatedVocabulary.h)."""
+
+    def __init__(self, blob, device=0):
+        self._L = load_library()
+        b = np.frombuffer(blob, dtype=np.uint8).copy()
+        self._h = C.c_void_p()
+        _check(self._L.vsg_vocab_load(int(device), _p(b, _u8p), len(b), C.byref(self._h)), "vsg_vocab_load")
+        v = [C.c_int32() for _ in range(6)]
+        self._L.vsg_vocab_info(self._h, *[C.byref(x) for x in v])
+        self.k, self.L, self.scoring, self.weighting, self.nnodes, self.nwords = [x.value for x in v]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.vsg_vocab_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def transform(self, desc, levelsup=4):
+        """Returns dict(bow_ids, bow_vals, fv=(node_ids, offsets, indices), word, node, weight)."""
+        d = _u8(desc).reshape(-1, 32)
+        n = len(d)
+        cap = n + 1
+        bi, bv = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        fn, fo, fi = np.zeros(cap, np.int32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+        w_of, n_of, wt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        nb, nf = C.c_int32(), C.c_int32()
+        f64p = C.POINTER(C.c_double)
+        _check(self._L.vsg_bow_transform(self._h, _p(d, _u8p), n, int(levelsup), _p(bi, _i32p), _p(bv, f64p), cap,
+                                         C.byref(nb), _p(fn, _i32p), _p(fo, _i32p), _p(fi, _i32p), cap, C.byref(nf),
+                                         _p(w_of, _i32p), _p(n_of, _i32p), _p(wt, f64p)), "vsg_bow_transform")
+        return dict(bow_ids=bi[:nb.value].copy(), bow_vals=bv[:nb.value].copy(),
+                    fv=(fn[:nf.value].copy(), fo[:nf.value + 1].copy(), fi[:fo[nf.value]].copy()),
+                    word=w_of[:n].copy(), node=n_of[:n].copy(), weight=wt[:n].copy())

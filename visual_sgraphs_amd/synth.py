@@ -68,3 +68,25 @@ def random_descriptors(n, seed):
     """n x 32 uint8 pseudo-random descriptors."""
     r = splitmix64(SEED_BASE ^ (seed << 8) ^ 0xD35C, n * 4)
     return r.view(np.uint8).reshape(n, 32).copy()
+
+
+def synthetic_vocabulary(k=10, L=3, seed=1, scoring=0, weighting=0, stop_fraction=0.02):
+    """A DBoW2 ORB vocabulary image in the reference's binary layout (TemplatedVocabulary.h:1495-1547):
+    int k, L, scoring, weighting; then per node (parents before children) int parent, uint8 isLeaf, uint8[32]
+    descriptor, double weight.  Full k-ary tree of depth L with pseudo-random descriptors; leaf weights are
+    positive (idf-like), a few are 0 ("stopped" words).  The real ORBvoc.txt.bin is not in the reference tree."""
+    import struct
+    n_nodes = (k ** (L + 1) - 1) // (k - 1)
+    r = splitmix64(SEED_BASE ^ 0xB0C ^ (seed << 12), (n_nodes - 1) * 5)
+    desc = r.reshape(n_nodes - 1, 5)[:, :4].copy().view(np.uint8).reshape(n_nodes - 1, 32)
+    wraw = r.reshape(n_nodes - 1, 5)[:, 4]
+    out = bytearray(struct.pack("<iiii", k, L, scoring, weighting))
+    first_leaf = (k ** L - 1) // (k - 1)  # BFS numbering: node i has parent (i - 1) // k
+    for i in range(1, n_nodes):
+        leaf = i >= first_leaf
+        w = 0.0
+        if leaf:
+            u = int(wraw[i - 1] % np.uint64(10000))
+            w = 0.0 if u < stop_fraction * 10000 else 0.5 + u / 1000.0
+        out += struct.pack("<iB", (i - 1) // k, 1 if leaf else 0) + desc[i - 1].tobytes() + struct.pack("<d", w)
+    return bytes(out)
