@@ -205,6 +205,12 @@ int vsg_search_window(int device, const uint8_t *q_desc, const uint8_t *query_bl
                       const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *t_desc, uint8_t *train_blocked,
                       int n_t, int th_high, int32_t *q_best_idx, int32_t *q_best_dist, int32_t *train_match);
 
+/* void MapPoint::ComputeDistinctiveDescriptors() (MapPoint.cc:340-415) for ngroups map points at once:
+ * group g = descriptor rows off[g] .. off[g+1]-1 (the observations' descriptors in the order the reference pushes
+ * them); best[g] = index inside the group of the descriptor with the least median distance to the rest (first one
+ * on ties), -1 for an empty group.  Groups of more than 128 descriptors return VSG_ERR_UNSUPPORTED. */
+int vsg_distinctive_descriptors(int device, const uint8_t *desc, const int32_t *off, int ngroups, int32_t *best);
+
 /* ---- Frame grid: Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:521-553, 870-880) and
  * Frame::GetFeaturesInArea / KeyFrame::GetFeaturesInArea (Frame.cc:802-868, KeyFrame.cc:834-874) on the device.
  * 64 x 48 cells (Frame.h:49-50).  kps = the (undistorted) keypoints the reference indexes (host pointer). */

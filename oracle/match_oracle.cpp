@@ -348,6 +348,35 @@ int or_search_by_projection_local(const uint8_t *qDesc, const uint8_t *queryBloc
   return nmatches;
 }
 
+void or_distinctive_descriptors(const uint8_t *desc, const int *off, int ngroups, int *best) {
+  for (int g = 0; g < ngroups; g++) {
+    const size_t N = (size_t)(off[g + 1] - off[g]);
+    best[g] = -1;
+    if (N == 0) continue;
+    const uint8_t *d = desc + (size_t)off[g] * 32;
+    std::vector<float> Distances(N * N);
+    for (size_t i = 0; i < N; i++) {
+      Distances[i * N + i] = 0;
+      for (size_t j = i + 1; j < N; j++) {
+        int distij = DescriptorDistance(d + i * 32, d + j * 32);
+        Distances[i * N + j] = (float)distij;
+        Distances[j * N + i] = (float)distij;
+      }
+    }
+    int BestMedian = INT_MAX, BestIdx = 0;
+    for (size_t i = 0; i < N; i++) {
+      std::vector<int> vDists(Distances.begin() + i * N, Distances.begin() + (i + 1) * N);
+      std::sort(vDists.begin(), vDists.end());
+      int median = vDists[(size_t)(0.5 * (N - 1))];
+      if (median < BestMedian) {
+        BestMedian = median;
+        BestIdx = (int)i;
+      }
+    }
+    best[g] = BestIdx;
+  }
+}
+
 int or_search_window(const uint8_t *qDesc, const uint8_t *queryBlocks, int nQ, const int *candOff, const int *candIdx,
                      const uint8_t *tDesc, uint8_t *trainBlocked, int nT, int thHigh, int *qBestIdx, int *qBestDist,
                      int *trainMatch) {

@@ -168,6 +168,11 @@ int or_search_window(const uint8_t *qDesc, const uint8_t *queryBlocks, int nQ, c
                      const uint8_t *tDesc, uint8_t *trainBlocked, int nT, int thHigh, int *qBestIdx, int *qBestDist,
                      int *trainMatch);
 
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:380-415) for `ngroups` map points at once: group g owns the
+ * descriptor rows off[g] .. off[g+1]-1 (its observations, in std::map iteration order); best[g] = row index inside
+ * the group with the least median Hamming distance to the rest (first one on ties), -1 for an empty group. */
+void or_distinctive_descriptors(const uint8_t *desc, const int *off, int ngroups, int *best);
+
 /* SearchForInitialization (ORBmatcher.cc:643-756): octave-0 keypoints of F1, candidate lists per F1 kp
  * from F2.GetFeaturesInArea(prevMatched, windowSize, 0, 0).  candOff/candIdx as above (empty for octave>0). */
 int or_search_for_initialization(const uint8_t *desc1, const float *angle1, const int *octave1, int n1,

@@ -84,6 +84,8 @@ def lib():
         L.or_search_for_initialization.argtypes = [_u8p, _f32p, _i32p, C.c_int, _i32p, _i32p, _u8p, _f32p, C.c_int,
                                                    C.c_float, C.c_int, _i32p]
         L.or_block_best2.argtypes = [_u8p, C.c_int, _u8p, C.c_int, _i32p, _i32p, _i32p]
+        L.or_distinctive_descriptors.argtypes = [_u8p, _i32p, C.c_int, _i32p]
+        L.or_distinctive_descriptors.restype = None
         L.or_search_window.argtypes = [_u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _u8p, C.c_int, C.c_int, _i32p, _i32p,
                                        _i32p]
         L.or_vocab_load.restype = C.c_void_p
@@ -459,3 +461,12 @@ class OracleVocabulary:
         return dict(bow_ids=bi[:nb.value].copy(), bow_vals=bv[:nb.value].copy(),
                     fv=(fn[:nf.value].copy(), fo[:nf.value + 1].copy(), fi[:fo[nf.value]].copy()),
                     word=w_of[:n].copy(), node=n_of[:n].copy(), weight=wt[:n].copy())
+
+
+def distinctive_descriptors(desc, off):
+    d, o = _u8c(desc).reshape(-1, 32), _i32c(off)
+    if len(d) == 0:
+        d = np.zeros((1, 32), np.uint8)
+    best = np.zeros(len(o) - 1, np.int32)
+    lib().or_distinctive_descriptors(_ptr(d, _u8p), _ptr(o, _i32p), len(o) - 1, _ptr(best, _i32p))
+    return best

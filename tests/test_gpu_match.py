@@ -265,3 +265,23 @@ def test_search_window_generic(frames, seed, blocking):
         assert np.array_equal(a, b)
     if blocking is not None:
         assert np.array_equal(got[4], want[4])
+
+
+def test_distinctive_descriptors(frames):
+    """SURVEY 8f N5: MapPoint::ComputeDistinctiveDescriptors (N^2 Hamming + per-row median), many map points."""
+    (k0, d0), (k1, d1) = frames
+    rng = np.random.default_rng(77)
+    sizes = [1, 2, 3, 4, 7, 0, 16, 33, 64, 100, 128, 5, 5, 2]
+    groups, off = [], [0]
+    for n in sizes:
+        base = d0[rng.integers(0, len(d0))]
+        g = near_duplicates(np.repeat(base[None], n, 0), rng, 4) if n else np.zeros((0, 32), np.uint8)
+        if n >= 4:
+            g[1] = g[0]  # exact duplicates: equal medians -> the first row must win
+        groups.append(g)
+        off.append(off[-1] + n)
+    desc = np.concatenate(groups)
+    got = orb.ComputeDistinctiveDescriptors(desc, off)
+    want = ol.distinctive_descriptors(desc, off)
+    assert np.array_equal(got, want)
+    assert want[5] == -1

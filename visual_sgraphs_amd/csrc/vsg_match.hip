@@ -275,6 +275,53 @@ __global__ __launch_bounds__(64) void k_search_init(const uint8_t *desc1, const 
   if (lane == 0) result[0] = nmatches;
 }
 
+// ---- MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:380-415): one workgroup per map point.  The N x N
+// distance matrix lives in LDS; thread i finds the element of rank floor(0.5*(N-1)) of row i by counting (no
+// sort needed: the median VALUE does not depend on how ties are ordered); the first row with the least median
+// wins (strict '<').
+enum { kDistinctMaxN = 128 };
+__global__ __launch_bounds__(128) void k_distinctive(const uint8_t *desc, const int *off, int *best) {
+  __shared__ uint16_t D[kDistinctMaxN * kDistinctMaxN];
+  __shared__ uint32_t s_key[kDistinctMaxN];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int o = off[g], N = off[g + 1] - o;
+  if (N <= 0) {
+    if (tid == 0) best[g] = -1;
+    return;
+  }
+  for (int i = tid; i < N; i += 128) {
+    uint4 a0, a1;
+    load_desc(desc, o + i, a0, a1);
+    for (int j = 0; j < N; j++) {
+      uint4 b0, b1;
+      load_desc(desc, o + j, b0, b1);
+      D[i * N + j] = (uint16_t)hamming256(a0, a1, b0, b1);
+    }
+  }
+  __syncthreads();
+  const int k = (int)(0.5 * (N - 1));
+  for (int i = tid; i < N; i += 128) {
+    int median = 0;
+    for (int j = 0; j < N; j++) {
+      const int v = D[i * N + j];
+      int less = 0, le = 0;
+      for (int t = 0; t < N; t++) {
+        const int x = D[i * N + t];
+        less += x < v;
+        le += x <= v;
+      }
+      if (less <= k && k < le) median = v;
+    }
+    s_key[i] = ((uint32_t)median << 16) | (uint32_t)i;  // smallest key = least median, first index
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t b = 0xFFFFFFFFu;
+    for (int i = 0; i < N; i++) b = min(b, s_key[i]);
+    best[g] = (int)(b & 0xFFFF);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 thread_local std::string g_merr;
 
@@ -557,6 +604,23 @@ int vsg_search_by_projection_local(int device, const uint8_t *q_desc, const uint
   if (!cand_off || !train_blocked || !train_match || !t_octave || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
   return search_window(device, 1, q_desc, nullptr, query_blocks, n_q, cand_off, cand_idx, t_desc, nullptr, t_octave,
                        train_blocked, n_t, TH_HIGH, nnratio, 0, train_match);
+}
+
+int vsg_distinctive_descriptors(int device, const uint8_t *desc, const int32_t *off, int ngroups, int32_t *best) {
+  if (!off || !best || ngroups < 0) return VSG_ERR_INVALID;
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  if (ngroups == 0) return VSG_OK;
+  for (int g = 0; g < ngroups; g++)
+    if (off[g + 1] - off[g] > kDistinctMaxN) return VSG_ERR_UNSUPPORTED;
+  const int n = off[ngroups];
+  DevBuf dD, dOff, dBest;
+  M_TRY(dD.upload(desc, (size_t)n * 32));
+  M_TRY(dOff.upload(off, (size_t)(ngroups + 1) * 4));
+  M_TRY(dBest.alloc((size_t)ngroups * 4));
+  hipLaunchKernelGGL(k_distinctive, dim3(ngroups), dim3(128), 0, 0, dD.as<uint8_t>(), dOff.as<int>(), dBest.as<int>());
+  M_TRY(hipMemcpy(best, dBest.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost));
+  return VSG_OK;
 }
 
 int vsg_search_window(int device, const uint8_t *q_desc, const uint8_t *query_blocks, int n_q,

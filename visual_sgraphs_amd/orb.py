@@ -40,7 +40,7 @@ EXPORTS = [
     "vsg_search_by_projection_local", "vsg_search_for_initialization", "vsg_search_window", "vsg_grid_build",
     "vsg_grid_destroy", "vsg_grid_query", "vsg_stereo_matches", "vsg_orb_set_gray_coeffs",
     "vsg_orb_extract_batch_device_color", "vsg_orb_extract_batch_color", "vsg_vocab_load", "vsg_vocab_destroy",
-    "vsg_vocab_info", "vsg_bow_transform",
+    "vsg_vocab_info", "vsg_bow_transform", "vsg_distinctive_descriptors",
 ]
 
 
@@ -117,6 +117,7 @@ def load_library():
     L.vsg_vocab_info.argtypes = [C.c_void_p] + [_i32p] * 6
     L.vsg_bow_transform.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, _i32p, _f64p, C.c_int, _i32p, _i32p, _i32p,
                                     _i32p, C.c_int, _i32p, _i32p, _i32p, _f64p]
+    L.vsg_distinctive_descriptors.argtypes = [C.c_int, _u8p, _i32p, C.c_int, _i32p]
     L.vsg_grid_build.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.POINTER(C.c_void_p)]
     L.vsg_grid_destroy.argtypes = [C.c_void_p]
@@ -569,3 +570,14 @@ class ORBVocabulary:
         return dict(bow_ids=bi[:nb.value].copy(), bow_vals=bv[:nb.value].copy(),
                     fv=(fn[:nf.value].copy(), fo[:nf.value + 1].copy(), fi[:fo[nf.value]].copy()),
                     word=w_of[:n].copy(), node=n_of[:n].copy(), weight=wt[:n].copy())
+
+
+def ComputeDistinctiveDescriptors(desc, off, device=0):
+    """MapPoint::ComputeDistinctiveDescriptors for many map points: returns the chosen row index per group."""
+    d, o = _u8(desc).reshape(-1, 32), _i32(off)
+    if len(d) == 0:
+        d = np.zeros((1, 32), np.uint8)
+    best = np.zeros(max(len(o) - 1, 1), np.int32)
+    _check(load_library().vsg_distinctive_descriptors(int(device), _p(d, _u8p), _p(o, _i32p), len(o) - 1,
+                                                      _p(best, _i32p)), "vsg_distinctive_descriptors")
+    return best[:len(o) - 1]
