@@ -48,8 +48,9 @@ def algorithmic_bytes(ex, n_kp):
         "fast": P,
         "blur": 2 * P,
         "orient_desc": 60 * n_kp,
+        "match": 64 * n_kp,  # both descriptor sets read once (32*(n_q + n_t) bytes per block)
     }
-    return stages, sum(stages.values())
+    return stages, sum(v for k, v in stages.items() if k != "match")
 
 
 def effective_cores():
@@ -128,15 +129,26 @@ def main():
         recv = torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev)
     L = orb.load_library()
     import ctypes as C
-    stream = torch.cuda.current_stream().cuda_stream
+    # All work of a step is ordered on ONE explicit (non-default) HIP stream: torch copies, the extractor's stage
+    # chain, the match kernel and the RCCL all-gather.  (Passing torch's default stream handle -- 0 -- would make the
+    # C ABI fall back to the handle's own stream and un-order the match kernel from the extraction.)
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
-    def step():
+    match_events = []
+
+    def step(time_match=False):
         # carry the last frame of the previous batch into slot 0
         d_desc[0].copy_(d_desc[B])
         d_counts[0].copy_(d_counts[B])
         ex.extract_batch_device(d_gray.data_ptr(), B, H * W, H, W, W, d_kps[1].data_ptr(), d_desc[1].data_ptr(),
                                 d_counts[1].data_ptr(), cap, (0, 0), stream)
         if not args.no_match:
+            if time_match:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(tstream)
             rc = L.vsg_hamming_block_best2_device(local_rank, C.c_void_p(d_desc[1].data_ptr()),
                                                   C.c_void_p(d_desc[0].data_ptr()), cap * 32,
                                                   C.c_void_p(d_counts[1].data_ptr()), C.c_void_p(d_counts[0].data_ptr()),
@@ -144,6 +156,9 @@ def main():
                                                   C.c_void_p(d_second.data_ptr()), C.c_void_p(d_arg.data_ptr()),
                                                   C.c_void_p(stream))
             assert rc == 0, rc
+            if time_match:
+                e1.record(tstream)
+                match_events.append((e0, e1))
         if distributed and not args.no_gather:
             sharding.pack_records(send, d_counts[1:], d_kps[1:], d_desc[1:])
             sharding.all_gather_records(recv, send)
@@ -177,9 +192,11 @@ def main():
         ex.set_serialize(True)
         ex.enable_timing(True)
         for _ in range(K):
-            step()
+            step(time_match=True)
         barrier()
         stage_ms = ex.timing_ms()
+        if match_events:
+            stage_ms["match"] = sum(a.elapsed_time(b) for a, b in match_events) / len(match_events)
         ex.set_serialize(False)
 
     # parity gate on this rank: first and last frame of the batch vs the CPU oracle, bit for bit
@@ -213,7 +230,8 @@ def main():
     fps = total_frames / dt
     stages, bytes_per_frame = algorithmic_bytes(ex, n_kp)
     roofline = None
-    timed = {k: stage_ms[k] for k in ("pyramid", "fast", "blur", "orient_desc", "octree") if stage_ms.get(k, 0) > 0}
+    timed = {k: stage_ms[k] for k in ("pyramid", "fast", "blur", "orient_desc", "octree", "match")
+             if stage_ms.get(k, 0) > 0}
     if timed:
         dom = max(timed, key=timed.get)
         dom_bytes = stages.get(dom, 0) * B  # algorithmic bytes one launch (batch of B frames) moves
