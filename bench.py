@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget per CPU baseline leg (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo for dry runs")
+    ap.add_argument("--one-device", action="store_true",
+                    help="dry run of the multi-rank path on a single GPU: every rank uses device 0 (needs gloo)")
     args = ap.parse_args()
 
     import torch
@@ -100,11 +103,16 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the ORB front-end has no CPU fallback)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     W, H, nfeat = WORKLOADS[args.workload]
     B, K, Wu = args.batch, args.steps, args.warmup
@@ -180,7 +188,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     stage_ms_timed = ex.timing_ms() if not args.no_stage_timing else {}
@@ -230,8 +238,8 @@ def main():
     fps = total_frames / dt
     stages, bytes_per_frame = algorithmic_bytes(ex, n_kp)
     roofline = None
-    timed = {k: stage_ms[k] for k in ("pyramid", "fast", "blur", "orient_desc", "octree", "match")
-             if stage_ms.get(k, 0) > 0}
+    # the octree moves almost no bytes (latency-bound list surgery): it has no HBM roofline, so it is not a candidate
+    timed = {k: stage_ms[k] for k in ("pyramid", "fast", "blur", "orient_desc", "match") if stage_ms.get(k, 0) > 0}
     if timed:
         dom = max(timed, key=timed.get)
         dom_bytes = stages.get(dom, 0) * B  # algorithmic bytes one launch (batch of B frames) moves
@@ -276,7 +284,8 @@ def main():
         "config": {"workload": f"{args.workload}: {W}x{H} gray, nFeatures={nfeat}, 8 levels, scale 1.2, FAST 20/7, "
                                f"extract{'' if args.no_match else ' + brute-force Hamming best2 match vs previous frame'}",
                    "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded x{world}"
-                   + (", RCCL all-gather of keypoint/descriptor records per step" if distributed and not args.no_gather else ""),
+                   + (f", {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} all-gather of "
+                      "keypoint/descriptor records per step" if distributed and not args.no_gather else ""),
                    "keypoints_per_frame": round(n_kp, 1), "inputs": "resident in HBM"},
         "parity": {"bit_exact_vs_oracle": parity, "checked_frames": [0, B - 1]},
         "roofline": roofline, "cpu_baseline": cpu,

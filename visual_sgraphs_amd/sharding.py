@@ -46,7 +46,13 @@ def unpack_records(recv, cap):
 def all_gather_records(recv, send):
     """One collective per batch: recv [world*B, rec] <- every rank's send [B, rec] (rank-major)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_gather_into_tensor(recv, send)
+        if send.is_cuda and dist.get_backend() == "gloo":
+            # CPU-side collective (tests / single-GPU dry runs of the multi-rank path): stage through the host
+            r = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_gather_into_tensor(r, send.cpu())
+            recv.copy_(r)
+        else:
+            dist.all_gather_into_tensor(recv, send)
     else:
         recv.copy_(send)
     return recv
