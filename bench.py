@@ -269,6 +269,10 @@ def main():
         cpu = {"value": round(v1, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                "sample": f"{n1} frames of the same {W}x{H}/{nfeat} workload, extract + brute-force match, "
                          f"{args.cpu_seconds:.0f} s, CPU oracle (port of the reference algorithm)"}
+        v2, n2 = cpu_baseline(W, H, nfeat, sample, max(2.0, args.cpu_seconds / 2), 2)
+        extra["cpu_baseline_2_threads"] = {"value": round(v2, 2), "unit": "frames/s", "cores": 2, "kind": "port",
+                                           "sample": f"{n2} frames; the reference's stereo analogue (Frame.cc:129-132: "
+                                                     "one extractor per eye on two host threads)"}
         ncores = effective_cores()  # the box advertises 256 hardware threads but the cgroup quota is what we get
         va, na = cpu_baseline(W, H, nfeat, sample, args.cpu_seconds, ncores)
         extra["cpu_baseline_all_cores"] = {"value": round(va, 2), "unit": "frames/s", "cores": ncores, "kind": "port",

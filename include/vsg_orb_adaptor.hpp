@@ -8,6 +8,7 @@
 // and a `mvImagePyramid` refresh for Frame::ComputeStereoMatches (Frame.cc:964,1054-1069).
 // See INTEGRATION.md for the three-line change in Tracking.cc / Frame.cc that swaps the extractor.
 #pragma once
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -119,6 +120,226 @@ inline int DescriptorDistance(const uint8_t *a, const uint8_t *b, int device = 0
   int rc = vsg_hamming_pairs(device, a, 1, b, 1, &zero, &zero, 1, &d);
   if (rc != VSG_OK) throw std::runtime_error("vsg_hamming_pairs failed");
   return d;
+}
+
+inline void check(int rc, const char *what) {
+  if (rc < 0) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + vsg_last_error());
+}
+
+// DBoW2::FeatureVector is std::map<NodeId, std::vector<unsigned>> (FeatureVector.h:25-26); the C ABI takes it as
+// CSR with ascending node ids, which is the map's iteration order.
+struct FeatureVectorCSR {
+  std::vector<int32_t> node, off, idx;
+  FeatureVectorCSR() : off(1, 0) {}
+  template <class Map>
+  explicit FeatureVectorCSR(const Map &fv) : off(1, 0) {
+    for (const auto &kv : fv) {
+      node.push_back((int32_t)kv.first);
+      for (auto i : kv.second) idx.push_back((int32_t)i);
+      off.push_back((int32_t)idx.size());
+    }
+  }
+  int nodes() const { return (int)node.size(); }
+};
+
+// One side of a match as the reference's Frame / KeyFrame members expose it: mDescriptors rows (Frame.h:280),
+// mvKeysUn[i].angle / .octave, and per feature whether it carries a usable MapPoint.
+struct FeatureView {
+  const uint8_t *desc = nullptr;   // n x 32, contiguous
+  const float *angle = nullptr;    // n (may be null when the call does not check orientation)
+  const int32_t *octave = nullptr; // n (only SearchByProjection(Frame&, vector<MapPoint*>) / SearchForInitialization)
+  int n = 0;
+};
+
+// CSR candidate lists = the concatenated results of Frame::GetFeaturesInArea per query (see vsg::FrameGrid).
+struct Candidates {
+  std::vector<int32_t> off, idx;
+};
+
+// Frame::mGrid (Frame.h:290) on the device: AssignFeaturesToGrid + GetFeaturesInArea (Frame.cc:521-553, 802-868).
+class FrameGrid {
+ public:
+  FrameGrid(const vsg_keypoint *keysUn, int n, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY, int device = 0) {
+    check(vsg_grid_build(device, keysUn, n, mnMinX, mnMinY, mnMaxX, mnMaxY, &g_), "vsg_grid_build");
+  }
+  ~FrameGrid() { vsg_grid_destroy(g_); }
+  FrameGrid(const FrameGrid &) = delete;
+  FrameGrid &operator=(const FrameGrid &) = delete;
+  // nq windows at once; minLevel/maxLevel may be null (= -1, -1 as KeyFrame::GetFeaturesInArea)
+  Candidates GetFeaturesInArea(const float *x, const float *y, const float *r, const int32_t *minLevel,
+                               const int32_t *maxLevel, int nq) const {
+    Candidates c;
+    c.off.resize(nq + 1);
+    c.idx.resize(64 * (size_t)nq + 64);
+    int total = vsg_grid_query(g_, x, y, r, minLevel, maxLevel, nq, c.off.data(), c.idx.data(), (int)c.idx.size());
+    check(total, "vsg_grid_query");
+    if (total > (int)c.idx.size()) {
+      c.idx.resize(total);
+      check(vsg_grid_query(g_, x, y, r, minLevel, maxLevel, nq, c.off.data(), c.idx.data(), total), "vsg_grid_query");
+    }
+    c.idx.resize(total);
+    return c;
+  }
+
+ private:
+  vsg_grid *g_ = nullptr;
+};
+
+// ORBVocabulary (= DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>, ORBVocabulary.h:29-30): loadFromBinFile
+// image + transform() as Frame::ComputeBoW calls it (Frame.cc:882-889).
+class ORBVocabulary {
+ public:
+  ORBVocabulary(const uint8_t *bin_image, size_t size, int device = 0) {
+    check(vsg_vocab_load(device, bin_image, size, &v_), "vsg_vocab_load");
+  }
+  ~ORBVocabulary() { vsg_vocab_destroy(v_); }
+  ORBVocabulary(const ORBVocabulary &) = delete;
+  ORBVocabulary &operator=(const ORBVocabulary &) = delete;
+  // mBowVec as std::map<WordId, WordValue> (BowVector.h:57-58), mFeatVec as CSR
+  void transform(const uint8_t *desc, int n, std::map<unsigned, double> &bowVec, FeatureVectorCSR &featVec,
+                 int levelsup = 4) const {
+    std::vector<int32_t> ids(n > 0 ? n : 1);
+    std::vector<double> vals(n > 0 ? n : 1);
+    featVec.node.assign(n > 0 ? n : 1, 0);
+    featVec.off.assign((n > 0 ? n : 1) + 1, 0);
+    featVec.idx.assign(n > 0 ? n : 1, 0);
+    int nb = 0, nf = 0;
+    check(vsg_bow_transform(v_, desc, n, levelsup, ids.data(), vals.data(), (int)ids.size(), &nb, featVec.node.data(),
+                            featVec.off.data(), featVec.idx.data(), (int)featVec.node.size(), &nf, nullptr, nullptr,
+                            nullptr),
+          "vsg_bow_transform");
+    bowVec.clear();
+    for (int i = 0; i < nb; ++i) bowVec.emplace_hint(bowVec.end(), (unsigned)ids[i], vals[i]);
+    featVec.node.resize(nf);
+    featVec.off.resize(nf + 1);
+    featVec.idx.resize(featVec.off[nf]);
+  }
+
+ private:
+  vsg_vocab *v_ = nullptr;
+};
+
+// VS_GRAPHS::ORBmatcher (ORBmatcher.h:34-99) on flattened views.  The reference's methods take Frame& / KeyFrame* /
+// MapPoint* graphs; a maintainer's glue builds the views from those (INTEGRATION.md shows it for each method) and
+// writes the returned indices back as MapPoint* assignments.  Same constants, same return values (number of matches).
+class ORBmatcher {
+ public:
+  static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;  // ORBmatcher.cc:34-36
+
+  explicit ORBmatcher(float nnratio = 0.6f, bool checkOri = true, int device = 0)
+      : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device) {}
+
+  static int DescriptorDistance(const uint8_t *a, const uint8_t *b, int device = 0) {
+    return vsg::DescriptorDistance(a, b, device);
+  }
+
+  // SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)  (ORBmatcher.cc:226-428)
+  // kfValid[i] = (vpMapPointsKF[i] && !isBad()); matchF[iF] = KF feature index or -1.
+  int SearchByBoW(const FeatureView &kf, const uint8_t *kfValid, const FeatureVectorCSR &kfFeatVec,
+                  const FeatureView &f, const FeatureVectorCSR &fFeatVec, std::vector<int32_t> &matchF) const {
+    matchF.assign(f.n, -1);
+    int rc = vsg_search_by_bow_kf_f(device_, kf.desc, kf.angle, kfValid, kf.n, kfFeatVec.node.data(),
+                                    kfFeatVec.off.data(), kfFeatVec.idx.data(), kfFeatVec.nodes(), f.desc, f.angle,
+                                    f.n, fFeatVec.node.data(), fFeatVec.off.data(), fFeatVec.idx.data(),
+                                    fFeatVec.nodes(), mfNNratio, mbCheckOrientation, matchF.data());
+    check(rc, "vsg_search_by_bow_kf_f");
+    return rc;
+  }
+
+  // SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12)  (ORBmatcher.cc:758-900)
+  int SearchByBoW(const FeatureView &kf1, const uint8_t *valid1, const FeatureVectorCSR &fv1, const FeatureView &kf2,
+                  const uint8_t *valid2, const FeatureVectorCSR &fv2, std::vector<int32_t> &matches12) const {
+    matches12.assign(kf1.n, -1);
+    int rc = vsg_search_by_bow_kf_kf(device_, kf1.desc, kf1.angle, valid1, kf1.n, fv1.node.data(), fv1.off.data(),
+                                     fv1.idx.data(), fv1.nodes(), kf2.desc, kf2.angle, valid2, kf2.n,
+                                     fv2.node.data(), fv2.off.data(), fv2.idx.data(), fv2.nodes(), mfNNratio,
+                                     mbCheckOrientation, matches12.data());
+    check(rc, "vsg_search_by_bow_kf_kf");
+    return rc;
+  }
+
+  // SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  (ORBmatcher.cc:1667-1878).
+  // q = LastFrame's map points that project into the image (descriptor + keypoint angle of the last frame's feature),
+  // cand = CurrentFrame.GetFeaturesInArea per q; trainBlocked / trainMatch are CurrentFrame-sized.
+  int SearchByProjection(const FeatureView &q, const uint8_t *queryBlocks, const Candidates &cand,
+                         const FeatureView &cur, std::vector<uint8_t> &trainBlocked,
+                         std::vector<int32_t> &trainMatch) const {
+    trainMatch.assign(cur.n, -1);
+    trainBlocked.resize(cur.n, 0);
+    int rc = vsg_search_by_projection_last(device_, q.desc, q.angle, queryBlocks, q.n, cand.off.data(),
+                                           cand.idx.data(), cur.desc, cur.angle, trainBlocked.data(), cur.n, TH_HIGH,
+                                           mbCheckOrientation, trainMatch.data());
+    check(rc, "vsg_search_by_projection_last");
+    return rc;
+  }
+
+  // SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, ...)  (ORBmatcher.cc:42-216)
+  int SearchByProjection(const FeatureView &q, const uint8_t *queryBlocks, const Candidates &cand,
+                         const FeatureView &frame, std::vector<uint8_t> &trainBlocked,
+                         std::vector<int32_t> &trainMatch, bool localMap) const {
+    (void)localMap;
+    trainMatch.assign(frame.n, -1);
+    trainBlocked.resize(frame.n, 0);
+    int rc = vsg_search_by_projection_local(device_, q.desc, queryBlocks, q.n, cand.off.data(), cand.idx.data(),
+                                            frame.desc, frame.octave, trainBlocked.data(), frame.n, mfNNratio,
+                                            trainMatch.data());
+    check(rc, "vsg_search_by_projection_local");
+    return rc;
+  }
+
+  // Common core of SearchByProjection(KeyFrame*, Sim3, ...) x2, SearchByProjection(Frame&, KeyFrame*, ...),
+  // SearchBySim3 and Fuse (see include/vsg_orb.h: vsg_search_window).
+  int SearchWindow(const FeatureView &q, const uint8_t *queryBlocks, const Candidates &cand, const FeatureView &train,
+                   int thHigh, std::vector<int32_t> &qBestIdx, std::vector<int32_t> &qBestDist,
+                   std::vector<uint8_t> *trainBlocked = nullptr, std::vector<int32_t> *trainMatch = nullptr) const {
+    qBestIdx.assign(q.n, -1);
+    qBestDist.assign(q.n, 256);
+    if (trainMatch) trainMatch->assign(train.n, -1);
+    if (trainBlocked) trainBlocked->resize(train.n, 0);
+    int rc = vsg_search_window(device_, q.desc, queryBlocks, q.n, cand.off.data(), cand.idx.data(), train.desc,
+                               trainBlocked ? trainBlocked->data() : nullptr, train.n, thHigh, qBestIdx.data(),
+                               qBestDist.data(), trainMatch ? trainMatch->data() : nullptr);
+    check(rc, "vsg_search_window");
+    return rc;
+  }
+
+  // SearchForInitialization(Frame &F1, Frame &F2, vbPrevMatched, vnMatches12, windowSize)  (ORBmatcher.cc:643-756)
+  int SearchForInitialization(const FeatureView &f1, const Candidates &cand, const FeatureView &f2,
+                              std::vector<int32_t> &vnMatches12) const {
+    vnMatches12.assign(f1.n, -1);
+    int rc = vsg_search_for_initialization(device_, f1.desc, f1.angle, f1.octave, f1.n, cand.off.data(),
+                                           cand.idx.data(), f2.desc, f2.angle, f2.n, mfNNratio, mbCheckOrientation,
+                                           vnMatches12.data());
+    check(rc, "vsg_search_for_initialization");
+    return rc;
+  }
+
+ protected:
+  float mfNNratio;          // ORBmatcher.h:97
+  bool mbCheckOrientation;  // ORBmatcher.h:98
+  int device_;
+};
+
+// Frame::ComputeStereoMatches (Frame.cc:957-1127): mvuRight / mvDepth from the two extractors' device pyramids.
+inline int ComputeStereoMatches(const ORBextractor &left, const ORBextractor &right,
+                                const std::vector<vsg_keypoint> &kpsL, const uint8_t *descL,
+                                const std::vector<vsg_keypoint> &kpsR, const uint8_t *descR, float mb, float mbf,
+                                std::vector<float> &mvuRight, std::vector<float> &mvDepth) {
+  mvuRight.assign(kpsL.size(), -1.0f);
+  mvDepth.assign(kpsL.size(), -1.0f);
+  int rc = vsg_stereo_matches(left.handle(), 0, right.handle(), 0, kpsL.data(), descL, (int)kpsL.size(), kpsR.data(),
+                              descR, (int)kpsR.size(), mb, mbf, mvuRight.data(), mvDepth.data());
+  check(rc, "vsg_stereo_matches");
+  return rc;
+}
+
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:380-415) for many map points in one call.
+inline std::vector<int32_t> ComputeDistinctiveDescriptors(const uint8_t *desc, const std::vector<int32_t> &off,
+                                                          int device = 0) {
+  std::vector<int32_t> best(off.empty() ? 0 : off.size() - 1, -1);
+  if (!best.empty()) check(vsg_distinctive_descriptors(device, desc, off.data(), (int)best.size(), best.data()),
+                           "vsg_distinctive_descriptors");
+  return best;
 }
 
 }  // namespace vsg

@@ -1,0 +1,95 @@
+// End-to-end exercise of include/vsg_orb_adaptor.hpp from plain C++ (no Python, no OpenCV): two synthetic frames
+// -> vsg::ORBextractor -> vsg::FrameGrid -> vsg::ORBmatcher::SearchWindow / SearchByBoW (with vsg::ORBVocabulary).
+// Every output is dumped to a flat binary file that tests/test_gpu_adaptor.py compares with the CPU oracle.
+//   usage: adaptor_check <vocab.bin> <out.bin>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iterator>
+
+#include "vsg_orb_adaptor.hpp"
+#include "vsg_synth.h"
+
+template <class T>
+static void dump(std::ofstream &f, const std::vector<T> &v) {
+  int32_t n = (int32_t)v.size();
+  f.write((const char *)&n, 4);
+  if (n) f.write((const char *)v.data(), sizeof(T) * v.size());
+}
+
+int main(int argc, char **argv) {
+  if (argc < 3) return 2;
+  try {
+    const int W = 640, H = 480;
+    std::vector<uint8_t> img[2] = {std::vector<uint8_t>(W * H), std::vector<uint8_t>(W * H)};
+    for (int t = 0; t < 2; ++t)
+      if (vsg_synth_sequence_frame(W, H, 5, t, 1, 6, img[t].data(), W)) return 2;
+
+    vsg::ORBextractor ex(1000, 1.2f, 8, 20, 7);
+    std::vector<vsg_keypoint> kps[2];
+    std::vector<uint8_t> desc[2];
+    std::vector<int> lap{0, 0};
+    int mono[2];
+    for (int t = 0; t < 2; ++t) mono[t] = ex(img[t].data(), H, W, W, kps[t], desc[t], lap);
+
+    // window search: frame-0 keypoints looked up in frame 1's grid at the known (3,2) px shift, r = 15 * scale
+    std::vector<float> angle[2], qx, qy, qr;
+    std::vector<int32_t> octave[2], lo, hi;
+    for (int t = 0; t < 2; ++t)
+      for (auto &k : kps[t]) angle[t].push_back(k.angle), octave[t].push_back(k.octave);
+    const std::vector<float> scale = ex.GetScaleFactors();
+    for (auto &k : kps[0]) {
+      qx.push_back(k.x - 3.0f), qy.push_back(k.y - 2.0f), qr.push_back(15.0f * scale[k.octave]);
+      lo.push_back(k.octave - 1), hi.push_back(k.octave + 1);
+    }
+    vsg::FrameGrid grid(kps[1].data(), (int)kps[1].size(), 0.f, 0.f, (float)W, (float)H);
+    vsg::Candidates cand = grid.GetFeaturesInArea(qx.data(), qy.data(), qr.data(), lo.data(), hi.data(), (int)qx.size());
+
+    vsg::ORBmatcher matcher(0.7f, true);
+    vsg::FeatureView q{desc[0].data(), angle[0].data(), octave[0].data(), (int)kps[0].size()};
+    vsg::FeatureView tr{desc[1].data(), angle[1].data(), octave[1].data(), (int)kps[1].size()};
+    std::vector<int32_t> bestIdx, bestDist, trainMatch;
+    std::vector<uint8_t> trainBlocked;
+    std::vector<uint8_t> qBlocks(q.n, 1);
+    int nwin = matcher.SearchWindow(q, qBlocks.data(), cand, tr, vsg::ORBmatcher::TH_HIGH, bestIdx, bestDist,
+                                    &trainBlocked, &trainMatch);
+
+    // BoW: vocabulary image from disk, transform both frames, SearchByBoW(KF = frame 0, F = frame 1)
+    std::ifstream vf(argv[1], std::ios::binary);
+    std::vector<uint8_t> blob((std::istreambuf_iterator<char>(vf)), std::istreambuf_iterator<char>());
+    vsg::ORBVocabulary voc(blob.data(), blob.size());
+    std::map<unsigned, double> bow[2];
+    vsg::FeatureVectorCSR fv[2];
+    for (int t = 0; t < 2; ++t) voc.transform(desc[t].data(), (int)kps[t].size(), bow[t], fv[t], 2);
+    // round trip through the reference's container type
+    std::map<unsigned, std::vector<unsigned>> featVecMap;
+    for (int i = 0; i < fv[0].nodes(); ++i)
+      featVecMap[(unsigned)fv[0].node[i]].assign(fv[0].idx.begin() + fv[0].off[i], fv[0].idx.begin() + fv[0].off[i + 1]);
+    vsg::FeatureVectorCSR fv0(featVecMap);
+    std::vector<uint8_t> kfValid(q.n, 1);
+    for (int i = 0; i < q.n; i += 7) kfValid[i] = 0;
+    std::vector<int32_t> matchF;
+    int nbow = matcher.SearchByBoW(q, kfValid.data(), fv0, tr, fv[1], matchF);
+
+    std::vector<int32_t> init12;
+    int ninit = matcher.SearchForInitialization(q, cand, tr, init12);
+
+    const int d01 = vsg::ORBmatcher::DescriptorDistance(desc[0].data(), desc[1].data());
+
+    std::ofstream f(argv[2], std::ios::binary);
+    std::vector<int32_t> head{mono[0], mono[1], nwin, nbow, ninit, d01};
+    dump(f, head);
+    for (int t = 0; t < 2; ++t) dump(f, kps[t]), dump(f, desc[t]);
+    dump(f, cand.off), dump(f, cand.idx), dump(f, bestIdx), dump(f, bestDist), dump(f, trainMatch), dump(f, matchF);
+    dump(f, init12);
+    std::vector<int32_t> bow_ids;
+    std::vector<double> bow_vals;
+    for (auto &kv : bow[1]) bow_ids.push_back((int32_t)kv.first), bow_vals.push_back(kv.second);
+    dump(f, bow_ids), dump(f, bow_vals);
+    printf("OK %zu %zu win=%d bow=%d init=%d\n", kps[0].size(), kps[1].size(), nwin, nbow, ninit);
+    return 0;
+  } catch (const std::exception &e) {
+    printf("THROW %s\n", e.what());
+    return 3;
+  }
+}

@@ -8,6 +8,7 @@
 #include "vsg_introsort.h"
 #include "vsg_math.h"
 #include "vsg_octree_core.h"
+#include "../../include/vsg_synth.h"
 
 using namespace vsg;
 
@@ -79,6 +80,9 @@ int hc_octree(int l, const int *x, const int *y, const int *resp, int n, int N_o
 
 void hc_sort(uint64_t *items, int n) { introsort::sort(items, n); }
 float hc_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
+int hc_synth_frame(int w, int h, unsigned seq, int t, int div, int noise, uint8_t *out, size_t stride) {
+  return vsg_synth_sequence_frame(w, h, seq, t, div, noise, out, stride);
+}
 void hc_brief_rotation(float angle, float *a, float *b) { brief_rotation(angle, a, b); }
 void hc_brief_offset(int px, int py, float a, float b, int *dx, int *dy) { brief_offset(px, py, a, b, dx, dy); }
 float hc_sinf(float x, int fma) { return fma ? SinCosF<true>::eval(x, false) : SinCosF<false>::eval(x, false); }

@@ -73,3 +73,15 @@ def test_cpp_adaptor_compiles_and_fails_loudly_without_device(lib, tmp_path):
         assert r.returncode == 0 and r.stdout.startswith("OK 0 0")  # constant image: 0 keypoints
     else:
         assert r.returncode == 3 and "THROW" in r.stdout
+
+
+def test_cpp_adaptor_full_surface_compiles(lib):
+    """tests/_adaptor/adaptor_check.cpp uses every class of the C++ adaptor (extractor, grid, vocabulary, matcher);
+    it must build with plain g++ and, without a GPU, refuse to run (the GPU run is tests/test_gpu_adaptor.py)."""
+    import subprocess
+    d = ROOT / "tests" / "_adaptor"
+    subprocess.check_call(["make", "-C", str(d)], stdout=subprocess.DEVNULL)
+    if lib.vsg_device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([str(d / "adaptor_check"), "/dev/null", "/dev/null"], capture_output=True, text=True)
+    assert r.returncode == 3 and "no CPU fallback" in r.stdout

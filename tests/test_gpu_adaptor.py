@@ -1,0 +1,91 @@
+"""GPU parity test of the C++ drop-in layer: tests/_adaptor/adaptor_check.cpp drives include/vsg_orb_adaptor.hpp
+(vsg::ORBextractor / FrameGrid / ORBVocabulary / ORBmatcher) from plain C++ over the C ABI, generating its inputs
+with include/vsg_synth.h; everything it produces must equal the CPU oracle bit for bit."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from visual_sgraphs_amd import orb, synth
+
+pytestmark = pytest.mark.gpu
+DIR = Path(__file__).resolve().parent / "_adaptor"
+
+
+def _read(path):
+    raw = Path(path).read_bytes()
+    pos = 0
+
+    def take(dtype):
+        nonlocal pos
+        n = int(np.frombuffer(raw, np.int32, 1, pos)[0])
+        pos += 4
+        a = np.frombuffer(raw, dtype, n, pos).copy()
+        pos += a.nbytes
+        return a
+    out = {"head": take(np.int32)}
+    for t in range(2):
+        out[f"kps{t}"] = take(orb.KP_DTYPE)
+        out[f"desc{t}"] = take(np.uint8).reshape(-1, 32)
+    for k in ("cand_off", "cand_idx", "best_idx", "best_dist", "train_match", "match_f", "init12", "bow_ids"):
+        out[k] = take(np.int32)
+    out["bow_vals"] = take(np.float64)
+    assert pos == len(raw)
+    return out
+
+
+def test_cpp_adaptor_end_to_end_equals_oracle(tmp_path):
+    from visual_sgraphs_amd import build
+    build.build()
+    subprocess.check_call(["make", "-C", str(DIR)], stdout=subprocess.DEVNULL)
+    blob = synth.synthetic_vocabulary(k=10, L=3, seed=4)
+    (tmp_path / "voc.bin").write_bytes(blob)
+    r = subprocess.run([str(DIR / "adaptor_check"), str(tmp_path / "voc.bin"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+    got = _read(tmp_path / "out.bin")
+
+    # extractor
+    ref = ol.OracleExtractor(1000, 1.2, 8, 20, 7)
+    want = [ref(synth.sequence_frame(640, 480, 5, t)) for t in range(2)]
+    for t in range(2):
+        assert int(got["head"][t]) == want[t][0]
+        assert got[f"kps{t}"].tobytes() == want[t][1].tobytes()
+        assert np.array_equal(got[f"desc{t}"], want[t][2])
+    (_, k0, d0), (_, k1, d1) = want
+    assert len(k0) > 900 and len(k1) > 900
+
+    # grid candidates
+    g = ol.OracleGrid(k1, 0.0, 0.0, 640.0, 480.0)
+    scale = ref.tables()["scale"]
+    off, idx = [0], []
+    for k in k0:
+        c = g.query(np.float32(k["x"]) - np.float32(3), np.float32(k["y"]) - np.float32(2),
+                    np.float32(15) * np.float32(scale[k["octave"]]), int(k["octave"]) - 1, int(k["octave"]) + 1)
+        idx.extend(c.tolist())
+        off.append(len(idx))
+    assert np.array_equal(got["cand_off"], off) and np.array_equal(got["cand_idx"], idx)
+    assert len(idx) > len(k0)  # the windows are not trivially empty
+
+    # window search
+    n, qi, qd, tm, _ = ol.search_window(d0, np.ones(len(d0), np.uint8), off, idx, d1, np.zeros(len(d1), np.uint8), 100)
+    assert int(got["head"][2]) == n > 300
+    assert np.array_equal(got["best_idx"], qi) and np.array_equal(got["best_dist"], qd)
+    assert np.array_equal(got["train_match"], tm)
+
+    # vocabulary + SearchByBoW
+    voc = ol.OracleVocabulary(blob)
+    t0, t1 = voc.transform(d0, 2), voc.transform(d1, 2)
+    assert np.array_equal(got["bow_ids"], t1["bow_ids"]) and got["bow_vals"].tobytes() == t1["bow_vals"].tobytes()
+    valid = np.ones(len(d0), np.uint8)
+    valid[::7] = 0
+    nb, mf = ol.search_by_bow_kf_f(d0, k0["angle"], valid, t0["fv"], d1, k1["angle"], t1["fv"], 0.7, True)
+    assert int(got["head"][3]) == nb > 50
+    assert np.array_equal(got["match_f"], mf)
+
+    # SearchForInitialization + DescriptorDistance
+    ni, m12 = ol.search_for_initialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"], 0.7, True)
+    assert int(got["head"][4]) == ni and np.array_equal(got["init12"], m12)
+    assert int(got["head"][5]) == ol.descriptor_distance(d0[0], d1[0])

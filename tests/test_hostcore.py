@@ -216,3 +216,16 @@ def test_octree_core_multiple_initial_nodes(hc):
         kp = e.level_keypoints(l)
         gx, gy, gr = hc_octree(hc, l, x[::-1], y[::-1], r[::-1])
         assert np.array_equal(gx + 16, kp["x"].astype(np.int32)) and np.array_equal(gy + 16, kp["y"].astype(np.int32))
+
+
+def test_synth_header_matches_python(hc):
+    """include/vsg_synth.h (the C mirror of the SURVEY 8d frame generator) equals synth.py byte for byte."""
+    hc.hc_synth_frame.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    for (w, h, seq, t, div, noise) in [(640, 480, 0, 0, 1, 6), (320, 240, 7, 5, 1, 6), (200, 150, 3, 40, 8, 6),
+                                       (96, 64, 9, 2, 1, 0), (177, 131, 11, 33, 3, 2)]:
+        out = np.zeros((h, w + 5), np.uint8)
+        assert hc.hc_synth_frame(w, h, seq, t, div, noise, out.ctypes.data, out.strides[0]) == 0
+        want = synth.sequence_frame(w, h, seq, t, amplitude_div=div, noise=noise)
+        assert np.array_equal(out[:, :w], want), (w, h, seq, t, div, noise)
+        assert not out[:, w:].any()
+    assert hc.hc_synth_frame(0, 10, 0, 0, 1, 6, None, 0) == -1

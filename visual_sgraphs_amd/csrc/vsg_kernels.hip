@@ -272,8 +272,7 @@ __device__ __forceinline__ uint32_t fast_quick4(uint32_t C, uint32_t U, uint32_t
 // candidates).
 __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                     const CellDesc *__restrict__ cells, Src0 s0,
-                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count,
-                                                    int dbg) {
+                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[(kCellMax + 6) * kTileP];
   __shared__ __attribute__((aligned(16))) uint8_t score[(kCellMax + 2) * kScoreP];
   __shared__ uint16_t queue[kCellMax * kCellMax];
@@ -294,7 +293,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int r = div_small(i, inv_tdw), c = i - r * tdw;
     *(uint32_t *)&tile[r * kTileP + 4 * c] = *(const uint32_t *)(img + (size_t)(cell.y0 - 3 + r) * pitch + ax + 4 * c);
   }
-  if (dbg == 1) return;
   // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1
   const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0;
   const int ngroups = ng * vh;
@@ -340,7 +338,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     }
     __syncthreads();
     nq = s_cnt[1];
-    if (dbg == 2) return;
     // ---- phase 2: exact score of the queued pixels
     for (int q = tid; q < nq; q += 256) {
       const int i = queue[q];
@@ -349,7 +346,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
       if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
     }
     __syncthreads();
-    if (dbg == 3) return;
     // ---- phase 3: non-max suppression inside the cell
     keep = 0;  // bit per loop iteration: queued pixel survives NMS
     int it = 0;
@@ -612,8 +608,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ sel,
                                                      const int *__restrict__ slots, const FrameHeader *__restrict__ hdr,
                                                      const int8_t *__restrict__ pattern, KeyPointPOD *__restrict__ kps,
-                                                     uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity,
-                                                     int dbg) {
+                                                     uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity) {
   __shared__ int8_t pat[1024];
   __shared__ int s_hdr[kMaxLevels + 3];  // n, mono, level_start[0..kMaxLevels]
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchW * kPatchP];
@@ -682,14 +677,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   }
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   float a, b;
-  if (dbg == 1) {
-    a = angle * 0.001f, b = 1.0f - a;  // ablation: no sincos
-  } else
-    brief_rotation(angle, &a, &b);
-  if (dbg == 2) {  // ablation: no descriptor
-    if (lane == 0 && slot < capacity) kps[(size_t)frame * capacity + slot].angle = a + b;
-    return;
-  }
+  brief_rotation(angle, &a, &b);
   // ---- descriptor.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38), so the 37x37 blurred
   // patch is staged in LDS with row-major (coalesced) byte loads; the 8 samples per lane are then LDS reads.
   uint8_t *patch = &s_patch[(tid >> 6) * (kPatchW * kPatchP)];
@@ -954,8 +942,7 @@ void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sh
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
                  uint32_t *cand, int *cand_count, const FrameGeom &fg, int nframes) {
   dim3 grid(fg.total_cells, nframes), block(256);
-  static const int dbg = getenv("VSG_FAST_DBG") ? atoi(getenv("VSG_FAST_DBG")) : 0;
-  hipLaunchKernelGGL(k_fast_cells, grid, block, 0, s, pyr, d_fg, d_cells, s0, cand, cand_count, dbg);
+  hipLaunchKernelGGL(k_fast_cells, grid, block, 0, s, pyr, d_fg, d_cells, s0, cand, cand_count);
 }
 void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, const int *cand_count,
                    uint16_t *node_of, uint32_t *sel, int *sel_count, const FrameGeom &fg, int maxQuota, int nframes) {
@@ -977,9 +964,8 @@ void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, 
                         const uint32_t *sel, const int *slots, const FrameHeader *hdr, const int8_t *pattern,
                         KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes) {
   dim3 grid((fg.out_cap + 3) / 4, nframes), block(256);
-  static const int dbg = getenv("VSG_ORIENT_DBG") ? atoi(getenv("VSG_ORIENT_DBG")) : 0;
   hipLaunchKernelGGL(k_orient_desc, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
-                     counts, capacity, dbg);
+                     counts, capacity);
 }
 void launch_border_copy(hipStream_t s, const uint8_t *img, int w, int h, int pitch, uint8_t *dst, int dpitch, int b) {
   dim3 grid((w + 2 * b + 255) / 256, h + 2 * b), block(256);

@@ -321,11 +321,7 @@ VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts,
           sortbuf[t] = ((introsort::item_t)key << 32) | (uint32_t)n;
         }
         g.sync();
-#ifdef VSG_OCT_ABLATE_SORT
-        if (g.tid == 0 && nV < 0) introsort::sort(sortbuf, nV);
-#else
         if (g.tid == 0) introsort::sort(sortbuf, nV);  // (:707)
-#endif
         g.sync();
         for (int t = g.tid; t < nV; t += g.nthreads) W.proc[t] = (uint16_t)(uint32_t)sortbuf[nV - 1 - t];  // (:708)
         g.sync();
