@@ -1,6 +1,7 @@
 // Host build of the PRODUCT's device-agnostic core (visual_sgraphs_amd/csrc/*.h) for CPU unit tests:
 // the octree algorithm runs here as a 1-thread group; geometry/tables are the same code the runtime
 // uses.  This library is test-only -- the shipped path is the HIP library and has no CPU fallback.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -75,10 +76,39 @@ int hc_octree(int l, const int *x, const int *y, const int *resp, int n, int N_o
   octree::SerialGroup g;
   int m = octree::distribute(g, P, cand.data(), n, node_of.data(), W, sel.data());
   for (int i = 0; i < m; i++) outPacked[i] = (int)sel[i];
+  // the register-resident points policy (the device's common path) must give the same list
+  if (n <= 8192) {
+    std::vector<uint64_t> buf2(buf.size());
+    octree::Work W2;
+    octree::carve(W2, buf2.data(), cap);
+    std::vector<uint32_t> sel2(cap);
+    const int m2 = octree::distribute_reg<8192>(g, P, cand.data(), n, W2, sel2.data());
+    if (m2 != m) return -1000;
+    for (int i = 0; i < m; i++)
+      if (sel2[i] != sel[i]) return -1001;
+  }
   return m;
 }
 
 void hc_sort(uint64_t *items, int n) { introsort::sort(items, n); }
+// the real thing, for comparison (same libstdc++ the oracle is built with)
+void hc_std_sort(uint64_t *items, int n) {
+  std::sort(items, items + n, [](uint64_t a, uint64_t b) { return (uint32_t)(a >> 32) < (uint32_t)(b >> 32); });
+}
+// the split the device uses: serial partition phase, then a stable rank of what it left
+void hc_sort_split(uint64_t *items, int n) {
+  if (n <= 0) return;
+  introsort::partition_phase(items, n);
+  std::vector<uint64_t> tmp(items, items + n);
+  for (int t = 0; t < n; t++) {
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+      const uint32_t kj = (uint32_t)(tmp[j] >> 32), kt = (uint32_t)(tmp[t] >> 32);
+      rank += (kj < kt) | ((kj == kt) & (j < t));
+    }
+    items[rank] = tmp[t];
+  }
+}
 float hc_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
 int hc_synth_frame(int w, int h, unsigned seq, int t, int div, int noise, uint8_t *out, size_t stride) {
   return vsg_synth_sequence_frame(w, h, seq, t, div, noise, out, stride);

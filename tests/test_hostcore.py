@@ -132,6 +132,26 @@ def test_introsort_is_libstdcxx_exact(hc):
             assert np.array_equal(buf, items[np.argsort(keys, kind="stable")])
 
 
+def test_introsort_and_its_device_split_equal_std_sort(hc):
+    """Move-for-move equality with the real std::sort (key-only comparator, tie-heavy inputs), both for the serial
+    replay and for the split the device runs: serial partition phase + parallel stable rank."""
+    rng = np.random.default_rng(1)
+    p64 = C.POINTER(C.c_uint64)
+    for trial in range(400):
+        n = int(rng.integers(1, 400))
+        nkeys = int(rng.choice([1, 2, 3, 8, 50, 100000]))
+        keys = rng.integers(0, nkeys, n).astype(np.uint64)
+        if trial % 5 == 0:
+            keys = np.sort(keys)[::-1].copy() if trial % 10 == 0 else np.sort(keys)
+        items = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        a, b, c = items.copy(), items.copy(), items.copy()
+        hc.hc_std_sort(a.ctypes.data_as(p64), n)
+        hc.hc_sort(b.ctypes.data_as(p64), n)
+        hc.hc_sort_split(c.ctypes.data_as(p64), n)
+        assert np.array_equal(a, b), (trial, n, nkeys)
+        assert np.array_equal(a, c), (trial, n, nkeys)
+
+
 def test_float_helpers_match_oracle_and_libm(hc):
     rng = np.random.default_rng(2)
     for _ in range(5000):

@@ -137,9 +137,11 @@ VSG_SORT_HD int lg_(int n) {  // std::__lg: floor(log2(n)), n > 0
   return r;
 }
 
-// std::sort(first, first + n, comp).  `depth_limit_override` < 0 uses the library's 2*lg(n).
-VSG_SORT_HD void sort(item_t *first, int n, int depth_limit_override = -1) {
-  if (n <= 0) return;
+// The __introsort_loop half of std::sort: quicksort partitioning down to runs of <= 16 (heapsort past the depth
+// limit).  What remains for std::sort is __final_insertion_sort, which moves an element left only past strictly
+// greater ones -- i.e. it is exactly a STABLE sort of the array this function leaves behind.  A caller with many
+// threads runs this on one of them and then ranks the items in parallel (rank = #smaller + #equal-before).
+VSG_SORT_HD void partition_phase(item_t *first, int n, int depth_limit_override = -1) {
   const int kThreshold = 16;
   // __introsort_loop, recursion on the right part turned into an explicit stack
   // (depth <= 2*lg(n) + 1 <= 64 for any int n)
@@ -173,6 +175,13 @@ VSG_SORT_HD void sort(item_t *first, int n, int depth_limit_override = -1) {
     hi = stack[sp].hi;
     depth = stack[sp].depth;
   }
+}
+
+// std::sort(first, first + n, comp).  `depth_limit_override` < 0 uses the library's 2*lg(n).
+VSG_SORT_HD void sort(item_t *first, int n, int depth_limit_override = -1) {
+  if (n <= 0) return;
+  const int kThreshold = 16;
+  partition_phase(first, n, depth_limit_override);
   // __final_insertion_sort
   if (n > kThreshold) {
     insertion_sort_(first, first + kThreshold);

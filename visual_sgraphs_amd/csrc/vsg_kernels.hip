@@ -424,6 +424,11 @@ struct BlockGroup {
   }
 };
 
+#ifndef VSG_OCT_K
+#define VSG_OCT_K 8
+#endif
+constexpr int kOctRegPts = VSG_OCT_K;  // candidates per thread held in registers (x 256 threads = 2048 per level; 12 costs a wave of occupancy and loses)
+
 __global__ __launch_bounds__(256) void k_octree(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ cand,
                                                 const int *__restrict__ cand_count, uint16_t *__restrict__ node_of,
                                                 uint32_t *__restrict__ sel, int *__restrict__ sel_count, int cap) {
@@ -449,8 +454,11 @@ __global__ __launch_bounds__(256) void k_octree(const FrameGeom *__restrict__ fg
   int npts = cand_count[frame * kMaxLevels + level];
   if (npts > L.cand_cap) npts = L.cand_cap;
   const size_t coff = (size_t)frame * fg->cand_frame + L.cand_off;
-  const int n = octree::distribute(g, P, cand + coff, npts, node_of + coff, W,
-                                   sel + (size_t)frame * fg->sel_frame + L.sel_off);
+  uint32_t *out = sel + (size_t)frame * fg->sel_frame + L.sel_off;
+  // candidates stay in registers across the passes when they fit (the common case); node_of[] is only touched by
+  // the fallback
+  const int n = npts <= kOctRegPts * 256 ? octree::distribute_reg<kOctRegPts>(g, P, cand + coff, npts, W, out)
+                                         : octree::distribute(g, P, cand + coff, npts, node_of + coff, W, out);
   if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;
 }
 

@@ -24,8 +24,10 @@
 
 #if defined(__HIPCC__)
 #define VSG_OCT_HD __host__ __device__ inline
+#define VSG_OCT_UNROLL _Pragma("unroll")
 #else
 #define VSG_OCT_HD inline
+#define VSG_OCT_UNROLL
 #endif
 
 namespace vsg {
@@ -72,6 +74,60 @@ struct Params {
 // size + 3*nToExpand <= N (:696) and adds <= 3 per split node; the careful phase adds <= 3 per split
 // and stops at the first size >= N (:753).
 VSG_OCT_HD int node_capacity(int N) { return (N + 3 > 4 * kMaxIniNodes ? N + 3 : 4 * kMaxIniNodes) + 4; }
+
+// ---- where a thread keeps "its" points (p = tid, tid + nthreads, ...) between passes.
+// MemPts: candidate words and node labels live in memory (cand[] read-only, node_of[] scratch) -- any npts.
+// RegPts<K>: both live in the thread's registers (npts <= K * nthreads): the per-pass sweeps then touch only the
+// node arrays in LDS, which takes the global-memory round trips out of the (latency-bound) pass loop.
+struct MemPts {
+  const uint32_t *cand;
+  uint16_t *node_of;
+  template <class G>
+  VSG_OCT_HD void load(G &, int) {}
+  template <class G, class F>
+  VSG_OCT_HD void for_each(G &g, int npts, F f) {
+    for (int p = g.tid; p < npts; p += g.nthreads) {
+      int n = node_of[p];
+      const int n0 = n;
+      f(cand[p], n);
+      if (n != n0) node_of[p] = (uint16_t)n;
+    }
+  }
+  template <class G, class F>
+  VSG_OCT_HD void init_each(G &g, int npts, F f) {  // first sweep: labels are written, not read
+    for (int p = g.tid; p < npts; p += g.nthreads) {
+      int n = 0;
+      f(cand[p], n);
+      node_of[p] = (uint16_t)n;
+    }
+  }
+};
+
+template <int K>
+struct RegPts {
+  const uint32_t *cand;
+  uint32_t c[K];
+  int n[K];
+  template <class G>
+  VSG_OCT_HD void load(G &g, int npts) {
+    VSG_OCT_UNROLL
+    for (int k = 0; k < K; k++) {
+      const int p = g.tid + k * g.nthreads;
+      c[k] = p < npts ? cand[p] : 0u;
+      n[k] = 0;
+    }
+  }
+  template <class G, class F>
+  VSG_OCT_HD void for_each(G &g, int npts, F f) {
+    VSG_OCT_UNROLL
+    for (int k = 0; k < K; k++)
+      if (g.tid + k * g.nthreads < npts) f(c[k], n[k]);
+  }
+  template <class G, class F>
+  VSG_OCT_HD void init_each(G &g, int npts, F f) {
+    for_each(g, npts, f);
+  }
+};
 
 // Workspace: carve from one byte buffer (LDS on the device).  Layout is 8-byte aligned.
 struct Work {
@@ -144,9 +200,9 @@ VSG_OCT_HD uint32_t cand_rank(const Params &P, int x, int y) {
 }
 
 // One splitting pass over proc[0..nProc).  Returns new list length; *nV_out = |V|.
-template <class G>
-VSG_OCT_HD int run_pass(G &g, const Params &P, Work &W, int &cur, int nL, int nProc, bool careful,
-                        const uint32_t *cand, int npts, uint16_t *node_of, int *nV_out) {
+template <class G, class PT>
+VSG_OCT_HD int run_pass(G &g, const Params &P, Work &W, int &cur, int nL, int nProc, bool careful, PT &pts, int npts,
+                        int *nV_out) {
   const int b = cur, nb = cur ^ 1;
   for (int i = g.tid; i < nL; i += g.nthreads) W.divided[i] = 0;
   g.sync();
@@ -160,13 +216,9 @@ VSG_OCT_HD int run_pass(G &g, const Params &P, Work &W, int &cur, int nL, int nP
   }
   if (g.tid == 0) W.ctrl[2] = nProc;
   g.sync();
-  for (int p = g.tid; p < npts; p += g.nthreads) {
-    const int n = node_of[p];
-    if (W.divided[n]) {
-      const uint32_t c = cand[p];
-      g.atomic_add(&W.childcnt[4 * n + quadrant(W, b, n, VSG_CAND_X(c), VSG_CAND_Y(c))], 1);
-    }
-  }
+  pts.for_each(g, npts, [&](uint32_t c, int &n) {
+    if (W.divided[n]) g.atomic_add(&W.childcnt[4 * n + quadrant(W, b, n, VSG_CAND_X(c), VSG_CAND_Y(c))], 1);
+  });
   g.sync();
   for (int t = g.tid; t < nProc; t += g.nthreads) {
     const int n = W.proc[t];
@@ -235,15 +287,9 @@ VSG_OCT_HD int run_pass(G &g, const Params &P, Work &W, int &cur, int nL, int nP
     }
   }
   g.sync();
-  for (int p = g.tid; p < npts; p += g.nthreads) {
-    const int n = node_of[p];
-    if (W.divided[n]) {
-      const uint32_t c = cand[p];
-      node_of[p] = W.childpos[4 * n + quadrant(W, b, n, VSG_CAND_X(c), VSG_CAND_Y(c))];
-    } else {
-      node_of[p] = W.keeppos[n];
-    }
-  }
+  pts.for_each(g, npts, [&](uint32_t c, int &n) {
+    n = W.divided[n] ? W.childpos[4 * n + quadrant(W, b, n, VSG_CAND_X(c), VSG_CAND_Y(c))] : W.keeppos[n];
+  });
   g.sync();
   cur = nb;
   *nV_out = E;
@@ -253,10 +299,10 @@ VSG_OCT_HD int run_pass(G &g, const Params &P, Work &W, int &cur, int nL, int nP
 // DistributeOctTree.  cand[0..npts): packed candidates in ANY order.  node_of: npts uint16 scratch.
 // sel_out: receives the chosen candidate of every final node, in the reference's list order.
 // Returns the number of selected keypoints.  Must be called by every thread of the group.
-template <class G>
-VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts, uint16_t *node_of, Work &W,
-                          uint32_t *sel_out) {
+template <class G, class PT>
+VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W, uint32_t *sel_out) {
   int cur = 0;
+  pts.load(g, npts);
   // initial nodes (:575-586)
   for (int i = g.tid; i < P.nIni; i += g.nthreads) {
     W.ulx[0][i] = (int16_t)P.iniUL[i];
@@ -267,13 +313,13 @@ VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts,
   }
   g.sync();
   // vpIniNodes[kp.pt.x / hX] (:589-593)
-  for (int p = g.tid; p < npts; p += g.nthreads) {
-    const int x = VSG_CAND_X(cand[p]);
+  pts.init_each(g, npts, [&](uint32_t c, int &n) {
+    const int x = VSG_CAND_X(c);
     int idx = 0;
     for (int i = 1; i < P.nIni; i++) idx += (x >= P.iniThresh[i]);
-    node_of[p] = (uint16_t)idx;
+    n = idx;
     g.atomic_add(&W.cnt[0][idx], 1);
-  }
+  });
   g.sync();
   // erase empty initial nodes, keep order (:597-608)
   if (g.tid == 0) {
@@ -292,7 +338,7 @@ VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts,
     W.ctrl[0] = pos;
   }
   g.sync();
-  for (int p = g.tid; p < npts; p += g.nthreads) node_of[p] = W.keeppos[node_of[p]];
+  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.keeppos[n]; });
   cur = 1;
   int nL = W.ctrl[0];
   g.sync();
@@ -307,7 +353,7 @@ VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts,
       if (W.cnt[cur][i] > 1) W.proc[W.scanA[i]] = (uint16_t)i;
     g.sync();
     int nV = 0;
-    nL = run_pass(g, P, W, cur, nL, nProc, false, cand, npts, node_of, &nV);
+    nL = run_pass(g, P, W, cur, nL, nProc, false, pts, npts, &nV);
     if (nL >= P.N || nL == prevSize) {  // (:692)
       finish = true;
     } else if (nL + nV * 3 > P.N) {  // (:696)
@@ -321,12 +367,24 @@ VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts,
           sortbuf[t] = ((introsort::item_t)key << 32) | (uint32_t)n;
         }
         g.sync();
-        if (g.tid == 0) introsort::sort(sortbuf, nV);  // (:707)
+        // std::sort (:707) = serial quicksort partitioning + a stable sort of what it leaves (vsg_introsort.h);
+        // the stable part is a rank computation spread over the group, written straight into the back-to-front
+        // processing order of (:708).
+        if (g.tid == 0) introsort::partition_phase(sortbuf, nV);
         g.sync();
-        for (int t = g.tid; t < nV; t += g.nthreads) W.proc[t] = (uint16_t)(uint32_t)sortbuf[nV - 1 - t];  // (:708)
+        for (int t = g.tid; t < nV; t += g.nthreads) {
+          const introsort::item_t it = sortbuf[t];
+          const uint32_t key = (uint32_t)(it >> 32);
+          int rank = 0;
+          for (int j = 0; j < nV; j++) {
+            const uint32_t kj = (uint32_t)(sortbuf[j] >> 32);
+            rank += (kj < key) | ((kj == key) & (j < t));
+          }
+          W.proc[nV - 1 - rank] = (uint16_t)(uint32_t)it;
+        }
         g.sync();
         int nV2 = 0;
-        nL = run_pass(g, P, W, cur, nL, nV, true, cand, npts, node_of, &nV2);
+        nL = run_pass(g, P, W, cur, nL, nV, true, pts, npts, &nV2);
         nV = nV2;
         if (nL >= P.N || nL == prev2) finish = true;  // (:757)
       }
@@ -337,19 +395,33 @@ VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts,
   uint32_t *bestkey = (uint32_t *)W.childcnt;
   for (int i = g.tid; i < nL; i += g.nthreads) bestkey[i] = 0;
   g.sync();
-  for (int p = g.tid; p < npts; p += g.nthreads) {
-    const uint32_t c = cand[p];
+  pts.for_each(g, npts, [&](uint32_t c, int &n) {
     const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c)));
-    g.atomic_max(&bestkey[node_of[p]], key);
-  }
+    g.atomic_max(&bestkey[n], key);
+  });
   g.sync();
-  for (int p = g.tid; p < npts; p += g.nthreads) {
-    const uint32_t c = cand[p];
+  pts.for_each(g, npts, [&](uint32_t c, int &n) {
     const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c)));
-    if (bestkey[node_of[p]] == key) sel_out[node_of[p]] = c;
-  }
+    if (bestkey[n] == key) sel_out[n] = c;
+  });
   g.sync();
   return nL;
+}
+
+// Points in memory: works for any npts (the host tests and the device fallback).
+template <class G>
+VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts, uint16_t *node_of, Work &W,
+                          uint32_t *sel_out) {
+  MemPts pts{cand, node_of};
+  return distribute_pts(g, P, pts, npts, W, sel_out);
+}
+
+// Points in registers: npts <= K * g.nthreads.
+template <int K, class G>
+VSG_OCT_HD int distribute_reg(G &g, const Params &P, const uint32_t *cand, int npts, Work &W, uint32_t *sel_out) {
+  RegPts<K> pts;
+  pts.cand = cand;
+  return distribute_pts(g, P, pts, npts, W, sel_out);
 }
 
 }  // namespace octree
