@@ -263,6 +263,12 @@ __device__ __forceinline__ uint32_t fast_quick4(uint32_t C, uint32_t U, uint32_t
   return m;
 }
 
+#ifndef VSG_FAST_RUN
+#define VSG_FAST_RUN 2
+#endif
+constexpr int kFastRun = VSG_FAST_RUN;  // dwords per thread in the necessary test (1, 2 or 4)
+constexpr int kFastCntBits = kFastRun == 1 ? 3 : kFastRun == 2 ? 4 : 5;  // popcount of 4 * kFastRun mask bits
+
 // One workgroup per FAST cell.  The cell's valid region (3 px inside the reference's sub-image) is staged in LDS
 // with aligned 32-bit loads; a cheap necessary test runs on 4 pixels per thread from packed dwords and the pixels
 // that pass are COMPACTED into an LDS queue, so the exact score (packed 16-bit min/max) and the non-max suppression
@@ -295,45 +301,64 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   }
   // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1
   const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0;
-  const int ngroups = ng * vh;
-  const float inv_ng = 1.0f / (float)ng, inv_vw = 1.0f / (float)vw;
+  const int nrun = (ng + kFastRun - 1) / kFastRun, nruns = nrun * vh;  // runs of kFastRun dwords per row
+  const float inv_nrun = 1.0f / (float)nrun, inv_vw = 1.0f / (float)vw;
   uint32_t keep = 0;
   int nq = 0, thr = fg->iniTh;
   for (int pass = 0; pass < 2; pass++) {
     for (int i = tid; i < (vh + 2) * (kScoreP / 4); i += 256) ((uint32_t *)score)[i] = 0;
     if (tid < 4) s_cnt[tid] = 0;
     __syncthreads();
-    // ---- phase 1: necessary test, 4 pixels per thread, compaction of the passers
-    for (int i0 = 0; i0 < ngroups; i0 += 256) {
+    // ---- phase 1: necessary test on kFastRun dwords (4 px each) per thread, compaction of the passers.  A longer
+    // run amortises the index arithmetic, the neighbour loads and the wave-level prefix over more pixels.
+    for (int i0 = 0; i0 < nruns; i0 += 256) {
       const int i = i0 + tid;
       uint32_t m = 0;
       int r = 0, cb = 0;
-      if (i < ngroups) {
-        r = div_small(i, inv_ng);
-        const int g = g0 + (i - r * ng);
+      if (i < nruns) {
+        r = div_small(i, inv_nrun);
+        const int g = g0 + (i - r * nrun) * kFastRun;
         const uint8_t *t = &tile[(r + 3) * kTileP + 4 * g];
-        const uint32_t C = *(const uint32_t *)t, Lf = *(const uint32_t *)(t - 4), Rt = *(const uint32_t *)(t + 4);
-        const uint32_t U = *(const uint32_t *)(t - 3 * kTileP), Dn = *(const uint32_t *)(t + 3 * kTileP);
-        m = fast_quick4(C, U, Dn, __builtin_amdgcn_alignbyte(C, Lf, 1), __builtin_amdgcn_alignbyte(Rt, C, 3), thr);
-        cb = 4 * g - 3 - ox;  // valid-region column of byte 0 of this group
+        uint32_t Cw[kFastRun + 2];
+#pragma unroll
+        for (int k = 0; k < kFastRun + 2; k++) Cw[k] = *(const uint32_t *)(t + 4 * (k - 1));
+#pragma unroll
+        for (int k = 0; k < kFastRun; k++) {
+          const uint32_t U = *(const uint32_t *)(t - 3 * kTileP + 4 * k), Dn = *(const uint32_t *)(t + 3 * kTileP + 4 * k);
+          m |= fast_quick4(Cw[k + 1], U, Dn, __builtin_amdgcn_alignbyte(Cw[k + 1], Cw[k], 1),
+                           __builtin_amdgcn_alignbyte(Cw[k + 2], Cw[k + 1], 3), thr)
+               << (4 * k);
+        }
+        cb = 4 * g - 3 - ox;  // valid-region column of bit 0 of this run (>= -3)
         // mask pixels outside [0, vw)
-        if (cb < 0) m &= 0xFu << (-cb);
-        if (cb + 4 > vw) m &= 0xFu >> (cb + 4 - vw);
+        if (cb < 0) m &= ~0u << (-cb);
+        const int over = cb + 4 * kFastRun - vw;
+        if (over > 0) m &= over >= 4 * kFastRun ? 0u : (1u << (4 * kFastRun - over)) - 1u;
       }
-      // compaction: wave-level exclusive prefix of popcount(m) (0..4) from three ballots, one LDS atomic per wave
+      // compaction: wave-level exclusive prefix of popcount(m) from one ballot per count bit, one LDS atomic per wave
       const int cnt = __popc(m);
-      const uint64_t b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
-      if (b0 | b1 | b2) {
+      uint64_t bb[kFastCntBits], any = 0;
+#pragma unroll
+      for (int b = 0; b < kFastCntBits; b++) {
+        bb[b] = __ballot(cnt & (1 << b));
+        any |= bb[b];
+      }
+      if (any) {
         const uint64_t lt = (1ull << lane) - 1;
-        const int total = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
-        int pos = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt);
+        int total = 0, pos = 0;
+#pragma unroll
+        for (int b = 0; b < kFastCntBits; b++) {
+          total += __popcll(bb[b]) << b;
+          pos += __popcll(bb[b] & lt) << b;
+        }
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_cnt[1], total);
-        pos += __shfl(base, 0);
+        pos += __builtin_amdgcn_readfirstlane(base);
         const int pix = r * vw + cb;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          if ((m >> j) & 1) queue[pos++] = (uint16_t)(pix + j);
+        while (m) {
+          queue[pos++] = (uint16_t)(pix + __builtin_ctz(m));
+          m &= m - 1;
+        }
       }
     }
     __syncthreads();
