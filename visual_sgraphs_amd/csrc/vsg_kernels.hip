@@ -494,6 +494,8 @@ __global__ __launch_bounds__(256) void k_octree(const FrameGeom *__restrict__ fg
 // horizontal 8.8 sums with v_alignbyte + v_dot4_u32_u8, and once the window is full emits 4 output bytes
 // (one 32-bit store) from 7 v_mad_u32_u24 per pixel.  Adjacent lanes own adjacent column groups, so every
 // wave-level load/store is one contiguous 256-byte row segment.
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));  // gfx950 global dword loads need no alignment
+
 __device__ __forceinline__ int reflect101(int p, int len) {
   while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
   return p;
@@ -530,26 +532,41 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 #pragma unroll
   for (int j = 0; j < 7; j++) k[j] = fg->taps[j];
   const bool interior = x0 >= 4 && x0 + 8 <= w;  // all 12 source bytes exist: aligned dword loads
+  // Edge groups (the first and the last two of a row) also fetch 12 contiguous bytes per row -- columns 0..11 on
+  // the left, w-12..w-1 on the right (w >= 16, checked with the geometry) -- which hold every REFLECT_101 source
+  // column they need; the 12 wanted bytes are then picked with v_perm selectors that are computed once per thread.
+  const int base = interior ? x0 - 4 : (x0 == 0 ? 0 : w - 12);
+  uint32_t selLo[3] = {0, 0, 0}, selHi[3] = {0, 0, 0};
+  if (!interior) {
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint32_t sidx = (uint32_t)(reflect101(x0 - 4 + 4 * q + b, w) - base);  // 0..11
+        selLo[q] |= (sidx < 8 ? sidx : 0x0Cu) << (8 * b);
+        selHi[q] |= (sidx >= 8 ? sidx - 8 : 0x0Cu) << (8 * b);
+      }
+  }
   uint32_t win[7][4];
 #pragma unroll
   for (int turn = 0; turn < (kBlurStrip + 6) / 7; turn++) {
-    // issue the loads of the next 7 rows together (the kernel is latency-, not issue-bound), then consume them
+    // issue the loads of the next 7 rows together, then consume them
     uint32_t d0[7], d1[7], d2[7];
 #pragma unroll
     for (int s = 0; s < 7; s++) {
       const int ysrc = reflect101(y0 - 3 + turn * 7 + s, h);
-      const uint8_t *row = img + (size_t)ysrc * spitch;
-      if (interior) {
-        d0[s] = *(const uint32_t *)(row + x0 - 4);
-        d1[s] = *(const uint32_t *)(row + x0);
-        d2[s] = *(const uint32_t *)(row + x0 + 4);
-      } else {
-        uint32_t b[12];
+      const uint8_t *row = img + (size_t)ysrc * spitch + base;
+      d0[s] = *(const u32_unaligned *)(row);
+      d1[s] = *(const u32_unaligned *)(row + 4);
+      d2[s] = *(const u32_unaligned *)(row + 8);
+    }
+    if (!interior) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) b[i] = row[reflect101(x0 - 4 + i, w)];
-        d0[s] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-        d1[s] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-        d2[s] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+      for (int s = 0; s < 7; s++) {
+        const uint32_t a0 = d0[s], a1 = d1[s], a2 = d2[s];
+        d0[s] = __builtin_amdgcn_perm(a1, a0, selLo[0]) | __builtin_amdgcn_perm(0u, a2, selHi[0]);
+        d1[s] = __builtin_amdgcn_perm(a1, a0, selLo[1]) | __builtin_amdgcn_perm(0u, a2, selHi[1]);
+        d2[s] = __builtin_amdgcn_perm(a1, a0, selLo[2]) | __builtin_amdgcn_perm(0u, a2, selHi[2]);
       }
     }
 #pragma unroll
@@ -716,7 +733,6 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   uint8_t *patch = &s_patch[(tid >> 6) * (kPatchW * kPatchP)];
   {
     // 37 rows x 10 (unaligned) dwords; gfx950 global loads accept any byte alignment
-    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
     const uint8_t *corner = blur + foff + (size_t)(cy - kPatchR) * L.pitch + (cx - kPatchR);
     const int pitch = L.pitch;
     constexpr int kDw = kPatchP / 4, kN = kPatchW * kDw, kIt = (kN + 63) / 64;
