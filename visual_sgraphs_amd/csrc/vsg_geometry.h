@@ -80,6 +80,7 @@ struct CellDesc {  // one FAST cell: valid region [x0,x1) x [y0,y1) in level coo
 struct PyrTile {
   int16_t need[kMaxLevels][4];
   int16_t own[kMaxLevels][4];
+  int32_t tab_off, tab_n;  // this tile's slice of Geometry::pyrTileTab
 };
 enum { kPyrTile = 32 };  // top-level tile edge
 
@@ -88,6 +89,10 @@ struct Geometry {
   std::vector<PyrTile> pyrTiles;
   int pyrLdsA = 0, pyrLdsB = 0;  // LDS bytes for even / odd levels of the ping-pong
   int pyrTabMax = 0;             // max over tiles of staged table entries
+  bool pyrFusedOk = true;        // k_pyramid's 8-byte source window covers 4 adjacent destination columns
+  // Per tile, per level 1..top: the tile's slice of the resize tables, already rebased to the tile's LDS images:
+  //   x entries {sx - sx0a, a0, a1, sx1 - sx0a}   then   y entries {(sy0 - y0) * spitch, (sy1 - y0) * spitch, b0, b1}
+  std::vector<Short4> pyrTileTab;
   std::vector<Short4> resizeTab;  // all levels, x tables then y tables (offsets in LevelGeom)
   std::vector<CellDesc> cells;
   int maxQuota = 0;
@@ -245,18 +250,32 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   G.pyrTiles.clear();
   G.pyrLdsA = G.pyrLdsB = 0;
   G.pyrTabMax = 0;
+  G.pyrFusedOk = true;
+  for (int l = 1; l < T.nlevels; l++) {
+    // k_pyramid picks the (sx, sx + 1) pairs of 4 adjacent columns out of 8 source bytes: sx may advance by at
+    // most 6 over 3 columns (any scale factor up to 2); larger ratios take the per-level kernel.
+    const LevelGeom &D = fg.lv[l];
+    const Short4 *tabx = &G.resizeTab[D.tab_x_off];
+    for (int x = 0; x + 1 < D.w; x++) {
+      const int x3 = x + 3 < D.w ? x + 3 : D.w - 1;
+      if (tabx[x3].a - tabx[x].a > 6) G.pyrFusedOk = false;
+    }
+  }
   if (T.nlevels > 1) {
     const int top = T.nlevels - 1;
-    const int ntx = (fg.lv[top].w + kPyrTile - 1) / kPyrTile, nty = (fg.lv[top].h + kPyrTile - 1) / kPyrTile;
+    // balanced split of the top level into tiles of at most kPyrTile x kPyrTile
+    const int tw = fg.lv[top].w, thh = fg.lv[top].h;
+    const int ntx = (tw + kPyrTile - 1) / kPyrTile, nty = (thh + kPyrTile - 1) / kPyrTile;
+    G.pyrTileTab.clear();
     for (int ty = 0; ty < nty; ty++)
       for (int tx = 0; tx < ntx; tx++) {
         PyrTile t;
         memset(&t, 0, sizeof(t));
         int16_t *o = t.own[top];
-        o[0] = (int16_t)(tx * kPyrTile);
-        o[1] = (int16_t)(ty * kPyrTile);
-        o[2] = (int16_t)(tx + 1 == ntx ? fg.lv[top].w : (tx + 1) * kPyrTile);
-        o[3] = (int16_t)(ty + 1 == nty ? fg.lv[top].h : (ty + 1) * kPyrTile);
+        o[0] = (int16_t)((long long)tx * tw / ntx);
+        o[1] = (int16_t)((long long)ty * thh / nty);
+        o[2] = (int16_t)((long long)(tx + 1) * tw / ntx);
+        o[3] = (int16_t)((long long)(ty + 1) * thh / nty);
         memcpy(t.need[top], o, sizeof(t.need[top]));
         for (int l = top; l >= 1; l--) {
           const LevelGeom &D = fg.lv[l], &S = fg.lv[l - 1];
@@ -278,6 +297,26 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
         int tabn = 0;
         for (int l = 1; l <= top; l++) tabn += (t.need[l][2] - t.need[l][0]) + (t.need[l][3] - t.need[l][1]);
         if (tabn > G.pyrTabMax) G.pyrTabMax = tabn;
+        t.tab_off = (int32_t)G.pyrTileTab.size();
+        t.tab_n = tabn;
+        for (int l = 1; l <= top; l++) {
+          const LevelGeom &D = fg.lv[l];
+          const int sx0a = t.need[l - 1][0] & ~3, sy0 = t.need[l - 1][1];
+          const int spitch = ((t.need[l - 1][2] - sx0a) + 3) & ~3;
+          for (int x = t.need[l][0]; x < t.need[l][2]; x++) {
+            Short4 e = G.resizeTab[D.tab_x_off + x];
+            e.a = (int16_t)(e.a - sx0a);
+            e.d = (int16_t)(e.d - sx0a);
+            G.pyrTileTab.push_back(e);
+          }
+          for (int y = t.need[l][1]; y < t.need[l][3]; y++) {
+            Short4 e = G.resizeTab[D.tab_y_off + y];
+            if ((e.b - sy0) * spitch > 32767) G.pyrFusedOk = false;  // LDS row offsets are kept in 16 bits
+            e.a = (int16_t)((e.a - sy0) * spitch);
+            e.b = (int16_t)((e.b - sy0) * spitch);
+            G.pyrTileTab.push_back(e);
+          }
+        }
         for (int l = 0; l <= top; l++) {
           // LDS image of a level: columns start at the 4-byte aligned column below need.x0, pitch multiple of 4
           const int x0a = t.need[l][0] & ~3;

@@ -14,7 +14,7 @@ void launch_cvt_gray(hipStream_t s, const uint8_t *src, size_t sframe, int spitc
 void launch_zero(hipStream_t s, int *p, int n);
 void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
                    const FrameGeom &fg, int level, int nframes);
-void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
+void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tile_tab, const Src0 &s0,
                     const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes);
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
                  uint32_t *cand, int *cand_count, const FrameGeom &fg, int nframes);

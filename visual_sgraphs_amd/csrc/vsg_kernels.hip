@@ -68,6 +68,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const
 // every integer, far more than the float rounding error, so the truncation is exact (3 VALU ops, no v_rcp chain).
 __device__ __forceinline__ int div_small(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
 // Fused pyramid: ONE launch builds levels 1..L-1 of every frame.  A workgroup owns one tile of the top level and
 // walks DOWN the dependency cone: it stages the level-0 region that feeds the tile in LDS, then produces level 1,
 // 2, ... in LDS ping-pong buffers (each level resized from the previous LEVEL, exactly like the reference's chain,
@@ -75,42 +77,17 @@ __device__ __forceinline__ int div_small(int i, float inv) { return (int)(((floa
 // indices of the destination boundaries, so tiles partition every level without gaps or overlaps; the ~25 % halo
 // is recomputed instead of communicated.  HBM traffic: level 0 read once (+halo), levels 1.. written once.
 __global__ __launch_bounds__(256) void k_pyramid(uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
-                                                 const Short4 *__restrict__ tab, Src0 s0,
+                                                 const Short4 *__restrict__ tile_tab, Src0 s0,
                                                  const PyrTile *__restrict__ tiles, int ldsA, int ldsAB) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
-  __shared__ int s_tab_off[2 * kMaxLevels];  // [2l] = x slice of level l, [2l+1] = y slice
   const PyrTile &T = tiles[blockIdx.x];
   const int frame = blockIdx.y, tid = threadIdx.x;
   uint8_t *buf0 = pyr_lds, *buf1 = pyr_lds + ldsA;
   Short4 *s_tab = (Short4 *)(pyr_lds + ldsAB);  // the tile's slices of the resize tables, all levels
-  {  // stage the table slices once, already converted to LDS offsets of the source image:
-     //   x entry {sx - sx0a, a0, a1, sx1 - sx0a}     y entry {(sy0 - y0)*pitch, (sy1 - y0)*pitch, b0, b1}
-    int off = 0;
-    for (int l = 1; l < fg->nlevels; l++) {
-      const LevelGeom &D = fg->lv[l];
-      const int dw = T.need[l][2] - T.need[l][0], dh = T.need[l][3] - T.need[l][1];
-      const int sx0a = T.need[l - 1][0] & ~3, sy0 = T.need[l - 1][1];
-      const int spitch = ((T.need[l - 1][2] - sx0a) + 3) & ~3;
-      if (tid == 0) {
-        s_tab_off[2 * l] = off;
-        s_tab_off[2 * l + 1] = off + dw;
-      }
-      for (int i = tid; i < dw; i += 256) {
-        Short4 e = tab[D.tab_x_off + T.need[l][0] + i];
-        e.a = (int16_t)(e.a - sx0a);
-        e.d = (int16_t)(e.d - sx0a);
-        s_tab[off + i] = e;
-      }
-      for (int i = tid; i < dh; i += 256) {
-        Short4 e = tab[D.tab_y_off + T.need[l][1] + i];
-        e.a = (int16_t)((e.a - sy0) * spitch);
-        e.b = (int16_t)((e.b - sy0) * spitch);
-        s_tab[off + dw + i] = e;
-      }
-      off += dw + dh;
-    }
-  }
-  {  // level-0 region -> LDS, aligned dwords
+  // One round of independent global loads: the tile's (pre-rebased, contiguous) table slice and the level-0 region.
+  {
+    const Short4 *tt = tile_tab + T.tab_off;
+    for (int i = tid; i < T.tab_n; i += 256) s_tab[i] = tt[i];
     const int x0a = T.need[0][0] & ~3, y0 = T.need[0][1];
     const int w4 = ((T.need[0][2] - x0a) + 3) >> 2, hh = T.need[0][3] - y0, pitch = 4 * w4;
     const uint8_t *src = s0.base + (size_t)frame * s0.frame_stride + (size_t)y0 * s0.pitch + x0a;
@@ -122,67 +99,97 @@ __global__ __launch_bounds__(256) void k_pyramid(uint8_t *__restrict__ pyr, cons
   }
   __syncthreads();
   uint8_t *frame_base = pyr + (size_t)frame * fg->pyr_frame_bytes;
+  int toff = 0;
   for (int l = 1; l < fg->nlevels; l++) {
     const LevelGeom &D = fg->lv[l];
     const uint8_t *src = (l & 1) ? buf0 : buf1;
     uint8_t *dst = (l & 1) ? buf1 : buf0;
     const int dx0 = T.need[l][0], dy0 = T.need[l][1], dw = T.need[l][2] - dx0, dh = T.need[l][3] - dy0;
     const int dx0a = dx0 & ~3, dpitch = ((T.need[l][2] - dx0a) + 3) & ~3;
-    // thread = one destination column, looping over rows; narrower levels use more row groups
-    const int shift = dw <= 32 ? 5 : dw <= 64 ? 6 : 7;
-    const int c = tid & ((1 << shift) - 1), rg = tid >> shift, nrg = 256 >> shift;
-    if (c < dw) {
-      const Short4 tx = s_tab[s_tab_off[2 * l] + c];
-      const Short4 *tyv = &s_tab[s_tab_off[2 * l + 1]];
-      const uint8_t *sa = src + tx.a, *sd = src + tx.d;
-      const int a0 = tx.b, a1 = tx.c;
-      uint8_t *dcol = dst + (dx0 - dx0a) + c;
-      // 4 independent rows per trip: 4 table reads, then 16 byte reads in flight, then the arithmetic
-      for (int r = rg; r < dh; r += 4 * nrg) {
-        Short4 ty[4];
-        int p[4][4];
+    const Short4 *txv = &s_tab[toff], *tyv = &s_tab[toff + dw];
+    toff += dw + dh;
+    // Thread = 4 adjacent destination columns (one aligned dword of the LDS image and of the level in HBM)
+    // walking DOWN a chunk of rows.
+    //  * a source row is fetched as 12 aligned bytes, shifted to start at the first source column, and the
+    //    (sx, sx+1) byte pair of each column is picked with a per-thread v_perm selector; the horizontal 11-bit
+    //    interpolation of a pair is then ONE v_dot2_u32_u16 (weights a0 | a1 << 16).  Where the reference clamps
+    //    sx1 to sx (image edge) its weight a1 is 0, so reading sx + 1 instead changes nothing.
+    //  * consecutive destination rows share a source row 5 times out of 6 (scale 1.2): the horizontal sums of the
+    //    lower row are kept in registers and reused as the upper row of the next destination row.
+    //  * the dword goes to the LDS image (source of the next level) and, where this tile OWNS it, straight to HBM.
+    const int ncg = dpitch >> 2;  // column groups
+    const int shift = ncg <= 8 ? 3 : ncg <= 16 ? 4 : ncg <= 32 ? 5 : 6;
+    const int cg = tid & ((1 << shift) - 1), rg = tid >> shift, nrg = 256 >> shift;
+    const int chunk = (dh + nrg - 1) / nrg, ya = rg * chunk, yb = min(dh, ya + chunk);
+    if (cg < ncg && ya < yb) {
+      uint32_t sel[4];
+      u16x2 wgt[4];
+      int o = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int rr = r + k * nrg;
-          ty[k] = tyv[rr < dh ? rr : dh - 1];
+      for (int k = 0; k < 4; k++) {
+        const int ci = min(max(4 * cg + k - (dx0 - dx0a), 0), dw - 1);  // columns outside the needed range: any value
+        const Short4 tx = txv[ci];
+        if (k == 0) o = tx.a;
+        const uint32_t f = (uint32_t)(tx.a - o);  // 0..6 (vsg_geometry.h checks the span)
+        sel[k] = f | (0x0Cu << 8) | ((f + 1) << 16) | (0x0Cu << 24);
+        wgt[k] = (u16x2){(unsigned short)tx.b, (unsigned short)tx.c};
+      }
+      const uint8_t *swin = src + (o & ~3);
+      const uint32_t sh = (uint32_t)(o & 3);
+      auto hrow = [&](int off, uint32_t (&H)[4]) {
+        const uint32_t *q = (const uint32_t *)(swin + off);
+        const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+        const uint32_t A = __builtin_amdgcn_alignbyte(w1, w0, sh), B = __builtin_amdgcn_alignbyte(w2, w1, sh);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(B, A, sel[k])), wgt[k], 0u,
+                                        false) >> 4;
+      };
+      // ownership of this column group: all 4 bytes, some (a seam between tiles), or none
+      const int gx = dx0a + 4 * cg;  // level column of byte 0
+      const int ox0 = T.own[l][0], oy0 = T.own[l][1], ox1 = T.own[l][2], oy1 = T.own[l][3];
+      const bool full = gx >= ox0 && gx + 4 <= ox1, part = !full && gx < ox1 && gx + 4 > ox0;
+      uint32_t Hc[4] = {0, 0, 0, 0};
+      int offc = -1;  // LDS row offset whose horizontal sums are cached in Hc
+      uint8_t *drow = dst + ya * dpitch + 4 * cg;
+      uint8_t *grow = frame_base + D.img_off + (size_t)(dy0 + ya) * D.pitch + gx;
+      for (int y = ya; y < yb; y++, drow += dpitch, grow += D.pitch) {
+        const Short4 ty = tyv[y];
+        uint32_t H0[4], H1[4];
+        if (ty.a == offc) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) H0[k] = Hc[k];
+        } else {
+          hrow(ty.a, H0);
         }
+        if (ty.b == ty.a) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          p[k][0] = sa[ty[k].a];
-          p[k][1] = sd[ty[k].a];
-          p[k][2] = sa[ty[k].b];
-          p[k][3] = sd[ty[k].b];
+          for (int k = 0; k < 4; k++) H1[k] = H0[k];
+        } else {
+          hrow(ty.b, H1);
         }
+        uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const int rr = r + k * nrg;
-          const int h0 = p[k][0] * a0 + p[k][1] * a1, h1 = p[k][2] * a0 + p[k][3] * a1;
-          const int v = (((((int)ty[k].c * (h0 >> 4)) >> 16) + (((int)ty[k].d * (h1 >> 4)) >> 16) + 2) >> 2);
-          if (rr < dh) dcol[rr * dpitch] = (uint8_t)v;
+          const uint32_t v = ((__umul24((uint32_t)ty.c, H0[k]) >> 16) + (__umul24((uint32_t)ty.d, H1[k]) >> 16) + 2u) >> 2;
+          out |= v << (8 * k);
+          Hc[k] = H1[k];
+        }
+        offc = ty.b;
+        *(uint32_t *)drow = out;
+        const int gy = dy0 + y;
+        if (gy >= oy0 && gy < oy1) {
+          if (full) {
+            *(uint32_t *)grow = out;
+          } else if (part) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              if (gx + j >= ox0 && gx + j < ox1) grow[j] = (uint8_t)(out >> (8 * j));
+          }
         }
       }
     }
     __syncthreads();
-    // write the owned part of this level: aligned dwords where all 4 bytes are owned, bytes at the seams
-    {
-      const int ox0 = T.own[l][0], oy0 = T.own[l][1], ox1 = T.own[l][2], oy1 = T.own[l][3];
-      const int g0 = ox0 >> 2, ng = ((ox1 + 3) >> 2) - g0, nrow = oy1 - oy0;
-      uint8_t *gl = frame_base + D.img_off;
-      const float inv = 1.0f / (float)ng;
-      for (int i = tid; i < ng * nrow; i += 256) {
-        const int r = div_small(i, inv), g = g0 + (i - r * ng);
-        const int y = oy0 + r, x = 4 * g;
-        const uint8_t *lp = dst + (y - dy0) * dpitch + (x - dx0a);
-        uint8_t *gp = gl + (size_t)y * D.pitch + x;
-        if (x >= ox0 && x + 4 <= ox1) {
-          *(uint32_t *)gp = *(const uint32_t *)lp;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            if (x + j >= ox0 && x + j < ox1) gp[j] = lp[j];
-        }
-      }
-    }
   }
 }
 
@@ -982,11 +989,11 @@ void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sho
   dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, nframes), block(64, 4);
   hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, d_fg, d_tab, s0, level);
 }
-void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
+void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tile_tab, const Src0 &s0,
                     const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes) {
   const int a16 = (ldsA + 15) & ~15, ab16 = a16 + ((ldsB + 15) & ~15);
-  hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(256), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg, d_tab,
-                     s0, d_tiles, a16, ab16);
+  hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(256), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
+                     d_tile_tab, s0, d_tiles, a16, ab16);
 }
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
                  uint32_t *cand, int *cand_count, const FrameGeom &fg, int nframes) {

@@ -56,6 +56,7 @@ struct vsg_orb {
   Short4 *d_tab = nullptr;
   CellDesc *d_cells = nullptr;
   PyrTile *d_ptiles = nullptr;
+  Short4 *d_ptab = nullptr;  // Geometry::pyrTileTab
   uint8_t *d_in = nullptr;  // level-0 staging for host images / unaligned device images, pitch in_pitch
   int in_pitch = 0;
   Src0 last_src0 = {nullptr, 0, 0};
@@ -91,7 +92,8 @@ struct vsg_orb {
 
 static void free_image_buffers(vsg_orb *h) {
   hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in), hipFree(h->d_ptiles);
-  h->d_ptiles = nullptr;
+  hipFree(h->d_ptab);
+  h->d_ptiles = nullptr, h->d_ptab = nullptr;
   hipFree(h->d_pyr), hipFree(h->d_blur), hipFree(h->d_cand), hipFree(h->d_sel), hipFree(h->d_nodeof);
   hipFree(h->d_counts2), hipFree(h->d_flags), hipFree(h->d_slots), hipFree(h->d_hdr);
   hipFree(h->d_kps), hipFree(h->d_desc), hipFree(h->d_out_counts);
@@ -134,6 +136,9 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   HIP_TRY(hipMalloc(&h->d_ptiles, sizeof(PyrTile) * (h->G.pyrTiles.size() + 1)));
   if (!h->G.pyrTiles.empty())
     HIP_TRY(hipMemcpy(h->d_ptiles, h->G.pyrTiles.data(), sizeof(PyrTile) * h->G.pyrTiles.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&h->d_ptab, sizeof(Short4) * (h->G.pyrTileTab.size() + 1)));
+  if (!h->G.pyrTileTab.empty())
+    HIP_TRY(hipMemcpy(h->d_ptab, h->G.pyrTileTab.data(), sizeof(Short4) * h->G.pyrTileTab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&h->d_pyr, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMalloc(&h->d_blur, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMemset(h->d_pyr, 0, B * fg.pyr_frame_bytes));
@@ -189,10 +194,10 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   FrameHeader *hdr = h->d_hdr + F;
   if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
   static const bool per_level = getenv("VSG_PYR_PER_LEVEL") != nullptr;  // A/B switch: 7 chained launches
-  if (per_level || h->G.pyrLdsA + h->G.pyrLdsB + 8 * h->G.pyrTabMax > 64000) {
+  if (per_level || !h->G.pyrFusedOk || h->G.pyrLdsA + h->G.pyrLdsB + 8 * h->G.pyrTabMax > 64000) {
     for (int l = 1; l < fg.nlevels; l++) launch_resize(s, pyr, h->d_fg, h->d_tab, s0, fg, l, nf);
   } else if (fg.nlevels > 1) {
-    launch_pyramid(s, pyr, h->d_fg, h->d_tab, s0, h->d_ptiles, (int)h->G.pyrTiles.size(), h->G.pyrLdsA, h->G.pyrLdsB,
+    launch_pyramid(s, pyr, h->d_fg, h->d_ptab, s0, h->d_ptiles, (int)h->G.pyrTiles.size(), h->G.pyrLdsA, h->G.pyrLdsB,
                    h->G.pyrTabMax, nf);
   }
   if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
