@@ -125,6 +125,11 @@ int vsg_orb_enable_timing(vsg_orb *h, int enable);
 int vsg_orb_set_serialize(vsg_orb *h, int serialize);
 int vsg_orb_get_timing(vsg_orb *h, float *ms_out, int cap);
 
+/* Test hook: sorts items[0..n) (n <= 2048) by their upper 32 bits with the device code DistributeOctTree uses for
+ * `std::sort(vSizeAndPointerToNode...)` (ORBextractor.cc:707): a replay of libstdc++'s introsort whose result --
+ * including the order of equal keys -- must equal std::sort's.  Lets tests compare the two directly. */
+int vsg_debug_device_sort(int device, uint64_t *items, int n);
+
 /* void Frame::ComputeStereoMatches() (Frame.cc:957-1127) for a rectified pair.  hl/hr = the
  * extractors that just processed the left/right image (their mvImagePyramid is read on the device; one handle
  * with a 2-frame batch works too: frame_l/frame_r index the batch).  kps/desc = the operator() outputs (host).

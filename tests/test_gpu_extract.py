@@ -213,3 +213,28 @@ def test_colour_input_cvtcolor_fused(channels, rgb):
     assert np.array_equal(ex.image_pyramid(0), gray)
     assert_same_output(got[0], want, "colour frame 0")
     assert_same_output(got[1], want, "colour frame 1")
+
+
+def test_device_sort_replay_equals_std_sort():
+    """The octree's device sort (wave-parallel quicksort partitioning + stable rank) against the real std::sort
+    (tests/_hostcore, same libstdc++ as the oracle) on tie-heavy inputs: the ORDER of equal keys must match."""
+    import ctypes as C
+    import subprocess
+    hc_dir = Path(__file__).resolve().parent / "_hostcore"
+    subprocess.check_call(["make", "-C", str(hc_dir)], stdout=subprocess.DEVNULL)
+    hc = C.CDLL(str(hc_dir / "libvsg_hostcore.so"))
+    hc.hc_std_sort.argtypes = [C.POINTER(C.c_uint64), C.c_int]
+    rng = np.random.default_rng(3)
+    for trial in range(300):
+        n = int(rng.integers(1, 300)) if trial % 20 else int(rng.integers(300, 2048))
+        nkeys = int(rng.choice([1, 2, 3, 8, 50, 100000]))
+        keys = rng.integers(0, nkeys, n).astype(np.uint64)
+        if trial % 5 == 0:
+            keys = np.sort(keys)[::-1].copy() if trial % 10 == 0 else np.sort(keys)
+        if trial % 7 == 3:  # organ pipe / many-duplicates patterns that stress the median-of-3 pivot
+            keys = np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]).astype(np.uint64) // np.uint64(3)
+        items = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        want = items.copy()
+        hc.hc_std_sort(want.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        got = orb.debug_device_sort(items)
+        assert np.array_equal(got, want), (trial, n, nkeys)

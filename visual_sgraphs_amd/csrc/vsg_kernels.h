@@ -20,6 +20,7 @@ void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const
                  uint32_t *cand, int *cand_count, const FrameGeom &fg, int nframes);
 void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, const int *cand_count,
                    uint16_t *node_of, uint32_t *sel, int *sel_count, const FrameGeom &fg, int maxQuota, int nframes);
+void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                  const FrameGeom &fg, int nframes);
 void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, const int *sel_count, int *flags,

@@ -418,9 +418,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // Workgroup implementation of the octree Group concept.
+enum { kSortStack = 24 };  // >= 2 * lg(n) + 1 pending ranges for n < 2048
+
 struct BlockGroup {
   int tid, nthreads;
   int *wtot;  // LDS, one int per wave
+  int *stk;   // LDS, 3 * kSortStack ints: the quicksort range stack of sort_partition_phase
   __device__ void sync() { __syncthreads(); }
   __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
   __device__ void atomic_max(uint32_t *p, uint32_t v) { atomicMax(p, v); }
@@ -454,6 +457,72 @@ struct BlockGroup {
     __syncthreads();
     return total;
   }
+
+  // introsort::partition_phase replayed by the 64 lanes of wave 0 with the SAME resulting array (bit for bit).
+  // The serial loop `while (*first < pivot) ++first; --last; while (pivot < *last) --last; swap` visits, in the
+  // ORIGINAL data of the range, the ascending positions A_0 < A_1 < ... of the elements >= pivot and the descending
+  // positions B_0 > B_1 > ... of the elements <= pivot (then the pivot slot itself), swapping (A_k, B_k) while
+  // A_k < B_k; it returns min(A_K, B_{K-1}) at the first K with A_K >= B_K.  The pairs are disjoint, so ranks from
+  // wave ballots, one parallel round of swaps and a popcount reproduce a whole partition step.  Median selection
+  // and the (rare) heapsort fallback stay on lane 0.  Other waves fall through; the caller's barrier orders them.
+  __device__ void sort_partition_phase(introsort::item_t *a, int n, uint16_t *posA, uint16_t *posB) {
+    if (tid >= 64) return;
+    const int lane = tid;
+    const uint64_t lt = (1ull << lane) - 1;
+    int sp = 0, lo = 0, hi = n, depth = 2 * introsort::lg_(n > 0 ? n : 1);
+    while (true) {
+      while (hi - lo > 16) {
+        if (depth == 0) {
+          if (lane == 0) introsort::heap_sort_(a + lo, hi - lo);
+          __threadfence_block();
+          break;
+        }
+        --depth;
+        if (lane == 0) introsort::move_median_to_first_(a + lo, a + lo + 1, a + lo + (hi - lo) / 2, a + hi - 1);
+        __threadfence_block();
+        const uint32_t P = (uint32_t)(a[lo] >> 32);
+        const int s = lo + 1, e = hi;
+        int nA = 0, nB = 0;
+        for (int c = 0; s + c < e; c += 64) {
+          const int ia = s + c + lane, ib = e - 1 - c - lane;
+          const bool fa = ia < e && (uint32_t)(a[ia] >> 32) >= P;
+          const bool fb = ib >= s && (uint32_t)(a[ib] >> 32) <= P;
+          const uint64_t ba = __ballot(fa), bb = __ballot(fb);
+          if (fa) posA[nA + __popcll(ba & lt)] = (uint16_t)ia;
+          if (fb) posB[nB + __popcll(bb & lt)] = (uint16_t)ib;
+          nA += __popcll(ba);
+          nB += __popcll(bb);
+        }
+        if (lane == 0) posB[nB] = (uint16_t)lo;  // the pivot slot stops the downward scan
+        nB++;
+        __threadfence_block();
+        const int np = nA < nB ? nA : nB;
+        int K = 0;
+        for (int c = 0; c < np; c += 64) {
+          const int j = c + lane;
+          const bool sw = j < np && posA[j] < posB[j];
+          const uint64_t bs = __ballot(sw);
+          if (sw) {
+            const int ia = posA[j], ib = posB[j];
+            const introsort::item_t t = a[ia];
+            a[ia] = a[ib];
+            a[ib] = t;
+          }
+          K += __popcll(bs);
+        }
+        const int cutA = K < nA ? (int)posA[K] : 0x7FFFFFFF, cutB = K >= 1 ? (int)posB[K - 1] : e;
+        const int cut = cutA < cutB ? cutA : cutB;
+        __threadfence_block();
+        if (lane == 0) stk[3 * sp] = lo, stk[3 * sp + 1] = cut, stk[3 * sp + 2] = depth;  // uniform values
+        sp++;
+        lo = cut;
+      }
+      if (sp == 0) break;
+      --sp;
+      __threadfence_block();
+      lo = stk[3 * sp], hi = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+    }
+  }
 };
 
 #ifndef VSG_OCT_K
@@ -466,6 +535,7 @@ __global__ __launch_bounds__(256) void k_octree(const FrameGeom *__restrict__ fg
                                                 uint32_t *__restrict__ sel, int *__restrict__ sel_count, int cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[8];
+  __shared__ int sort_stack[3 * kSortStack];
   const int level = blockIdx.x, frame = blockIdx.y;
   const LevelGeom &L = fg->lv[level];
   octree::Params P;
@@ -483,6 +553,7 @@ __global__ __launch_bounds__(256) void k_octree(const FrameGeom *__restrict__ fg
   g.tid = threadIdx.x;
   g.nthreads = blockDim.x;
   g.wtot = wtot;
+  g.stk = sort_stack;
   int npts = cand_count[frame * kMaxLevels + level];
   if (npts > L.cand_cap) npts = L.cand_cap;
   const size_t coff = (size_t)frame * fg->cand_frame + L.cand_off;
@@ -492,6 +563,35 @@ __global__ __launch_bounds__(256) void k_octree(const FrameGeom *__restrict__ fg
   const int n = npts <= kOctRegPts * 256 ? octree::distribute_reg<kOctRegPts>(g, P, cand + coff, npts, W, out)
                                          : octree::distribute(g, P, cand + coff, npts, node_of + coff, W, out);
   if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;
+}
+
+// Test hook (vsg_debug_device_sort): the octree's std::sort replay -- wave-parallel partition phase + stable rank --
+// on arbitrary items, so that tests can compare it with the real std::sort directly.
+__global__ __launch_bounds__(256) void k_debug_sort(uint64_t *items, int n) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t dbg_lds[];
+  __shared__ int wtot[8];
+  __shared__ int sort_stack[3 * kSortStack];
+  introsort::item_t *buf = (introsort::item_t *)dbg_lds;
+  uint16_t *posA = (uint16_t *)(buf + n), *posB = posA + n + 2;
+  BlockGroup g;
+  g.tid = threadIdx.x;
+  g.nthreads = blockDim.x;
+  g.wtot = wtot;
+  g.stk = sort_stack;
+  for (int i = g.tid; i < n; i += g.nthreads) buf[i] = items[i];
+  __syncthreads();
+  g.sort_partition_phase(buf, n, posA, posB);
+  __syncthreads();
+  for (int t = g.tid; t < n; t += g.nthreads) {
+    const introsort::item_t it = buf[t];
+    const uint32_t key = (uint32_t)(it >> 32);
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+      const uint32_t kj = (uint32_t)(buf[j] >> 32);
+      rank += (kj < key) | ((kj == key) & (j < t));
+    }
+    items[rank] = it;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -641,6 +741,7 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
   g.tid = tid;
   g.nthreads = 256;
   g.wtot = wtot;
+  g.stk = nullptr;
   const int T = g.exclusive_scan(fl, n);  // fl[i] = lapping keypoints before i
   for (int i = tid; i < n; i += 256) {
     const int before = fl[i];
@@ -1006,6 +1107,9 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   const size_t lds = octree::work_bytes(cap);
   dim3 grid(fg.nlevels, nframes), block(256);
   hipLaunchKernelGGL(k_octree, grid, block, lds, s, d_fg, cand, cand_count, node_of, sel, sel_count, cap);
+}
+void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n) {
+  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(256), (size_t)n * 8 + 2 * (n + 2) * 2 + 16, s, d_items, n);
 }
 void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                  const FrameGeom &fg, int nframes) {

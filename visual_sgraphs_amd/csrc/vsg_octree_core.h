@@ -58,6 +58,11 @@ struct SerialGroup {
     }
     return s;
   }
+  // std::sort's quicksort half on items[0..n) (see vsg_introsort.h); posA/posB: n + 1 uint16 of scratch each.
+  // The caller syncs afterwards.
+  VSG_OCT_HD void sort_partition_phase(introsort::item_t *items, int n, uint16_t *, uint16_t *) {
+    introsort::partition_phase(items, n);
+  }
 };
 
 struct Params {
@@ -370,7 +375,7 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
         // std::sort (:707) = serial quicksort partitioning + a stable sort of what it leaves (vsg_introsort.h);
         // the stable part is a rank computation spread over the group, written straight into the back-to-front
         // processing order of (:708).
-        if (g.tid == 0) introsort::partition_phase(sortbuf, nV);
+        g.sort_partition_phase(sortbuf, nV, (uint16_t *)W.scanA, (uint16_t *)W.scanB);
         g.sync();
         for (int t = g.tid; t < nV; t += g.nthreads) {
           const introsort::item_t it = sortbuf[t];

@@ -705,6 +705,27 @@ int vsg_orb_enable_timing(vsg_orb *h, int enable) {
   return VSG_OK;
 }
 
+int vsg_debug_device_sort(int device, uint64_t *items, int n) {
+  if (!items || n < 0 || n > 2048) return VSG_ERR_INVALID;
+  if (vsg_device_count() <= device || device < 0) return VSG_ERR_NO_DEVICE;
+  if (n == 0) return VSG_OK;
+  HIP_TRY(hipSetDevice(device));
+  uint64_t *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(uint64_t) * n));
+  hipError_t e = hipMemcpy(d, items, sizeof(uint64_t) * n, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    launch_debug_sort(nullptr, d, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(items, d, sizeof(uint64_t) * n, hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (e != hipSuccess) {
+    set_err(std::string("vsg_debug_device_sort: ") + hipGetErrorString(e));
+    return VSG_ERR_HIP;
+  }
+  return VSG_OK;
+}
+
 int vsg_orb_get_timing(vsg_orb *h, float *ms_out, int cap) {
   if (!h) return VSG_ERR_INVALID;
   harvest_timing(h);

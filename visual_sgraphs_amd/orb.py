@@ -40,7 +40,7 @@ EXPORTS = [
     "vsg_search_by_projection_local", "vsg_search_for_initialization", "vsg_search_window", "vsg_grid_build",
     "vsg_grid_destroy", "vsg_grid_query", "vsg_stereo_matches", "vsg_orb_set_gray_coeffs",
     "vsg_orb_extract_batch_device_color", "vsg_orb_extract_batch_color", "vsg_vocab_load", "vsg_vocab_destroy",
-    "vsg_vocab_info", "vsg_bow_transform", "vsg_distinctive_descriptors",
+    "vsg_vocab_info", "vsg_bow_transform", "vsg_distinctive_descriptors", "vsg_debug_device_sort",
 ]
 
 
@@ -51,6 +51,15 @@ class VsgError(RuntimeError):
 
 
 _lib = None
+
+
+def debug_device_sort(items, device=0):
+    """Test hook: the device's std::sort replay (see include/vsg_orb.h) on uint64 items (key = upper 32 bits)."""
+    L = load_library()
+    a = np.ascontiguousarray(items, dtype=np.uint64).copy()
+    L.vsg_debug_device_sort.argtypes = [C.c_int, C.POINTER(C.c_uint64), C.c_int]
+    _check(L.vsg_debug_device_sort(device, a.ctypes.data_as(C.POINTER(C.c_uint64)), len(a)), "vsg_debug_device_sort")
+    return a
 
 
 def load_library():
