@@ -761,29 +761,56 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 enum { kPatchR = 18, kPatchW = 2 * kPatchR + 1, kPatchP = 40 };  // rBRIEF patch radius / width / LDS row pitch
 
+// Disc membership of the IC_Angle patch in the lane layout used below: lane = 32 * hh + (u + 15); bit `it` of entry
+// `lane` says that pixel (u, v = 2 * it + hh - 15) lies inside the 749-px patch (|u| <= umax[|v|], ORBextractor.cc:454-469).
+struct DiscTable {
+  uint32_t v[64];
+};
+constexpr DiscTable make_disc_table() {
+  DiscTable t{};
+  for (int lane = 0; lane < 64; lane++) {
+    const int u = (lane & 31) - kHalfPatch, au = u < 0 ? -u : u, hh = lane >> 5;
+    uint32_t m = 0;
+    for (int it = 0; it < 16; it++) {
+      const int v = 2 * it + hh - kHalfPatch, av = v < 0 ? -v : v;
+      const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * (av & 15))) & 15);  // umax[|v|]
+      if (u <= kHalfPatch && v <= kHalfPatch && au <= um) m |= 1u << it;
+    }
+    t.v[lane] = m;
+  }
+  return t;
+}
+__constant__ DiscTable c_disc = make_disc_table();
+
+// Sum over the 64 lanes of a wavefront, returned wave-uniform (SGPR): two quad permutes and two row mirrors on
+// the DPP path give every lane its 16-lane row sum, four v_readlane + scalar adds finish.  Integer, exact.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);  // row_mirror
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                      const FrameGeom *__restrict__ fg, Src0 s0,
                                                      const uint32_t *__restrict__ sel,
                                                      const int *__restrict__ slots, const FrameHeader *__restrict__ hdr,
                                                      const int8_t *__restrict__ pattern, KeyPointPOD *__restrict__ kps,
                                                      uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity) {
-  __shared__ int8_t pat[1024];
+  __shared__ f32x4 patf[256];            // test k: (x0, y0, x1, y1) of bit_pattern_31_ as floats
   __shared__ int s_hdr[kMaxLevels + 3];  // n, mono, level_start[0..kMaxLevels]
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchW * kPatchP];
-  __shared__ uint32_t s_disc[64];
   const int frame = blockIdx.y, tid = threadIdx.x;
-  ((uint32_t *)pat)[tid] = ((const uint32_t *)pattern)[tid];
-  if (tid < kMaxLevels + 3) s_hdr[tid] = ((const int *)&hdr[frame])[tid];
-  if (tid < 64) {  // disc membership of the IC_Angle patch for lane layout (u = (tid & 31) - 15, rows 2*it + (tid >> 5) - 15)
-    const int u = (tid & 31) - kHalfPatch, au = u < 0 ? -u : u, hh = tid >> 5;
-    uint32_t m = 0;
-    for (int it = 0; it < 16; it++) {
-      const int v = 2 * it + hh - kHalfPatch, av = v < 0 ? -v : v;
-      const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * (av & 15))) & 15);  // umax[|v|], ORBextractor.cc:454-469
-      if (u <= kHalfPatch && v <= kHalfPatch && au <= um) m |= 1u << it;
-    }
-    s_disc[tid] = m;
+  {
+    const uint32_t pw = ((const uint32_t *)pattern)[tid];
+    patf[tid] = (f32x4){(float)(int8_t)pw, (float)(int8_t)(pw >> 8), (float)(int8_t)(pw >> 16), (float)(int8_t)(pw >> 24)};
   }
+  if (tid < kMaxLevels + 3) s_hdr[tid] = ((const int *)&hdr[frame])[tid];
   __syncthreads();
   const int n = s_hdr[0];
   if (blockIdx.x == 0 && tid == 0) {
@@ -813,7 +840,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   {
     const int u = (lane & 31) - kHalfPatch, h = lane >> 5;
     // bit `it` of the lane's disc mask: pixel (u, v = 2*it + h - 15) lies inside the 749-px patch
-    const uint32_t disc = s_disc[lane];
+    const uint32_t disc = c_disc.v[lane];
     const uint8_t *ptr = unblurred + (ptrdiff_t)(cy + h - kHalfPatch) * upitch + cx + (u > kHalfPatch ? 0 : u);
     const ptrdiff_t step2 = 2 * (ptrdiff_t)upitch;
     int sum_u = 0;
@@ -828,11 +855,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
     }
     m10 = u * sum_u;
   }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    m10 += __shfl_xor(m10, d);
-    m01 += __shfl_xor(m01, d);
-  }
+  m10 = wave_sum_i32(m10);
+  m01 = wave_sum_i32(m01);
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   float a, b;
   brief_rotation(angle, &a, &b);
@@ -840,24 +864,23 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   // patch is staged in LDS with row-major (coalesced) byte loads; the 8 samples per lane are then LDS reads.
   uint8_t *patch = &s_patch[(tid >> 6) * (kPatchW * kPatchP)];
   {
-    // 37 rows x 10 (unaligned) dwords; gfx950 global loads accept any byte alignment
-    const uint8_t *corner = blur + foff + (size_t)(cy - kPatchR) * L.pitch + (cx - kPatchR);
+    // 37 rows x 10 (unaligned) dwords, 6 rows (60 lanes) per trip; gfx950 global loads accept any byte alignment
+    constexpr int kDw = kPatchP / 4, kRows = 64 / kDw, kIt = (kPatchW + kRows - 1) / kRows;
+    const int r0 = lane / kDw, cc = lane - r0 * kDw;
     const int pitch = L.pitch;
-    constexpr int kDw = kPatchP / 4, kN = kPatchW * kDw, kIt = (kN + 63) / 64;
+    const uint8_t *gp = blur + foff + (size_t)(cy - kPatchR + r0) * pitch + (cx - kPatchR) + 4 * cc;
+    uint8_t *lp = patch + r0 * kPatchP + 4 * cc;
+    const bool act = r0 < kRows;
     uint32_t pv[kIt];
 #pragma unroll
     for (int it = 0; it < kIt; it++) {
-      int i = it * 64 + lane;
-      i = i < kN ? i : kN - 1;
-      const int r = i / kDw, cc = i - r * kDw;
-      pv[it] = *(const u32_unaligned *)(corner + r * pitch + 4 * cc);
+      // rows past the patch (last trip) re-read the last row: stays inside the image, never stored
+      const int back = it * kRows + r0 < kPatchW ? 0 : it * kRows + r0 - (kPatchW - 1);
+      pv[it] = act ? *(const u32_unaligned *)(gp + (ptrdiff_t)(it * kRows - back) * pitch) : 0u;
     }
 #pragma unroll
-    for (int it = 0; it < kIt; it++) {
-      int i = it * 64 + lane;
-      i = i < kN ? i : kN - 1;
-      *(uint32_t *)(patch + 4 * i) = pv[it];  // r * kPatchP + 4 * cc == 4 * i
-    }
+    for (int it = 0; it < kIt; it++)
+      if (act && it * kRows + r0 < kPatchW) *(uint32_t *)(lp + it * kRows * kPatchP) = pv[it];
   }
   // the patch is private to this wavefront: LDS writes complete in order before the reads below
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -866,10 +889,14 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   uint64_t word = 0;
 #pragma unroll
   for (int r = 0; r < 4; r++) {  // lane handles tests lane, lane+64, lane+128, lane+192
-    const int k = r * 64 + lane;
-    int dx0, dy0, dx1, dy1;
-    brief_offset(pat[4 * k + 0], pat[4 * k + 1], a, b, &dx0, &dy0);
-    brief_offset(pat[4 * k + 2], pat[4 * k + 3], a, b, &dx1, &dy1);
+    // both points of the test at once on the packed-fp32 path; every product and sum is rounded separately
+    // (no contraction: the file is built with -ffp-contract=off), exactly like the scalar code
+    //   dy = cvRound(x*b + y*a), dx = cvRound(x*a - y*b)     (ORBextractor.cc:113-115)
+    const f32x4 pt = patf[r * 64 + lane];
+    const f32x2 X = pt.xz, Y = pt.yw;
+    const f32x2 fy = X * b + Y * a, fx = X * a - Y * b;
+    const int dy0 = round_half_even(fy.x), dy1 = round_half_even(fy.y);
+    const int dx0 = round_half_even(fx.x), dx1 = round_half_even(fx.y);
     const int t0 = center[dy0 * kPatchP + dx0], t1 = center[dy1 * kPatchP + dx1];
     const uint64_t m = __ballot(t0 < t1);
     if (lane == r) word = m;
