@@ -89,6 +89,7 @@ struct Geometry {
   std::vector<PyrTile> pyrTiles;
   int pyrLdsA = 0, pyrLdsB = 0;  // LDS bytes for even / odd levels of the ping-pong
   int pyrTabMax = 0;             // max over tiles of staged table entries
+  int fastMaxVh = 0, fastMaxVw = 0, fastMaxArea = 0;  // over all FAST cells: rows and pixels of the valid region (LDS sizing)
   bool pyrFusedOk = true;        // k_pyramid's 8-byte source window covers 4 adjacent destination columns
   // Per tile, per level 1..top: the tile's slice of the resize tables, already rebased to the tile's LDS images:
   //   x entries {sx - sx0a, a0, a1, sx1 - sx0a}   then   y entries {(sy0 - y0) * spitch, (sy1 - y0) * spitch, b0, b1}
@@ -144,6 +145,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   memset(&fg, 0, sizeof(fg));
   G.resizeTab.clear();
   G.cells.clear();
+  G.fastMaxVh = G.fastMaxVw = G.fastMaxArea = 0;
   G.maxQuota = 0;
   fg.nlevels = T.nlevels;
   fg.rows = rows;
@@ -192,6 +194,9 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
         if (c.x1 < c.x0) c.x1 = c.x0;  // empty (the reference `continue`s or FAST finds nothing)
         if (c.y1 < c.y0) c.y1 = c.y0;
         G.cells.push_back(c);
+        if (c.y1 - c.y0 > G.fastMaxVh) G.fastMaxVh = c.y1 - c.y0;
+        if (c.x1 - c.x0 > G.fastMaxVw) G.fastMaxVw = c.x1 - c.x0;
+        if ((c.x1 - c.x0) * (c.y1 - c.y0) > G.fastMaxArea) G.fastMaxArea = (c.x1 - c.x0) * (c.y1 - c.y0);
         // a strict 3x3 local maximum occupies a 2x2 block: worst-case survivors per cell
         cand_cap += ((c.x1 - c.x0 + 1) / 2) * ((c.y1 - c.y0 + 1) / 2);
       }

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void k_pyramid(uint8_t *__restrict__ pyr, cons
 // FAST-9-16 ([OCV] fast.cpp FAST_t<16>, fast_score.cpp cornerScore<16>) on an LDS tile of row pitch kTileP.
 //   score = max over the 16 contiguous 9-arcs of min(+-(v - ring)) - 1;  corner-at-t <=> score >= t, and the
 //   score does not depend on t.
-enum { kTileP = 84, kScoreP = 72 };
+// The LDS row pitches are template parameters (52/44, 68/60, 84/76 bytes for cells up to 40, 56, 70 px wide) so that
+// the 16 ring offsets stay instruction immediates while the footprint follows the geometry.
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
@@ -206,6 +207,7 @@ __device__ __forceinline__ s16x2 pk_swap(s16x2 a) { return a.yx; }
 
 // Exact score with packed 16-bit min/max: lane pair P[k] = (d[k], d[k+8]) so one v_pk_min/max_i16 advances the
 // sliding 9-arc minimum/maximum of two opposite arcs at once.  Returns 0 below `floor_t`.
+template <int kTileP>
 __device__ __forceinline__ int fast_score(const uint8_t *c, int floor_t) {
   const int P = kTileP;
   const short v = c[0];
@@ -270,6 +272,10 @@ __device__ __forceinline__ uint32_t fast_quick4(uint32_t C, uint32_t U, uint32_t
   return m;
 }
 
+#ifndef VSG_FAST_NT
+#define VSG_FAST_NT 128  // threads per FAST cell: 2 waves keep more cells resident per CU than 4 (measured: 0.47 ->
+                         // 0.38 ms per 256 frames); 1 wave runs out of LDS before it runs out of wave slots
+#endif
 #ifndef VSG_FAST_RUN
 #define VSG_FAST_RUN 2
 #endif
@@ -283,12 +289,16 @@ constexpr int kFastCntBits = kFastRun == 1 ? 3 : kFastRun == 2 ? 4 : 5;  // popc
 // nothing at minThFAST (ORBextractor.cc:832-851); NMS only looks at neighbours INSIDE the valid region (outside
 // counts as 0, exactly like the zeroed row buffers of FAST_t).  Emission order is irrelevant (the octree ranks
 // candidates).
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
+template <int NT, int kTileP, int kScoreP>
+__global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                     const CellDesc *__restrict__ cells, Src0 s0,
-                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count) {
-  __shared__ __attribute__((aligned(16))) uint8_t tile[(kCellMax + 6) * kTileP];
-  __shared__ __attribute__((aligned(16))) uint8_t score[(kCellMax + 2) * kScoreP];
-  __shared__ uint16_t queue[kCellMax * kCellMax];
+                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count,
+                                                    int tile_bytes, int score_bytes) {
+  // LDS is sized by the launch for the largest cell of THIS geometry (rows x fixed pitches, queue = largest
+  // valid area), not for the 70 x 70 worst case: more cells resident per CU.
+  extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
+  uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
+  uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);
   __shared__ int s_cnt[4];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base
   const CellDesc cell = cells[blockIdx.x];
   const int frame = blockIdx.y;
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   const int ax = (cell.x0 - 3) & ~3, ox = (cell.x0 - 3) - ax;
   const int tdw = (ox + vw + 6 + 3) >> 2, th = vh + 6;  // dwords per tile row (<= 21)
   const float inv_tdw = 1.0f / (float)tdw;
-  for (int i = tid; i < tdw * th; i += 256) {
+  for (int i = tid; i < tdw * th; i += NT) {
     const int r = div_small(i, inv_tdw), c = i - r * tdw;
     *(uint32_t *)&tile[r * kTileP + 4 * c] = *(const uint32_t *)(img + (size_t)(cell.y0 - 3 + r) * pitch + ax + 4 * c);
   }
@@ -313,12 +323,12 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   uint32_t keep = 0;
   int nq = 0, thr = fg->iniTh;
   for (int pass = 0; pass < 2; pass++) {
-    for (int i = tid; i < (vh + 2) * (kScoreP / 4); i += 256) ((uint32_t *)score)[i] = 0;
+    for (int i = tid; i < (vh + 2) * (kScoreP / 4); i += NT) ((uint32_t *)score)[i] = 0;
     if (tid < 4) s_cnt[tid] = 0;
     __syncthreads();
     // ---- phase 1: necessary test on kFastRun dwords (4 px each) per thread, compaction of the passers.  A longer
     // run amortises the index arithmetic, the neighbour loads and the wave-level prefix over more pixels.
-    for (int i0 = 0; i0 < nruns; i0 += 256) {
+    for (int i0 = 0; i0 < nruns; i0 += NT) {
       const int i = i0 + tid;
       uint32_t m = 0;
       int r = 0, cb = 0;
@@ -371,17 +381,17 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     __syncthreads();
     nq = s_cnt[1];
     // ---- phase 2: exact score of the queued pixels
-    for (int q = tid; q < nq; q += 256) {
+    for (int q = tid; q < nq; q += NT) {
       const int i = queue[q];
       const int r = div_small(i, inv_vw), c = i - r * vw;
-      const int s = fast_score(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr);
+      const int s = fast_score<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr);
       if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
     }
     __syncthreads();
     // ---- phase 3: non-max suppression inside the cell
     keep = 0;  // bit per loop iteration: queued pixel survives NMS
     int it = 0;
-    for (int q = tid; q < nq; q += 256, it++) {
+    for (int q = tid; q < nq; q += NT, it++) {
       const int i = queue[q];
       const int r = div_small(i, inv_vw), c = i - r * vw;
       const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
   const int base = s_cnt[3];
   uint32_t *out = cand + (size_t)frame * fg->cand_frame + L.cand_off;
   int it = 0;
-  for (int q = tid; q < nq; q += 256, it++) {
+  for (int q = tid; q < nq; q += NT, it++) {
     if (!(keep & (1u << it))) continue;
     const int i = queue[q];
     const int r = div_small(i, inv_vw), c = i - r * vw;
@@ -1123,10 +1133,26 @@ void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sh
   hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(256), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
                      d_tile_tab, s0, d_tiles, a16, ab16);
 }
+template <int NT, int TP, int SP>
+static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells,
+                          const Src0 &s0, uint32_t *cand, int *cand_count, const FrameGeom &fg, int maxVh, int maxArea,
+                          int nframes) {
+  dim3 grid(fg.total_cells, nframes), block(NT);
+  // + one spare row: the necessary test reads (masked) dwords just past the last tile row
+  const int tile_bytes = ((maxVh + 6 + 1) * TP + 15) & ~15, score_bytes = ((maxVh + 2) * SP + 15) & ~15;
+  const size_t lds = (size_t)tile_bytes + score_bytes + (((size_t)maxArea * 2 + 15) & ~(size_t)15);
+  hipLaunchKernelGGL((k_fast_cells<NT, TP, SP>), grid, block, lds, s, pyr, d_fg, d_cells, s0, cand, cand_count,
+                     tile_bytes, score_bytes);
+}
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
-                 uint32_t *cand, int *cand_count, const FrameGeom &fg, int nframes) {
-  dim3 grid(fg.total_cells, nframes), block(256);
-  hipLaunchKernelGGL(k_fast_cells, grid, block, 0, s, pyr, d_fg, d_cells, s0, cand, cand_count);
+                 uint32_t *cand, int *cand_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea, int nframes) {
+  // tile row = up to 3 alignment bytes + vw + 6 ring bytes, rounded up to dwords; score row = vw + 2
+  if (maxVw <= 40)
+    launch_fast_t<VSG_FAST_NT, 52, 44>(s, pyr, d_fg, d_cells, s0, cand, cand_count, fg, maxVh, maxArea, nframes);
+  else if (maxVw <= 56)
+    launch_fast_t<VSG_FAST_NT, 68, 60>(s, pyr, d_fg, d_cells, s0, cand, cand_count, fg, maxVh, maxArea, nframes);
+  else
+    launch_fast_t<VSG_FAST_NT, 84, 76>(s, pyr, d_fg, d_cells, s0, cand, cand_count, fg, maxVh, maxArea, nframes);
 }
 void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, const int *cand_count,
                    uint16_t *node_of, uint32_t *sel, int *sel_count, const FrameGeom &fg, int maxQuota, int nframes) {
