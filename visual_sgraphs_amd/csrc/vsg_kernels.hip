@@ -540,7 +540,12 @@ struct BlockGroup {
 #endif
 constexpr int kOctRegPts = VSG_OCT_K;  // candidates per thread held in registers (x 256 threads = 2048 per level; 12 costs a wave of occupancy and loses)
 
-__global__ __launch_bounds__(256) void k_octree(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ cand,
+#ifndef VSG_OCT_NT
+#define VSG_OCT_NT 256
+#endif
+constexpr int kOctThreads = VSG_OCT_NT;  // threads per (frame, level) octree
+
+__global__ __launch_bounds__(kOctThreads) void k_octree(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ cand,
                                                 const int *__restrict__ cand_count, uint16_t *__restrict__ node_of,
                                                 uint32_t *__restrict__ sel, int *__restrict__ sel_count, int cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
@@ -570,7 +575,7 @@ __global__ __launch_bounds__(256) void k_octree(const FrameGeom *__restrict__ fg
   uint32_t *out = sel + (size_t)frame * fg->sel_frame + L.sel_off;
   // candidates stay in registers across the passes when they fit (the common case); node_of[] is only touched by
   // the fallback
-  const int n = npts <= kOctRegPts * 256 ? octree::distribute_reg<kOctRegPts>(g, P, cand + coff, npts, W, out)
+  const int n = npts <= kOctRegPts * kOctThreads ? octree::distribute_reg<kOctRegPts>(g, P, cand + coff, npts, W, out)
                                          : octree::distribute(g, P, cand + coff, npts, node_of + coff, W, out);
   if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;
 }
@@ -1158,7 +1163,7 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
                    uint16_t *node_of, uint32_t *sel, int *sel_count, const FrameGeom &fg, int maxQuota, int nframes) {
   const int cap = octree::node_capacity(maxQuota);
   const size_t lds = octree::work_bytes(cap);
-  dim3 grid(fg.nlevels, nframes), block(256);
+  dim3 grid(fg.nlevels, nframes), block(kOctThreads);
   hipLaunchKernelGGL(k_octree, grid, block, lds, s, d_fg, cand, cand_count, node_of, sel, sel_count, cap);
 }
 void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n) {

@@ -68,9 +68,16 @@ __global__ void k_hamming_pairs(const uint8_t *a, const uint8_t *b, const int *i
   dist[i] = hamming256(a0, a1, b0, b1);
 }
 
-// ---- brute-force best / second best: 4 lanes share one row of A and scan interleaved quarters of B, which is
-// streamed through LDS in 256-row tiles.  Packed keys (dist << 20 | index) keep the reference's strict-'<' scan
-// semantics: the smallest key is the first minimum, the second smallest is "bestDist2".
+// ---- brute-force best / second best: 4 lanes share TWO rows of A (row, row + 64 of a 128-row block) and scan
+// interleaved quarters of B, which is streamed through LDS in 256-row tiles; each B row read from LDS serves both
+// A rows.  Packed keys (dist << 20 | index) are unique and keep the reference's strict-'<' scan semantics: the
+// smallest key is the first minimum, the second smallest is "bestDist2".  With k1 <= k2 the update is
+// k2 = median(k1, k2, key), k1 = min(k1, key): one v_med3_u32 and one v_min_u32 per pair.
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  return min(max(a, b), max(min(a, b), c));  // folded to v_med3_u32
+}
+enum { kBest2Rows = 128 };  // A rows per workgroup
+
 __global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, const uint8_t *b_base, size_t block_stride,
                                                      const int *counts_a, const int *counts_b, int count_stride,
                                                      int fixed_na, int fixed_nb, int max_rows, int *best, int *second,
@@ -80,11 +87,12 @@ __global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, cons
   const int na = counts_a ? min(counts_a[blk * count_stride], max_rows) : fixed_na;
   const int nb = counts_b ? min(counts_b[blk * count_stride], max_rows) : fixed_nb;
   const uint8_t *A = a_base + (size_t)blk * block_stride, *B = b_base + (size_t)blk * block_stride;
-  if (blockIdx.x * 64 >= na) return;
-  const int row = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
-  uint4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-  if (row < na) load_desc(A, row, a0, a1);
-  uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+  if (blockIdx.x * kBest2Rows >= na) return;
+  const int row0 = blockIdx.x * kBest2Rows + (threadIdx.x >> 2), row1 = row0 + 64, sub = threadIdx.x & 3;
+  uint4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+  if (row0 < na) load_desc(A, row0, a0, a1);
+  if (row1 < na) load_desc(A, row1, c0, c1);
+  uint32_t k1 = KEY_NONE, k2 = KEY_NONE, m1 = KEY_NONE, m2 = KEY_NONE;
   for (int t0 = 0; t0 < nb; t0 += 256) {
     const int nt = min(256, nb - t0);
     __syncthreads();
@@ -96,25 +104,36 @@ __global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, cons
     }
     __syncthreads();
     for (int j = sub; j < nt; j += 4) {
-      const uint32_t key = ((uint32_t)hamming256(a0, a1, tile[2 * j], tile[2 * j + 1]) << 20) | (uint32_t)(t0 + j);
-      if (key < k1) {
-        k2 = k1;
-        k1 = key;
-      } else {
-        k2 = min(k2, key);
-      }
+      const uint4 b0 = tile[2 * j], b1 = tile[2 * j + 1];
+      const uint32_t idx = (uint32_t)(t0 + j);
+      const uint32_t key = ((uint32_t)hamming256(a0, a1, b0, b1) << 20) | idx;
+      const uint32_t kez = ((uint32_t)hamming256(c0, c1, b0, b1) << 20) | idx;
+      k2 = umed3(k1, k2, key);
+      k1 = min(k1, key);
+      m2 = umed3(m1, m2, kez);
+      m1 = min(m1, kez);
     }
   }
 #pragma unroll
   for (int d = 1; d <= 2; d <<= 1) {
     const uint32_t o1 = __shfl_xor(k1, d), o2 = __shfl_xor(k2, d);
     merge2(k1, k2, o1, o2);
+    const uint32_t p1 = __shfl_xor(m1, d), p2 = __shfl_xor(m2, d);
+    merge2(m1, m2, p1, p2);
   }
-  if (row < na && sub == 0) {
-    const size_t o = (size_t)blk * max_rows + row;
-    best[o] = (int)(k1 >> 20);
-    second[o] = (int)(k2 >> 20);
-    argbest[o] = k1 == KEY_NONE ? -1 : (int)(k1 & 0xFFFFF);
+  if (sub == 0) {
+    if (row0 < na) {
+      const size_t o = (size_t)blk * max_rows + row0;
+      best[o] = (int)(k1 >> 20);
+      second[o] = (int)(k2 >> 20);
+      argbest[o] = k1 == KEY_NONE ? -1 : (int)(k1 & 0xFFFFF);
+    }
+    if (row1 < na) {
+      const size_t o = (size_t)blk * max_rows + row1;
+      best[o] = (int)(m1 >> 20);
+      second[o] = (int)(m2 >> 20);
+      argbest[o] = m1 == KEY_NONE ? -1 : (int)(m1 & 0xFFFFF);
+    }
   }
 }
 
@@ -432,7 +451,7 @@ int vsg_hamming_block_best2_device(int device, const uint8_t *d_a, const uint8_t
   if (!d_a || !d_b || !d_best || !d_second || !d_argbest || nblocks < 1 || max_rows < 1) return VSG_ERR_INVALID;
   int rc = use_device(device);
   if (rc != VSG_OK) return rc;
-  dim3 grid((max_rows + 63) / 64, nblocks);
+  dim3 grid((max_rows + kBest2Rows - 1) / kBest2Rows, nblocks);
   hipLaunchKernelGGL(k_block_best2, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes, d_counts_a,
                      d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
   M_TRY(hipGetLastError());
@@ -451,7 +470,7 @@ int vsg_hamming_block_best2(int device, const uint8_t *a, int na, const uint8_t 
   M_TRY(d1.alloc((size_t)na * 4));
   M_TRY(d2.alloc((size_t)na * 4));
   M_TRY(d3.alloc((size_t)na * 4));
-  hipLaunchKernelGGL(k_block_best2, dim3((na + 63) / 64, 1), dim3(256), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(),
+  hipLaunchKernelGGL(k_block_best2, dim3((na + kBest2Rows - 1) / kBest2Rows, 1), dim3(256), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(),
                      (size_t)0, (const int *)nullptr, (const int *)nullptr, 0, na, nb, na, d1.as<int>(), d2.as<int>(),
                      d3.as<int>());
   M_TRY(hipMemcpy(best, d1.p, (size_t)na * 4, hipMemcpyDeviceToHost));
