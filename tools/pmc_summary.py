@@ -6,13 +6,22 @@ import glob
 import sys
 
 
+def kernel_key(name):
+    """'void vsg::k_fast_cells<128, 52, 44>(unsigned char const*, ...)' -> 'vsg::k_fast_cells'."""
+    name = name.split('(')[0].strip()
+    if name.startswith('void '):
+        name = name[5:]
+    name = name.split('<')[0]
+    return name[-26:]
+
+
 def load(pat):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     seen = set()
     for f in glob.glob(pat):
         for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name'].split('(')[0][-26:]
+            k = kernel_key(r['Kernel_Name'])
             agg[k][r['Counter_Name']] += float(r['Counter_Value'])
             key = (f, r['Dispatch_Id'])
             if key not in seen:
