@@ -137,6 +137,155 @@ __global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, cons
   }
 }
 
+// ---- the same best / second-best scan on the matrix cores.  A Hamming distance matrix is a GEMM over +-1 vectors:
+// with s(x) = 2*bit - 1, sum_k s(a_k) * s(b_k) = 256 - 2 * dist.  The train rows are expanded with their bits
+// INVERTED (so each product is negated) and the accumulator starts at 256, hence
+//     D[i][j] = 256 + sum_k (-s(train_i,k)) * s(query_j,k) = 2 * dist(train_i, query_j)          (exact, int32)
+// from eight v_mfma_i32_32x32x32_i8 per 32 x 32 tile (K = 256).  A wave owns 32 queries (the MFMA's columns, kept
+// expanded in 32 VGPRs for the whole scan); the workgroup expands each tile of 32 train rows once into LDS for its
+// four waves.  C/D layout: lane = column + 32 * h, register g holds row (g & 3) + 8 * (g >> 2) + 4 * h, so a lane
+// folds its 16 rows into the packed-key best/second pair with v_lshl_or + v_min_u32 + v_med3_u32 per pair; the
+// two lanes of a column merge at the end.  Keys (2 * dist << 19 | index == dist << 20 | index) and therefore tie
+// handling are identical to the VALU kernel above.
+#ifndef VSG_MATCH_TR
+#define VSG_MATCH_TR 1
+#endif
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// 4 bits -> 4 bytes: bit set -> 0x01 (+1), bit clear -> 0xFF (-1)
+__device__ __forceinline__ uint32_t expand_pm1(uint32_t nib) {
+  const uint32_t m = (nib * 0x00204081u) & 0x01010101u;  // bit i -> byte i (the four shifted copies do not overlap)
+  return m | ((m ^ 0x01010101u) * 0xFFu);
+}
+// 16 bits -> 16 bytes
+__device__ __forceinline__ i32x4 expand16_pm1(uint32_t h16) {
+  return (i32x4){(int)expand_pm1(h16 & 0xF), (int)expand_pm1((h16 >> 4) & 0xF), (int)expand_pm1((h16 >> 8) & 0xF),
+                 (int)expand_pm1((h16 >> 12) & 0xF)};
+}
+
+__global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base, const uint8_t *b_base,
+                                                          size_t block_stride, const int *counts_a, const int *counts_b,
+                                                          int count_stride, int fixed_na, int fixed_nb, int max_rows,
+                                                          int *best, int *second, int *argbest) {
+  constexpr int TR = VSG_MATCH_TR;  // 32-row train tiles per iteration (independent MFMA chains, one barrier)
+  __shared__ i32x4 tiles[2][TR][8 * 2 * 32];  // double buffer of [tile][k-step s][half h][train row r]: 16 bytes each
+  __shared__ uint2 lut[256];                  // byte -> its 8 bits as +-1 bytes (expansion = 4 lookups per dword)
+  lut[threadIdx.x] = (uint2){expand_pm1(threadIdx.x & 0xF), expand_pm1(threadIdx.x >> 4)};
+  const int blk = blockIdx.y;
+  const int na = counts_a ? min(counts_a[blk * count_stride], max_rows) : fixed_na;
+  const int nb = counts_b ? min(counts_b[blk * count_stride], max_rows) : fixed_nb;
+  const uint8_t *A = a_base + (size_t)blk * block_stride, *B = b_base + (size_t)blk * block_stride;
+  if (blockIdx.x * kBest2Rows >= na) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int q = blockIdx.x * kBest2Rows + wave * 32 + r;  // this lane's query (column)
+  const bool wave_active = blockIdx.x * kBest2Rows + wave * 32 < na;
+  // queries: half h of every dword of the descriptor, expanded once
+  i32x4 Q[8];
+  {
+    const uint32_t *qd = (const uint32_t *)(A + (size_t)(q < na ? q : 0) * 32);
+#pragma unroll
+    for (int s = 0; s < 8; s++) Q[s] = expand16_pm1((qd[s] >> (16 * h)) & 0xFFFFu);
+  }
+  uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+  // tile expansion: thread = (train row, dword); the row runs along the lanes so that a wave's 16-byte LDS stores
+  // are contiguous (the dword-fastest mapping put 8 lanes on the same banks: an 8-way conflict on every store)
+  const int erow = tid & 31, es = tid >> 5;
+  auto fetch = [&](int row0) {  // one dword of a train row, inverted (negated products); past the end: any valid row
+    const int tr = row0 + erow;
+    return ~((const uint32_t *)(B + (size_t)(tr < nb ? tr : 0) * 32))[es];
+  };
+  // The train dwords are prefetched a GROUP of kPf tiles ahead (register double bank): an iteration is ~600 cycles,
+  // a global round trip several thousand, so a one-iteration prefetch left every iteration waiting on memory.
+  constexpr int kPf = 8;
+  uint32_t wa[kPf], wn[kPf];
+#pragma unroll
+  for (int j = 0; j < kPf; j++) wa[j] = fetch(32 * j), wn[j] = 0u;
+  const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  __syncthreads();  // lut
+  int buf = 0;
+  for (int tg = 0; tg < nb; tg += 32 * kPf) {
+    if (tg + 32 * kPf < nb) {
+#pragma unroll
+      for (int j = 0; j < kPf; j++) wn[j] = fetch(tg + 32 * (kPf + j));
+    }
+#pragma unroll
+    for (int j = 0; j < kPf; j += TR) {
+      const int t0 = tg + 32 * j;
+      if (t0 >= nb) break;
+#pragma unroll
+      for (int t = 0; t < TR; t++) {
+        i32x4 *tile = tiles[buf][t];
+        const uint32_t ww = wa[j + t];
+        const uint2 e0 = lut[ww & 255], e1 = lut[(ww >> 8) & 255], e2 = lut[(ww >> 16) & 255], e3 = lut[ww >> 24];
+        tile[(es * 2 + 0) * 32 + erow] = (i32x4){(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
+        tile[(es * 2 + 1) * 32 + erow] = (i32x4){(int)e2.x, (int)e2.y, (int)e3.x, (int)e3.y};
+      }
+      // one barrier per iteration: nobody can overwrite this buffer before every wave has passed the NEXT
+      // barrier, i.e. finished reading it
+      __syncthreads();
+      if (wave_active) {
+        // acc = sum of negated products = 2 * dist - 256 (C operand: inline 0)
+        i32x16 acc[TR];
+#pragma unroll
+        for (int t = 0; t < TR; t++)
+          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tiles[buf][t][h * 32 + r], Q[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int s = 1; s < 8; s++)
+#pragma unroll
+          for (int t = 0; t < TR; t++)
+            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tiles[buf][t][(s * 2 + h) * 32 + r], Q[s], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TR; t++) {
+          const int tb = t0 + 32 * t + 4 * h;  // row of register 0 of this lane
+          if (tb - 4 * h + 32 <= nb) {
+            // full tile: best two of the lane's 16 rows on keys local to the tile -- (acc << 19) + (256 << 19 | row
+            // offset), the constant living in an SGPR: one v_lshl_add_u32 -- then move them to absolute rows
+            uint32_t l1 = KEY_NONE, l2 = KEY_NONE;
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+              const uint32_t key = ((uint32_t)acc[t][g] << 19) + ((256u << 19) | (uint32_t)((g & 3) + 8 * (g >> 2)));
+              l2 = umed3(l1, l2, key);
+              l1 = min(l1, key);
+            }
+            l1 += (uint32_t)tb;
+            l2 += (uint32_t)tb;
+            k2 = min(max(k1, l1), min(k2, l2));
+            k1 = min(k1, l1);
+          } else {
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+              const int row = tb + (g & 3) + 8 * (g >> 2);
+              uint32_t key = ((uint32_t)(acc[t][g] + 256) << 19) | (uint32_t)row;
+              if (row >= nb) key = KEY_NONE;
+              k2 = umed3(k1, k2, key);
+              k1 = min(k1, key);
+            }
+          }
+        }
+      }
+      buf ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < kPf; j++) wa[j] = wn[j];
+  }
+  {
+    const uint32_t o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
+    merge2(k1, k2, o1, o2);
+  }
+  if (h == 0 && q < na) {
+    const size_t o = (size_t)blk * max_rows + q;
+    best[o] = (int)(k1 >> 20);
+    second[o] = (int)(k2 >> 20);
+    argbest[o] = k1 == KEY_NONE ? -1 : (int)(k1 & 0xFFFFF);
+  }
+}
+
+static bool match_on_valu() {
+  static const bool v = getenv("VSG_MATCH_VALU") != nullptr;  // A/B switch: the xor + popcount kernel
+  return v;
+}
+
 // ---- SearchByBoW: one wavefront per shared vocabulary node (node pairs merged on the host).
 // mode 0: KF -> Frame  (ORBmatcher.cc:254-392): skip F features already in match_f; accept bestDist1 <= TH_LOW
 // mode 1: KF -> KF     (ORBmatcher.cc:790-864): skip vbMatched2 / invalid; accept bestDist1 <  TH_LOW
@@ -452,8 +601,12 @@ int vsg_hamming_block_best2_device(int device, const uint8_t *d_a, const uint8_t
   int rc = use_device(device);
   if (rc != VSG_OK) return rc;
   dim3 grid((max_rows + kBest2Rows - 1) / kBest2Rows, nblocks);
-  hipLaunchKernelGGL(k_block_best2, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes, d_counts_a,
-                     d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
+  if (match_on_valu())
+    hipLaunchKernelGGL(k_block_best2, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes,
+                       d_counts_a, d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
+  else
+    hipLaunchKernelGGL(k_block_best2_mfma, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes,
+                       d_counts_a, d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
   M_TRY(hipGetLastError());
   return VSG_OK;
 }
@@ -470,9 +623,14 @@ int vsg_hamming_block_best2(int device, const uint8_t *a, int na, const uint8_t 
   M_TRY(d1.alloc((size_t)na * 4));
   M_TRY(d2.alloc((size_t)na * 4));
   M_TRY(d3.alloc((size_t)na * 4));
-  hipLaunchKernelGGL(k_block_best2, dim3((na + kBest2Rows - 1) / kBest2Rows, 1), dim3(256), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(),
-                     (size_t)0, (const int *)nullptr, (const int *)nullptr, 0, na, nb, na, d1.as<int>(), d2.as<int>(),
-                     d3.as<int>());
+  if (match_on_valu())
+    hipLaunchKernelGGL(k_block_best2, dim3((na + kBest2Rows - 1) / kBest2Rows, 1), dim3(256), 0, 0, da.as<uint8_t>(),
+                       db.as<uint8_t>(), (size_t)0, (const int *)nullptr, (const int *)nullptr, 0, na, nb, na,
+                       d1.as<int>(), d2.as<int>(), d3.as<int>());
+  else
+    hipLaunchKernelGGL(k_block_best2_mfma, dim3((na + kBest2Rows - 1) / kBest2Rows, 1), dim3(256), 0, 0,
+                       da.as<uint8_t>(), db.as<uint8_t>(), (size_t)0, (const int *)nullptr, (const int *)nullptr, 0, na,
+                       nb, na, d1.as<int>(), d2.as<int>(), d3.as<int>());
   M_TRY(hipMemcpy(best, d1.p, (size_t)na * 4, hipMemcpyDeviceToHost));
   M_TRY(hipMemcpy(second, d2.p, (size_t)na * 4, hipMemcpyDeviceToHost));
   M_TRY(hipMemcpy(argbest, d3.p, (size_t)na * 4, hipMemcpyDeviceToHost));
