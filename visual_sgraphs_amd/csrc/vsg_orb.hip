@@ -202,9 +202,8 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   }
   if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
   // The blur only needs the pyramid and runs on its own stream next to FAST -> octree -> slots.  Measured on
-  // MI355X the placement hardly matters (every kernel here is issue-bound, so concurrency just shares the CUs):
-  // released right after the pyramid 139.1k fps, after FAST (VSG_BLUR_LATE=1) 136.6k, fully serialised 134.4k
-  // (C2, 256-frame batches).
+  // MI355X the placement matters little (most kernels here are issue-bound, so concurrency mostly shares the
+  // CUs): released right after the pyramid is 1-2 % ahead of VSG_BLUR_LATE=1 with the default sub-batching.
   static const bool blur_early = getenv("VSG_BLUR_LATE") == nullptr;
   if (!blur_early) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
