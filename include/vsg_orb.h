@@ -176,6 +176,23 @@ int vsg_search_by_bow_kf_kf(int device, const uint8_t *desc1, const float *angle
                             const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
                             float nnratio, int check_orientation, int32_t *matches12);
 
+/* int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vMatchedPairs, bOnlyStereo, bCoarse)
+ * (ORBmatcher.h:72, ORBmatcher.cc:902-1146), NLeft == -1.  eligible1[i] = !pKF1->GetMapPoint(i) && (!bOnlyStereo ||
+ * stereo(i)) (:969-979), eligible2 likewise (:998-1005; the reference never sets vbMatched2).  The geometric
+ * predicate of :1031-1071 (epipole distance gate, then bCoarse || epipolarConstrain) is a pure function of the pair
+ * and stays with the adaptor: for the s-th SHARED vocabulary node (ascending node id = merge-join order), bit
+ * pair_off[s] + i1 * n2(s) + i2 of pair_ok says whether (node list position i1 of KF1, i2 of KF2) passes;
+ * pair_off has (shared nodes + 1) entries; pair_ok == NULL means every pair passes.  Among the passing candidates
+ * with dist <= TH_LOW the smallest distance wins, the LATER one on ties (`dist > bestDist` skips, :1015).
+ * matches12[idx1] = idx2 or -1 (vMatchedPairs = the non-negative entries in index order).  Returns nmatches after
+ * the rotation-histogram filter. */
+int vsg_search_for_triangulation(int device, const uint8_t *desc1, const float *angle1, const uint8_t *eligible1,
+                                 int n1, const int32_t *node_id1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                                 const uint8_t *desc2, const float *angle2, const uint8_t *eligible2, int n2,
+                                 const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                                 const uint32_t *pair_ok, const int32_t *pair_off, int check_orientation,
+                                 int32_t *matches12);
+
 /* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
  * (ORBmatcher.h:50, ORBmatcher.cc:1667-1878), Nleft == -1.  The adaptor projects the map points and
  * runs Frame::GetFeaturesInArea; query q brings its descriptor, keypoint angle and candidate list

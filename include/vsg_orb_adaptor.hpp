@@ -11,6 +11,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "vsg_orb.h"
@@ -255,6 +256,48 @@ class ORBmatcher {
                                      fv2.node.data(), fv2.off.data(), fv2.idx.data(), fv2.nodes(), mfNNratio,
                                      mbCheckOrientation, matches12.data());
     check(rc, "vsg_search_by_bow_kf_kf");
+    return rc;
+  }
+
+  // SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vMatchedPairs, bOnlyStereo, bCoarse)  (ORBmatcher.cc:902-1146)
+  // eligible = no MapPoint yet (and stereo when bOnlyStereo).  pairOk(i1, i2, idx1, idx2) is the caller's geometric
+  // predicate (:1031-1071: epipole gate, then bCoarse || epipolarConstrain); it is evaluated here for every pair of
+  // every shared node and shipped as a bitmask.  Pass nullptr for "every pair passes".
+  template <class Pred>
+  int SearchForTriangulation(const FeatureView &kf1, const uint8_t *eligible1, const FeatureVectorCSR &fv1,
+                             const FeatureView &kf2, const uint8_t *eligible2, const FeatureVectorCSR &fv2, Pred pairOk,
+                             std::vector<std::pair<size_t, size_t>> &vMatchedPairs) const {
+    std::vector<uint32_t> bits(1, 0u);
+    std::vector<int32_t> off(1, 0);
+    size_t a = 0, b = 0;
+    while (a < fv1.node.size() && b < fv2.node.size()) {  // the reference's merge-join, shared nodes in id order
+      if (fv1.node[a] == fv2.node[b]) {
+        for (int i1 = fv1.off[a]; i1 < fv1.off[a + 1]; i1++)
+          for (int i2 = fv2.off[b]; i2 < fv2.off[b + 1]; i2++) {
+            const long long bit = (long long)off.back() + (long long)(i1 - fv1.off[a]) * (fv2.off[b + 1] - fv2.off[b]) +
+                                  (i2 - fv2.off[b]);
+            if ((size_t)(bit >> 5) >= bits.size()) bits.resize((size_t)(bit >> 5) + 64, 0u);
+            if (eligible1[fv1.idx[i1]] && eligible2[fv2.idx[i2]] && pairOk(fv1.idx[i1], fv2.idx[i2]))
+              bits[bit >> 5] |= 1u << (bit & 31);
+          }
+        off.push_back(off.back() + (fv1.off[a + 1] - fv1.off[a]) * (fv2.off[b + 1] - fv2.off[b]));
+        a++, b++;
+      } else if (fv1.node[a] < fv2.node[b]) {
+        a++;
+      } else {
+        b++;
+      }
+    }
+    bits.resize((size_t)(off.back() >> 5) + 2, 0u);
+    std::vector<int32_t> m12(kf1.n > 0 ? kf1.n : 1, -1);
+    int rc = vsg_search_for_triangulation(device_, kf1.desc, kf1.angle, eligible1, kf1.n, fv1.node.data(), fv1.off.data(),
+                                          fv1.idx.data(), fv1.nodes(), kf2.desc, kf2.angle, eligible2, kf2.n,
+                                          fv2.node.data(), fv2.off.data(), fv2.idx.data(), fv2.nodes(), bits.data(),
+                                          off.data(), mbCheckOrientation, m12.data());
+    check(rc, "vsg_search_for_triangulation");
+    vMatchedPairs.clear();
+    for (int i = 0; i < kf1.n; i++)
+      if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);  // :1136-1143
     return rc;
   }
 

@@ -269,6 +269,73 @@ int or_search_by_bow_kf_kf(const uint8_t *desc1, const float *angle1, const uint
   return nmatches;
 }
 
+int or_search_for_triangulation(const uint8_t *desc1, const float *angle1, const uint8_t *eligible1, int n1,
+                                const int *nodeId1, const int *off1, const int *idx1v, int nodes1,
+                                const uint8_t *desc2, const float *angle2, const uint8_t *eligible2, int n2,
+                                const int *nodeId2, const int *off2, const int *idx2v, int nodes2,
+                                const uint32_t *pairOk, const int *pairOff, int checkOri, int *matches12) {
+  // ORBmatcher.cc:902-1146 with NLeft == -1.  eligible1 = !GetMapPoint(idx1) && (!bOnlyStereo || bStereo1)
+  // (:969-979), eligible2 = !GetMapPoint(idx2) && (!bOnlyStereo || bStereo2) (:998-1005; vbMatched2 is never set by
+  // the reference).  The geometric predicate of (:1031-1071) -- epipole distance, epipolarConstrain or bCoarse -- is a
+  // pure function of (idx1, idx2): bit pairOff[s] + i1 * n2(s) + i2 of pairOk for the s-th SHARED node (NULL: true).
+  (void)n2;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nmatches = 0, shared = 0;
+  int f1it = 0, f2it = 0;
+  while (f1it != nodes1 && f2it != nodes2) {
+    if (nodeId1[f1it] == nodeId2[f2it]) {
+      const int nn2 = off2[f2it + 1] - off2[f2it];
+      for (int i1 = off1[f1it]; i1 < off1[f1it + 1]; i1++) {
+        const int idx1 = idx1v[i1];
+        if (!eligible1[idx1]) continue;
+        const uint8_t *d1 = desc1 + (size_t)idx1 * 32;
+        int bestDist = TH_LOW;
+        int bestIdx2 = -1;
+        for (int i2 = off2[f2it]; i2 < off2[f2it + 1]; i2++) {
+          const int idx2 = idx2v[i2];
+          if (!eligible2[idx2]) continue;
+          const int dist = DescriptorDistance(d1, desc2 + (size_t)idx2 * 32);
+          if (dist > TH_LOW || dist > bestDist) continue;
+          bool ok = true;
+          if (pairOk) {
+            const long long bit = (long long)pairOff[shared] + (long long)(i1 - off1[f1it]) * nn2 + (i2 - off2[f2it]);
+            ok = (pairOk[bit >> 5] >> (bit & 31)) & 1u;
+          }
+          if (ok) {
+            bestIdx2 = idx2;
+            bestDist = dist;
+          }
+        }
+        if (bestIdx2 >= 0) {
+          matches12[idx1] = bestIdx2;
+          nmatches++;
+          if (checkOri) rotHist[rotBin(angle1[idx1], angle2[bestIdx2])].push_back(idx1);
+        }
+      }
+      shared++;
+      f1it++;
+      f2it++;
+    } else if (nodeId1[f1it] < nodeId2[f2it]) {
+      f1it = lowerBound(nodeId1, nodes1, nodeId2[f2it]);
+    } else {
+      f2it = lowerBound(nodeId2, nodes2, nodeId1[f1it]);
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    ComputeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        matches12[rotHist[i][j]] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
 int or_search_by_projection_last(const uint8_t *qDesc, const float *qAngle, const uint8_t *queryBlocks, int nQ,
                                  const int *candOff, const int *candIdx, const uint8_t *tDesc, const float *tAngle,
                                  uint8_t *trainBlocked, int nT, int thHigh, int checkOri, int *trainMatch) {

@@ -144,6 +144,15 @@ int or_search_by_bow_kf_kf(const uint8_t *desc1, const float *angle1, const uint
                            const float *angle2, const uint8_t *valid2, int n2, const int *nodeId2, const int *off2,
                            const int *idx2, int nodes2, float nnratio, int checkOri, int *matches12);
 
+/* SearchForTriangulation(KeyFrame*, KeyFrame*, vMatchedPairs, bOnlyStereo, bCoarse) (ORBmatcher.cc:902-1146),
+ * NLeft == -1.  eligible = no MapPoint yet (and stereo when bOnlyStereo); pairOk/pairOff = the geometric predicate of
+ * :1031-1071 for every pair of every shared node (NULL = always true, i.e. bCoarse without the epipole gate). */
+int or_search_for_triangulation(const uint8_t *desc1, const float *angle1, const uint8_t *eligible1, int n1,
+                                const int *nodeId1, const int *off1, const int *idx1, int nodes1, const uint8_t *desc2,
+                                const float *angle2, const uint8_t *eligible2, int n2, const int *nodeId2,
+                                const int *off2, const int *idx2, int nodes2, const uint32_t *pairOk,
+                                const int *pairOff, int checkOri, int *matches12);
+
 /* SearchByProjection(Frame &Cur, const Frame &Last, th, bMono) (ORBmatcher.cc:1667-1878),
  * Nleft == -1, with the geometry (projection, GetFeaturesInArea, mvuRight gate)
  * done by the caller: query q has candidate list cand[candOff[q]..candOff[q+1]).

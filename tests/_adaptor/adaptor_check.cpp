@@ -74,10 +74,20 @@ int main(int argc, char **argv) {
     std::vector<int32_t> init12;
     int ninit = matcher.SearchForInitialization(q, cand, tr, init12);
 
+    // SearchForTriangulation with an arbitrary pure pair predicate standing in for the epipolar test
+    std::vector<uint8_t> elig0(q.n, 1), elig1(tr.n, 1);
+    for (int i = 0; i < q.n; i += 5) elig0[i] = 0;
+    for (int i = 0; i < tr.n; i += 9) elig1[i] = 0;
+    std::vector<std::pair<size_t, size_t>> tri;
+    int ntri = matcher.SearchForTriangulation(q, elig0.data(), fv0, tr, elig1.data(), fv[1],
+                                              [](int i1, int i2) { return (i1 * 7 + i2 * 3) % 5 != 0; }, tri);
+    std::vector<int32_t> tri_flat;
+    for (auto &pr : tri) tri_flat.push_back((int32_t)pr.first), tri_flat.push_back((int32_t)pr.second);
+
     const int d01 = vsg::ORBmatcher::DescriptorDistance(desc[0].data(), desc[1].data());
 
     std::ofstream f(argv[2], std::ios::binary);
-    std::vector<int32_t> head{mono[0], mono[1], nwin, nbow, ninit, d01};
+    std::vector<int32_t> head{mono[0], mono[1], nwin, nbow, ninit, d01, ntri};
     dump(f, head);
     for (int t = 0; t < 2; ++t) dump(f, kps[t]), dump(f, desc[t]);
     dump(f, cand.off), dump(f, cand.idx), dump(f, bestIdx), dump(f, bestDist), dump(f, trainMatch), dump(f, matchF);
@@ -86,6 +96,7 @@ int main(int argc, char **argv) {
     std::vector<double> bow_vals;
     for (auto &kv : bow[1]) bow_ids.push_back((int32_t)kv.first), bow_vals.push_back(kv.second);
     dump(f, bow_ids), dump(f, bow_vals);
+    dump(f, tri_flat);
     printf("OK %zu %zu win=%d bow=%d init=%d\n", kps[0].size(), kps[1].size(), nwin, nbow, ninit);
     return 0;
   } catch (const std::exception &e) {

@@ -77,6 +77,9 @@ def lib():
         L.or_search_by_bow_kf_kf.argtypes = [_u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
                                              _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
                                              C.c_float, C.c_int, _i32p]
+        L.or_search_for_triangulation.argtypes = [_u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                                  _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_int, _i32p]
         L.or_search_by_projection_last.argtypes = [_u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _u8p, _f32p, _u8p,
                                                    C.c_int, C.c_int, C.c_int, _i32p]
         L.or_search_by_projection_local.argtypes = [_u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _i32p, _u8p,
@@ -322,6 +325,24 @@ def search_by_bow_kf_kf(d1, a1, v1, fv1, d2, a2, v2, fv2, nnratio, check_ori):
                                      _ptr(v2, _u8p), len(d2), _ptr(n2, _i32p), _ptr(o2, _i32p), _ptr(i2, _i32p),
                                      len(n2), float(nnratio), int(check_ori), _ptr(out, _i32p))
     return n, out
+
+
+def search_for_triangulation(d1, a1, e1, fv1, d2, a2, e2, fv2, pair_ok, pair_off, check_ori):
+    """pair_ok: uint32 bit array (or None = every pair passes), pair_off: int32 per shared node + 1."""
+    d1, d2 = _u8c(d1), _u8c(d2)
+    a1, a2 = _f32c(a1), _f32c(a2)
+    e1, e2 = _u8c(e1), _u8c(e2)
+    n1, o1, i1 = (_i32c(a) for a in fv1)
+    n2, o2, i2 = (_i32c(a) for a in fv2)
+    out = np.zeros(max(len(d1), 1), np.int32)
+    ok = np.ascontiguousarray(pair_ok, np.uint32) if pair_ok is not None else None
+    po = _i32c(pair_off) if pair_ok is not None else None
+    n = lib().or_search_for_triangulation(_ptr(d1, _u8p), _ptr(a1, _f32p), _ptr(e1, _u8p), len(d1), _ptr(n1, _i32p),
+                                          _ptr(o1, _i32p), _ptr(i1, _i32p), len(n1), _ptr(d2, _u8p), _ptr(a2, _f32p),
+                                          _ptr(e2, _u8p), len(d2), _ptr(n2, _i32p), _ptr(o2, _i32p), _ptr(i2, _i32p),
+                                          len(n2), ok.ctypes.data if ok is not None else None,
+                                          po.ctypes.data if po is not None else None, int(check_ori), _ptr(out, _i32p))
+    return n, out[:len(d1)]
 
 
 def search_by_projection_last(q_desc, q_angle, q_blocks, cand_off, cand_idx, t_desc, t_angle, t_blocked, th_high,

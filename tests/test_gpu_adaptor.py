@@ -32,6 +32,7 @@ def _read(path):
     for k in ("cand_off", "cand_idx", "best_idx", "best_dist", "train_match", "match_f", "init12", "bow_ids"):
         out[k] = take(np.int32)
     out["bow_vals"] = take(np.float64)
+    out["tri"] = take(np.int32).reshape(-1, 2)
     assert pos == len(raw)
     return out
 
@@ -84,6 +85,28 @@ def test_cpp_adaptor_end_to_end_equals_oracle(tmp_path):
     nb, mf = ol.search_by_bow_kf_f(d0, k0["angle"], valid, t0["fv"], d1, k1["angle"], t1["fv"], 0.7, True)
     assert int(got["head"][3]) == nb > 50
     assert np.array_equal(got["match_f"], mf)
+
+    # SearchForTriangulation through the adaptor's predicate-to-bitmask glue
+    e0, e1 = np.ones(len(d0), np.uint8), np.ones(len(d1), np.uint8)
+    e0[::5] = 0
+    e1[::9] = 0
+    ids0, off0, idx0 = t0["fv"]
+    ids1, off1, idx1 = t1["fv"]
+    pair_off, bits = [0], []
+    for s_ in np.intersect1d(ids0, ids1):
+        a, b = int(np.searchsorted(ids0, s_)), int(np.searchsorted(ids1, s_))
+        for i1 in idx0[off0[a]:off0[a + 1]]:
+            for i2 in idx1[off1[b]:off1[b + 1]]:
+                bits.append(bool(e0[i1] and e1[i2] and (int(i1) * 7 + int(i2) * 3) % 5 != 0))
+        pair_off.append(len(bits))
+    words = np.zeros(len(bits) // 32 + 2, np.uint32)
+    for i in np.nonzero(bits)[0]:
+        words[i >> 5] |= np.uint32(1 << (i & 31))
+    nt, m12 = ol.search_for_triangulation(d0, k0["angle"], e0, t0["fv"], d1, k1["angle"], e1, t1["fv"], words,
+                                          np.array(pair_off, np.int32), True)
+    assert int(got["head"][6]) == nt > 20
+    want_pairs = np.array([(i, m12[i]) for i in range(len(m12)) if m12[i] >= 0], np.int32).reshape(-1, 2)
+    assert np.array_equal(got["tri"], want_pairs)
 
     # SearchForInitialization + DescriptorDistance
     ni, m12 = ol.search_for_initialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"], 0.7, True)

@@ -285,3 +285,56 @@ def test_distinctive_descriptors(frames):
     want = ol.distinctive_descriptors(desc, off)
     assert np.array_equal(got, want)
     assert want[5] == -1
+
+
+def shared_pair_bits(fv1, fv2, rng, p_ok):
+    """Random geometric-predicate bits for every pair of every SHARED node, in the layout of
+    vsg_search_for_triangulation: pair_off[s] + i1 * n2(s) + i2."""
+    ids1, off1, _ = fv1
+    ids2, off2, _ = fv2
+    shared = np.intersect1d(ids1, ids2)
+    pair_off = [0]
+    for s in shared:
+        a, b = int(np.searchsorted(ids1, s)), int(np.searchsorted(ids2, s))
+        pair_off.append(pair_off[-1] + int(off1[a + 1] - off1[a]) * int(off2[b + 1] - off2[b]))
+    nbits = pair_off[-1]
+    bits = rng.random(max(nbits, 1)) < p_ok
+    words = np.zeros((nbits + 31) // 32 + 1, np.uint32)
+    for i in np.nonzero(bits[:nbits])[0]:
+        words[i >> 5] |= np.uint32(1 << (i & 31))
+    return words, np.array(pair_off, np.int32)
+
+
+@pytest.mark.parametrize("seed,n_nodes,p_ok,ori", [(0, 40, 0.7, True), (1, 5, 0.3, True), (2, 200, 1.0, False),
+                                                   (3, 60, None, True)])
+def test_search_for_triangulation(frames, seed, n_nodes, p_ok, ori):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:902-1146): predicate bits from the adaptor, dist <= TH_LOW,
+    LAST minimum wins -- the duplicated descriptors make equal distances common."""
+    (k0, d0), _ = frames
+    rng = np.random.default_rng(300 + seed)
+    perm = rng.permutation(len(d0))
+    d2 = near_duplicates(d0[perm], rng, 4)
+    d2[::3] = d2[1::3][:len(d2[::3])]  # exact duplicates inside KF2: ties on the distance
+    a2 = k0["angle"][perm]
+    e1 = (rng.random(len(d0)) > 0.2).astype(np.uint8)
+    e2 = (rng.random(len(d2)) > 0.2).astype(np.uint8)
+    # a feature and its near-duplicate land in the same vocabulary node (as similar descriptors do)
+    node1 = rng.integers(0, n_nodes, len(d0)) * 7 + 3
+
+    def fv_of(node):
+        ids = np.unique(node)
+        off_, idx_ = [0], []
+        for i in ids:
+            idx_ += np.nonzero(node == i)[0].tolist()
+            off_.append(len(idx_))
+        return ids.astype(np.int32), np.array(off_, np.int32), np.array(idx_, np.int32)
+    fv1, fv2 = fv_of(node1), fv_of(node1[perm])
+    ok, off = shared_pair_bits(fv1, fv2, rng, p_ok) if p_ok is not None else (None, None)
+    m = orb.ORBmatcher(0.6, ori)
+    n_got, got = m.SearchForTriangulation(d0, k0["angle"], e1, fv1, d2, a2, e2, fv2, ok, off)
+    n_want, want = ol.search_for_triangulation(d0, k0["angle"], e1, fv1, d2, a2, e2, fv2, ok, off, ori)
+    assert n_got == n_want and np.array_equal(got, want)
+    assert n_want > 20
+    # matches only between eligible features of the same node, inside TH_LOW, with the predicate bit set
+    for i1 in np.nonzero(want >= 0)[0][:50]:
+        assert e1[i1] and e2[want[i1]] and ol.descriptor_distance(d0[i1], d2[want[i1]]) <= 50

@@ -441,3 +441,24 @@ def test_grid_query_matches_bruteforce_filter():
             if hi >= 0:
                 m &= kps["octave"] <= hi
         assert sorted(got.tolist()) == np.nonzero(m)[0].tolist()
+
+
+def test_search_for_triangulation_last_minimum_and_predicate():
+    """ORBmatcher.cc:1015 `dist > bestDist -> continue` lets a LATER equal distance win; the geometric predicate is
+    consulted only through the pair bits; dist > TH_LOW never matches."""
+    d1 = np.zeros((1, 32), np.uint8)
+    d2 = np.zeros((4, 32), np.uint8)
+    d2[1, 0] = 1          # distances 0, 1, 0, 64
+    d2[3, :8] = 0xFF
+    fv1 = (np.array([5], np.int32), np.array([0, 1], np.int32), np.array([0], np.int32))
+    fv2 = (np.array([5], np.int32), np.array([0, 4], np.int32), np.array([0, 1, 2, 3], np.int32))
+    a1, a2 = np.zeros(1, np.float32), np.zeros(4, np.float32)
+    off = np.array([0, 4], np.int32)
+    run = lambda bits, e2=(1, 1, 1, 1): ol.search_for_triangulation(
+        d1, a1, [1], fv1, d2, a2, list(e2), fv2, None if bits is None else np.array([bits], np.uint32), off, False)
+    assert run(None)[1].tolist() == [2]           # last of the two zero distances
+    assert run(0b1011)[1].tolist() == [0]         # pair (0,2) fails the predicate
+    assert run(0b1010)[1].tolist() == [1]         # only the dist-1 candidate passes
+    assert run(0b1000)[1].tolist() == [-1]        # the only passing pair is beyond TH_LOW
+    assert run(None, (1, 1, 0, 1))[1].tolist() == [0]  # KF2 feature 2 already has a MapPoint
+    assert ol.search_for_triangulation(d1, a1, [0], fv1, d2, a2, [1, 1, 1, 1], fv2, None, None, False)[0] == 0

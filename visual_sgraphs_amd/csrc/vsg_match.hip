@@ -334,6 +334,45 @@ __global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, in
   }
 }
 
+// ---- SearchForTriangulation (ORBmatcher.cc:902-1146): one wavefront per shared vocabulary node.  For every eligible
+// KF1 feature of the node: best KF2 feature of the node with dist <= TH_LOW whose (idx1, idx2) pair passes the
+// caller's geometric predicate bit; the reference's `dist > bestDist -> continue` lets a LATER equal distance win, so
+// keys are (dist << 20 | 0xFFFFF - position) and the wave takes their minimum.  No greedy state (vbMatched2 is never
+// set by the reference), so nodes and features are independent.
+__global__ __launch_bounds__(256) void k_search_triangulation(const NodePair *pairs, int npairs, const uint8_t *descA,
+                                                              const uint8_t *eligA, const int *idxA,
+                                                              const uint8_t *descB, const uint8_t *eligB,
+                                                              const int *idxB, const uint32_t *pairOk,
+                                                              const int *pairOff, int *matches12) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= npairs) return;
+  const NodePair np = pairs[wave];
+  const int nb = np.b_end - np.b_begin;
+  const long long bit0 = pairOk ? (long long)pairOff[wave] : 0;
+  for (int ia = np.a_begin; ia < np.a_end; ia++) {
+    const int ra = idxA[ia];
+    if (!eligA[ra]) continue;
+    uint4 a0, a1;
+    load_desc(descA, ra, a0, a1);
+    uint32_t k = KEY_NONE;
+    for (int j = lane; j < nb; j += 64) {
+      const int rb = idxB[np.b_begin + j];
+      if (!eligB[rb]) continue;
+      if (pairOk) {
+        const long long bit = bit0 + (long long)(ia - np.a_begin) * nb + j;
+        if (!((pairOk[bit >> 5] >> (bit & 31)) & 1u)) continue;
+      }
+      uint4 b0, b1;
+      load_desc(descB, rb, b0, b1);
+      const int dist = hamming256(a0, a1, b0, b1);
+      if (dist > TH_LOW) continue;
+      k = min(k, ((uint32_t)dist << 20) | (0xFFFFFu - (uint32_t)j));
+    }
+    k = wave_min(k);
+    if (lane == 0 && k != KEY_NONE) matches12[ra] = idxB[np.b_begin + (int)(0xFFFFFu - (k & 0xFFFFFu))];
+  }
+}
+
 // ---- windowed searches: one wavefront walks the queries in order (greedy state), lanes over candidates.
 // mode 0: SearchByProjection(Cur, Last)   (:1686-1784)  best only, accept <= thHigh, events for the rot. histogram
 // mode 1: SearchByProjection(F, MapPoints)(:48-144)     best+second with octave-aware ratio test
@@ -691,6 +730,62 @@ static int search_by_bow(int device, int mode, const uint8_t *descA, const float
       if (i == ind1 || i == ind2 || i == ind3) continue;
       for (size_t j = 0; j < rotHist[i].size(); j++) {
         out[rotHist[i][j]] = -1;
+        nmatches--;
+      }
+    }
+  }
+  return nmatches;
+}
+
+int vsg_search_for_triangulation(int device, const uint8_t *desc1, const float *angle1, const uint8_t *eligible1,
+                                 int n1, const int32_t *node_id1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                                 const uint8_t *desc2, const float *angle2, const uint8_t *eligible2, int n2,
+                                 const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                                 const uint32_t *pair_ok, const int32_t *pair_off, int check_orientation,
+                                 int32_t *matches12) {
+  if (!matches12 || n1 < 0 || n2 < 0 || (pair_ok && !pair_off)) return VSG_ERR_INVALID;
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  std::vector<NodePair> pairs;
+  join_nodes(node_id1, off1, nodes1, node_id2, off2, nodes2, pairs);
+  if (pairs.empty() || n1 == 0 || n2 == 0) return 0;
+  const int npairs = (int)pairs.size();
+  DevBuf dPairs, dD1, dE1, dI1, dD2, dE2, dI2, dOk, dOff, dM;
+  M_TRY(dPairs.upload(pairs.data(), pairs.size() * sizeof(NodePair)));
+  M_TRY(dD1.upload(desc1, (size_t)n1 * 32));
+  M_TRY(dE1.upload(eligible1, (size_t)n1));
+  M_TRY(dI1.upload(idx1, (size_t)off1[nodes1] * 4));
+  M_TRY(dD2.upload(desc2, (size_t)n2 * 32));
+  M_TRY(dE2.upload(eligible2, (size_t)n2));
+  M_TRY(dI2.upload(idx2, (size_t)off2[nodes2] * 4));
+  if (pair_ok) {
+    // bits of shared node s start at pair_off[s]; the last node ends at pair_off[npairs]
+    const long long nbits = pair_off[npairs];
+    M_TRY(dOk.upload(pair_ok, (size_t)((nbits + 31) / 32 + 1) * 4));
+    M_TRY(dOff.upload(pair_off, (size_t)(npairs + 1) * 4));
+  }
+  M_TRY(dM.alloc((size_t)n1 * 4));
+  M_TRY(hipMemset(dM.p, 0xFF, (size_t)n1 * 4));
+  hipLaunchKernelGGL(k_search_triangulation, dim3((npairs + 3) / 4), dim3(256), 0, 0, dPairs.as<NodePair>(), npairs,
+                     dD1.as<uint8_t>(), dE1.as<uint8_t>(), dI1.as<int>(), dD2.as<uint8_t>(), dE2.as<uint8_t>(),
+                     dI2.as<int>(), pair_ok ? dOk.as<uint32_t>() : (const uint32_t *)nullptr,
+                     pair_ok ? dOff.as<int>() : (const int *)nullptr, dM.as<int>());
+  M_TRY(hipMemcpy(matches12, dM.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < n1; i++) {
+    if (matches12[i] < 0) continue;
+    nmatches++;
+    if (check_orientation) rotHist[rot_bin(angle1[i], angle2[matches12[i]])].push_back(i);
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) {
+        matches12[rotHist[i][j]] = -1;
         nmatches--;
       }
     }

@@ -41,6 +41,7 @@ EXPORTS = [
     "vsg_grid_destroy", "vsg_grid_query", "vsg_stereo_matches", "vsg_orb_set_gray_coeffs",
     "vsg_orb_extract_batch_device_color", "vsg_orb_extract_batch_color", "vsg_vocab_load", "vsg_vocab_destroy",
     "vsg_vocab_info", "vsg_bow_transform", "vsg_distinctive_descriptors", "vsg_debug_device_sort",
+    "vsg_search_for_triangulation",
 ]
 
 
@@ -103,6 +104,9 @@ def load_library():
     L.vsg_search_by_bow_kf_kf.argtypes = [C.c_int, _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
                                           _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_float,
                                           C.c_int, _i32p]
+    L.vsg_search_for_triangulation.argtypes = [C.c_int, _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                               _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_int, _i32p]
     L.vsg_search_by_projection_last.argtypes = [C.c_int, _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _u8p, _f32p, _u8p,
                                                 C.c_int, C.c_int, C.c_int, _i32p]
     L.vsg_search_by_projection_local.argtypes = [C.c_int, _u8p, _u8p, C.c_int, _i32p, _i32p, _u8p, _i32p, _u8p,
@@ -432,6 +436,25 @@ class ORBmatcher:
                                                    _p(o2, _i32p), _p(i2, _i32p), len(fv2[0]), self.mfNNratio,
                                                    int(self.mbCheckOrientation), _p(out, _i32p)),
                    "vsg_search_by_bow_kf_kf")
+        return n, out[:len(d1)]
+
+    def SearchForTriangulation(self, d1, a1, eligible1, fv1, d2, a2, eligible2, fv2, pair_ok=None, pair_off=None):
+        """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:902-1146) on flattened views; pair_ok / pair_off carry
+        the adaptor-evaluated geometric predicate per pair of every shared node (see include/vsg_orb.h).
+        Returns (nmatches, matches12)."""
+        d1, d2 = _u8(d1).reshape(-1, 32), _u8(d2).reshape(-1, 32)
+        a1, a2, e1, e2 = _f32(a1), _f32(a2), _u8(eligible1), _u8(eligible2)
+        n1, o1, i1 = (_i32(x) for x in fv1)
+        n2, o2, i2 = (_i32(x) for x in fv2)
+        ok = np.ascontiguousarray(pair_ok, np.uint32) if pair_ok is not None else None
+        po = _i32(pair_off) if pair_ok is not None else None
+        out = np.full(max(len(d1), 1), -1, np.int32)
+        n = _check(self._L.vsg_search_for_triangulation(
+            self.device, _p(d1, _u8p), _p(a1, _f32p), _p(e1, _u8p), len(d1), _p(n1, _i32p), _p(o1, _i32p),
+            _p(i1, _i32p), len(fv1[0]), _p(d2, _u8p), _p(a2, _f32p), _p(e2, _u8p), len(d2), _p(n2, _i32p),
+            _p(o2, _i32p), _p(i2, _i32p), len(fv2[0]), ok.ctypes.data if ok is not None else None,
+            po.ctypes.data if po is not None else None, int(self.mbCheckOrientation), _p(out, _i32p)),
+            "vsg_search_for_triangulation")
         return n, out[:len(d1)]
 
     def SearchByProjection_Last(self, q_desc, q_angle, q_blocks, cand_off, cand_idx, t_desc, t_angle, t_blocked,
