@@ -96,13 +96,18 @@ void hc_std_sort(uint64_t *items, int n) {
   std::sort(items, items + n, [](uint64_t a, uint64_t b) { return (uint32_t)(a >> 32) < (uint32_t)(b >> 32); });
 }
 // the split the device uses: serial partition phase, then a stable rank of what it left
-void hc_sort_split(uint64_t *items, int n) {
+void hc_sort_depth(uint64_t *items, int n, int depth) { introsort::sort(items, n, depth); }
+void hc_sort_split_depth(uint64_t *items, int n, int depth);
+void hc_sort_split(uint64_t *items, int n) { hc_sort_split_depth(items, n, -1); }
+void hc_sort_split_depth(uint64_t *items, int n, int depth) {
   if (n <= 0) return;
-  introsort::partition_phase(items, n);
+  introsort::partition_phase(items, n, depth);
   std::vector<uint64_t> tmp(items, items + n);
   for (int t = 0; t < n; t++) {
-    int rank = 0;
-    for (int j = 0; j < n; j++) {
+    // windowed stable rank, exactly as vsg_octree_core.h computes it
+    const int lo = t > 15 ? t - 15 : 0, hi = t + 15 < n - 1 ? t + 15 : n - 1;
+    int rank = lo;
+    for (int j = lo; j <= hi; j++) {
       const uint32_t kj = (uint32_t)(tmp[j] >> 32), kt = (uint32_t)(tmp[t] >> 32);
       rank += (kj < kt) | ((kj == kt) & (j < t));
     }

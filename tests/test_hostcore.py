@@ -152,6 +152,24 @@ def test_introsort_and_its_device_split_equal_std_sort(hc):
         assert np.array_equal(a, c), (trial, n, nkeys)
 
 
+def test_split_sort_with_forced_heapsort_fallback(hc):
+    """A tiny depth limit sends large ranges to the heapsort branch of introsort; the windowed stable rank that
+    follows the partition phase must still reproduce the serial replay (same depth limit) exactly."""
+    rng = np.random.default_rng(2)
+    p64 = C.POINTER(C.c_uint64)
+    hc.hc_sort_depth.argtypes = [p64, C.c_int, C.c_int]
+    hc.hc_sort_split_depth.argtypes = [p64, C.c_int, C.c_int]
+    for trial in range(200):
+        n = int(rng.integers(17, 500))
+        keys = rng.integers(0, int(rng.choice([2, 5, 1000])), n).astype(np.uint64)
+        items = (keys << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+        for depth in (0, 1, 2):
+            a, b = items.copy(), items.copy()
+            hc.hc_sort_depth(a.ctypes.data_as(p64), n, depth)
+            hc.hc_sort_split_depth(b.ctypes.data_as(p64), n, depth)
+            assert np.array_equal(a, b), (trial, n, depth)
+
+
 def test_float_helpers_match_oracle_and_libm(hc):
     rng = np.random.default_rng(2)
     for _ in range(5000):

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
 
 // ------------------------------------------------------------------------------------------------
 // Workgroup implementation of the octree Group concept.
-enum { kSortStack = 24 };  // >= 2 * lg(n) + 1 pending ranges for n < 2048
+enum { kSortStack = 24, kMaxWaves = 16 };  // kMaxWaves: wavefronts per workgroup the block scans support  // >= 2 * lg(n) + 1 pending ranges for n < 2048
 
 struct BlockGroup {
   int tid, nthreads;
@@ -438,18 +438,24 @@ struct BlockGroup {
   __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
   __device__ void atomic_max(uint32_t *p, uint32_t v) { atomicMax(p, v); }
   __device__ void atomic_min(int *p, int v) { atomicMin(p, v); }
+  // inclusive wave scan on the DPP path (no LDS round trips): Hillis-Steele inside each 16-lane row with zero-filled
+  // row shifts, then lane 15 / lane 31 broadcasts carry the row totals across rows
+  static __device__ __forceinline__ int wave_inclusive_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+  }
   __device__ int exclusive_scan(int *a, int n) {
     const int per = (n + nthreads - 1) / nthreads;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
     int s = 0;
     for (int i = lo; i < hi; i++) s += a[i];
     const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
-    int incl = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(incl, d);
-      if (lane >= d) incl += t;
-    }
+    const int incl = wave_inclusive_scan(s);
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
     int base = 0, total = 0;
@@ -466,6 +472,32 @@ struct BlockGroup {
     }
     __syncthreads();
     return total;
+  }
+  // the same over two arrays at once (one pair of barriers); returns total of a, *total_b = total of b
+  __device__ int exclusive_scan2(int *a, int *b, int n, int *total_b) {
+    const int per = (n + nthreads - 1) / nthreads;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int sa = 0, sb = 0;
+    for (int i = lo; i < hi; i++) sa += a[i], sb += b[i];
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int ia = wave_inclusive_scan(sa), ib = wave_inclusive_scan(sb);
+    if (lane == 63) wtot[wave] = ia, wtot[kMaxWaves + wave] = ib;
+    __syncthreads();
+    int basea = 0, ta = 0, baseb = 0, tb = 0;
+    for (int w = 0; w < nwaves; w++) {
+      const int x = wtot[w], y = wtot[kMaxWaves + w];
+      if (w < wave) basea += x, baseb += y;
+      ta += x, tb += y;
+    }
+    int ra = basea + ia - sa, rb = baseb + ib - sb;
+    for (int i = lo; i < hi; i++) {
+      const int va = a[i], vb = b[i];
+      a[i] = ra, b[i] = rb;
+      ra += va, rb += vb;
+    }
+    __syncthreads();
+    *total_b = tb;
+    return ta;
   }
 
   // introsort::partition_phase replayed by the 64 lanes of wave 0 with the SAME resulting array (bit for bit).
@@ -545,11 +577,12 @@ constexpr int kOctRegPts = VSG_OCT_K;  // candidates per thread held in register
 #endif
 constexpr int kOctThreads = VSG_OCT_NT;  // threads per (frame, level) octree
 
-__global__ __launch_bounds__(kOctThreads) void k_octree(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ cand,
+// 4 waves per SIMD = 4 octrees per CU: the kernel is latency-bound, so residency is worth more than registers
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ cand,
                                                 const int *__restrict__ cand_count, uint16_t *__restrict__ node_of,
                                                 uint32_t *__restrict__ sel, int *__restrict__ sel_count, int cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
-  __shared__ int wtot[8];
+  __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[3 * kSortStack];
   const int level = blockIdx.x, frame = blockIdx.y;
   const LevelGeom &L = fg->lv[level];
@@ -584,7 +617,7 @@ __global__ __launch_bounds__(kOctThreads) void k_octree(const FrameGeom *__restr
 // on arbitrary items, so that tests can compare it with the real std::sort directly.
 __global__ __launch_bounds__(256) void k_debug_sort(uint64_t *items, int n) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dbg_lds[];
-  __shared__ int wtot[8];
+  __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[3 * kSortStack];
   introsort::item_t *buf = (introsort::item_t *)dbg_lds;
   uint16_t *posA = (uint16_t *)(buf + n), *posB = posA + n + 2;
@@ -600,8 +633,9 @@ __global__ __launch_bounds__(256) void k_debug_sort(uint64_t *items, int n) {
   for (int t = g.tid; t < n; t += g.nthreads) {
     const introsort::item_t it = buf[t];
     const uint32_t key = (uint32_t)(it >> 32);
-    int rank = 0;
-    for (int j = 0; j < n; j++) {
+    const int lo = t > 15 ? t - 15 : 0, hi = t + 15 < n - 1 ? t + 15 : n - 1;
+    int rank = lo;
+    for (int j = lo; j <= hi; j++) {
       const uint32_t kj = (uint32_t)(buf[j] >> 32);
       rank += (kj < key) | ((kj == key) & (j < t));
     }
@@ -727,7 +761,7 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
                                                const int *__restrict__ sel_count, int *__restrict__ flags,
                                                int *__restrict__ slots, FrameHeader *__restrict__ hdr, int lap0,
                                                int lap1) {
-  __shared__ int wtot[8];
+  __shared__ int wtot[2 * kMaxWaves];
   __shared__ int lstart[kMaxLevels + 1];
   const int frame = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {

@@ -58,6 +58,10 @@ struct SerialGroup {
     }
     return s;
   }
+  VSG_OCT_HD int exclusive_scan2(int *a, int *b, int n, int *total_b) {
+    *total_b = exclusive_scan(b, n);
+    return exclusive_scan(a, n);
+  }
   // std::sort's quicksort half on items[0..n) (see vsg_introsort.h); posA/posB: n + 1 uint16 of scratch each.
   // The caller syncs afterwards.
   VSG_OCT_HD void sort_partition_phase(introsort::item_t *items, int n, uint16_t *, uint16_t *) {
@@ -136,8 +140,17 @@ struct RegPts {
 
 // Workspace: carve from one byte buffer (LDS on the device).  Layout is 8-byte aligned.
 struct Work {
-  int16_t *ulx[2], *uly[2], *urx[2], *bly[2];
-  int *cnt[2];
+  // The two generations (ping-pong index b) of the node boxes / counts are addressed by arithmetic, not through
+  // pointer arrays: `ptr[b]` with a run-time b made the compiler keep the whole struct in scratch memory (every
+  // access a scratch load, and the kernel a scratch user).
+  int16_t *box;  // [b][ulx|uly|urx|bly][capa]
+  int *cntb;     // [b][capa]
+  int capa;
+  VSG_OCT_HD int16_t *ulx(int b) const { return box + (size_t)(4 * b + 0) * capa; }
+  VSG_OCT_HD int16_t *uly(int b) const { return box + (size_t)(4 * b + 1) * capa; }
+  VSG_OCT_HD int16_t *urx(int b) const { return box + (size_t)(4 * b + 2) * capa; }
+  VSG_OCT_HD int16_t *bly(int b) const { return box + (size_t)(4 * b + 3) * capa; }
+  VSG_OCT_HD int *cnt(int b) const { return cntb + (size_t)b * capa; }
   int *childcnt;        // 4 per node; aliased by sortbuf (item_t per node) and bestkey
   uint16_t *childpos;   // 4 per node
   uint16_t *keeppos;
@@ -158,10 +171,9 @@ VSG_OCT_HD void carve(Work &W, void *buf, int cap) {
   uint8_t *p = (uint8_t *)buf;
   W.childcnt = (int *)p;
   p += capa * 16;
-  for (int b = 0; b < 2; b++) {
-    W.cnt[b] = (int *)p;
-    p += capa * 4;
-  }
+  W.capa = (int)capa;
+  W.cntb = (int *)p;
+  p += 2 * capa * 4;
   W.scanA = (int *)p;
   p += capa * 4;
   W.scanB = (int *)p;
@@ -170,16 +182,8 @@ VSG_OCT_HD void carve(Work &W, void *buf, int cap) {
   p += 64;
   W.childpos = (uint16_t *)p;
   p += capa * 8;
-  for (int b = 0; b < 2; b++) {
-    W.ulx[b] = (int16_t *)p;
-    p += capa * 2;
-    W.uly[b] = (int16_t *)p;
-    p += capa * 2;
-    W.urx[b] = (int16_t *)p;
-    p += capa * 2;
-    W.bly[b] = (int16_t *)p;
-    p += capa * 2;
-  }
+  W.box = (int16_t *)p;
+  p += 8 * capa * 2;
   W.keeppos = (uint16_t *)p;
   p += capa * 2;
   W.proc = (uint16_t *)p;
@@ -190,9 +194,9 @@ VSG_OCT_HD void carve(Work &W, void *buf, int cap) {
 }
 
 VSG_OCT_HD int quadrant(const Work &W, int b, int n, int x, int y) {
-  const int ulx = W.ulx[b][n], uly = W.uly[b][n];
-  const int midX = ulx + ((W.urx[b][n] - ulx + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)  (:484)
-  const int midY = uly + ((W.bly[b][n] - uly + 1) >> 1);
+  const int ulx = W.ulx(b)[n], uly = W.uly(b)[n];
+  const int midX = ulx + ((W.urx(b)[n] - ulx + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)  (:484)
+  const int midY = uly + ((W.bly(b)[n] - uly + 1) >> 1);
   return (x >= midX ? 1 : 0) | (y >= midY ? 2 : 0);       // n1,n2,n3,n4 (:513-527)
 }
 
@@ -262,18 +266,18 @@ VSG_OCT_HD int run_pass(G &g, const Params &P, Work &W, int &cur, int nL, int nP
   for (int t = g.tid; t < nEff; t += g.nthreads) {
     const int n = W.proc[t];
     const int q0 = W.scanA[t] & 0xFFFF, e0 = W.scanA[t] >> 16;
-    const int ulx = W.ulx[b][n], uly = W.uly[b][n], urx = W.urx[b][n], bly = W.bly[b][n];
+    const int ulx = W.ulx(b)[n], uly = W.uly(b)[n], urx = W.urx(b)[n], bly = W.bly(b)[n];
     const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
     int m = 0, ev = 0;
     for (int c = 0; c < 4; c++) {
       const int cc = W.childcnt[4 * n + c];
       if (cc > 0) {
         const int pos = K - 1 - (q0 + m);  // push_front => reversed creation order
-        W.ulx[nb][pos] = (int16_t)((c & 1) ? midX : ulx);
-        W.urx[nb][pos] = (int16_t)((c & 1) ? urx : midX);
-        W.uly[nb][pos] = (int16_t)((c & 2) ? midY : uly);
-        W.bly[nb][pos] = (int16_t)((c & 2) ? bly : midY);
-        W.cnt[nb][pos] = cc;
+        W.ulx(nb)[pos] = (int16_t)((c & 1) ? midX : ulx);
+        W.urx(nb)[pos] = (int16_t)((c & 1) ? urx : midX);
+        W.uly(nb)[pos] = (int16_t)((c & 2) ? midY : uly);
+        W.bly(nb)[pos] = (int16_t)((c & 2) ? bly : midY);
+        W.cnt(nb)[pos] = cc;
         W.childpos[4 * n + c] = (uint16_t)pos;
         if (cc > 1) W.V[e0 + ev++] = (uint16_t)pos;
         m++;
@@ -283,11 +287,91 @@ VSG_OCT_HD int run_pass(G &g, const Params &P, Work &W, int &cur, int nL, int nP
   for (int i = g.tid; i < nL; i += g.nthreads) {
     if (!W.divided[i]) {
       const int pos = K + W.scanB[i];
-      W.ulx[nb][pos] = W.ulx[b][i];
-      W.urx[nb][pos] = W.urx[b][i];
-      W.uly[nb][pos] = W.uly[b][i];
-      W.bly[nb][pos] = W.bly[b][i];
-      W.cnt[nb][pos] = W.cnt[b][i];
+      W.ulx(nb)[pos] = W.ulx(b)[i];
+      W.urx(nb)[pos] = W.urx(b)[i];
+      W.uly(nb)[pos] = W.uly(b)[i];
+      W.bly(nb)[pos] = W.bly(b)[i];
+      W.cnt(nb)[pos] = W.cnt(b)[i];
+      W.keeppos[i] = (uint16_t)pos;
+    }
+  }
+  g.sync();
+  pts.for_each(g, npts, [&](uint32_t c, int &n) {
+    n = W.divided[n] ? W.childpos[4 * n + quadrant(W, b, n, VSG_CAND_X(c), VSG_CAND_Y(c))] : W.keeppos[n];
+  });
+  g.sync();
+  cur = nb;
+  *nV_out = E;
+  return newL;
+}
+
+// A MAIN pass (:617-690): every node with more than one point is split, in list order.  Same result as
+// run_pass(proc = those nodes, careful = false) but with one fused scan -- children created before a node (K),
+// children with > 1 point before it (E, the sort input order) and kept nodes before it all ride the same pair of
+// barriers -- 7 barriers per pass instead of ~20 (the passes are latency-bound: barriers and LDS round trips).
+template <class G, class PT>
+VSG_OCT_HD int run_main_pass(G &g, const Params &P, Work &W, int &cur, int nL, PT &pts, int npts, int *nV_out) {
+  (void)P;
+  const int b = cur, nb = cur ^ 1;
+  for (int i = g.tid; i < nL; i += g.nthreads) {
+    const bool d = W.cnt(b)[i] > 1;
+    W.divided[i] = d;
+    if (d) {
+      W.childcnt[4 * i + 0] = 0;
+      W.childcnt[4 * i + 1] = 0;
+      W.childcnt[4 * i + 2] = 0;
+      W.childcnt[4 * i + 3] = 0;
+    }
+  }
+  g.sync();
+  pts.for_each(g, npts, [&](uint32_t c, int &n) {
+    if (W.divided[n]) g.atomic_add(&W.childcnt[4 * n + quadrant(W, b, n, VSG_CAND_X(c), VSG_CAND_Y(c))], 1);
+  });
+  g.sync();
+  for (int i = g.tid; i < nL; i += g.nthreads) {
+    int k = 0, e = 0;
+    if (W.divided[i]) {
+      for (int c = 0; c < 4; c++) {
+        const int cc = W.childcnt[4 * i + c];
+        k += cc > 0;
+        e += cc > 1;
+      }
+    }
+    W.scanA[i] = k | (e << 16);
+    W.scanB[i] = W.divided[i] ? 0 : 1;
+  }
+  g.sync();
+  int kept = 0;
+  const int total = g.exclusive_scan2(W.scanA, W.scanB, nL, &kept);
+  const int K = total & 0xFFFF, E = total >> 16;
+  const int newL = K + kept;
+  for (int i = g.tid; i < nL; i += g.nthreads) {
+    const int ulx = W.ulx(b)[i], uly = W.uly(b)[i], urx = W.urx(b)[i], bly = W.bly(b)[i];
+    if (W.divided[i]) {
+      const int q0 = W.scanA[i] & 0xFFFF, e0 = W.scanA[i] >> 16;
+      const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
+      int m = 0, ev = 0;
+      for (int c = 0; c < 4; c++) {
+        const int cc = W.childcnt[4 * i + c];
+        if (cc > 0) {
+          const int pos = K - 1 - (q0 + m);  // push_front => reversed creation order
+          W.ulx(nb)[pos] = (int16_t)((c & 1) ? midX : ulx);
+          W.urx(nb)[pos] = (int16_t)((c & 1) ? urx : midX);
+          W.uly(nb)[pos] = (int16_t)((c & 2) ? midY : uly);
+          W.bly(nb)[pos] = (int16_t)((c & 2) ? bly : midY);
+          W.cnt(nb)[pos] = cc;
+          W.childpos[4 * i + c] = (uint16_t)pos;
+          if (cc > 1) W.V[e0 + ev++] = (uint16_t)pos;
+          m++;
+        }
+      }
+    } else {
+      const int pos = K + W.scanB[i];
+      W.ulx(nb)[pos] = (int16_t)ulx;
+      W.urx(nb)[pos] = (int16_t)urx;
+      W.uly(nb)[pos] = (int16_t)uly;
+      W.bly(nb)[pos] = (int16_t)bly;
+      W.cnt(nb)[pos] = W.cnt(b)[i];
       W.keeppos[i] = (uint16_t)pos;
     }
   }
@@ -310,11 +394,11 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
   pts.load(g, npts);
   // initial nodes (:575-586)
   for (int i = g.tid; i < P.nIni; i += g.nthreads) {
-    W.ulx[0][i] = (int16_t)P.iniUL[i];
-    W.urx[0][i] = (int16_t)P.iniUL[i + 1];
-    W.uly[0][i] = 0;
-    W.bly[0][i] = (int16_t)P.height;
-    W.cnt[0][i] = 0;
+    W.ulx(0)[i] = (int16_t)P.iniUL[i];
+    W.urx(0)[i] = (int16_t)P.iniUL[i + 1];
+    W.uly(0)[i] = 0;
+    W.bly(0)[i] = (int16_t)P.height;
+    W.cnt(0)[i] = 0;
   }
   g.sync();
   // vpIniNodes[kp.pt.x / hX] (:589-593)
@@ -323,19 +407,19 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
     int idx = 0;
     for (int i = 1; i < P.nIni; i++) idx += (x >= P.iniThresh[i]);
     n = idx;
-    g.atomic_add(&W.cnt[0][idx], 1);
+    g.atomic_add(&W.cnt(0)[idx], 1);
   });
   g.sync();
   // erase empty initial nodes, keep order (:597-608)
   if (g.tid == 0) {
     int pos = 0;
     for (int i = 0; i < P.nIni; i++) {
-      if (W.cnt[0][i] > 0) {
-        W.ulx[1][pos] = W.ulx[0][i];
-        W.urx[1][pos] = W.urx[0][i];
-        W.uly[1][pos] = W.uly[0][i];
-        W.bly[1][pos] = W.bly[0][i];
-        W.cnt[1][pos] = W.cnt[0][i];
+      if (W.cnt(0)[i] > 0) {
+        W.ulx(1)[pos] = W.ulx(0)[i];
+        W.urx(1)[pos] = W.urx(0)[i];
+        W.uly(1)[pos] = W.uly(0)[i];
+        W.bly(1)[pos] = W.bly(0)[i];
+        W.cnt(1)[pos] = W.cnt(0)[i];
         W.keeppos[i] = (uint16_t)pos;
         pos++;
       }
@@ -351,14 +435,8 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
   bool finish = false;
   while (!finish) {  // (:617)
     const int prevSize = nL;
-    for (int i = g.tid; i < nL; i += g.nthreads) W.scanA[i] = W.cnt[cur][i] > 1;
-    g.sync();
-    const int nProc = g.exclusive_scan(W.scanA, nL);
-    for (int i = g.tid; i < nL; i += g.nthreads)
-      if (W.cnt[cur][i] > 1) W.proc[W.scanA[i]] = (uint16_t)i;
-    g.sync();
     int nV = 0;
-    nL = run_pass(g, P, W, cur, nL, nProc, false, pts, npts, &nV);
+    nL = run_main_pass(g, P, W, cur, nL, pts, npts, &nV);
     if (nL >= P.N || nL == prevSize) {  // (:692)
       finish = true;
     } else if (nL + nV * 3 > P.N) {  // (:696)
@@ -368,7 +446,7 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
         for (int t = g.tid; t < nV; t += g.nthreads) {
           const int n = W.V[t];
           // compareNodes: (size, UL.x) ascending (:539-560)
-          const uint32_t key = ((uint32_t)W.cnt[cur][n] << 13) | (uint32_t)(uint16_t)W.ulx[cur][n];
+          const uint32_t key = ((uint32_t)W.cnt(cur)[n] << 13) | (uint32_t)(uint16_t)W.ulx(cur)[n];
           sortbuf[t] = ((introsort::item_t)key << 32) | (uint32_t)n;
         }
         g.sync();
@@ -380,8 +458,12 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
         for (int t = g.tid; t < nV; t += g.nthreads) {
           const introsort::item_t it = sortbuf[t];
           const uint32_t key = (uint32_t)(it >> 32);
-          int rank = 0;
-          for (int j = 0; j < nV; j++) {
+          // The partition phase leaves consecutive runs of <= 16 items, every run >= the ones before it (a
+          // heap-sorted run is already in order), so only the 15 neighbours on either side can change an item's
+          // stable rank: everything further left counts, nothing further right does.
+          const int lo = t > 15 ? t - 15 : 0, hi = t + 15 < nV - 1 ? t + 15 : nV - 1;
+          int rank = lo;
+          for (int j = lo; j <= hi; j++) {
             const uint32_t kj = (uint32_t)(sortbuf[j] >> 32);
             rank += (kj < key) | ((kj == key) & (j < t));
           }
