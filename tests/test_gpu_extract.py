@@ -241,15 +241,15 @@ def test_device_sort_replay_equals_std_sort():
 
 
 def test_large_batch_runs_as_sub_batches():
-    """Batches of >= 128 frames are cut into two sub-batches on separate stream pairs: results per frame are the
+    """Batches of >= 256 frames are cut into two sub-batches on separate stream pairs: results per frame are the
     same as single-frame calls (checked against the oracle around the cut and at both ends)."""
-    B = 131
+    B = 259
     imgs = np.stack([synth.sequence_frame(320, 240, 9, t % 40) for t in range(B)])
     ex = orb.ORBextractor(500, 1.2, 4, 20, 7, max_batch=B)
     ref = ol.OracleExtractor(500, 1.2, 4, 20, 7)
     outs = ex.extract_batch(imgs)
     assert len(outs) == B
-    for t in (0, 1, 64, 65, 66, 67, 129, 130):
+    for t in (0, 1, 128, 129, 130, 131, 257, 258):
         assert_same_output(outs[t], ref(imgs[t]), f"frame {t} of {B}")
     # frames with identical content give identical output wherever they sit in the batch
     for t in range(40, B):

@@ -241,9 +241,10 @@ static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, i
                             uint8_t *d_desc, int *d_counts, int capacity, hipStream_t s) {
   h->last_src0 = s0;
   const bool no_overlap = h->serialize;
-  // auto (VSG_SUBBATCH unset): two sub-batches once each still fills the chip (measured on MI355X, C2, 256
-  // frames: 179k -> 186k fps; at 64 frames one batch is better)
-  int nsub = no_overlap ? 1 : h->nsub > 0 ? h->nsub : (nframes >= 128 ? 2 : 1);
+  // auto (VSG_SUBBATCH unset): two sub-batches once each half still fills the chip.  Measured on MI355X (C2): 256
+  // frames 210k -> 212k fps, 128 frames 190k -> 187k, so the cut is at 256; the gain was larger (4 %) while the
+  // octree was latency-bound.
+  int nsub = no_overlap ? 1 : h->nsub > 0 ? h->nsub : (nframes >= 256 ? 2 : 1);
   if (nsub > nframes) nsub = nframes;
   const bool tm = h->timing && nsub == 1;
   if (tm) harvest_timing(h);
