@@ -710,7 +710,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     uint32_t d0[7], d1[7], d2[7];
 #pragma unroll
     for (int s = 0; s < 7; s++) {
-      const int ysrc = reflect101(y0 - 3 + turn * 7 + s, h);
+      // REFLECT_101 of the row without a loop: rows start at >= -3 and overshoot the bottom by < h (levels are
+      // >= 64 rows, a strip is 36 + 6), so one fold per side is exact; rows past the fold are never stored
+      int ysrc = y0 - 3 + turn * 7 + s;
+      ysrc = ysrc < 0 ? -ysrc : ysrc;
+      ysrc = ysrc >= h ? 2 * h - 2 - ysrc : ysrc;
       const uint8_t *row = img + (size_t)ysrc * spitch + base;
       d0[s] = *(const u32_unaligned *)(row);
       d1[s] = *(const u32_unaligned *)(row + 4);
