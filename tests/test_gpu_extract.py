@@ -254,3 +254,35 @@ def test_large_batch_runs_as_sub_batches():
     # frames with identical content give identical output wherever they sit in the batch
     for t in range(40, B):
         assert outs[t][1].tobytes() == outs[t - 40][1].tobytes() and np.array_equal(outs[t][2], outs[t - 40][2])
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        w, h = int(rng.integers(150, 1000)), int(rng.integers(120, 760))
+        nl = int(rng.integers(1, 9))
+        sc = float(rng.choice([1.1, 1.2, 1.25, 1.3, 1.5, 2.0, 2.5]))
+        nf = int(rng.integers(50, 3000))
+        ini = int(rng.integers(8, 60))
+        mn = int(rng.integers(2, ini + 1))
+        div = int(rng.choice([1, 1, 1, 2, 4, 8]))
+        top = sc ** (nl - 1)
+        # every level holds a FAST cell; 1..4 initial octree nodes (nIni = round(width / height) must be >= 1: the
+        # reference divides by it, ORBextractor.cc:566-571)
+        if w / top < 80 or h / top < 80 or w / h > 3.5 or w < 0.6 * h:
+            continue
+        cases.append((w, h, nf, sc, nl, ini, mn, div, int(rng.integers(0, 1 << 20))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(40, 2024), ids=lambda c: f"{c[0]}x{c[1]}_n{c[2]}_s{c[3]}_l{c[4]}_t{c[5]}-{c[6]}")
+def test_fuzz_random_geometries(case):
+    """Seeded random image sizes (odd widths, widths not divisible by 4), level counts, scale factors (incl. > 2: the
+    per-level resize fallback), feature counts and thresholds: whatever the reference can process must come out
+    bit-identical (the generator keeps every level large enough for one FAST cell, which the reference needs)."""
+    w, h, nf, sc, nl, ini, mn, div, seed = case
+    img = synth.frame(w, h, seed, amplitude_div=div)
+    want = ol.OracleExtractor(nf, sc, nl, ini, mn)(img)
+    got = orb.ORBextractor(nf, sc, nl, ini, mn)(img)
+    assert_same_output(got, want, f"fuzz {case}")
