@@ -270,6 +270,8 @@ def _fuzz_cases(n, seed):
         top = sc ** (nl - 1)
         # every level holds a FAST cell; 1..4 initial octree nodes (nIni = round(width / height) must be >= 1: the
         # reference divides by it, ORBextractor.cc:566-571)
+        if nl == 1 and nf > 2400:  # one level would hold more than kMaxQuota features (refused, see the test below)
+            continue
         if w / top < 80 or h / top < 80 or w / h > 3.5 or w < 0.6 * h:
             continue
         cases.append((w, h, nf, sc, nl, ini, mn, div, int(rng.integers(0, 1 << 20))))
@@ -286,3 +288,14 @@ def test_fuzz_random_geometries(case):
     want = ol.OracleExtractor(nf, sc, nl, ini, mn)(img)
     got = orb.ORBextractor(nf, sc, nl, ini, mn)(img)
     assert_same_output(got, want, f"fuzz {case}")
+
+
+def test_single_level_with_large_quota_needs_more_than_64kb_of_lds():
+    """nlevels = 1 puts the whole feature budget on one level: quota 2400 -> a 150 KB octree workspace (the
+    launch raises the dynamic-LDS limit); beyond kMaxQuota the handle refuses the geometry."""
+    img = synth.frame(640, 480, 77)
+    ref = ol.OracleExtractor(2400, 1.2, 1, 20, 7)
+    assert_same_output(orb.ORBextractor(2400, 1.2, 1, 20, 7)(img), ref(img), "quota 2400")
+    with pytest.raises(orb.VsgError) as ei:
+        orb.ORBextractor(3000, 1.2, 1, 20, 7)(img)
+    assert ei.value.code == -3

@@ -11,7 +11,7 @@ enum {
   kHalfPatch = 15,       // ORBextractor.cc:70
   kFastBorder = 16,      // EDGE_THRESHOLD - 3 (ORBextractor.cc:795)
   kCellMax = 70,         // valid FAST cell extent is < 70 px: ceil(d / floor(d/35)) for d >= 35
-  kMaxQuota = 4000,      // per-level feature quota the octree workspace supports
+  kMaxQuota = 2500,      // per-level feature quota: the octree workspace (63 B per node) must fit the 160 KB LDS
 };
 
 // FAST candidate / selected keypoint packed in 32 bits: x | y<<12 | response<<24.

@@ -1201,6 +1201,13 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
                    uint16_t *node_of, uint32_t *sel, int *sel_count, const FrameGeom &fg, int maxQuota, int nframes) {
   const int cap = octree::node_capacity(maxQuota);
   const size_t lds = octree::work_bytes(cap);
+  // beyond 64 KB of dynamic LDS the launch needs the limit raised (quotas above ~1000 per level, e.g. a single
+  // level holding every feature); gfx950 has 160 KB per workgroup
+  static size_t lds_limit = 64 * 1024;
+  if (lds > lds_limit) {
+    if (hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+      lds_limit = lds;
+  }
   dim3 grid(fg.nlevels, nframes), block(kOctThreads);
   hipLaunchKernelGGL(k_octree, grid, block, lds, s, d_fg, cand, cand_count, node_of, sel, sel_count, cap);
 }
