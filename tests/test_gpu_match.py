@@ -338,3 +338,32 @@ def test_search_for_triangulation(frames, seed, n_nodes, p_ok, ori):
     # matches only between eligible features of the same node, inside TH_LOW, with the predicate bit set
     for i1 in np.nonzero(want >= 0)[0][:50]:
         assert e1[i1] and e2[want[i1]] and ol.descriptor_distance(d0[i1], d2[want[i1]]) <= 50
+
+
+def test_block_best2_tile_boundaries_of_the_mfma_kernel():
+    """The matrix-core matcher works on 32-row train tiles, 32-query column blocks, 128-query workgroups and an
+    8-tile prefetch group: sizes on and around every one of those boundaries, tie-heavy data."""
+    rng = np.random.default_rng(5)
+    m = orb.ORBmatcher()
+    sizes = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 287, 288, 289, 511, 513]
+    base = rng.integers(0, 256, (9, 32), dtype=np.uint8)
+    for na in sizes:
+        for nb in (sizes if na in (1, 33, 129, 257) else (1, 31, 33, 256, 289)):
+            a = near_duplicates(base[rng.integers(0, 9, na)], rng, 2)
+            b = near_duplicates(base[rng.integers(0, 9, nb)], rng, 1)
+            for g, w in zip(m.block_best2(a, b), ol.block_best2(a, b)):
+                assert np.array_equal(g, w), (na, nb)
+    # all-equal descriptors: distance 0 everywhere, the first train row must win and the second-best is 0 too
+    z = np.zeros((70, 32), np.uint8)
+    best, second, arg = m.block_best2(z, z)
+    assert not best.any() and not second.any() and not arg.any()
+    # complementary descriptors: distance 256 (the accumulator's extreme value) is never "better than 256": like
+    # the reference's strict '<' scan from bestDist = 256, no best index
+    comp = np.full((40, 32), 255, np.uint8)
+    for g, w in zip(m.block_best2(z[:5], comp), ol.block_best2(z[:5], comp)):
+        assert np.array_equal(g, w)
+    assert m.block_best2(z[:5], comp)[2].tolist() == [-1] * 5
+    off = np.array([0, 40], np.int32)
+    n, qi, qd, tm, _ = orb.search_window(z[:1], None, off, np.arange(40, dtype=np.int32), comp, None, 256)
+    assert (n, qi.tolist(), qd.tolist()) == (0, [-1], [256])
+    assert ol.search_window(z[:1], None, off, np.arange(40, dtype=np.int32), comp, None, 256)[:3][0] == 0

@@ -25,6 +25,9 @@ const int TH_HIGH = 100;      // ORBmatcher.cc:34
 const int TH_LOW = 50;        // ORBmatcher.cc:35
 const int HISTO_LENGTH = 30;  // ORBmatcher.cc:36
 const uint32_t KEY_NONE = (256u << 20) | 0xFFFFFu;
+// The reference's scans start from bestDist = 256 and update on a strict '<', so a candidate at distance 256 (every
+// bit different) is never selected: any key whose distance field is 256 means "no best".
+__device__ __forceinline__ bool key_is_none(uint32_t k) { return (k >> 20) >= 256u; }
 
 __device__ __forceinline__ int hamming256(const uint4 a0, const uint4 a1, const uint4 b0, const uint4 b1) {
   return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
@@ -126,13 +129,13 @@ __global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, cons
       const size_t o = (size_t)blk * max_rows + row0;
       best[o] = (int)(k1 >> 20);
       second[o] = (int)(k2 >> 20);
-      argbest[o] = k1 == KEY_NONE ? -1 : (int)(k1 & 0xFFFFF);
+      argbest[o] = key_is_none(k1) ? -1 : (int)(k1 & 0xFFFFF);
     }
     if (row1 < na) {
       const size_t o = (size_t)blk * max_rows + row1;
       best[o] = (int)(m1 >> 20);
       second[o] = (int)(m2 >> 20);
-      argbest[o] = m1 == KEY_NONE ? -1 : (int)(m1 & 0xFFFFF);
+      argbest[o] = key_is_none(m1) ? -1 : (int)(m1 & 0xFFFFF);
     }
   }
 }
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
     const size_t o = (size_t)blk * max_rows + q;
     best[o] = (int)(k1 >> 20);
     second[o] = (int)(k2 >> 20);
-    argbest[o] = k1 == KEY_NONE ? -1 : (int)(k1 & 0xFFFFF);
+    argbest[o] = key_is_none(k1) ? -1 : (int)(k1 & 0xFFFFF);
   }
 }
 
@@ -404,17 +407,17 @@ __global__ __launch_bounds__(64) void k_search_window(const uint8_t *qDesc, cons
     }
     wave_best2(k1, k2);
     const int bestDist = (int)(k1 >> 20);
-    if (qBest && lane == 0 && k1 != KEY_NONE) {
+    if (qBest && lane == 0 && !key_is_none(k1)) {
       qBest[2 * q] = candIdx[c0 + (int)(k1 & 0xFFFFF)];
       qBest[2 * q + 1] = bestDist;
     }
-    if (bestDist > thHigh || k1 == KEY_NONE) continue;
+    if (bestDist > thHigh || key_is_none(k1)) continue;
     const int bestIdx = candIdx[c0 + (int)(k1 & 0xFFFFF)];
     bool accept = true;
     if (mode == 1) {
       const int bestDist2 = (int)(k2 >> 20);
       const int bestLevel = tOctave[bestIdx];
-      const int bestLevel2 = k2 == KEY_NONE ? -1 : tOctave[candIdx[c0 + (int)(k2 & 0xFFFFF)]];
+      const int bestLevel2 = key_is_none(k2) ? -1 : tOctave[candIdx[c0 + (int)(k2 & 0xFFFFF)]];
       if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) accept = false;       // :125-126
       else if (!(bestLevel != bestLevel2 || (float)bestDist <= nnratio * (float)bestDist2)) accept = false;  // :128
     }
