@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity sweep (runs on the GPU box; not part of the pytest suites because it is open
+ended).  Every case draws an entry point and random, reference-processable parameters; any mismatch prints the
+case and exits 1.
+
+    python tools/fuzz_gpu.py --cases 300 --seed 1
+"""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import oracle_lib as ol  # noqa: E402
+from visual_sgraphs_amd import orb, synth  # noqa: E402
+
+
+def same(got, want):
+    return got[0] == want[0] and got[1].tobytes() == want[1].tobytes() and np.array_equal(got[2], want[2])
+
+
+def geometry(rng):
+    while True:
+        w, h = int(rng.integers(150, 1000)), int(rng.integers(120, 760))
+        nl = int(rng.integers(1, 9))
+        sc = float(rng.choice([1.1, 1.2, 1.25, 1.3, 1.5, 2.0, 2.5]))
+        nf = int(rng.integers(50, 2400))
+        top = sc ** (nl - 1)
+        if w / top < 80 or h / top < 80 or w / h > 3.5 or w < 0.6 * h:
+            continue
+        ini = int(rng.integers(8, 60))
+        return w, h, nf, sc, nl, ini, int(rng.integers(2, ini + 1))
+
+
+def case_batch(rng):
+    w, h, nf, sc, nl, ini, mn = geometry(rng)
+    B = int(rng.integers(1, 7))
+    lap = (int(rng.integers(-10, w)), int(rng.integers(-10, w + 50)))
+    imgs = np.stack([synth.frame(w, h, int(rng.integers(0, 1 << 20)), amplitude_div=int(rng.choice([1, 1, 4])))
+                     for _ in range(B)])
+    ex = orb.ORBextractor(nf, sc, nl, ini, mn, max_batch=B)
+    ref = ol.OracleExtractor(nf, sc, nl, ini, mn)
+    outs = ex.extract_batch(imgs, lap)
+    return all(same(outs[i], ref(imgs[i], lap)) for i in range(B)), ("batch", w, h, nf, sc, nl, ini, mn, B, lap)
+
+
+def case_colour(rng):
+    w, h, nf, sc, nl, ini, mn = geometry(rng)
+    ch, rgb = int(rng.choice([3, 4])), bool(rng.integers(0, 2))
+    base = synth.frame(w, h, int(rng.integers(0, 1 << 20)))
+    col = np.stack([np.clip(base.astype(np.int32) + rng.integers(-25, 26, base.shape), 0, 255).astype(np.uint8)
+                    for _ in range(ch)], axis=-1)
+    gray = ol.cvt_gray(col, rgb)
+    ex = orb.ORBextractor(nf, sc, nl, ini, mn, max_batch=1)
+    got = ex.extract_batch_color(col[None], rgb)[0]
+    return same(got, ol.OracleExtractor(nf, sc, nl, ini, mn)(gray)), ("colour", w, h, nf, sc, nl, ini, mn, ch, rgb)
+
+
+def case_best2(rng):
+    na, nb = int(rng.integers(0, 700)), int(rng.integers(0, 700))
+    base = rng.integers(0, 256, (int(rng.integers(1, 40)), 32), dtype=np.uint8)
+    a = base[rng.integers(0, len(base), na)] if na else np.zeros((0, 32), np.uint8)
+    b = base[rng.integers(0, len(base), nb)] if nb else np.zeros((0, 32), np.uint8)
+    flips = int(rng.integers(0, 30))
+    for arr in (a, b):
+        for r in range(len(arr)):
+            for bit in rng.integers(0, 256, flips):
+                arr[r, bit >> 3] ^= np.uint8(1 << (bit & 7))
+    if na == 0:
+        return True, ("best2", na, nb)
+    g, w_ = orb.ORBmatcher().block_best2(a, b), ol.block_best2(a, b)
+    return all(np.array_equal(x, y) for x, y in zip(g, w_)), ("best2", na, nb, flips)
+
+
+def case_stereo(rng):
+    w, h = int(rng.integers(400, 800)), int(rng.integers(300, 520))
+    nf = int(rng.integers(300, 1500))
+    seq, t = int(rng.integers(0, 1 << 16)), int(rng.integers(0, 10))
+    L, R = synth.sequence_frame(w, h, seq, t + 2), synth.sequence_frame(w, h, seq, t)
+    exl, exr = orb.ORBextractor(nf, 1.2, 8, 20, 7), orb.ORBextractor(nf, 1.2, 8, 20, 7)
+    rl, rr = ol.OracleExtractor(nf, 1.2, 8, 20, 7), ol.OracleExtractor(nf, 1.2, 8, 20, 7)
+    (_, kl, dl), (_, kr, dr) = exl(L), exr(R)
+    rl(L), rr(R)
+    mb, mbf = 0.11, 47.9
+    gu, gd = orb.ComputeStereoMatches(exl, 0, exr, 0, kl, dl, kr, dr, mb, mbf)
+    wu, wd = ol.stereo_matches(rl, rr, kl, dl, kr, dr, mb, mbf)
+    return gu.tobytes() == wu.tobytes() and gd.tobytes() == wd.tobytes(), ("stereo", w, h, nf, seq, t)
+
+
+def case_bow(rng):
+    k, L = int(rng.choice([3, 6, 10])), int(rng.integers(2, 5))
+    blob = synth.synthetic_vocabulary(k=k, L=L, seed=int(rng.integers(0, 1000)), scoring=int(rng.integers(0, 2)),
+                                      weighting=int(rng.integers(0, 4)))
+    n = int(rng.integers(0, 1500))
+    desc = synth.random_descriptors(max(n, 1), int(rng.integers(0, 1 << 16)))[:n]
+    lv = int(rng.integers(0, L + 2))
+    got = orb.ORBVocabulary(blob).transform(desc, lv)
+    want = ol.OracleVocabulary(blob).transform(desc, lv)
+    ok = np.array_equal(got["bow_ids"], want["bow_ids"]) and got["bow_vals"].tobytes() == want["bow_vals"].tobytes()
+    ok = ok and all(np.array_equal(x, y) for x, y in zip(got["fv"], want["fv"]))
+    return ok, ("bow", k, L, n, lv)
+
+
+CASES = {"batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    names = [n for n in CASES if not args.only or n in args.only.split(",")]
+    counts = {n: 0 for n in names}
+    for i in range(args.cases):
+        name = names[int(rng.integers(0, len(names)))]
+        try:
+            ok, desc = CASES[name](rng)
+        except orb.VsgError as e:
+            print("REFUSED", name, e)
+            continue
+        counts[name] += 1
+        if not ok:
+            print("MISMATCH", desc)
+            sys.exit(1)
+    print("fuzz ok:", counts)
+
+
+if __name__ == "__main__":
+    main()
