@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="make every step wait for its own all-gather (default: the exchange of batch k overlaps the "
+                         "kernels of batch k+1, two record buffers in flight)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget per CPU baseline leg (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo for dry runs")
@@ -133,8 +136,12 @@ def main():
     if distributed and not args.no_gather:
         # one fixed-capacity record block per frame: {n, monoIndex} + keypoints + descriptors
         rec_bytes = sharding.record_bytes(cap)
-        send = torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev)
-        recv = torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev)
+        # two buffer pairs: the all-gather of batch k is still in flight while batch k+1 is packed
+        send = [torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+        recv = [torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
+    pending = [None, None]
+    step_no = [0]
+    async_gather = distributed and args.dist_backend == "nccl" and not args.sync_gather
     L = orb.load_library()
     import ctypes as C
     # All work of a step is ordered on ONE explicit (non-default) HIP stream: torch copies, the extractor's stage
@@ -168,10 +175,19 @@ def main():
                 e1.record(tstream)
                 match_events.append((e0, e1))
         if distributed and not args.no_gather:
-            sharding.pack_records(send, d_counts[1:], d_kps[1:], d_desc[1:])
-            sharding.all_gather_records(recv, send)
+            slot = step_no[0] & 1
+            step_no[0] += 1
+            if pending[slot] is not None:  # the exchange that used this buffer pair two steps ago
+                pending[slot].wait()
+                pending[slot] = None
+            sharding.pack_records(send[slot], d_counts[1:], d_kps[1:], d_desc[1:])
+            pending[slot] = sharding.all_gather_records(recv[slot], send[slot], async_op=async_gather)
 
     def barrier():
+        for i in range(2):  # every exchange belongs to the region it was issued in
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -290,7 +306,9 @@ def main():
                                f"extract{'' if args.no_match else ' + brute-force Hamming best2 match vs previous frame'}",
                    "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded x{world}"
                    + (f", {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} all-gather of "
-                      "keypoint/descriptor records per step" if distributed and not args.no_gather else ""),
+                      "keypoint/descriptor records per step"
+                      + (" (overlapped with the next batch's kernels)" if async_gather else "")
+                      if distributed and not args.no_gather else ""),
                    "keypoints_per_frame": round(n_kp, 1), "inputs": "resident in HBM"},
         "parity": {"bit_exact_vs_oracle": parity, "checked_frames": [0, B - 1]},
         "roofline": roofline, "cpu_baseline": cpu,

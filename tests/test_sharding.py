@@ -39,6 +39,21 @@ def _worker(rank, world, port, B, cap, q):
     sharding.all_gather_records(recv, send)
     c, k, d = sharding.unpack_records(recv, cap)
     ok = True
+    # the overlapped protocol of bench.py: two buffer pairs, a Work handle per exchange, wait before reuse
+    sends = [send.clone(), send.clone()]
+    recvs = [torch.zeros_like(recv), torch.zeros_like(recv)]
+    pending = [None, None]
+    for step in range(5):
+        slot = step & 1
+        if pending[slot] is not None:
+            pending[slot].wait()
+            ok &= torch.equal(recvs[slot], recv)
+        sends[slot][:, 8:12] = sends[slot][:, 8:12]  # "refill" only after the wait
+        pending[slot] = sharding.all_gather_records(recvs[slot], sends[slot], async_op=True)
+        ok &= pending[slot] is not None
+    for w in pending:
+        w.wait()
+    ok &= torch.equal(recvs[0], recv) and torch.equal(recvs[1], recv)
     for r in range(world):
         rc, rk, rd = _fake_records(r, B, cap)
         ok &= torch.equal(c[r * B:(r + 1) * B], rc) and torch.equal(k[r * B:(r + 1) * B], rk)

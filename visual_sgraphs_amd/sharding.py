@@ -43,19 +43,25 @@ def unpack_records(recv, cap):
     return counts, kps, desc
 
 
-def all_gather_records(recv, send):
-    """One collective per batch: recv [world*B, rec] <- every rank's send [B, rec] (rank-major)."""
+def all_gather_records(recv, send, async_op=False):
+    """One collective per batch: recv [world*B, rec] <- every rank's send [B, rec] (rank-major).
+
+    async_op=True (device tensors on the nccl = RCCL backend only) returns the collective's Work handle instead of
+    making the caller's stream wait for it: the exchange of batch k then runs under the kernels of batch k+1.  The
+    caller must `wait()` on the handle before it touches `recv` or refills `send`."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         if send.is_cuda and dist.get_backend() == "gloo":
             # CPU-side collective (tests / single-GPU dry runs of the multi-rank path): stage through the host
             r = torch.empty(recv.shape, dtype=recv.dtype)
             dist.all_gather_into_tensor(r, send.cpu())
             recv.copy_(r)
+        elif async_op:
+            return dist.all_gather_into_tensor(recv, send, async_op=True)
         else:
             dist.all_gather_into_tensor(recv, send)
     else:
         recv.copy_(send)
-    return recv
+    return None
 
 
 def global_frame_index(rank, local_index, world):
