@@ -198,9 +198,9 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
     const int tr = row0 + erow;
     return ~((const uint32_t *)(B + (size_t)(tr < nb ? tr : 0) * 32))[es];
   };
-  // The train dwords are prefetched a GROUP of kPf tiles ahead (register double bank): an iteration is ~600 cycles,
+  // The train dwords are prefetched a GROUP of kPf tiles ahead (register double bank; 4 keeps the kernel at 5 waves per SIMD): an iteration is ~600 cycles,
   // a global round trip several thousand, so a one-iteration prefetch left every iteration waiting on memory.
-  constexpr int kPf = 8;
+  constexpr int kPf = 4;
   uint32_t wa[kPf], wn[kPf];
 #pragma unroll
   for (int j = 0; j < kPf; j++) wa[j] = fetch(32 * j), wn[j] = 0u;
