@@ -142,6 +142,7 @@ def main():
     pending = [None, None]
     step_no = [0]
     async_gather = distributed and args.dist_backend == "nccl" and not args.sync_gather
+    gather_mode = [async_gather]
     L = orb.load_library()
     import ctypes as C
     # All work of a step is ordered on ONE explicit (non-default) HIP stream: torch copies, the extractor's stage
@@ -181,7 +182,14 @@ def main():
                 pending[slot].wait()
                 pending[slot] = None
             sharding.pack_records(send[slot], d_counts[1:], d_kps[1:], d_desc[1:])
-            pending[slot] = sharding.all_gather_records(recv[slot], send[slot], async_op=async_gather)
+            try:
+                pending[slot] = sharding.all_gather_records(recv[slot], send[slot], async_op=gather_mode[0])
+            except Exception as e:  # a backend without async support: fall back to the blocking exchange
+                if not gather_mode[0]:
+                    raise
+                print(f"[bench] async all-gather unavailable ({e}); using the blocking form", file=sys.stderr)
+                gather_mode[0] = False
+                pending[slot] = sharding.all_gather_records(recv[slot], send[slot], async_op=False)
 
     def barrier():
         for i in range(2):  # every exchange belongs to the region it was issued in
