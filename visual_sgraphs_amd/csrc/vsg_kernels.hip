@@ -319,11 +319,12 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1
   const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0;
   const int nrun = (ng + kFastRun - 1) / kFastRun, nruns = nrun * vh;  // runs of kFastRun dwords per row
-  const float inv_nrun = 1.0f / (float)nrun, inv_vw = 1.0f / (float)vw;
+  const float inv_nrun = 1.0f / (float)nrun;
   uint32_t keep = 0;
   int nq = 0, thr = fg->iniTh;
   for (int pass = 0; pass < 2; pass++) {
-    for (int i = tid; i < (vh + 2) * (kScoreP / 4); i += NT) ((uint32_t *)score)[i] = 0;
+    // (vh + 2) score rows, cleared 16 bytes per lane (the region is allocated in multiples of 16 bytes)
+    for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
     if (tid < 4) s_cnt[tid] = 0;
     __syncthreads();
     // ---- phase 1: necessary test on kFastRun dwords (4 px each) per thread, compaction of the passers.  A longer
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_cnt[1], total);
         pos += __builtin_amdgcn_readfirstlane(base);
-        const int pix = r * vw + cb;
+        const int pix = (r << 8) + cb;  // queue entry = row << 8 | column (both < 70): no division to unpack
         while (m) {
           queue[pos++] = (uint16_t)(pix + __builtin_ctz(m));
           m &= m - 1;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     // ---- phase 2: exact score of the queued pixels
     for (int q = tid; q < nq; q += NT) {
       const int i = queue[q];
-      const int r = div_small(i, inv_vw), c = i - r * vw;
+      const int r = i >> 8, c = i & 255;
       const int s = fast_score<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr);
       if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
     }
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     int it = 0;
     for (int q = tid; q < nq; q += NT, it++) {
       const int i = queue[q];
-      const int r = div_small(i, inv_vw), c = i - r * vw;
+      const int r = i >> 8, c = i & 255;
       const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
       const int s = sp[0];
       if (s == 0) continue;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   for (int q = tid; q < nq; q += NT, it++) {
     if (!(keep & (1u << it))) continue;
     const int i = queue[q];
-    const int r = div_small(i, inv_vw), c = i - r * vw;
+    const int r = i >> 8, c = i & 255;
     const int s = score[(r + 1) * kScoreP + (c + 1)];
     const int slot = base + atomicAdd(&s_cnt[2], 1);
     if (slot < L.cand_cap) out[slot] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
