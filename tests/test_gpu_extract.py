@@ -299,3 +299,35 @@ def test_single_level_with_large_quota_needs_more_than_64kb_of_lds():
     with pytest.raises(orb.VsgError) as ei:
         orb.ORBextractor(3000, 1.2, 1, 20, 7)(img)
     assert ei.value.code == -3
+
+
+@pytest.mark.parametrize("offset,pad", [(0, 0), (1, 5), (3, 2), (0, 6)])
+def test_device_entry_with_aligned_and_unaligned_layouts(offset, pad):
+    """vsg_orb_extract_batch_device reads level 0 in place when base / stride / frame stride are 4-byte aligned and
+    restages otherwise: both must equal the oracle, on the caller's stream, outputs left on the device."""
+    torch = pytest.importorskip("torch")
+    B, H, W = 3, 240, 322
+    imgs = np.stack([synth.frame(W, H, 500 + i) for i in range(B)])
+    dev = torch.device("cuda", 0)
+    big = torch.zeros((B, H, W + pad + offset + 2), dtype=torch.uint8, device=dev)
+    big[:, :, offset:offset + W] = torch.from_numpy(imgs).to(dev)
+    view = big[:, :, offset:offset + W]
+    ex = orb.ORBextractor(600, 1.2, 5, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ex.extract_batch_device(view.data_ptr(), B, view.stride(0), H, W, view.stride(1), d_kps.data_ptr(),
+                                d_desc.data_ptr(), d_counts.data_ptr(), cap, (0, 0), stream.cuda_stream)
+    stream.synchronize()
+    counts = d_counts.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(orb.KP_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy()
+    ref = ol.OracleExtractor(600, 1.2, 5, 20, 7)
+    for f in range(B):
+        mono, rk, rd = ref(imgs[f])
+        n = int(counts[f, 0])
+        assert (n, int(counts[f, 1])) == (len(rk), mono)
+        assert kps[f, :n].tobytes() == rk.tobytes() and np.array_equal(desc[f, :n], rd)
