@@ -268,15 +268,24 @@ def main():
         dom = max(timed, key=timed.get)
         dom_bytes = stages.get(dom, 0) * B  # algorithmic bytes one launch (batch of B frames) moves
         ach = dom_bytes / (timed[dom] * 1e-3) / 1e9 if timed[dom] > 0 else 0.0
-        traffic = None
-        try:  # PMC-derived HBM bytes per launch of that kernel, collected offline (profiles/README.md)
+        traffic, valu = None, None
+        try:  # PMC-derived HBM bytes / VALU instructions per launch of that kernel, collected offline (profiles/)
             tr = json.load(open(ROOT / "profiles" / "traffic_r01.json")).get(f"{args.workload}/{B}", {}).get(dom)
             if tr:
                 traffic = tr["fetch_bytes"] + tr["write_bytes"]
+                if tr.get("valu_insts") and timed[dom] > 0:
+                    # what actually bounds the kernel: VALU issue.  1024 SIMDs, measured issue cost 2.3 cycles per
+                    # wave64 instruction for plain add/logic/fp32 and 4.2 for everything else (tools/ubench.hip)
+                    simd_cycles = 1024 * timed[dom] * 1e-3 * 2.4e9
+                    valu = {"insts_per_launch": tr["valu_insts"],
+                            "busy_frac_range": [round(min(1.0, tr["valu_insts"] * 2.3 / simd_cycles), 3),
+                                                round(min(1.0, tr["valu_insts"] * 4.2 / simd_cycles), 3)],
+                            "source": "SQ_INSTS_VALU (profiles/), issue cycles from profiles/r01_c_ubench_valu_rates.txt"}
         except (OSError, ValueError):
             pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    **({"valu_issue": valu} if valu else {}),
                     "launch_ms": round(timed[dom], 4), "bytes_per_launch": int(dom_bytes),
                     "timing": "HIP events per kernel, serialized pass of the same steps (stage_ms); the timed "
                               "region itself overlaps streams and sub-batches",
