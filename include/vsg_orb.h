@@ -168,6 +168,17 @@ int vsg_search_by_bow_kf_f(int device, const uint8_t *kf_desc, const float *kf_a
                            const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
                            float nnratio, int check_orientation, int32_t *match_f);
 
+/* The same for a fisheye-stereo Frame (F.Nleft != -1, ORBmatcher.cc:277-326, 362-389): features [0, f_nleft) come
+ * from the left camera, [f_nleft, n_f) from the right (descriptors vconcat'ed, Frame.cc:296).  Left and right
+ * candidates keep separate best / second-best pairs; the right best is accepted at dist <= TH_LOW without a ratio
+ * test, but only when the left best also is <= TH_LOW (the reference nests the block).  f_nleft = -1 is the call
+ * above. */
+int vsg_search_by_bow_kf_f_stereo(int device, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid,
+                                  int n_kf, const int32_t *kf_node_id, const int32_t *kf_off, const int32_t *kf_idx,
+                                  int kf_nodes, const uint8_t *f_desc, const float *f_angle, int n_f, int f_nleft,
+                                  const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
+                                  float nnratio, int check_orientation, int32_t *match_f);
+
 /* int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (ORBmatcher.h:65,
  * ORBmatcher.cc:758-900), NLeft == -1.  matches12[idx1] = idx2 or -1. */
 int vsg_search_by_bow_kf_kf(int device, const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,

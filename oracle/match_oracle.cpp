@@ -149,11 +149,13 @@ int or_grid_query(const OrGrid *g, float x, float y, float r, int minLevel, int 
   return count;
 }
 
-int or_search_by_bow_kf_f(const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfValid, int nKF,
-                          const int *kfNodeId, const int *kfOff, const int *kfIdx, int kfNodes,
-                          const uint8_t *fDesc, const float *fAngle, int nF, const int *fNodeId, const int *fOff,
-                          const int *fIdx, int fNodes, float mfNNratio, int checkOri, int *matchF) {
-  // ORBmatcher.cc:226-428 with F.Nleft == -1
+int or_search_by_bow_kf_f_stereo(const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfValid, int nKF,
+                                 const int *kfNodeId, const int *kfOff, const int *kfIdx, int kfNodes,
+                                 const uint8_t *fDesc, const float *fAngle, int nF, int nleftF, const int *fNodeId,
+                                 const int *fOff, const int *fIdx, int fNodes, float mfNNratio, int checkOri,
+                                 int *matchF) {
+  // ORBmatcher.cc:226-428.  nleftF = F.Nleft (-1: monocular / rectified stereo; >= 0: fisheye stereo, features
+  // [0, Nleft) come from the left camera and [Nleft, N) from the right, descriptors vconcat'ed, Frame.cc:296)
   (void)nKF;
   for (int i = 0; i < nF; i++) matchF[i] = -1;
   int nmatches = 0;
@@ -166,16 +168,27 @@ int or_search_by_bow_kf_f(const uint8_t *kfDesc, const float *kfAngle, const uin
         if (!kfValid[realIdxKF]) continue;  // !pMP || pMP->isBad()
         const uint8_t *dKF = kfDesc + (size_t)realIdxKF * 32;
         int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        int bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
         for (int iF = fOff[Fit]; iF < fOff[Fit + 1]; iF++) {
           const int realIdxF = fIdx[iF];
           if (matchF[realIdxF] >= 0) continue;
           const int dist = DescriptorDistance(dKF, fDesc + (size_t)realIdxF * 32);
-          if (dist < bestDist1) {
-            bestDist2 = bestDist1;
-            bestDist1 = dist;
-            bestIdxF = realIdxF;
-          } else if (dist < bestDist2) {
-            bestDist2 = dist;
+          if (nleftF == -1 || realIdxF < nleftF) {  // (:277-315)
+            if (dist < bestDist1) {
+              bestDist2 = bestDist1;
+              bestDist1 = dist;
+              bestIdxF = realIdxF;
+            } else if (dist < bestDist2) {
+              bestDist2 = dist;
+            }
+          } else {  // (:317-326)
+            if (dist < bestDist1R) {
+              bestDist2R = bestDist1R;
+              bestDist1R = dist;
+              bestIdxFR = realIdxF;
+            } else if (dist < bestDist2R) {
+              bestDist2R = dist;
+            }
           }
         }
         if (bestDist1 <= TH_LOW) {
@@ -184,6 +197,13 @@ int or_search_by_bow_kf_f(const uint8_t *kfDesc, const float *kfAngle, const uin
             if (checkOri) rotHist[rotBin(kfAngle[realIdxKF], fAngle[bestIdxF])].push_back(bestIdxF);
             nmatches++;
           }
+          // (:362-389) nested in the left test, ratio test short-circuited by `|| true`
+          if (bestDist1R <= TH_LOW) {
+            matchF[bestIdxFR] = realIdxKF;
+            if (checkOri) rotHist[rotBin(kfAngle[realIdxKF], fAngle[bestIdxFR])].push_back(bestIdxFR);
+            nmatches++;
+          }
+          (void)bestDist2R;
         }
       }
       KFit++;
@@ -206,6 +226,14 @@ int or_search_by_bow_kf_f(const uint8_t *kfDesc, const float *kfAngle, const uin
     }
   }
   return nmatches;
+}
+
+int or_search_by_bow_kf_f(const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfValid, int nKF,
+                          const int *kfNodeId, const int *kfOff, const int *kfIdx, int kfNodes,
+                          const uint8_t *fDesc, const float *fAngle, int nF, const int *fNodeId, const int *fOff,
+                          const int *fIdx, int fNodes, float mfNNratio, int checkOri, int *matchF) {
+  return or_search_by_bow_kf_f_stereo(kfDesc, kfAngle, kfValid, nKF, kfNodeId, kfOff, kfIdx, kfNodes, fDesc, fAngle, nF,
+                                      -1, fNodeId, fOff, fIdx, fNodes, mfNNratio, checkOri, matchF);
 }
 
 int or_search_by_bow_kf_kf(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,

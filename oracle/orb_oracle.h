@@ -137,6 +137,14 @@ int or_search_by_bow_kf_f(const uint8_t *kfDesc, const float *kfAngle, const uin
                           const uint8_t *fDesc, const float *fAngle, int nF, const int *fNodeId, const int *fOff,
                           const int *fIdx, int fNodes, float nnratio, int checkOri, int *matchF);
 
+/* The same with F.Nleft given (fisheye stereo: a second best/second pair over the right-camera features,
+ * ORBmatcher.cc:277-326, 362-389); nleftF = -1 is the monocular form above. */
+int or_search_by_bow_kf_f_stereo(const uint8_t *kfDesc, const float *kfAngle, const uint8_t *kfValid, int nKF,
+                                 const int *kfNodeId, const int *kfOff, const int *kfIdx, int kfNodes,
+                                 const uint8_t *fDesc, const float *fAngle, int nF, int nleftF, const int *fNodeId,
+                                 const int *fOff, const int *fIdx, int fNodes, float nnratio, int checkOri,
+                                 int *matchF);
+
 /* SearchByBoW(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:758-900), NLeft == -1.
  * matches12[idx1] = idx2 or -1. */
 int or_search_by_bow_kf_kf(const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,

@@ -74,6 +74,9 @@ def lib():
         L.or_search_by_bow_kf_f.argtypes = [_u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
                                             _u8p, _f32p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
                                             C.c_float, C.c_int, _i32p]
+        L.or_search_by_bow_kf_f_stereo.argtypes = [_u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                                   _u8p, _f32p, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                                   C.c_float, C.c_int, _i32p]
         L.or_search_by_bow_kf_kf.argtypes = [_u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
                                              _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
                                              C.c_float, C.c_int, _i32p]
@@ -298,7 +301,7 @@ class OracleGrid:
         return out[:n].copy()
 
 
-def search_by_bow_kf_f(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv, nnratio, check_ori):
+def search_by_bow_kf_f(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv, nnratio, check_ori, f_nleft=-1):
     """fv = (node_ids, offsets, indices) CSR. Returns (nmatches, matchF)."""
     kd, fd = _u8c(kf_desc), _u8c(f_desc)
     ka, fa = _f32c(kf_angle), _f32c(f_angle)
@@ -306,10 +309,10 @@ def search_by_bow_kf_f(kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv
     kn, ko, ki = (_i32c(a) for a in kf_fv)
     fn, fo, fi = (_i32c(a) for a in f_fv)
     out = np.zeros(len(fd), np.int32)
-    n = lib().or_search_by_bow_kf_f(_ptr(kd, _u8p), _ptr(ka, _f32p), _ptr(kv, _u8p), len(kd), _ptr(kn, _i32p),
-                                    _ptr(ko, _i32p), _ptr(ki, _i32p), len(kn), _ptr(fd, _u8p), _ptr(fa, _f32p),
-                                    len(fd), _ptr(fn, _i32p), _ptr(fo, _i32p), _ptr(fi, _i32p), len(fn),
-                                    float(nnratio), int(check_ori), _ptr(out, _i32p))
+    n = lib().or_search_by_bow_kf_f_stereo(_ptr(kd, _u8p), _ptr(ka, _f32p), _ptr(kv, _u8p), len(kd), _ptr(kn, _i32p),
+                                           _ptr(ko, _i32p), _ptr(ki, _i32p), len(kn), _ptr(fd, _u8p),
+                                           _ptr(fa, _f32p), len(fd), int(f_nleft), _ptr(fn, _i32p), _ptr(fo, _i32p),
+                                           _ptr(fi, _i32p), len(fn), float(nnratio), int(check_ori), _ptr(out, _i32p))
     return n, out
 
 

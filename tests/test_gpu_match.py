@@ -367,3 +367,38 @@ def test_block_best2_tile_boundaries_of_the_mfma_kernel():
     n, qi, qd, tm, _ = orb.search_window(z[:1], None, off, np.arange(40, dtype=np.int32), comp, None, 256)
     assert (n, qi.tolist(), qd.tolist()) == (0, [-1], [256])
     assert ol.search_window(z[:1], None, off, np.arange(40, dtype=np.int32), comp, None, 256)[:3][0] == 0
+
+
+@pytest.mark.parametrize("seed,n_nodes,ratio,ori", [(0, 60, 0.7, True), (1, 8, 0.9, True), (2, 1, 0.6, False)])
+def test_search_by_bow_kf_f_fisheye_stereo(frames, seed, n_nodes, ratio, ori):
+    """SearchByBoW(KeyFrame*, Frame&) with F.Nleft != -1 (ORBmatcher.cc:277-326, 362-389): the frame holds the left
+    camera's features followed by the right camera's; a KF feature can claim one of each, the right one without a
+    ratio test but only if the left best is within TH_LOW."""
+    (k0, d0), _ = frames
+    rng = np.random.default_rng(400 + seed)
+    n = len(d0)
+    permL, permR = rng.permutation(n), rng.permutation(n)
+    keepR = rng.random(n) < 0.7
+    f_desc = np.concatenate([near_duplicates(d0[permL], rng, 6), near_duplicates(d0[permR][keepR], rng, 9)])
+    f_angle = np.concatenate([k0["angle"][permL], k0["angle"][permR][keepR]]).astype(np.float32)
+    nleft = n
+    kf_valid = (rng.random(n) > 0.2).astype(np.uint8)
+    node_of_kf = rng.integers(0, n_nodes, n)
+    node_of_f = np.concatenate([node_of_kf[permL], node_of_kf[permR][keepR]])
+
+    def csr(node):
+        ids = np.unique(node)
+        idx = np.concatenate([np.nonzero(node == i)[0] for i in ids])
+        off = np.concatenate([[0], np.cumsum([np.sum(node == i) for i in ids])])
+        return ids.astype(np.int32), off.astype(np.int32), idx.astype(np.int32)
+
+    kf_fv, f_fv = csr(node_of_kf), csr(node_of_f)
+    m = orb.ORBmatcher(ratio, ori)
+    n_got, got = m.SearchByBoW_KF_F(d0, k0["angle"], kf_valid, kf_fv, f_desc, f_angle, f_fv, f_nleft=nleft)
+    n_want, want = ol.search_by_bow_kf_f(d0, k0["angle"], kf_valid, kf_fv, f_desc, f_angle, f_fv, ratio, ori, nleft)
+    assert n_got == n_want and np.array_equal(got, want)
+    assert (want[:nleft] >= 0).sum() > 50 and (want[nleft:] >= 0).sum() > 50  # both cameras really matched
+    # with Nleft = -1 the same arrays are one block: different result, and it equals the mono entry point
+    n_m, got_m = m.SearchByBoW_KF_F(d0, k0["angle"], kf_valid, kf_fv, f_desc, f_angle, f_fv)
+    n_w, want_m = ol.search_by_bow_kf_f(d0, k0["angle"], kf_valid, kf_fv, f_desc, f_angle, f_fv, ratio, ori)
+    assert n_m == n_w and np.array_equal(got_m, want_m) and not np.array_equal(want_m, want)

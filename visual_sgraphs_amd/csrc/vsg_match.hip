@@ -299,6 +299,7 @@ struct NodePair {
 __global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, int npairs, const uint8_t *descA,
                                                        const uint8_t *validA, const int *idxA, const uint8_t *descB,
                                                        const uint8_t *validB, const int *idxB, float nnratio, int mode,
+                                                       int nleftB /*mode0: F.Nleft or -1*/,
                                                        int *matchA /*mode1: matches12*/, int *matchB /*mode0: match_f; mode1: matched2 flags*/) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= npairs) return;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, in
     if (!validA[ra]) continue;  // !pMP || pMP->isBad()
     uint4 a0, a1;
     load_desc(descA, ra, a0, a1);
-    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+    uint32_t k1 = KEY_NONE, k2 = KEY_NONE, r1 = KEY_NONE, r2 = KEY_NONE;  // left / right-camera (fisheye) candidates
     for (int j = lane; j < nb; j += 64) {
       const int rb = idxB[np.b_begin + j];
       const bool skip = mode == 0 ? (matchB[rb] >= 0) : (matchB[rb] != 0 || !validB[rb]);
@@ -317,10 +318,20 @@ __global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, in
       uint4 b0, b1;
       load_desc(descB, rb, b0, b1);
       const uint32_t key = ((uint32_t)hamming256(a0, a1, b0, b1) << 20) | (uint32_t)j;
-      merge2(k1, k2, key, KEY_NONE);
+      if (nleftB < 0 || rb < nleftB)
+        merge2(k1, k2, key, KEY_NONE);
+      else
+        merge2(r1, r2, key, KEY_NONE);
     }
     wave_best2(k1, k2);
     const int bestDist1 = (int)(k1 >> 20), bestDist2 = (int)(k2 >> 20);
+    if (nleftB >= 0 && bestDist1 <= TH_LOW) {  // right block, nested in the left test, no ratio test (:362-389)
+      r1 = wave_min(r1);
+      if ((int)(r1 >> 20) <= TH_LOW) {
+        if (lane == 0) matchB[idxB[np.b_begin + (int)(r1 & 0xFFFFF)]] = ra;
+        __threadfence_block();  // later KF features of this node must see the claim
+      }
+    }
     const bool pass = mode == 0 ? bestDist1 <= TH_LOW : bestDist1 < TH_LOW;
     if (pass && (float)bestDist1 < nnratio * (float)bestDist2) {  // :335-337 / :843-845
       const int rb = idxB[np.b_begin + (int)(k1 & 0xFFFFF)];
@@ -679,7 +690,7 @@ int vsg_hamming_block_best2(int device, const uint8_t *a, int na, const uint8_t 
   return VSG_OK;
 }
 
-static int search_by_bow(int device, int mode, const uint8_t *descA, const float *angleA, const uint8_t *validA, int nA,
+static int search_by_bow(int device, int mode, int nleftB, const uint8_t *descA, const float *angleA, const uint8_t *validA, int nA,
                          const int *idA, const int *offA, const int *idxA, int nodesA, const uint8_t *descB,
                          const float *angleB, const uint8_t *validB, int nB, const int *idB, const int *offB,
                          const int *idxB, int nodesB, float nnratio, int checkOri, int *out) {
@@ -713,7 +724,8 @@ static int search_by_bow(int device, int mode, const uint8_t *descA, const float
   const int npairs = (int)pairs.size();
   hipLaunchKernelGGL(k_search_by_bow, dim3((npairs + 3) / 4), dim3(256), 0, 0, dPairs.as<NodePair>(), npairs,
                      dDescA.as<uint8_t>(), dValidA.as<uint8_t>(), dIdxA.as<int>(), dDescB.as<uint8_t>(),
-                     dValidB.as<uint8_t>(), dIdxB.as<int>(), nnratio, mode, dMatchA.as<int>(), dMatchB.as<int>());
+                     dValidB.as<uint8_t>(), dIdxB.as<int>(), nnratio, mode, nleftB, dMatchA.as<int>(),
+                     dMatchB.as<int>());
   M_TRY(hipMemcpy(out, mode == 0 ? dMatchB.p : dMatchA.p, (size_t)nOut * 4, hipMemcpyDeviceToHost));
   // rotation consistency (:407-425 / :879-897): every match sits in exactly one bin
   int nmatches = 0;
@@ -802,8 +814,19 @@ int vsg_search_by_bow_kf_f(int device, const uint8_t *kf_desc, const float *kf_a
                            const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
                            float nnratio, int check_orientation, int32_t *match_f) {
   if (!match_f || n_kf < 0 || n_f < 0) return VSG_ERR_INVALID;
-  return search_by_bow(device, 0, kf_desc, kf_angle, kf_valid, n_kf, kf_node_id, kf_off, kf_idx, kf_nodes, f_desc,
+  return search_by_bow(device, 0, -1, kf_desc, kf_angle, kf_valid, n_kf, kf_node_id, kf_off, kf_idx, kf_nodes, f_desc,
                        f_angle, nullptr, n_f, f_node_id, f_off, f_idx, f_nodes, nnratio, check_orientation, match_f);
+}
+
+int vsg_search_by_bow_kf_f_stereo(int device, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid,
+                                  int n_kf, const int32_t *kf_node_id, const int32_t *kf_off, const int32_t *kf_idx,
+                                  int kf_nodes, const uint8_t *f_desc, const float *f_angle, int n_f, int f_nleft,
+                                  const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
+                                  float nnratio, int check_orientation, int32_t *match_f) {
+  if (!match_f || n_kf < 0 || n_f < 0 || f_nleft < -1 || f_nleft > n_f) return VSG_ERR_INVALID;
+  return search_by_bow(device, 0, f_nleft, kf_desc, kf_angle, kf_valid, n_kf, kf_node_id, kf_off, kf_idx, kf_nodes,
+                       f_desc, f_angle, nullptr, n_f, f_node_id, f_off, f_idx, f_nodes, nnratio, check_orientation,
+                       match_f);
 }
 
 int vsg_search_by_bow_kf_kf(int device, const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
@@ -812,7 +835,7 @@ int vsg_search_by_bow_kf_kf(int device, const uint8_t *desc1, const float *angle
                             const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
                             float nnratio, int check_orientation, int32_t *matches12) {
   if (!matches12 || n1 < 0 || n2 < 0) return VSG_ERR_INVALID;
-  return search_by_bow(device, 1, desc1, angle1, valid1, n1, node_id1, off1, idx1, nodes1, desc2, angle2, valid2, n2,
+  return search_by_bow(device, 1, -1, desc1, angle1, valid1, n1, node_id1, off1, idx1, nodes1, desc2, angle2, valid2, n2,
                        node_id2, off2, idx2, nodes2, nnratio, check_orientation, matches12);
 }
 

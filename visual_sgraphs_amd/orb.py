@@ -41,7 +41,7 @@ EXPORTS = [
     "vsg_grid_destroy", "vsg_grid_query", "vsg_stereo_matches", "vsg_orb_set_gray_coeffs",
     "vsg_orb_extract_batch_device_color", "vsg_orb_extract_batch_color", "vsg_vocab_load", "vsg_vocab_destroy",
     "vsg_vocab_info", "vsg_bow_transform", "vsg_distinctive_descriptors", "vsg_debug_device_sort",
-    "vsg_search_for_triangulation",
+    "vsg_search_for_triangulation", "vsg_search_by_bow_kf_f_stereo",
 ]
 
 
@@ -101,6 +101,9 @@ def load_library():
                                                  C.c_void_p]
     L.vsg_search_by_bow_kf_f.argtypes = [C.c_int, _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
                                          _u8p, _f32p, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_float, C.c_int, _i32p]
+    L.vsg_search_by_bow_kf_f_stereo.argtypes = [C.c_int, _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
+                                                _u8p, _f32p, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_float,
+                                                C.c_int, _i32p]
     L.vsg_search_by_bow_kf_kf.argtypes = [C.c_int, _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int,
                                           _u8p, _f32p, _u8p, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_float,
                                           C.c_int, _i32p]
@@ -409,19 +412,19 @@ class ORBmatcher:
                    "vsg_hamming_block_best2")
         return best, second, arg
 
-    def SearchByBoW_KF_F(self, kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv):
-        """SearchByBoW(KeyFrame*, Frame&, ...).  fv = (node_ids, offsets, indices).  Returns (nmatches, matchF)."""
+    def SearchByBoW_KF_F(self, kf_desc, kf_angle, kf_valid, kf_fv, f_desc, f_angle, f_fv, f_nleft=-1):
+        """SearchByBoW(KeyFrame*, Frame&, ...).  fv = (node_ids, offsets, indices); f_nleft = F.Nleft (fisheye
+        stereo: right-camera features start there).  Returns (nmatches, matchF)."""
         kd, fd = _u8(kf_desc).reshape(-1, 32), _u8(f_desc).reshape(-1, 32)
         ka, fa, kv = _f32(kf_angle), _f32(f_angle), _u8(kf_valid)
         kn, ko, ki = (_i32(x) for x in kf_fv)
         fn, fo, fi = (_i32(x) for x in f_fv)
         out = np.full(max(len(fd), 1), -1, np.int32)
-        n = _check(self._L.vsg_search_by_bow_kf_f(self.device, _p(kd, _u8p), _p(ka, _f32p), _p(kv, _u8p), len(kd),
-                                                  _p(kn, _i32p), _p(ko, _i32p), _p(ki, _i32p), len(kf_fv[0]),
-                                                  _p(fd, _u8p), _p(fa, _f32p), len(fd), _p(fn, _i32p), _p(fo, _i32p),
-                                                  _p(fi, _i32p), len(f_fv[0]), self.mfNNratio,
-                                                  int(self.mbCheckOrientation), _p(out, _i32p)),
-                   "vsg_search_by_bow_kf_f")
+        n = _check(self._L.vsg_search_by_bow_kf_f_stereo(
+            self.device, _p(kd, _u8p), _p(ka, _f32p), _p(kv, _u8p), len(kd), _p(kn, _i32p), _p(ko, _i32p),
+            _p(ki, _i32p), len(kf_fv[0]), _p(fd, _u8p), _p(fa, _f32p), len(fd), int(f_nleft), _p(fn, _i32p),
+            _p(fo, _i32p), _p(fi, _i32p), len(f_fv[0]), self.mfNNratio, int(self.mbCheckOrientation),
+            _p(out, _i32p)), "vsg_search_by_bow_kf_f_stereo")
         return n, out[:len(fd)]
 
     def SearchByBoW_KF_KF(self, d1, a1, v1, fv1, d2, a2, v2, fv2):
