@@ -387,113 +387,19 @@ __global__ __launch_bounds__(256) void k_search_triangulation(const NodePair *pa
   }
 }
 
-// ---- windowed searches: one wavefront walks the queries in order (greedy state), lanes over candidates.
-// mode 0: SearchByProjection(Cur, Last)   (:1686-1784)  best only, accept <= thHigh, events for the rot. histogram
-// mode 1: SearchByProjection(F, MapPoints)(:48-144)     best+second with octave-aware ratio test
-__global__ __launch_bounds__(64) void k_search_window(const uint8_t *qDesc, const uint8_t *queryBlocks, int nQ,
-                                                      const int *candOff, const int *candIdx, const uint8_t *tDesc,
-                                                      const int *tOctave, uint8_t *trainBlocked, int thHigh,
-                                                      float nnratio, int mode, int *trainMatch, int *events,
-                                                      int *qBest /*optional [nQ][2] = idx, dist*/,
-                                                      int *result /*[0]=nmatches [1]=nevents*/) {
-  const int lane = threadIdx.x;
-  int nmatches = 0, nev = 0;
-  for (int q = 0; q < nQ; q++) {
-    const int c0 = candOff[q], c1 = candOff[q + 1];
-    if (qBest && lane == 0) {
-      qBest[2 * q] = -1;
-      qBest[2 * q + 1] = 256;
-    }
-    if (c0 == c1) continue;
-    uint4 a0, a1;
-    load_desc(qDesc, q, a0, a1);
-    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
-    for (int c = c0 + lane; c < c1; c += 64) {
-      const int i2 = candIdx[c];
-      if (trainBlocked[i2]) continue;
-      uint4 b0, b1;
-      load_desc(tDesc, i2, b0, b1);
-      const uint32_t key = ((uint32_t)hamming256(a0, a1, b0, b1) << 20) | (uint32_t)(c - c0);
-      merge2(k1, k2, key, KEY_NONE);
-    }
-    wave_best2(k1, k2);
-    const int bestDist = (int)(k1 >> 20);
-    if (qBest && lane == 0 && !key_is_none(k1)) {
-      qBest[2 * q] = candIdx[c0 + (int)(k1 & 0xFFFFF)];
-      qBest[2 * q + 1] = bestDist;
-    }
-    if (bestDist > thHigh || key_is_none(k1)) continue;
-    const int bestIdx = candIdx[c0 + (int)(k1 & 0xFFFFF)];
-    bool accept = true;
-    if (mode == 1) {
-      const int bestDist2 = (int)(k2 >> 20);
-      const int bestLevel = tOctave[bestIdx];
-      const int bestLevel2 = key_is_none(k2) ? -1 : tOctave[candIdx[c0 + (int)(k2 & 0xFFFFF)]];
-      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) accept = false;       // :125-126
-      else if (!(bestLevel != bestLevel2 || (float)bestDist <= nnratio * (float)bestDist2)) accept = false;  // :128
-    }
-    if (!accept) continue;
-    if (lane == 0) {
-      trainMatch[bestIdx] = q;
-      trainBlocked[bestIdx] = queryBlocks ? queryBlocks[q] : 0;
-      if (events) {
-        events[2 * nev] = q;
-        events[2 * nev + 1] = bestIdx;
-      }
-    }
-    nmatches++;
-    nev++;
-    __threadfence_block();
-  }
-  if (lane == 0) {
-    result[0] = nmatches;
-    result[1] = nev;
-  }
-}
-
-// ---- SearchForInitialization (:656-724): state = vMatchedDistance / vnMatches21 / vnMatches12
-__global__ __launch_bounds__(64) void k_search_init(const uint8_t *desc1, const int *octave1, int n1, const int *candOff,
-                                                    const int *candIdx, const uint8_t *desc2, float nnratio,
-                                                    int *matchedDistance, int *matches21, int *matches12, int *partner,
-                                                    int *result) {
-  const int lane = threadIdx.x;
-  int nmatches = 0;
-  for (int i1 = 0; i1 < n1; i1++) {
-    if (octave1[i1] > 0) continue;
-    const int c0 = candOff[i1], c1 = candOff[i1 + 1];
-    if (c0 == c1) continue;
-    uint4 a0, a1;
-    load_desc(desc1, i1, a0, a1);
-    uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
-    for (int c = c0 + lane; c < c1; c += 64) {
-      const int i2 = candIdx[c];
-      uint4 b0, b1;
-      load_desc(desc2, i2, b0, b1);
-      const int dist = hamming256(a0, a1, b0, b1);
-      if (matchedDistance[i2] <= dist) continue;  // :682
-      merge2(k1, k2, ((uint32_t)dist << 20) | (uint32_t)(c - c0), KEY_NONE);
-    }
-    wave_best2(k1, k2);
-    if (k1 == KEY_NONE) continue;  // bestDist stays INT_MAX
-    const int bestDist = (int)(k1 >> 20);
-    // bestDist2 stays INT_MAX when there is no second candidate: (float)INT_MAX * ratio is still > bestDist
-    const float second = k2 == KEY_NONE ? (float)2147483647 : (float)(int)(k2 >> 20);
-    if (bestDist <= TH_LOW && (float)bestDist < second * nnratio) {  // :697-699
-      const int bestIdx2 = candIdx[c0 + (int)(k1 & 0xFFFFF)];
-      const int prev = matches21[bestIdx2];
-      if (prev >= 0) nmatches--;
-      if (lane == 0) {
-        if (prev >= 0) matches12[prev] = -1;
-        matches12[i1] = bestIdx2;
-        matches21[bestIdx2] = i1;
-        matchedDistance[bestIdx2] = bestDist;
-        partner[i1] = bestIdx2;
-      }
-      nmatches++;
-      __threadfence_block();
-    }
-  }
-  if (lane == 0) result[0] = nmatches;
+// ---- windowed searches (SearchByProjection x5, SearchForInitialization, SearchBySim3, Fuse): every candidate
+// entry's Hamming distance in ONE data-parallel pass, dist[c] = |q_desc[q_of[c]] ^ t_desc[cand_idx[c]]|.  The walk over
+// the queries that follows is inherently sequential (a claimed feature blocks later queries) and touches a dozen
+// candidates per query: it runs on the host over these distances (below), like the reference's own loop -- the first
+// version walked the queries with a single wavefront on the device and took 1.3 ms for 1000 queries, 25x the CPU.
+__global__ __launch_bounds__(256) void k_cand_dist(const uint8_t *qDesc, const int *qOf, const int *candIdx,
+                                                   const uint8_t *tDesc, int ncand, uint16_t *dist) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncand) return;
+  uint4 a0, a1, b0, b1;
+  load_desc(qDesc, qOf[c], a0, a1);
+  load_desc(tDesc, candIdx[c], b0, b1);
+  dist[c] = (uint16_t)hamming256(a0, a1, b0, b1);
 }
 
 // ---- MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:380-415): one workgroup per map point.  The N x N
@@ -621,6 +527,48 @@ void join_nodes(const int *idA, const int *offA, int nA, const int *idB, const i
     } else {
       j = (int)(std::lower_bound(idB, idB + nB, idA[i]) - idB);
     }
+  }
+}
+
+// Distances of all candidate entries (device) for the windowed searches.  One staging buffer up, one array down.
+static int candidate_distances(int device, const uint8_t *q_desc, int n_q, const int32_t *cand_off,
+                               const int32_t *cand_idx, const uint8_t *t_desc, int n_t, std::vector<uint16_t> &dist) {
+  int rc = use_device(device);
+  if (rc != VSG_OK) return rc;
+  const int ncand = cand_off[n_q];
+  dist.assign((size_t)ncand, 0);
+  if (ncand == 0) return VSG_OK;
+  for (int c = 0; c < ncand; c++)
+    if (cand_idx[c] < 0 || cand_idx[c] >= n_t) return VSG_ERR_INVALID;
+  // [q_desc | t_desc | q_of | cand_idx] in one host block -> one H2D copy
+  const size_t oQ = 0, oT = oQ + (size_t)n_q * 32, oOf = oT + (size_t)n_t * 32, oIdx = oOf + (size_t)ncand * 4,
+               total = oIdx + (size_t)ncand * 4;
+  std::vector<uint8_t> stage(total);
+  memcpy(stage.data() + oQ, q_desc, (size_t)n_q * 32);
+  memcpy(stage.data() + oT, t_desc, (size_t)n_t * 32);
+  int32_t *qof = (int32_t *)(stage.data() + oOf);
+  for (int q = 0; q < n_q; q++)
+    for (int c = cand_off[q]; c < cand_off[q + 1]; c++) qof[c] = q;
+  memcpy(stage.data() + oIdx, cand_idx, (size_t)ncand * 4);
+  DevBuf dIn, dDist;
+  M_TRY(dIn.upload(stage.data(), total));
+  M_TRY(dDist.alloc((size_t)ncand * 2));
+  const uint8_t *base = dIn.as<uint8_t>();
+  hipLaunchKernelGGL(k_cand_dist, dim3((ncand + 255) / 256), dim3(256), 0, 0, base + oQ, (const int *)(base + oOf),
+                     (const int *)(base + oIdx), base + oT, ncand, dDist.as<uint16_t>());
+  M_TRY(hipGetLastError());
+  M_TRY(hipMemcpy(dist.data(), dDist.p, (size_t)ncand * 2, hipMemcpyDeviceToHost));
+  return VSG_OK;
+}
+
+// rotation-histogram filter shared by the searches: entries of the losing bins are handed to `drop`
+template <class Drop>
+static void filter_rotation(std::vector<int> (&rotHist)[HISTO_LENGTH], Drop drop) {
+  int ind1 = -1, ind2 = -1, ind3 = -1;
+  three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+  for (int i = 0; i < HISTO_LENGTH; i++) {
+    if (i == ind1 || i == ind2 || i == ind3) continue;
+    for (size_t j = 0; j < rotHist[i].size(); j++) drop(rotHist[i][j]);
   }
 }
 
@@ -839,60 +787,42 @@ int vsg_search_by_bow_kf_kf(int device, const uint8_t *desc1, const float *angle
                        node_id2, off2, idx2, nodes2, nnratio, check_orientation, matches12);
 }
 
-static int search_window(int device, int mode, const uint8_t *q_desc, const float *q_angle,
-                         const uint8_t *query_blocks, int n_q, const int32_t *cand_off, const int32_t *cand_idx,
-                         const uint8_t *t_desc, const float *t_angle, const int32_t *t_octave, uint8_t *train_blocked,
-                         int n_t, int th_high, float nnratio, int check_orientation, int32_t *train_match) {
-  int rc = use_device(device);
-  if (rc != VSG_OK) return rc;
-  if (n_q == 0 || n_t == 0) return 0;
-  const int ncand = cand_off[n_q];
-  DevBuf dQ, dQB, dOff, dIdx, dT, dOct, dBlocked, dMatch, dEvents, dResult;
-  M_TRY(dQ.upload(q_desc, (size_t)n_q * 32));
-  M_TRY(dQB.upload(query_blocks, (size_t)n_q));
-  M_TRY(dOff.upload(cand_off, (size_t)(n_q + 1) * 4));
-  M_TRY(dIdx.upload(cand_idx, (size_t)ncand * 4));
-  M_TRY(dT.upload(t_desc, (size_t)n_t * 32));
-  if (t_octave) M_TRY(dOct.upload(t_octave, (size_t)n_t * 4));
-  M_TRY(dBlocked.upload(train_blocked, (size_t)n_t));
-  M_TRY(dMatch.upload(train_match, (size_t)n_t * 4));
-  M_TRY(dEvents.alloc((size_t)n_q * 8));
-  M_TRY(dResult.alloc(8));
-  hipLaunchKernelGGL(k_search_window, dim3(1), dim3(64), 0, 0, dQ.as<uint8_t>(), dQB.as<uint8_t>(), n_q, dOff.as<int>(),
-                     dIdx.as<int>(), dT.as<uint8_t>(), dOct.as<int>(), dBlocked.as<uint8_t>(), th_high, nnratio, mode,
-                     dMatch.as<int>(), mode == 0 ? dEvents.as<int>() : (int *)nullptr, (int *)nullptr, dResult.as<int>());
-  int result[2] = {0, 0};
-  M_TRY(hipMemcpy(result, dResult.p, 8, hipMemcpyDeviceToHost));
-  M_TRY(hipMemcpy(train_match, dMatch.p, (size_t)n_t * 4, hipMemcpyDeviceToHost));
-  M_TRY(hipMemcpy(train_blocked, dBlocked.p, (size_t)n_t, hipMemcpyDeviceToHost));
-  int nmatches = result[0];
-  if (mode == 0 && check_orientation) {  // :1855-1875
-    std::vector<int> ev((size_t)result[1] * 2);
-    if (result[1] > 0) M_TRY(hipMemcpy(ev.data(), dEvents.p, ev.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<int> rotHist[HISTO_LENGTH];
-    for (int e = 0; e < result[1]; e++) rotHist[rot_bin(q_angle[ev[2 * e]], t_angle[ev[2 * e + 1]])].push_back(ev[2 * e + 1]);
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-    for (int i = 0; i < HISTO_LENGTH; i++) {
-      if (i != ind1 && i != ind2 && i != ind3) {
-        for (size_t j = 0; j < rotHist[i].size(); j++) {
-          train_match[rotHist[i][j]] = -1;
-          nmatches--;
-        }
-      }
-    }
-  }
-  return nmatches;
-}
-
 int vsg_search_by_projection_last(int device, const uint8_t *q_desc, const float *q_angle,
                                   const uint8_t *query_blocks, int n_q, const int32_t *cand_off,
                                   const int32_t *cand_idx, const uint8_t *t_desc, const float *t_angle,
                                   uint8_t *train_blocked, int n_t, int th_high, int check_orientation,
                                   int32_t *train_match) {
   if (!cand_off || !train_blocked || !train_match || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
-  return search_window(device, 0, q_desc, q_angle, query_blocks, n_q, cand_off, cand_idx, t_desc, t_angle, nullptr,
-                       train_blocked, n_t, th_high, 0.f, check_orientation, train_match);
+  if (n_q == 0 || n_t == 0) return use_device(device) == VSG_OK ? 0 : VSG_ERR_NO_DEVICE;
+  std::vector<uint16_t> dist;
+  int rc = candidate_distances(device, q_desc, n_q, cand_off, cand_idx, t_desc, n_t, dist);
+  if (rc != VSG_OK) return rc;
+  // ORBmatcher.cc:1686-1784 (left / mono block): best candidate only, strict '<' from 256
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int q = 0; q < n_q; q++) {
+    int bestDist = 256, bestIdx2 = -1;
+    for (int c = cand_off[q]; c < cand_off[q + 1]; c++) {
+      const int i2 = cand_idx[c];
+      if (train_blocked[i2]) continue;  // mvpMapPoints[i2] with Observations() > 0
+      if (dist[c] < bestDist) {
+        bestDist = dist[c];
+        bestIdx2 = i2;
+      }
+    }
+    if (bestDist <= th_high && bestIdx2 >= 0) {
+      train_match[bestIdx2] = q;
+      train_blocked[bestIdx2] = query_blocks ? query_blocks[q] : 0;
+      nmatches++;
+      if (check_orientation) rotHist[rot_bin(q_angle[q], t_angle[bestIdx2])].push_back(bestIdx2);
+    }
+  }
+  if (check_orientation)  // :1855-1875
+    filter_rotation(rotHist, [&](int i2) {
+      train_match[i2] = -1;
+      nmatches--;
+    });
+  return nmatches;
 }
 
 int vsg_search_by_projection_local(int device, const uint8_t *q_desc, const uint8_t *query_blocks, int n_q,
@@ -900,8 +830,39 @@ int vsg_search_by_projection_local(int device, const uint8_t *q_desc, const uint
                                    const int32_t *t_octave, uint8_t *train_blocked, int n_t, float nnratio,
                                    int32_t *train_match) {
   if (!cand_off || !train_blocked || !train_match || !t_octave || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
-  return search_window(device, 1, q_desc, nullptr, query_blocks, n_q, cand_off, cand_idx, t_desc, nullptr, t_octave,
-                       train_blocked, n_t, TH_HIGH, nnratio, 0, train_match);
+  if (n_q == 0 || n_t == 0) return use_device(device) == VSG_OK ? 0 : VSG_ERR_NO_DEVICE;
+  std::vector<uint16_t> dist;
+  int rc = candidate_distances(device, q_desc, n_q, cand_off, cand_idx, t_desc, n_t, dist);
+  if (rc != VSG_OK) return rc;
+  // ORBmatcher.cc:48-144 (left block): best + second best with their pyramid levels
+  int nmatches = 0;
+  for (int q = 0; q < n_q; q++) {
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int c = cand_off[q]; c < cand_off[q + 1]; c++) {
+      const int idx = cand_idx[c];
+      if (train_blocked[idx]) continue;
+      const int d = dist[c];
+      if (d < bestDist) {
+        bestDist2 = bestDist;
+        bestDist = d;
+        bestLevel2 = bestLevel;
+        bestLevel = t_octave[idx];
+        bestIdx = idx;
+      } else if (d < bestDist2) {
+        bestLevel2 = t_octave[idx];
+        bestDist2 = d;
+      }
+    }
+    if (bestDist <= TH_HIGH && bestIdx >= 0) {  // :123
+      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;  // :125-126
+      if (bestLevel != bestLevel2 || (float)bestDist <= nnratio * (float)bestDist2) {         // :128
+        train_match[bestIdx] = q;
+        train_blocked[bestIdx] = query_blocks ? query_blocks[q] : 0;
+        nmatches++;
+      }
+    }
+  }
+  return nmatches;
 }
 
 int vsg_distinctive_descriptors(int device, const uint8_t *desc, const int32_t *off, int ngroups, int32_t *best) {
@@ -925,87 +886,84 @@ int vsg_search_window(int device, const uint8_t *q_desc, const uint8_t *query_bl
                       const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *t_desc, uint8_t *train_blocked,
                       int n_t, int th_high, int32_t *q_best_idx, int32_t *q_best_dist, int32_t *train_match) {
   if (!cand_off || !q_best_idx || !q_best_dist || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
-  int rc = use_device(device);
-  if (rc != VSG_OK) return rc;
   for (int q = 0; q < n_q; q++) q_best_idx[q] = -1, q_best_dist[q] = 256;
-  if (n_q == 0 || n_t == 0) return 0;
-  const int ncand = cand_off[n_q];
-  DevBuf dQ, dQB, dOff, dIdx, dT, dBlocked, dMatch, dBest, dResult;
-  M_TRY(dQ.upload(q_desc, (size_t)n_q * 32));
-  if (query_blocks) M_TRY(dQB.upload(query_blocks, (size_t)n_q));
-  M_TRY(dOff.upload(cand_off, (size_t)(n_q + 1) * 4));
-  M_TRY(dIdx.upload(cand_idx, (size_t)ncand * 4));
-  M_TRY(dT.upload(t_desc, (size_t)n_t * 32));
-  std::vector<uint8_t> zeros((size_t)n_t, 0);
-  M_TRY(dBlocked.upload(train_blocked ? train_blocked : zeros.data(), (size_t)n_t));
-  std::vector<int> minus1((size_t)n_t, -1);
-  M_TRY(dMatch.upload(train_match ? train_match : minus1.data(), (size_t)n_t * 4));
-  M_TRY(dBest.alloc((size_t)n_q * 8));
-  M_TRY(dResult.alloc(8));
-  hipLaunchKernelGGL(k_search_window, dim3(1), dim3(64), 0, 0, dQ.as<uint8_t>(),
-                     query_blocks ? dQB.as<uint8_t>() : (uint8_t *)nullptr, n_q, dOff.as<int>(), dIdx.as<int>(),
-                     dT.as<uint8_t>(), (const int *)nullptr, dBlocked.as<uint8_t>(), th_high, 0.f, 0, dMatch.as<int>(),
-                     (int *)nullptr, dBest.as<int>(), dResult.as<int>());
-  int result[2] = {0, 0};
-  M_TRY(hipMemcpy(result, dResult.p, 8, hipMemcpyDeviceToHost));
-  std::vector<int> best((size_t)n_q * 2);
-  M_TRY(hipMemcpy(best.data(), dBest.p, (size_t)n_q * 8, hipMemcpyDeviceToHost));
-  for (int q = 0; q < n_q; q++) q_best_idx[q] = best[2 * q], q_best_dist[q] = best[2 * q + 1];
-  if (train_match) M_TRY(hipMemcpy(train_match, dMatch.p, (size_t)n_t * 4, hipMemcpyDeviceToHost));
-  if (train_blocked) M_TRY(hipMemcpy(train_blocked, dBlocked.p, (size_t)n_t, hipMemcpyDeviceToHost));
-  return result[0];
+  if (n_q == 0 || n_t == 0) return use_device(device) == VSG_OK ? 0 : VSG_ERR_NO_DEVICE;
+  std::vector<uint16_t> dist;
+  int rc = candidate_distances(device, q_desc, n_q, cand_off, cand_idx, t_desc, n_t, dist);
+  if (rc != VSG_OK) return rc;
+  int nmatches = 0;
+  for (int q = 0; q < n_q; q++) {
+    int bestDist = 256, bestIdx = -1;
+    for (int c = cand_off[q]; c < cand_off[q + 1]; c++) {
+      const int idx = cand_idx[c];
+      if (train_blocked && train_blocked[idx]) continue;
+      if (dist[c] < bestDist) {
+        bestDist = dist[c];
+        bestIdx = idx;
+      }
+    }
+    q_best_idx[q] = bestIdx;
+    q_best_dist[q] = bestDist;
+    if (bestIdx >= 0 && bestDist <= th_high) {
+      if (train_match) train_match[bestIdx] = q;
+      if (train_blocked) train_blocked[bestIdx] = query_blocks ? query_blocks[q] : 0;
+      nmatches++;
+    }
+  }
+  return nmatches;
 }
 
 int vsg_search_for_initialization(int device, const uint8_t *desc1, const float *angle1, const int32_t *octave1,
                                   int n1, const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *desc2,
                                   const float *angle2, int n2, float nnratio, int check_orientation,
                                   int32_t *matches12) {
-  if (!cand_off || !matches12 || n1 < 0 || n2 < 0) return VSG_ERR_INVALID;
-  int rc = use_device(device);
-  if (rc != VSG_OK) return rc;
+  if (!cand_off || !matches12 || !octave1 || n1 < 0 || n2 < 0) return VSG_ERR_INVALID;
   for (int i = 0; i < n1; i++) matches12[i] = -1;
-  if (n1 == 0 || n2 == 0) return 0;
-  const int ncand = cand_off[n1];
-  DevBuf d1, dOct, dOff, dIdx, d2, dDist, d21, d12, dPartner, dResult;
-  M_TRY(d1.upload(desc1, (size_t)n1 * 32));
-  M_TRY(dOct.upload(octave1, (size_t)n1 * 4));
-  M_TRY(dOff.upload(cand_off, (size_t)(n1 + 1) * 4));
-  M_TRY(dIdx.upload(cand_idx, (size_t)ncand * 4));
-  M_TRY(d2.upload(desc2, (size_t)n2 * 32));
-  std::vector<int> init((size_t)n2, 0x7FFFFFFF);
-  M_TRY(dDist.upload(init.data(), (size_t)n2 * 4));  // vMatchedDistance = INT_MAX (:653)
-  M_TRY(d21.alloc((size_t)n2 * 4));
-  M_TRY(hipMemset(d21.p, 0xFF, (size_t)n2 * 4));
-  M_TRY(d12.alloc((size_t)n1 * 4));
-  M_TRY(hipMemset(d12.p, 0xFF, (size_t)n1 * 4));
-  M_TRY(dPartner.alloc((size_t)n1 * 4));
-  M_TRY(hipMemset(dPartner.p, 0xFF, (size_t)n1 * 4));
-  M_TRY(dResult.alloc(8));
-  hipLaunchKernelGGL(k_search_init, dim3(1), dim3(64), 0, 0, d1.as<uint8_t>(), dOct.as<int>(), n1, dOff.as<int>(),
-                     dIdx.as<int>(), d2.as<uint8_t>(), nnratio, dDist.as<int>(), d21.as<int>(), d12.as<int>(),
-                     dPartner.as<int>(), dResult.as<int>());
+  if (n1 == 0 || n2 == 0) return use_device(device) == VSG_OK ? 0 : VSG_ERR_NO_DEVICE;
+  std::vector<uint16_t> dist;
+  int rc = candidate_distances(device, desc1, n1, cand_off, cand_idx, desc2, n2, dist);
+  if (rc != VSG_OK) return rc;
+  // ORBmatcher.cc:643-756
   int nmatches = 0;
-  M_TRY(hipMemcpy(&nmatches, dResult.p, 4, hipMemcpyDeviceToHost));
-  M_TRY(hipMemcpy(matches12, d12.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-  if (check_orientation) {  // :726-748
-    std::vector<int> partner((size_t)n1);
-    M_TRY(hipMemcpy(partner.data(), dPartner.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-    std::vector<int> rotHist[HISTO_LENGTH];
-    for (int i1 = 0; i1 < n1; i1++)
-      if (partner[i1] >= 0) rotHist[rot_bin(angle1[i1], angle2[partner[i1]])].push_back(i1);
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-    for (int i = 0; i < HISTO_LENGTH; i++) {
-      if (i == ind1 || i == ind2 || i == ind3) continue;
-      for (size_t j = 0; j < rotHist[i].size(); j++) {
-        const int idx1 = rotHist[i][j];
-        if (matches12[idx1] >= 0) {
-          matches12[idx1] = -1;
+  std::vector<int> vMatchedDistance((size_t)n2, 0x7FFFFFFF), vnMatches21((size_t)n2, -1);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i1 = 0; i1 < n1; i1++) {
+    if (octave1[i1] > 0) continue;  // :659-661
+    if (cand_off[i1] == cand_off[i1 + 1]) continue;
+    int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx2 = -1;
+    for (int c = cand_off[i1]; c < cand_off[i1 + 1]; c++) {
+      const int i2 = cand_idx[c];
+      const int d = dist[c];
+      if (vMatchedDistance[i2] <= d) continue;  // :682
+      if (d < bestDist) {
+        bestDist2 = bestDist;
+        bestDist = d;
+        bestIdx2 = i2;
+      } else if (d < bestDist2) {
+        bestDist2 = d;
+      }
+    }
+    if (bestDist <= TH_LOW) {
+      if ((float)bestDist < (float)bestDist2 * nnratio) {  // :697-699
+        if (vnMatches21[bestIdx2] >= 0) {
+          matches12[vnMatches21[bestIdx2]] = -1;
           nmatches--;
         }
+        matches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (check_orientation) rotHist[rot_bin(angle1[i1], angle2[bestIdx2])].push_back(i1);
       }
     }
   }
+  if (check_orientation)  // :726-748
+    filter_rotation(rotHist, [&](int idx1) {
+      if (matches12[idx1] >= 0) {
+        matches12[idx1] = -1;
+        nmatches--;
+      }
+    });
   return nmatches;
 }
 
