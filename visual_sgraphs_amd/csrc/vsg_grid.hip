@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string.h>
+
 #include <vector>
 
 #include "../../include/vsg_orb.h"
@@ -18,36 +20,29 @@ struct GridParams {
   float minX, minY, invW, invH;
 };
 
-// one thread per cell walks the keypoints in index order: a stable bucket fill without any sort
-__global__ void k_grid_cell_ids(const vsg_keypoint *kps, int n, GridParams P, int16_t *cell_of) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  // posX = round((kp.pt.x - mnMinX) * mfGridElementWidthInv)   (Frame.cc:872-873; libm round = half away from zero)
-  const int px = (int)roundf(vsg::fmul(vsg::fsub(kps[i].x, P.minX), P.invW));
-  const int py = (int)roundf(vsg::fmul(vsg::fsub(kps[i].y, P.minY), P.invH));
-  cell_of[i] = (px < 0 || px >= kCols || py < 0 || py >= kRows) ? (int16_t)-1 : (int16_t)(px * kRows + py);
-}
-__global__ void k_grid_count(const int16_t *cell_of, int n, int *cell_cnt) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= kCells) return;
-  int k = 0;
-  for (int i = 0; i < n; i++) k += cell_of[i] == c;
-  cell_cnt[c] = k;
-}
-__global__ void k_grid_scan(const int *cell_cnt, int *cell_start) {  // 3072 cells: one thread is plenty
+// exclusive prefix sum of the per-query candidate counts (one workgroup; nq is a few thousand at most)
+__global__ __launch_bounds__(256) void k_grid_offsets(const int *counts, int nq, int *cand_off) {
+  __shared__ int part[256];
+  const int tid = threadIdx.x, per = (nq + 255) / 256, lo = min(tid * per, nq), hi = min(lo + per, nq);
   int s = 0;
-  for (int c = 0; c < kCells; c++) {
-    cell_start[c] = s;
-    s += cell_cnt[c];
+  for (int i = lo; i < hi; i++) s += counts[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; t++) {
+      const int v = part[t];
+      part[t] = run;
+      run += v;
+    }
+    cand_off[nq] = run;
   }
-  cell_start[kCells] = s;
-}
-__global__ void k_grid_fill(const int16_t *cell_of, int n, const int *cell_start, int *entries) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= kCells) return;
-  int o = cell_start[c];
-  for (int i = 0; i < n; i++)
-    if (cell_of[i] == c) entries[o++] = i;  // insertion order == ascending keypoint index
+  __syncthreads();
+  int run = part[tid];
+  for (int i = lo; i < hi; i++) {
+    cand_off[i] = run;
+    run += counts[i];
+  }
 }
 
 // GetFeaturesInArea for one query per thread; pass 0 counts, pass 1 writes at cand_off[q]
@@ -93,6 +88,7 @@ __global__ void k_grid_query(const vsg_keypoint *kps, const int *cell_start, con
 struct vsg_grid {
   int device = 0, n = 0;
   GridParams P{};
+  void *d_block = nullptr;  // one allocation: keypoints | cell_start | entries
   vsg_keypoint *d_kps = nullptr;
   int *d_cell_start = nullptr, *d_entries = nullptr;
 };
@@ -107,7 +103,7 @@ extern "C" {
 void vsg_grid_destroy(vsg_grid *g) {
   if (!g) return;
   hipSetDevice(g->device);
-  hipFree(g->d_kps), hipFree(g->d_cell_start), hipFree(g->d_entries);
+  hipFree(g->d_block);
   delete g;
 }
 
@@ -123,26 +119,41 @@ int vsg_grid_build(int device, const vsg_keypoint *kps, int n, float min_x, floa
   g->n = n;
   // mfGridElementWidthInv = FRAME_GRID_COLS / (mnMaxX - mnMinX)   (Frame.cc:378-379)
   g->P = {min_x, min_y, (float)kCols / (max_x - min_x), (float)kRows / (max_y - min_y)};
-  int16_t *d_cell_of = nullptr;
-  int *d_cnt = nullptr;
-  hipError_t e = hipMalloc(&g->d_kps, sizeof(vsg_keypoint) * (n + 1));
-  if (e == hipSuccess) e = hipMalloc(&g->d_cell_start, sizeof(int) * (kCells + 1));
-  if (e == hipSuccess) e = hipMalloc(&g->d_entries, sizeof(int) * (n + 1));
-  if (e == hipSuccess) e = hipMalloc(&d_cell_of, sizeof(int16_t) * (n + 1));
-  if (e == hipSuccess) e = hipMalloc(&d_cnt, sizeof(int) * kCells);
-  if (e == hipSuccess && n) e = hipMemcpy(g->d_kps, kps, sizeof(vsg_keypoint) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    if (n) hipLaunchKernelGGL(k_grid_cell_ids, dim3((n + 255) / 256), dim3(256), 0, 0, g->d_kps, n, g->P, d_cell_of);
-    hipLaunchKernelGGL(k_grid_count, dim3(kCells / 256), dim3(256), 0, 0, d_cell_of, n, d_cnt);
-    hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1), 0, 0, d_cnt, g->d_cell_start);
-    hipLaunchKernelGGL(k_grid_fill, dim3(kCells / 256), dim3(256), 0, 0, d_cell_of, n, g->d_cell_start, g->d_entries);
-    e = hipDeviceSynchronize();
+  // AssignFeaturesToGrid (Frame.cc:521-553) is a stable bucket fill of a thousand keypoints: done here, on the
+  // host that hands the keypoints over, with the reference's float operations (PosInGrid, Frame.cc:870-880; libm
+  // round = half away from zero).  The device gets the finished CSR in the same copy as the keypoints; the queries
+  // (the part that scales with map points x cells) run there.
+  const size_t bK = sizeof(vsg_keypoint) * (size_t)(n + 1), bS = sizeof(int) * (kCells + 1), bE = sizeof(int) * (size_t)(n + 1);
+  std::vector<uint8_t> stage(bK + bS + bE, 0);
+  if (n) memcpy(stage.data(), kps, sizeof(vsg_keypoint) * (size_t)n);
+  int *cell_start = (int *)(stage.data() + bK), *entries = (int *)(stage.data() + bK + bS);
+  std::vector<int16_t> cell_of((size_t)n + 1);
+  std::vector<int> cnt(kCells, 0);
+  for (int i = 0; i < n; i++) {
+    const int px = (int)roundf(vsg::fmul(vsg::fsub(kps[i].x, g->P.minX), g->P.invW));
+    const int py = (int)roundf(vsg::fmul(vsg::fsub(kps[i].y, g->P.minY), g->P.invH));
+    const bool in = !(px < 0 || px >= kCols || py < 0 || py >= kRows);
+    cell_of[i] = in ? (int16_t)(px * kRows + py) : (int16_t)-1;
+    if (in) cnt[px * kRows + py]++;
   }
-  hipFree(d_cell_of), hipFree(d_cnt);
+  int run = 0;
+  for (int c = 0; c < kCells; c++) {
+    cell_start[c] = run;
+    run += cnt[c];
+    cnt[c] = cell_start[c];
+  }
+  cell_start[kCells] = run;
+  for (int i = 0; i < n; i++)
+    if (cell_of[i] >= 0) entries[cnt[cell_of[i]]++] = i;  // insertion order == ascending keypoint index
+  hipError_t e = hipMalloc(&g->d_block, stage.size());
+  if (e == hipSuccess) e = hipMemcpy(g->d_block, stage.data(), stage.size(), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     vsg_grid_destroy(g);
     return VSG_ERR_HIP;
   }
+  g->d_kps = (vsg_keypoint *)g->d_block;
+  g->d_cell_start = (int *)((uint8_t *)g->d_block + bK);
+  g->d_entries = (int *)((uint8_t *)g->d_block + bK + bS);
   *out = g;
   return VSG_OK;
 }
@@ -153,43 +164,39 @@ int vsg_grid_query(vsg_grid *g, const float *x, const float *y, const float *r, 
   G_TRY(hipSetDevice(g->device));
   cand_off[0] = 0;
   if (nq == 0) return 0;
-  float *dx = nullptr, *dy = nullptr, *dr = nullptr;
-  int *dlo = nullptr, *dhi = nullptr, *dcnt = nullptr, *doff = nullptr, *didx = nullptr;
+  // one block up (x | y | r | minLevel | maxLevel), count -> offsets -> fill on the device without a host round
+  // trip in between, offsets and indices down
+  const size_t Q = (size_t)nq;
+  std::vector<uint8_t> stage(Q * 20);
+  memcpy(stage.data(), x, Q * 4);
+  memcpy(stage.data() + Q * 4, y, Q * 4);
+  memcpy(stage.data() + Q * 8, r, Q * 4);
+  if (min_level) memcpy(stage.data() + Q * 12, min_level, Q * 4);
+  if (max_level) memcpy(stage.data() + Q * 16, max_level, Q * 4);
+  const size_t oCnt = Q * 20, oOff = oCnt + Q * 4, oIdx = oOff + (Q + 1) * 4, total_bytes = oIdx + (size_t)cap * 4 + 4;
+  uint8_t *d = nullptr;
+  G_TRY(hipMalloc(&d, total_bytes));
   int total = VSG_ERR_HIP;
-  std::vector<int> cnt((size_t)nq);
-  hipError_t e = hipMalloc(&dx, 4 * nq);
-  if (e == hipSuccess) e = hipMalloc(&dy, 4 * nq);
-  if (e == hipSuccess) e = hipMalloc(&dr, 4 * nq);
-  if (e == hipSuccess) e = hipMalloc(&dcnt, 4 * nq);
-  if (e == hipSuccess) e = hipMalloc(&doff, 4 * (nq + 1));
-  if (e == hipSuccess && min_level) e = hipMalloc(&dlo, 4 * nq);
-  if (e == hipSuccess && max_level) e = hipMalloc(&dhi, 4 * nq);
-  if (e == hipSuccess) e = hipMemcpy(dx, x, 4 * nq, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dy, y, 4 * nq, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dr, r, 4 * nq, hipMemcpyHostToDevice);
-  if (e == hipSuccess && min_level) e = hipMemcpy(dlo, min_level, 4 * nq, hipMemcpyHostToDevice);
-  if (e == hipSuccess && max_level) e = hipMemcpy(dhi, max_level, 4 * nq, hipMemcpyHostToDevice);
+  hipError_t e = hipMemcpy(d, stage.data(), stage.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
+    const float *dx = (const float *)d, *dy = dx + Q, *dr = dy + Q;
+    const int *dlo = min_level ? (const int *)(d + Q * 12) : nullptr, *dhi = max_level ? (const int *)(d + Q * 16) : nullptr;
+    int *dcnt = (int *)(d + oCnt), *doff = (int *)(d + oOff), *didx = (int *)(d + oIdx);
     hipLaunchKernelGGL(k_grid_query, dim3((nq + 63) / 64), dim3(64), 0, 0, g->d_kps, g->d_cell_start, g->d_entries,
                        g->P, dx, dy, dr, dlo, dhi, nq, dcnt, (const int *)nullptr, (int *)nullptr, 0);
-    e = hipMemcpy(cnt.data(), dcnt, 4 * nq, hipMemcpyDeviceToHost);
-  }
-  if (e == hipSuccess) {
-    for (int q = 0; q < nq; q++) cand_off[q + 1] = cand_off[q] + cnt[q];
-    total = cand_off[nq];
-    if (total > 0 && cand_idx && cap > 0) {
-      e = hipMalloc(&didx, 4 * (size_t)(total < cap ? total : cap));
-      if (e == hipSuccess) e = hipMemcpy(doff, cand_off, 4 * (nq + 1), hipMemcpyHostToDevice);
-      if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_grid_query, dim3((nq + 63) / 64), dim3(64), 0, 0, g->d_kps, g->d_cell_start,
-                           g->d_entries, g->P, dx, dy, dr, dlo, dhi, nq, (int *)nullptr, doff, didx,
-                           total < cap ? total : cap);
-        e = hipMemcpy(cand_idx, didx, 4 * (size_t)(total < cap ? total : cap), hipMemcpyDeviceToHost);
-      }
+    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(256), 0, 0, dcnt, nq, doff);
+    if (cand_idx && cap > 0)
+      hipLaunchKernelGGL(k_grid_query, dim3((nq + 63) / 64), dim3(64), 0, 0, g->d_kps, g->d_cell_start, g->d_entries,
+                         g->P, dx, dy, dr, dlo, dhi, nq, (int *)nullptr, doff, didx, cap);
+    e = hipMemcpy(cand_off, doff, (Q + 1) * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+      total = cand_off[nq];
+      const int nw = total < cap ? total : cap;
+      if (cand_idx && nw > 0) e = hipMemcpy(cand_idx, didx, (size_t)nw * 4, hipMemcpyDeviceToHost);
       if (e != hipSuccess) total = VSG_ERR_HIP;
     }
   }
-  hipFree(dx), hipFree(dy), hipFree(dr), hipFree(dlo), hipFree(dhi), hipFree(dcnt), hipFree(doff), hipFree(didx);
+  hipFree(d);
   return total;
 }
 
