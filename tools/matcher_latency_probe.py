@@ -55,3 +55,15 @@ bench("  oracle SearchByBoW KF-F", lambda: ol.search_by_bow_kf_f(d0, k0["angle"]
 bench("SearchForInitialization", lambda: m.SearchForInitialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"]))
 bench("  oracle SearchForInitialization", lambda: ol.search_for_initialization(d0, k0["angle"], k0["octave"], off, idx,
                                                                                d1, k1["angle"], 0.7, True))
+
+# ---- stereo and distinctive descriptors
+exl, exr = orb.ORBextractor(1200, 1.2, 8, 20, 7), orb.ORBextractor(1200, 1.2, 8, 20, 7)
+rl, rr = ol.OracleExtractor(1200, 1.2, 8, 20, 7), ol.OracleExtractor(1200, 1.2, 8, 20, 7)
+L_, R_ = synth.sequence_frame(752, 480, 8, 2), synth.sequence_frame(752, 480, 8, 0)
+(_, kl, dl), (_, kr, dr) = exl(L_), exr(R_)
+rl(L_), rr(R_)
+bench("ComputeStereoMatches 1200", lambda: orb.ComputeStereoMatches(exl, 0, exr, 0, kl, dl, kr, dr, 0.11, 47.9))
+bench("  oracle ComputeStereoMatches", lambda: ol.stereo_matches(rl, rr, kl, dl, kr, dr, 0.11, 47.9), 20)
+goff = np.arange(0, len(d0) + 1, 8, dtype=np.int32)
+bench("ComputeDistinctiveDescriptors 125 x 8", lambda: orb.ComputeDistinctiveDescriptors(d0[:goff[-1]], goff))
+bench("  oracle ComputeDistinctiveDescriptors", lambda: ol.distinctive_descriptors(d0[:goff[-1]], goff))
