@@ -105,7 +105,52 @@ def case_bow(rng):
     return ok, ("bow", k, L, n, lv)
 
 
-CASES = {"batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow}
+def case_window(rng):
+    """Frame grid -> candidate lists -> the four windowed searches, random blocking state and thresholds."""
+    w, h = int(rng.integers(300, 800)), int(rng.integers(240, 600))
+    nf = int(rng.integers(100, 1500))
+    seq = int(rng.integers(0, 1 << 16))
+    ref = ol.OracleExtractor(nf, 1.2, 8, 20, 7)
+    _, k0, d0 = ref(synth.sequence_frame(w, h, seq, 0))
+    _, k1, d1 = ref(synth.sequence_frame(w, h, seq, 1))
+    if len(k0) == 0 or len(k1) == 0:
+        return True, ("window-empty",)
+    g = orb.FrameGrid(k1, 0.0, 0.0, float(w), float(h))
+    og = ol.OracleGrid(k1, 0.0, 0.0, float(w), float(h))
+    r = rng.uniform(3, 40, len(k0)).astype(np.float32)
+    qx = (k0["x"] + rng.uniform(-8, 8, len(k0))).astype(np.float32)
+    qy = (k0["y"] + rng.uniform(-8, 8, len(k0))).astype(np.float32)
+    lo = rng.integers(-1, 4, len(k0)).astype(np.int32)
+    hi = (lo + rng.integers(-1, 4, len(k0))).astype(np.int32)
+    off, idx = g.GetFeaturesInArea(qx, qy, r, lo, hi)
+    woff, widx = [0], []
+    for i in range(len(k0)):
+        widx += og.query(qx[i], qy[i], r[i], int(lo[i]), int(hi[i])).tolist()
+        woff.append(len(widx))
+    if not (np.array_equal(off, woff) and np.array_equal(idx, widx)):
+        return False, ("grid", w, h, nf, seq)
+    qb = (rng.random(len(k0)) < 0.7).astype(np.uint8)
+    tb = (rng.random(len(k1)) < 0.2).astype(np.uint8)
+    th = int(rng.choice([50, 100, 255]))  # 256 would make the reference index [-1] when every candidate is blocked
+    ratio = float(rng.choice([0.6, 0.8, 0.9]))
+    ori = bool(rng.integers(0, 2))
+    m = orb.ORBmatcher(ratio, ori)
+    a = orb.search_window(d0, qb, off, idx, d1, tb, th)
+    b = ol.search_window(d0, qb, off, idx, d1, tb, th)
+    ok = a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+    a = m.SearchByProjection_Last(d0, k0["angle"], qb, off, idx, d1, k1["angle"], tb, th)
+    b = ol.search_by_projection_last(d0, k0["angle"], qb, off, idx, d1, k1["angle"], tb, th, ori)
+    ok = ok and a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+    a = m.SearchByProjection_Local(d0, qb, off, idx, d1, k1["octave"], tb)
+    b = ol.search_by_projection_local(d0, qb, off, idx, d1, k1["octave"], tb, ratio)
+    ok = ok and a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+    a = m.SearchForInitialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"])
+    b = ol.search_for_initialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"], ratio, ori)
+    ok = ok and a[0] == b[0] and np.array_equal(a[1], b[1])
+    return ok, ("window", w, h, nf, seq, th, ratio, ori)
+
+
+CASES = {"window": case_window, "batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow}
 
 
 def main():
