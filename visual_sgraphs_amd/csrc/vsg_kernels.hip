@@ -704,7 +704,12 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         selHi[q] |= (sidx >= 8 ? sidx - 8 : 0x0Cu) << (8 * b);
       }
   }
-  uint32_t win[7][4];
+  // Vertical pass on row PAIRS: a row's horizontal sums fit 16 bits (taps sum <= 257), so row r is kept as
+  // P[r] = H[r-1] | H[r] << 16 and an output row is three v_dot2_u32_u16 (taps 0-1, 2-3, 4-5 against P[r-5], P[r-3],
+  // P[r-1]) plus one multiply-add for tap 6 on the newest row: 4 + 1 (the pack) operations per pixel instead of 7.
+  uint32_t pw[7][4], hprev[4] = {0, 0, 0, 0};
+  const u16x2 K01 = {(unsigned short)k[0], (unsigned short)k[1]}, K23 = {(unsigned short)k[2], (unsigned short)k[3]},
+              K45 = {(unsigned short)k[4], (unsigned short)k[5]};
 #pragma unroll
   for (int turn = 0; turn < (kBlurStrip + 6) / 7; turn++) {
     // issue the loads of the next 7 rows together, then consume them
@@ -734,22 +739,29 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     for (int s = 0; s < 7; s++) {
       const int rr = turn * 7 + s;  // 0 .. kBlurStrip+5 : source row y0 - 3 + rr
       // pixel j: taps over bytes j+1 .. j+7 of {d0,d1,d2}
-      win[s][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 1), T0,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 1), T1, 0u, false), false);
-      win[s][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 2), T0,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 2), T1, 0u, false), false);
-      win[s][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 3), T0,
-                                         __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 3), T1, 0u, false), false);
-      win[s][3] = __builtin_amdgcn_udot4(d1[s], T0, __builtin_amdgcn_udot4(d2[s], T1, 0u, false), false);
+      uint32_t H[4];
+      H[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 1), T0,
+                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 1), T1, 0u, false), false);
+      H[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 2), T0,
+                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 2), T1, 0u, false), false);
+      H[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 3), T0,
+                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 3), T1, 0u, false), false);
+      H[3] = __builtin_amdgcn_udot4(d1[s], T0, __builtin_amdgcn_udot4(d2[s], T1, 0u, false), false);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        pw[s][j] = hprev[j] | (H[j] << 16);
+        hprev[j] = H[j];
+      }
       if (rr >= 6) {
         const int yo = y0 + rr - 6;
         if (yo < h) {
           uint32_t out = 0;
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            uint32_t acc = 32768u;
-#pragma unroll
-            for (int q = 0; q < 7; q++) acc += __umul24(k[q], win[(s + 1 + q) % 7][j]);  // oldest row first
+            uint32_t acc = __umul24(k[6], H[j]) + 32768u;
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 2) % 7][j]), K01, acc, false);  // rows r-6, r-5
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 4) % 7][j]), K23, acc, false);  // rows r-4, r-3
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 6) % 7][j]), K45, acc, false);  // rows r-2, r-1
             out |= min(acc >> 16, 255u) << (8 * j);
           }
           *(uint32_t *)(dst + (size_t)yo * L.pitch + x0) = out;
