@@ -755,15 +755,17 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
       if (rr >= 6) {
         const int yo = y0 + rr - 6;
         if (yo < h) {
-          uint32_t out = 0;
+          uint32_t cl[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             uint32_t acc = __umul24(k[6], H[j]) + 32768u;
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 2) % 7][j]), K01, acc, false);  // rows r-6, r-5
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 4) % 7][j]), K23, acc, false);  // rows r-4, r-3
             acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 6) % 7][j]), K45, acc, false);  // rows r-2, r-1
-            out |= min(acc >> 16, 255u) << (8 * j);
+            cl[j] = min(acc, 0x00FFFFFFu);  // saturate_cast<uchar>(acc >> 16): byte 2 of the clamped sum
           }
+          const uint32_t out = __builtin_amdgcn_perm(cl[1], cl[0], 0x0C0C0602u) |
+                               (__builtin_amdgcn_perm(cl[3], cl[2], 0x0C0C0602u) << 16);
           *(uint32_t *)(dst + (size_t)yo * L.pitch + x0) = out;
         }
       }
