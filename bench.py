@@ -290,6 +290,9 @@ def main():
                     "timing": "HIP events per kernel, serialized pass of the same steps (stage_ms); the timed "
                               "region itself overlaps streams and sub-batches",
                     "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                    # every stage against the same HBM roof: algorithmic bytes per launch / its duration
+                    "stage_algorithmic_GBs": {k: round(stages[k] * B / (v * 1e-3) / 1e9, 1)
+                                              for k, v in stage_ms.items() if k in stages and v > 0},
                     **({"stage_ms_timed_region": {k: round(v, 4) for k, v in stage_ms_timed.items()}}
                        if any(v > 0 for v in stage_ms_timed.values()) else {}),
                     "pipeline_achieved_GBs": round(bytes_per_frame * fps / world / 1e9, 2),
