@@ -831,21 +831,29 @@ enum { kPatchR = 18, kPatchW = 2 * kPatchR + 1, kPatchP = 40 };  // rBRIEF patch
 
 // Disc membership of the IC_Angle patch in the lane layout used below: lane = 32 * hh + (u + 15); bit `it` of entry
 // `lane` says that pixel (u, v = 2 * it + hh - 15) lies inside the 749-px patch (|u| <= umax[|v|], ORBextractor.cc:454-469).
-struct DiscTable {
-  uint32_t v[64];
+// IC_Angle lane layout: 8 rows x 8 dword columns per load instruction (lane = 8 * row + column), 4 instructions
+// cover the 31 x 31 patch (rows 8 * it + row - 15, pixels u = 4 * column + b - 15).  Per (it, lane) the table
+// holds byte weights for the lane's 4 pixels: wp = 1 inside the 749-px disc (|u| <= umax[|v|],
+// ORBextractor.cc:454-469), wu = (u + 15) inside, else 0 -- so  sum p = udot4(px, wp)  and
+// sum (u + 15) p = udot4(px, wu).
+struct alignas(8) DiscTable {
+  uint32_t w[4][64][2];
 };
 constexpr DiscTable make_disc_table() {
   DiscTable t{};
-  for (int lane = 0; lane < 64; lane++) {
-    const int u = (lane & 31) - kHalfPatch, au = u < 0 ? -u : u, hh = lane >> 5;
-    uint32_t m = 0;
-    for (int it = 0; it < 16; it++) {
-      const int v = 2 * it + hh - kHalfPatch, av = v < 0 ? -v : v;
-      const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * (av & 15))) & 15);  // umax[|v|]
-      if (u <= kHalfPatch && v <= kHalfPatch && au <= um) m |= 1u << it;
+  for (int it = 0; it < 4; it++)
+    for (int lane = 0; lane < 64; lane++) {
+      const int v = 8 * it + (lane >> 3) - kHalfPatch, av = v < 0 ? -v : v;
+      for (int b = 0; b < 4; b++) {
+        const int u = 4 * (lane & 7) + b - kHalfPatch, au = u < 0 ? -u : u;
+        if (v > kHalfPatch || u > kHalfPatch) continue;
+        const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * (av & 15))) & 15);  // umax[|v|]
+        if (au <= um) {
+          t.w[it][lane][0] |= 1u << (8 * b);
+          t.w[it][lane][1] |= (uint32_t)(u + kHalfPatch) << (8 * b);
+        }
+      }
     }
-    t.v[lane] = m;
-  }
   return t;
 }
 __constant__ DiscTable c_disc = make_disc_table();
@@ -873,7 +881,9 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   __shared__ f32x4 patf[256];            // test k: (x0, y0, x1, y1) of bit_pattern_31_ as floats
   __shared__ int s_hdr[kMaxLevels + 3];  // n, mono, level_start[0..kMaxLevels]
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchW * kPatchP];
+  __shared__ uint2 s_ic[4 * 64];  // c_disc, one 8-byte entry per (it, lane)
   const int frame = blockIdx.y, tid = threadIdx.x;
+  s_ic[tid] = ((const uint2 *)c_disc.w)[tid];
   {
     const uint32_t pw = ((const uint32_t *)pattern)[tid];
     patf[tid] = (f32x4){(float)(int8_t)pw, (float)(int8_t)(pw >> 8), (float)(int8_t)(pw >> 16), (float)(int8_t)(pw >> 24)};
@@ -902,26 +912,29 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   const size_t foff = (size_t)frame * fg->pyr_frame_bytes + L.img_off;
   int upitch;
   const uint8_t *unblurred = level_ptr(fg, s0, pyr, frame, l, upitch);
-  // ---- IC_Angle: lanes run ALONG image rows (lane & 31 = column u + 15, lane >> 5 = one of two rows per
-  // instruction), so each of the 16 byte-load instructions touches 2 rows instead of 31 cache lines.
+  // ---- IC_Angle: the kernel is bound by the number of vector-memory instructions (each one walks 64 lane
+  // addresses), so the 31 x 31 patch is read as dwords -- 8 rows x 8 (unaligned) dwords per instruction, 4
+  // instructions instead of 16 byte loads -- and the disc mask / column weights are v_dot4_u32_u8 operands.
   int m10 = 0, m01 = 0;
   {
-    const int u = (lane & 31) - kHalfPatch, h = lane >> 5;
-    // bit `it` of the lane's disc mask: pixel (u, v = 2*it + h - 15) lies inside the 749-px patch
-    const uint32_t disc = c_disc.v[lane];
-    const uint8_t *ptr = unblurred + (ptrdiff_t)(cy + h - kHalfPatch) * upitch + cx + (u > kHalfPatch ? 0 : u);
-    const ptrdiff_t step2 = 2 * (ptrdiff_t)upitch;
-    int sum_u = 0;
+    const int row = lane >> 3, col = lane & 7;
+    const uint8_t *ptr = unblurred + (ptrdiff_t)(cy + row - kHalfPatch) * upitch + (cx - kHalfPatch) + 4 * col;
+    uint32_t px[4];
 #pragma unroll
-    for (int it = 0; it < 16; it++) {
-      // row v = 16 (h = 1, it = 15) is masked; read row 15 again so the address stays inside the image
-      const int pv = (it == 15) ? (int)ptr[-(ptrdiff_t)h * upitch] : (int)ptr[0];
-      ptr += step2;
-      const int p = ((disc >> it) & 1) ? pv : 0;
-      sum_u += p;
-      m01 += (2 * it + h - kHalfPatch) * p;
+    for (int it = 0; it < 4; it++) {
+      // rows past v = 15 (it = 3, row = 7) are masked by the weights; re-read the previous row so the address stays
+      // inside the image
+      const int back = (it == 3 && row == 7) ? 1 : 0;
+      px[it] = *(const u32_unaligned *)(ptr + (ptrdiff_t)(8 * it - back) * upitch);
     }
-    m10 = u * sum_u;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const uint2 w = s_ic[it * 64 + lane];
+      const int sp = (int)__builtin_amdgcn_udot4(px[it], w.x, 0u, false);  // sum of the pixels inside the disc
+      const int su = (int)__builtin_amdgcn_udot4(px[it], w.y, 0u, false);  // sum of (u + 15) * pixel
+      m10 += su - kHalfPatch * sp;
+      m01 += (8 * it + row - kHalfPatch) * sp;
+    }
   }
   m10 = wave_sum_i32(m10);
   m01 = wave_sum_i32(m01);
