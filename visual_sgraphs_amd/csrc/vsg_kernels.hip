@@ -1,7 +1,8 @@
 // vsg_kernels.hip -- gfx950 kernels of the ORB extractor.  One launch per stage covers every pyramid
 // level and every frame of the batch (grid.y / grid.z = frame), so a 64-frame batch fills 256 CUs.
 //
-//   k_resize        ORBextractor::ComputePyramid            ORBextractor.cc:1171-1195  ([OCV] resize INTER_LINEAR 8U)
+//   k_pyramid       ORBextractor::ComputePyramid            ORBextractor.cc:1171-1195  ([OCV] resize INTER_LINEAR 8U)
+//                   (all levels in one launch; k_resize = one level per launch, for scale factors > 2)
 //   k_fast_cells    per-cell cv::FAST(20) else cv::FAST(7)  ORBextractor.cc:787-876    ([OCV] fast.cpp / fast_score.cpp)
 //   k_octree        DistributeOctTree                       ORBextractor.cc:562-785    (vsg_octree_core.h)
 //   k_blur          GaussianBlur 7x7 sigma 2                ORBextractor.cc:1129-1130  ([OCV] 8.8 fixed point)
@@ -283,7 +284,7 @@ constexpr int kFastRun = VSG_FAST_RUN;  // dwords per thread in the necessary te
 constexpr int kFastCntBits = kFastRun == 1 ? 3 : kFastRun == 2 ? 4 : 5;  // popcount of 4 * kFastRun mask bits
 
 // One workgroup per FAST cell.  The cell's valid region (3 px inside the reference's sub-image) is staged in LDS
-// with aligned 32-bit loads; a cheap necessary test runs on 4 pixels per thread from packed dwords and the pixels
+// with aligned 32-bit loads; a cheap necessary test runs on 8 pixels per thread from packed dwords and the pixels
 // that pass are COMPACTED into an LDS queue, so the exact score (packed 16-bit min/max) and the non-max suppression
 // run on dense wavefronts.  Like the reference the cell is first searched at iniThFAST and only if that yields
 // nothing at minThFAST (ORBextractor.cc:832-851); NMS only looks at neighbours INSIDE the valid region (outside
