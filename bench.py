@@ -80,8 +80,8 @@ def cpu_baseline(w, h, nfeatures, frames, budget_s, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-match", action="store_true")
