@@ -40,6 +40,11 @@ void hc_tables(float *scale, float *inv, int *quota, int *umax) {
   }
   for (int i = 0; i < 16; i++) umax[i] = g_tab.umax[i];
 }
+// fused-pyramid tiling i of the geometry built by hc_build: {ntiles, lds bytes, ok, tabMax, ldsA, ldsB}
+void hc_pyr_tiling(int i, int *out) {
+  const PyrTiling &P = g_geom.pyr[i];
+  out[0] = (int)P.tiles.size(), out[1] = P.lds_bytes(), out[2] = P.ok, out[3] = P.tabMax, out[4] = P.ldsA, out[5] = P.ldsB;
+}
 int hc_total_cells() { return g_geom.fg.total_cells; }
 int hc_out_cap() { return g_geom.fg.out_cap; }
 void hc_cell(int i, int *out) {

@@ -82,18 +82,27 @@ struct PyrTile {
   int16_t own[kMaxLevels][4];
   int32_t tab_off, tab_n;  // this tile's slice of Geometry::pyrTileTab
 };
-enum { kPyrTile = 32 };  // top-level tile edge
+// Candidate top-level tile edges of the fused pyramid.  A larger tile recomputes less halo but needs more LDS and
+// yields fewer workgroups: 36 is ahead for >= ~2000 workgroups per launch (0.214 -> 0.194 ms per 256 C2 frames),
+// 32 for small batches and for geometries whose 36-tiling would not leave three workgroups per CU.
+enum { kPyrTilings = 2 };
+constexpr int kPyrTileEdge[kPyrTilings] = {32, 36};
+
+struct PyrTiling {
+  std::vector<PyrTile> tiles;
+  // Per tile, per level 1..top: the tile's slice of the resize tables, already rebased to the tile's LDS images:
+  //   x entries {sx - sx0a, a0, a1, sx1 - sx0a}   then   y entries {(sy0 - y0) * spitch, (sy1 - y0) * spitch, b0, b1}
+  std::vector<Short4> tab;
+  int ldsA = 0, ldsB = 0;  // LDS bytes for even / odd levels of the ping-pong
+  int tabMax = 0;          // max over tiles of staged table entries
+  bool ok = false;         // usable by k_pyramid (16-bit LDS row offsets, column span)
+  int lds_bytes() const { return ((ldsA + 15) & ~15) + ((ldsB + 15) & ~15) + 8 * tabMax; }
+};
 
 struct Geometry {
   FrameGeom fg;
-  std::vector<PyrTile> pyrTiles;
-  int pyrLdsA = 0, pyrLdsB = 0;  // LDS bytes for even / odd levels of the ping-pong
-  int pyrTabMax = 0;             // max over tiles of staged table entries
-  int fastMaxVh = 0, fastMaxVw = 0, fastMaxArea = 0;  // over all FAST cells: rows and pixels of the valid region (LDS sizing)
-  bool pyrFusedOk = true;        // k_pyramid's 8-byte source window covers 4 adjacent destination columns
-  // Per tile, per level 1..top: the tile's slice of the resize tables, already rebased to the tile's LDS images:
-  //   x entries {sx - sx0a, a0, a1, sx1 - sx0a}   then   y entries {(sy0 - y0) * spitch, (sy1 - y0) * spitch, b0, b1}
-  std::vector<Short4> pyrTileTab;
+  PyrTiling pyr[kPyrTilings];
+  int fastMaxVh = 0, fastMaxVw = 0, fastMaxArea = 0;  // over all FAST cells: rows, columns and pixels of the valid region (LDS sizing)
   std::vector<Short4> resizeTab;  // all levels, x tables then y tables (offsets in LevelGeom)
   std::vector<CellDesc> cells;
   int maxQuota = 0;
@@ -252,10 +261,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
     }
   }
   // ---- fused-pyramid tiles
-  G.pyrTiles.clear();
-  G.pyrLdsA = G.pyrLdsB = 0;
-  G.pyrTabMax = 0;
-  G.pyrFusedOk = true;
+  bool spanOk = true;
   for (int l = 1; l < T.nlevels; l++) {
     // k_pyramid picks the (sx, sx + 1) pairs of 4 adjacent columns out of 8 source bytes: sx may advance by at
     // most 6 over 3 columns (any scale factor up to 2); larger ratios take the per-level kernel.
@@ -263,15 +269,19 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
     const Short4 *tabx = &G.resizeTab[D.tab_x_off];
     for (int x = 0; x + 1 < D.w; x++) {
       const int x3 = x + 3 < D.w ? x + 3 : D.w - 1;
-      if (tabx[x3].a - tabx[x].a > 6) G.pyrFusedOk = false;
+      if (tabx[x3].a - tabx[x].a > 6) spanOk = false;
     }
   }
-  if (T.nlevels > 1) {
+  for (int ti = 0; ti < kPyrTilings; ti++) {
+    PyrTiling &PT = G.pyr[ti];
+    PT = PyrTiling();
+    if (T.nlevels <= 1) continue;
+    PT.ok = spanOk;
+    const int kPyrTile = kPyrTileEdge[ti];
     const int top = T.nlevels - 1;
     // balanced split of the top level into tiles of at most kPyrTile x kPyrTile
     const int tw = fg.lv[top].w, thh = fg.lv[top].h;
     const int ntx = (tw + kPyrTile - 1) / kPyrTile, nty = (thh + kPyrTile - 1) / kPyrTile;
-    G.pyrTileTab.clear();
     for (int ty = 0; ty < nty; ty++)
       for (int tx = 0; tx < ntx; tx++) {
         PyrTile t;
@@ -301,8 +311,8 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
         }
         int tabn = 0;
         for (int l = 1; l <= top; l++) tabn += (t.need[l][2] - t.need[l][0]) + (t.need[l][3] - t.need[l][1]);
-        if (tabn > G.pyrTabMax) G.pyrTabMax = tabn;
-        t.tab_off = (int32_t)G.pyrTileTab.size();
+        if (tabn > PT.tabMax) PT.tabMax = tabn;
+        t.tab_off = (int32_t)PT.tab.size();
         t.tab_n = tabn;
         for (int l = 1; l <= top; l++) {
           const LevelGeom &D = fg.lv[l];
@@ -312,14 +322,14 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
             Short4 e = G.resizeTab[D.tab_x_off + x];
             e.a = (int16_t)(e.a - sx0a);
             e.d = (int16_t)(e.d - sx0a);
-            G.pyrTileTab.push_back(e);
+            PT.tab.push_back(e);
           }
           for (int y = t.need[l][1]; y < t.need[l][3]; y++) {
             Short4 e = G.resizeTab[D.tab_y_off + y];
-            if ((e.b - sy0) * spitch > 32767) G.pyrFusedOk = false;  // LDS row offsets are kept in 16 bits
+            if ((e.b - sy0) * spitch > 32767) PT.ok = false;  // LDS row offsets are kept in 16 bits
             e.a = (int16_t)((e.a - sy0) * spitch);
             e.b = (int16_t)((e.b - sy0) * spitch);
-            G.pyrTileTab.push_back(e);
+            PT.tab.push_back(e);
           }
         }
         for (int l = 0; l <= top; l++) {
@@ -328,12 +338,12 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
           const int pitch = ((t.need[l][2] - x0a) + 3) & ~3;
           const int bytes = pitch * (t.need[l][3] - t.need[l][1]);
           if (l & 1) {
-            if (bytes > G.pyrLdsB) G.pyrLdsB = bytes;
+            if (bytes > PT.ldsB) PT.ldsB = bytes;
           } else {
-            if (bytes > G.pyrLdsA) G.pyrLdsA = bytes;
+            if (bytes > PT.ldsA) PT.ldsA = bytes;
           }
         }
-        G.pyrTiles.push_back(t);
+        PT.tiles.push_back(t);
       }
   }
   fg.pyr_frame_bytes = (img_off + 255) & ~255;

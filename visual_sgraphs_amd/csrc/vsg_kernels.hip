@@ -1202,6 +1202,11 @@ void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sho
 void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tile_tab, const Src0 &s0,
                     const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes) {
   const int a16 = (ldsA + 15) & ~15, ab16 = a16 + ((ldsB + 15) & ~15);
+  const size_t lds = ab16 + tabMax * sizeof(Short4);
+  static size_t lds_limit = 64 * 1024;
+  if (lds > lds_limit &&
+      hipFuncSetAttribute((const void *)k_pyramid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+    lds_limit = lds;
   hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(256), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
                      d_tile_tab, s0, d_tiles, a16, ab16);
 }

@@ -55,8 +55,9 @@ struct vsg_orb {
   FrameGeom *d_fg = nullptr;
   Short4 *d_tab = nullptr;
   CellDesc *d_cells = nullptr;
-  PyrTile *d_ptiles = nullptr;
-  Short4 *d_ptab = nullptr;  // Geometry::pyrTileTab
+  int pyr_tiling = 0;                   // the tiling calibration found faster for a full batch of this geometry
+  PyrTile *d_ptiles[kPyrTilings] = {};  // Geometry::pyr[i].tiles
+  Short4 *d_ptab[kPyrTilings] = {};     // Geometry::pyr[i].tab
   uint8_t *d_in = nullptr;  // level-0 staging for host images / unaligned device images, pitch in_pitch
   int in_pitch = 0;
   Src0 last_src0 = {nullptr, 0, 0};
@@ -90,10 +91,15 @@ struct vsg_orb {
   bool ev_pending = false;
 };
 
+// dynamic LDS the fused pyramid may ask for (the launcher raises the 64 KB default limit; gfx950 has 160 KB)
+constexpr int kPyrLdsLimit = 150000;
+
 static void free_image_buffers(vsg_orb *h) {
-  hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in), hipFree(h->d_ptiles);
-  hipFree(h->d_ptab);
-  h->d_ptiles = nullptr, h->d_ptab = nullptr;
+  hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in);
+  for (int i = 0; i < kPyrTilings; i++) {
+    hipFree(h->d_ptiles[i]), hipFree(h->d_ptab[i]);
+    h->d_ptiles[i] = nullptr, h->d_ptab[i] = nullptr;
+  }
   hipFree(h->d_pyr), hipFree(h->d_blur), hipFree(h->d_cand), hipFree(h->d_sel), hipFree(h->d_nodeof);
   hipFree(h->d_counts2), hipFree(h->d_flags), hipFree(h->d_slots), hipFree(h->d_hdr);
   hipFree(h->d_kps), hipFree(h->d_desc), hipFree(h->d_out_counts);
@@ -133,12 +139,15 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   if (!h->G.resizeTab.empty())
     HIP_TRY(hipMemcpy(h->d_tab, h->G.resizeTab.data(), sizeof(Short4) * h->G.resizeTab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_cells, h->G.cells.data(), sizeof(CellDesc) * h->G.cells.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&h->d_ptiles, sizeof(PyrTile) * (h->G.pyrTiles.size() + 1)));
-  if (!h->G.pyrTiles.empty())
-    HIP_TRY(hipMemcpy(h->d_ptiles, h->G.pyrTiles.data(), sizeof(PyrTile) * h->G.pyrTiles.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMalloc(&h->d_ptab, sizeof(Short4) * (h->G.pyrTileTab.size() + 1)));
-  if (!h->G.pyrTileTab.empty())
-    HIP_TRY(hipMemcpy(h->d_ptab, h->G.pyrTileTab.data(), sizeof(Short4) * h->G.pyrTileTab.size(), hipMemcpyHostToDevice));
+  for (int i = 0; i < kPyrTilings; i++) {
+    const PyrTiling &PT = h->G.pyr[i];
+    HIP_TRY(hipMalloc(&h->d_ptiles[i], sizeof(PyrTile) * (PT.tiles.size() + 1)));
+    if (!PT.tiles.empty())
+      HIP_TRY(hipMemcpy(h->d_ptiles[i], PT.tiles.data(), sizeof(PyrTile) * PT.tiles.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&h->d_ptab[i], sizeof(Short4) * (PT.tab.size() + 1)));
+    if (!PT.tab.empty())
+      HIP_TRY(hipMemcpy(h->d_ptab[i], PT.tab.data(), sizeof(Short4) * PT.tab.size(), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMalloc(&h->d_pyr, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMalloc(&h->d_blur, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMemset(h->d_pyr, 0, B * fg.pyr_frame_bytes));
@@ -161,6 +170,35 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   HIP_TRY(hipHostMalloc(&h->h_out_counts, B * 2 * sizeof(int)));
   h->rows = rows;
   h->cols = cols;
+  // Which pyramid tiling is faster depends on how the top level happens to divide (measured: 36 wins at 640x480,
+  // 752x480 and 1920x1080, 32 at 1280x720), so both are timed once on a full batch of this geometry (the duration
+  // does not depend on the pixel values; the staging buffer's content is used as it is).
+  h->pyr_tiling = 0;
+  {
+    const PyrTiling &P0 = h->G.pyr[0], &P1 = h->G.pyr[1];
+    const int nf = h->max_batch;
+    if (fg.nlevels > 1 && P0.ok && P1.ok && P0.lds_bytes() <= kPyrLdsLimit && P1.lds_bytes() <= 50 * 1024 &&
+        (long long)P1.tiles.size() * nf >= 2048) {
+      const Src0 s0 = {h->d_in, (size_t)rows * h->in_pitch, h->in_pitch};
+      float best = 0.f;
+      for (int ti = 0; ti < kPyrTilings; ti++) {
+        const PyrTiling &PT = h->G.pyr[ti];
+        float ms = 0.f;
+        for (int rep = 0; rep < 2; rep++) {  // first launch warms up, second is timed
+          HIP_TRY(hipEventRecord(h->ev[0], h->s_main));
+          launch_pyramid(h->s_main, h->d_pyr, h->d_fg, h->d_ptab[ti], s0, h->d_ptiles[ti], (int)PT.tiles.size(), PT.ldsA,
+                         PT.ldsB, PT.tabMax, nf);
+          HIP_TRY(hipEventRecord(h->ev[1], h->s_main));
+          HIP_TRY(hipEventSynchronize(h->ev[1]));
+          HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+        }
+        if (ti == 0 || ms < best) {
+          best = ms;
+          h->pyr_tiling = ti;
+        }
+      }
+    }
+  }
   return VSG_OK;
 }
 
@@ -194,11 +232,24 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   FrameHeader *hdr = h->d_hdr + F;
   if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
   static const bool per_level = getenv("VSG_PYR_PER_LEVEL") != nullptr;  // A/B switch: 7 chained launches
-  if (per_level || !h->G.pyrFusedOk || h->G.pyrLdsA + h->G.pyrLdsB + 8 * h->G.pyrTabMax > 64000) {
+  // tiling: the coarser one when it still gives the chip enough workgroups and leaves three of them per CU
+  int ti = -1;
+  if (!per_level && fg.nlevels > 1) {
+    const PyrTiling &P0 = h->G.pyr[0], &P1 = h->G.pyr[1];
+    static const int forced = getenv("VSG_PYR_TILING") ? atoi(getenv("VSG_PYR_TILING")) : -1;  // A/B switch
+    if (forced == 0 || forced == 1)
+      ti = h->G.pyr[forced].ok ? forced : -1;
+    else if (h->pyr_tiling == 1 && (long long)P1.tiles.size() * nf >= 2048)  // calibrated choice, large launches only
+      ti = 1;
+    else if (P0.ok && P0.lds_bytes() <= kPyrLdsLimit)
+      ti = 0;
+  }
+  if (ti < 0) {
     for (int l = 1; l < fg.nlevels; l++) launch_resize(s, pyr, h->d_fg, h->d_tab, s0, fg, l, nf);
-  } else if (fg.nlevels > 1) {
-    launch_pyramid(s, pyr, h->d_fg, h->d_ptab, s0, h->d_ptiles, (int)h->G.pyrTiles.size(), h->G.pyrLdsA, h->G.pyrLdsB,
-                   h->G.pyrTabMax, nf);
+  } else {
+    const PyrTiling &PT = h->G.pyr[ti];
+    launch_pyramid(s, pyr, h->d_fg, h->d_ptab[ti], s0, h->d_ptiles[ti], (int)PT.tiles.size(), PT.ldsA, PT.ldsB,
+                   PT.tabMax, nf);
   }
   if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
   // The blur only needs the pyramid and runs on its own stream next to FAST -> octree -> slots.  Measured on
