@@ -256,19 +256,50 @@ __device__ __forceinline__ int fast_score(const uint8_t *c, int floor_t) {
   return s >= floor_t ? s : 0;
 }
 
-// Necessary condition on two opposing ring pairs for 4 horizontally adjacent pixels held in packed dwords:
-// C = centres, U/Dn = rows -3/+3 (same columns), W/E = columns -3/+3 (same row).  Bit j of the result is set
-// if pixel j may be a corner at threshold t (same idea as the tab[] pre-test of FAST_t).
-__device__ __forceinline__ uint32_t fast_quick4(uint32_t C, uint32_t U, uint32_t Dn, uint32_t W, uint32_t E, int t) {
-  uint32_t m = 0;
+// Necessary condition on two opposing ring pairs (same idea as the tab[] pre-test of FAST_t): a pixel can only be a
+// corner at threshold t if one of its N/S ring pixels AND one of its W/E ring pixels is darker than v - t, or one of
+// each is brighter than v + t.  Evaluated for a run of kRun dwords (4 px each) with SWAR arithmetic on plain 32-bit
+// adds / logic ops (2.3 issue cycles per wave64 instruction; the byte-select SDWA forms cost 4.2): every dword is
+// split into its even and odd bytes as two 16-bit lanes (x & 0x00FF00FF, (x >> 8) & 0x00FF00FF), and per lane
+//   dark   n < v - t  <=>  bit 9 of (v + 511 - t) - n      (value in [256 - t, 766 - t]: no borrow across lanes)
+//   bright n > v + t  <=>  bit 9 of (511 - t - v) + n
+// c points at the first centre dword of the run in the LDS tile; the dwords left and right of the run supply the
+// W/E neighbours (columns -3 / +3), which in split form are just lane-shifted neighbours of the centre splits.
+// Returns bit 4 * k + j = pixel j of dword k may be a corner.
+template <int kRun, int kTileP>
+__device__ __forceinline__ uint32_t fast_quick_run(const uint8_t *c, int t) {
+  const uint32_t K = 0x00FF00FFu, M9 = 0x02000200u;
+  const uint32_t bias = (uint32_t)(511 - t) * 0x00010001u;
+  uint32_t Ce[kRun + 2], Co[kRun + 2];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int v = (C >> (8 * j)) & 255, u = (U >> (8 * j)) & 255, d = (Dn >> (8 * j)) & 255;
-    const int w = (W >> (8 * j)) & 255, e = (E >> (8 * j)) & 255;
-    const int lo = v - t, hi = v + t;
-    const bool dark = ((u < lo) | (d < lo)) & ((w < lo) | (e < lo));
-    const bool bright = ((u > hi) | (d > hi)) & ((w > hi) | (e > hi));
-    m |= (uint32_t)(dark | bright) << j;
+  for (int k = 0; k < kRun + 2; k++) {
+    const uint32_t w = *(const uint32_t *)(c + 4 * (k - 1));
+    Ce[k] = w & K;
+    Co[k] = (w >> 8) & K;
+  }
+  uint32_t m = 0, T = 0;
+#pragma unroll
+  for (int k = 0; k < kRun; k++) {
+    const uint32_t U = *(const uint32_t *)(c - 3 * kTileP + 4 * k), Dn = *(const uint32_t *)(c + 3 * kTileP + 4 * k);
+    uint32_t P[2];
+#pragma unroll
+    for (int par = 0; par < 2; par++) {  // even / odd pixels of the dword
+      const uint32_t v = par ? Co[k + 1] : Ce[k + 1];
+      const uint32_t u = par ? (U >> 8) & K : U & K, d = par ? (Dn >> 8) & K : Dn & K;
+      // column -3: even pixels <- odd bytes of the previous dword; odd pixels <- (prev byte 2, own byte 0)
+      const uint32_t w = par ? __builtin_amdgcn_alignbit(Ce[k + 1], Ce[k], 16) : Co[k];
+      // column +3: even pixels <- (own byte 3, next byte 1); odd pixels <- even bytes of the next dword
+      const uint32_t e = par ? Ce[k + 2] : __builtin_amdgcn_alignbit(Co[k + 2], Co[k + 1], 16);
+      const uint32_t A = v + bias, B = bias - v;
+      const uint32_t dark = ((A - u) | (A - d)) & ((A - w) | (A - e));
+      const uint32_t bright = ((B + u) | (B + d)) & ((B + w) | (B + e));
+      P[par] = (dark | bright) & M9;
+    }
+    T |= (P[0] | (P[1] << 1)) << (4 * (k & 1));  // bits 9,10,25,26 (k even) / 13,14,29,30 (k odd)
+    if ((k & 1) || k == kRun - 1) {
+      m |= (((T >> 9) | (T >> 23)) & 0xFFu) << (8 * (k >> 1));
+      T = 0;
+    }
   }
   return m;
 }
@@ -338,16 +369,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
         r = div_small(i, inv_nrun);
         const int g = g0 + (i - r * nrun) * kFastRun;
         const uint8_t *t = &tile[(r + 3) * kTileP + 4 * g];
-        uint32_t Cw[kFastRun + 2];
-#pragma unroll
-        for (int k = 0; k < kFastRun + 2; k++) Cw[k] = *(const uint32_t *)(t + 4 * (k - 1));
-#pragma unroll
-        for (int k = 0; k < kFastRun; k++) {
-          const uint32_t U = *(const uint32_t *)(t - 3 * kTileP + 4 * k), Dn = *(const uint32_t *)(t + 3 * kTileP + 4 * k);
-          m |= fast_quick4(Cw[k + 1], U, Dn, __builtin_amdgcn_alignbyte(Cw[k + 1], Cw[k], 1),
-                           __builtin_amdgcn_alignbyte(Cw[k + 2], Cw[k + 1], 3), thr)
-               << (4 * k);
-        }
+        m = fast_quick_run<kFastRun, kTileP>(t, thr);
         cb = 4 * g - 3 - ox;  // valid-region column of bit 0 of this run (>= -3)
         // mask pixels outside [0, vw)
         if (cb < 0) m &= ~0u << (-cb);
