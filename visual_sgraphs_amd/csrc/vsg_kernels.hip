@@ -34,6 +34,29 @@ __device__ __forceinline__ const uint8_t *level_ptr(const FrameGeom *fg, const S
   return pyr + (size_t)frame * fg->pyr_frame_bytes + fg->lv[level].img_off;
 }
 
+// ------------------------------------------------------------------------------------------------
+// (work item, frame) grids: workgroups are dealt round-robin over the 8 XCDs by linear block id (observed, not
+// contractual: MI355X_MICROARCH.md "Workgroup dispatch"), so with the plain mapping the cells / tiles / keypoints of
+// ONE frame are spread over all eight private L2s and every L2 fetches the frame (and its halos) again.  The remap
+// gives the blocks that share an XCD whole frames: block L of the launch works on frame 8 * (slot / nx) + L % 8, item
+// slot % nx (slot = L / 8).  Bijective over the first ny & ~7 frames; the tail frames keep the plain mapping.  A
+// pure speed choice: results do not depend on it.  VSG_NO_XCD_REMAP builds without it (A/B).
+struct BlockXY {
+  int x, y;
+};
+__device__ __forceinline__ BlockXY frame_major_block() {
+  BlockXY b = {(int)blockIdx.x, (int)blockIdx.y};
+#ifndef VSG_NO_XCD_REMAP
+  const unsigned nx = gridDim.x, ny8 = gridDim.y & ~7u;
+  if (blockIdx.y < ny8) {
+    const unsigned L = blockIdx.y * nx + blockIdx.x, slot = L >> 3, q = slot / nx;
+    b.y = (int)(q * 8 + (L & 7));
+    b.x = (int)(slot - q * nx);
+  }
+#endif
+  return b;
+}
+
 // Pyramid: level `level` from level-1, chained like the reference (resize of the previous LEVEL).
 // Thread = 4 horizontally adjacent destination pixels -> one aligned 32-bit store.
 __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
@@ -81,8 +104,9 @@ __global__ __launch_bounds__(256) void k_pyramid(uint8_t *__restrict__ pyr, cons
                                                  const Short4 *__restrict__ tile_tab, Src0 s0,
                                                  const PyrTile *__restrict__ tiles, int ldsA, int ldsAB) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
-  const PyrTile &T = tiles[blockIdx.x];
-  const int frame = blockIdx.y, tid = threadIdx.x;
+  const BlockXY blk = frame_major_block();
+  const PyrTile &T = tiles[blk.x];
+  const int frame = blk.y, tid = threadIdx.x;
   uint8_t *buf0 = pyr_lds, *buf1 = pyr_lds + ldsA;
   Short4 *s_tab = (Short4 *)(pyr_lds + ldsAB);  // the tile's slices of the resize tables, all levels
   // One round of independent global loads: the tile's (pre-rebased, contiguous) table slice and the level-0 region.
@@ -332,8 +356,9 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
   uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);
   __shared__ int s_cnt[4];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base
-  const CellDesc cell = cells[blockIdx.x];
-  const int frame = blockIdx.y;
+  const BlockXY blk = frame_major_block();
+  const CellDesc cell = cells[blk.x];
+  const int frame = blk.y;
   const LevelGeom &L = fg->lv[cell.level];
   const int vw = cell.x1 - cell.x0, vh = cell.y1 - cell.y0;
   if (vw <= 0 || vh <= 0) return;
@@ -683,10 +708,11 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               const FrameGeom *__restrict__ fg, Src0 s0) {
+  const BlockXY blk = frame_major_block();
   int level = 0;
-  while (level + 1 < fg->nlevels && (int)blockIdx.x >= fg->lv[level + 1].blur_block_base) level++;
+  while (level + 1 < fg->nlevels && blk.x >= fg->lv[level + 1].blur_block_base) level++;
   const LevelGeom &L = fg->lv[level];
-  const int t = ((int)blockIdx.x - L.blur_block_base) * 256 + (int)threadIdx.x;
+  const int t = (blk.x - L.blur_block_base) * 256 + (int)threadIdx.x;
   if (t >= L.blur_nxg * L.blur_nys) return;
   // Interior column groups first, the three edge groups (which need per-byte REFLECT_101 loads) last, so that
   // whole wavefronts take either the fast or the slow load path instead of every wave diverging at a row end.
@@ -704,8 +730,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
   const int x0 = gx * 4, y0 = sy * kBlurStrip;
   const int w = L.w, h = L.h;
   int spitch;
-  const uint8_t *img = level_ptr(fg, s0, pyr, blockIdx.y, level, spitch);
-  uint8_t *dst = blur + (size_t)blockIdx.y * fg->pyr_frame_bytes + L.img_off;
+  const uint8_t *img = level_ptr(fg, s0, pyr, blk.y, level, spitch);
+  uint8_t *dst = blur + (size_t)blk.y * fg->pyr_frame_bytes + L.img_off;
   const uint32_t T0 = fg->taps[0] | (fg->taps[1] << 8) | (fg->taps[2] << 16) | ((uint32_t)fg->taps[3] << 24);
   const uint32_t T1 = fg->taps[4] | (fg->taps[5] << 8) | (fg->taps[6] << 16);
   uint32_t k[7];
@@ -905,7 +931,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   __shared__ int s_hdr[kMaxLevels + 3];  // n, mono, level_start[0..kMaxLevels]
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchW * kPatchP];
   __shared__ uint2 s_ic[4 * 64];  // c_disc, one 8-byte entry per (it, lane)
-  const int frame = blockIdx.y, tid = threadIdx.x;
+  const BlockXY blk = frame_major_block();
+  const int frame = blk.y, tid = threadIdx.x;
   s_ic[tid] = ((const uint2 *)c_disc.w)[tid];
   {
     const uint32_t pw = ((const uint32_t *)pattern)[tid];
@@ -914,14 +941,14 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   if (tid < kMaxLevels + 3) s_hdr[tid] = ((const int *)&hdr[frame])[tid];
   __syncthreads();
   const int n = s_hdr[0];
-  if (blockIdx.x == 0 && tid == 0) {
+  if (blk.x == 0 && tid == 0) {
     counts[frame * 2 + 0] = n;
     counts[frame * 2 + 1] = s_hdr[1];
   }
   const int lane = tid & 63;
   // everything derived from the keypoint index is wave-uniform: keep it in SGPRs so the per-level geometry comes
   // through the scalar cache in one round trip instead of a chain of dependent vector loads
-  const int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));
+  const int g = __builtin_amdgcn_readfirstlane(blk.x * 4 + (tid >> 6));
   if (g >= n) return;
   const int *level_start = &s_hdr[2];
   int l = 0;
