@@ -100,7 +100,12 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // ORBextractor.cc:1184), writing to HBM only the part of each level it owns.  Ownership boundaries are the source
 // indices of the destination boundaries, so tiles partition every level without gaps or overlaps; the ~25 % halo
 // is recomputed instead of communicated.  HBM traffic: level 0 read once (+halo), levels 1.. written once.
-__global__ __launch_bounds__(256) void k_pyramid(uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
+#ifndef VSG_PYR_NT
+#define VSG_PYR_NT 256
+#endif
+constexpr int kPyrThreads = VSG_PYR_NT;  // threads per pyramid tile (512: 0.196 -> 0.203 ms, 1024: 0.31 ms per 256 C2 frames)
+
+__global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                  const Short4 *__restrict__ tile_tab, Src0 s0,
                                                  const PyrTile *__restrict__ tiles, int ldsA, int ldsAB) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
@@ -112,12 +117,12 @@ __global__ __launch_bounds__(256) void k_pyramid(uint8_t *__restrict__ pyr, cons
   // One round of independent global loads: the tile's (pre-rebased, contiguous) table slice and the level-0 region.
   {
     const Short4 *tt = tile_tab + T.tab_off;
-    for (int i = tid; i < T.tab_n; i += 256) s_tab[i] = tt[i];
+    for (int i = tid; i < T.tab_n; i += kPyrThreads) s_tab[i] = tt[i];
     const int x0a = T.need[0][0] & ~3, y0 = T.need[0][1];
     const int w4 = ((T.need[0][2] - x0a) + 3) >> 2, hh = T.need[0][3] - y0, pitch = 4 * w4;
     const uint8_t *src = s0.base + (size_t)frame * s0.frame_stride + (size_t)y0 * s0.pitch + x0a;
     const float inv = 1.0f / (float)w4;
-    for (int i = tid; i < w4 * hh; i += 256) {
+    for (int i = tid; i < w4 * hh; i += kPyrThreads) {
       const int r = div_small(i, inv), c = i - r * w4;
       *(uint32_t *)(buf0 + r * pitch + 4 * c) = *(const uint32_t *)(src + (size_t)r * s0.pitch + 4 * c);
     }
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void k_pyramid(uint8_t *__restrict__ pyr, cons
     //  * the dword goes to the LDS image (source of the next level) and, where this tile OWNS it, straight to HBM.
     const int ncg = dpitch >> 2;  // column groups
     const int shift = ncg <= 8 ? 3 : ncg <= 16 ? 4 : ncg <= 32 ? 5 : 6;
-    const int cg = tid & ((1 << shift) - 1), rg = tid >> shift, nrg = 256 >> shift;
+    const int cg = tid & ((1 << shift) - 1), rg = tid >> shift, nrg = kPyrThreads >> shift;
     const int chunk = (dh + nrg - 1) / nrg, ya = rg * chunk, yb = min(dh, ya + chunk);
     if (cg < ncg && ya < yb) {
       uint32_t sel[4];
@@ -1256,7 +1261,7 @@ void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sh
   if (lds > lds_limit &&
       hipFuncSetAttribute((const void *)k_pyramid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
     lds_limit = lds;
-  hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(256), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
+  hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(kPyrThreads), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
                      d_tile_tab, s0, d_tiles, a16, ab16);
 }
 template <int NT, int TP, int SP>
