@@ -333,6 +333,18 @@ __device__ __forceinline__ uint32_t fast_quick_run(const uint8_t *c, int t) {
   return m;
 }
 
+// inclusive wave scan on the DPP path (no LDS round trips): Hillis-Steele inside each 16-lane row with zero-filled
+// row shifts, then lane 15 / lane 31 broadcasts carry the row totals across rows
+__device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
 #ifndef VSG_FAST_NT
 #define VSG_FAST_NT 128  // threads per FAST cell: 2 waves keep more cells resident per CU than 4 (measured: 0.47 ->
                          // 0.38 ms per 256 frames); 1 wave runs out of LDS before it runs out of wave slots
@@ -340,13 +352,15 @@ __device__ __forceinline__ uint32_t fast_quick_run(const uint8_t *c, int t) {
 #ifndef VSG_FAST_RUN
 #define VSG_FAST_RUN 2
 #endif
-constexpr int kFastRun = VSG_FAST_RUN;  // dwords per thread in the necessary test (1, 2 or 4)
-constexpr int kFastCntBits = kFastRun == 1 ? 3 : kFastRun == 2 ? 4 : 5;  // popcount of 4 * kFastRun mask bits
+constexpr int kFastRun = VSG_FAST_RUN;  // dwords per thread in the necessary test (2 or 4)
+static_assert(kFastRun == 2 || kFastRun == 4, "the run queue (4 bytes per run) must fit the score rows it aliases");
 
 // One workgroup per FAST cell.  The cell's valid region (3 px inside the reference's sub-image) is staged in LDS
 // with aligned 32-bit loads; a cheap necessary test runs on 8 pixels per thread from packed dwords and the pixels
 // that pass are COMPACTED into an LDS queue, so the exact score (packed 16-bit min/max) and the non-max suppression
-// run on dense wavefronts.  Like the reference the cell is first searched at iniThFAST and only if that yields
+// run on dense wavefronts.  The compaction has two levels: phase 1 appends one entry per RUN that has a passer (one
+// ballot, no per-lane loop: the run test executes ~3.6 sparse wave-iterations per cell), and one dense pass over
+// those entries (a wave scan of their popcounts) unpacks them into the pixel queue.  Like the reference the cell is first searched at iniThFAST and only if that yields
 // nothing at minThFAST (ORBextractor.cc:832-851); NMS only looks at neighbours INSIDE the valid region (outside
 // counts as 0, exactly like the zeroed row buffers of FAST_t).  Emission order is irrelevant (the octree ranks
 // candidates).
@@ -360,7 +374,8 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
   uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);
-  __shared__ int s_cnt[4];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base
+  uint32_t *runq = (uint32_t *)score;  // run entries (mask << 16 | row << 8 | column + 3); consumed before the score rows are cleared
+  __shared__ int s_cnt[5];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base [4]=run entries
   const BlockXY blk = frame_major_block();
   const CellDesc cell = cells[blk.x];
   const int frame = blk.y;
@@ -385,12 +400,10 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   uint32_t keep = 0;
   int nq = 0, thr = fg->iniTh;
   for (int pass = 0; pass < 2; pass++) {
-    // (vh + 2) score rows, cleared 16 bytes per lane (the region is allocated in multiples of 16 bytes)
-    for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
-    if (tid < 4) s_cnt[tid] = 0;
+    if (tid < 5) s_cnt[tid] = 0;
     __syncthreads();
-    // ---- phase 1: necessary test on kFastRun dwords (4 px each) per thread, compaction of the passers.  A longer
-    // run amortises the index arithmetic, the neighbour loads and the wave-level prefix over more pixels.
+    // ---- phase 1: necessary test on kFastRun dwords (4 px each) per thread; runs with a passer are appended to the
+    // run queue.  A longer run amortises the index arithmetic and the neighbour loads over more pixels.
     for (int i0 = 0; i0 < nruns; i0 += NT) {
       const int i = i0 + tid;
       uint32_t m = 0;
@@ -406,26 +419,29 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
         const int over = cb + 4 * kFastRun - vw;
         if (over > 0) m &= over >= 4 * kFastRun ? 0u : (1u << (4 * kFastRun - over)) - 1u;
       }
-      // compaction: wave-level exclusive prefix of popcount(m) from one ballot per count bit, one LDS atomic per wave
-      const int cnt = __popc(m);
-      uint64_t bb[kFastCntBits], any = 0;
-#pragma unroll
-      for (int b = 0; b < kFastCntBits; b++) {
-        bb[b] = __ballot(cnt & (1 << b));
-        any |= bb[b];
-      }
-      if (any) {
-        const uint64_t lt = (1ull << lane) - 1;
-        int total = 0, pos = 0;
-#pragma unroll
-        for (int b = 0; b < kFastCntBits; b++) {
-          total += __popcll(bb[b]) << b;
-          pos += __popcll(bb[b] & lt) << b;
-        }
+      const uint64_t hit = __ballot(m != 0);
+      if (hit) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&s_cnt[1], total);
-        pos += __builtin_amdgcn_readfirstlane(base);
-        const int pix = (r << 8) + cb;  // queue entry = row << 8 | column (both < 70): no division to unpack
+        if (lane == 0) base = atomicAdd(&s_cnt[4], __popcll(hit));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (m) runq[base + __popcll(hit & ((1ull << lane) - 1))] = (m << 16) | (uint32_t)((r << 8) + cb + 3);
+      }
+    }
+    __syncthreads();
+    // ---- run entries -> pixel queue (entry = row << 8 | column, both < 70: no division to unpack)
+    const int nr = s_cnt[4];
+    for (int e0 = 0; e0 < nr; e0 += NT) {
+      const int e = e0 + tid;
+      const uint32_t ent = e < nr ? runq[e] : 0u;
+      uint32_t m = ent >> 16;
+      const int cnt = __popc(m);
+      const int incl = wave_inclusive_scan_i32(cnt);
+      const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+      if (wtotal) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_cnt[1], wtotal);
+        int pos = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+        const int pix = (int)(ent & 0xFFFFu) - 3;
         while (m) {
           queue[pos++] = (uint16_t)(pix + __builtin_ctz(m));
           m &= m - 1;
@@ -434,6 +450,9 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     }
     __syncthreads();
     nq = s_cnt[1];
+    // (vh + 2) score rows, cleared 16 bytes per lane (the region is allocated in multiples of 16 bytes)
+    for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
     // ---- phase 2: exact score of the queued pixels
     for (int q = tid; q < nq; q += NT) {
       const int i = queue[q];
@@ -449,10 +468,13 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
       const int i = queue[q];
       const int r = i >> 8, c = i & 255;
       const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
+      // all eight neighbours in one round of LDS reads (no short-circuit chain); a zero score is never a maximum
       const int s = sp[0];
-      if (s == 0) continue;
-      const bool is_max = s > sp[-1] && s > sp[1] && s > sp[-kScoreP - 1] && s > sp[-kScoreP] && s > sp[-kScoreP + 1] &&
-                          s > sp[kScoreP - 1] && s > sp[kScoreP] && s > sp[kScoreP + 1];
+      int mx = max(max((int)sp[-1], (int)sp[1]), (int)sp[-kScoreP - 1]);
+      mx = max(max(mx, (int)sp[-kScoreP]), (int)sp[-kScoreP + 1]);
+      mx = max(max(mx, (int)sp[kScoreP - 1]), (int)sp[kScoreP]);
+      mx = max(mx, (int)sp[kScoreP + 1]);
+      const bool is_max = s > mx;
       if (is_max) {
         keep |= 1u << it;
         atomicAdd(&s_cnt[0], 1);
@@ -492,17 +514,7 @@ struct BlockGroup {
   __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
   __device__ void atomic_max(uint32_t *p, uint32_t v) { atomicMax(p, v); }
   __device__ void atomic_min(int *p, int v) { atomicMin(p, v); }
-  // inclusive wave scan on the DPP path (no LDS round trips): Hillis-Steele inside each 16-lane row with zero-filled
-  // row shifts, then lane 15 / lane 31 broadcasts carry the row totals across rows
-  static __device__ __forceinline__ int wave_inclusive_scan(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
-    return v;
-  }
+  static __device__ __forceinline__ int wave_inclusive_scan(int v) { return wave_inclusive_scan_i32(v); }
   __device__ int exclusive_scan(int *a, int n) {
     const int per = (n + nthreads - 1) / nthreads;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
