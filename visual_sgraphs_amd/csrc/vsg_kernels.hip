@@ -121,10 +121,11 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ p
     const int x0a = T.need[0][0] & ~3, y0 = T.need[0][1];
     const int w4 = ((T.need[0][2] - x0a) + 3) >> 2, hh = T.need[0][3] - y0, pitch = 4 * w4;
     const uint8_t *src = s0.base + (size_t)frame * s0.frame_stride + (size_t)y0 * s0.pitch + x0a;
-    const float inv = 1.0f / (float)w4;
+    const float inv = __builtin_amdgcn_rcpf((float)w4);
     for (int i = tid; i < w4 * hh; i += kPyrThreads) {
       const int r = div_small(i, inv), c = i - r * w4;
-      *(uint32_t *)(buf0 + r * pitch + 4 * c) = *(const uint32_t *)(src + (size_t)r * s0.pitch + 4 * c);
+      // wave-uniform base + 32-bit lane offset: no 64-bit multiply per element
+      *(uint32_t *)(buf0 + r * pitch + 4 * c) = *(const uint32_t *)(src + (uint32_t)(r * s0.pitch + 4 * c));
     }
   }
   __syncthreads();
@@ -388,15 +389,19 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   // tile column 0 <-> image column ax (4-byte aligned); valid-region column c sits at tile column c + 3 + ox
   const int ax = (cell.x0 - 3) & ~3, ox = (cell.x0 - 3) - ax;
   const int tdw = (ox + vw + 6 + 3) >> 2, th = vh + 6;  // dwords per tile row (<= 21)
-  const float inv_tdw = 1.0f / (float)tdw;
-  for (int i = tid; i < tdw * th; i += NT) {
-    const int r = div_small(i, inv_tdw), c = i - r * tdw;
-    *(uint32_t *)&tile[r * kTileP + 4 * c] = *(const uint32_t *)(img + (size_t)(cell.y0 - 3 + r) * pitch + ax + 4 * c);
+  const float inv_tdw = __builtin_amdgcn_rcpf((float)tdw);  // div_small has a margin of 0.5 / tdw: 1 ulp is plenty
+  {
+    // wave-uniform base + 32-bit lane offset (rows x pitch < 2^18): no 64-bit multiply per element
+    const uint8_t *tsrc = img + (ptrdiff_t)(cell.y0 - 3) * pitch + ax;
+    for (int i = tid; i < tdw * th; i += NT) {
+      const int r = div_small(i, inv_tdw), c = i - r * tdw;
+      *(uint32_t *)&tile[r * kTileP + 4 * c] = *(const uint32_t *)(tsrc + (uint32_t)(r * pitch + 4 * c));
+    }
   }
   // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1
   const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0;
   const int nrun = (ng + kFastRun - 1) / kFastRun, nruns = nrun * vh;  // runs of kFastRun dwords per row
-  const float inv_nrun = 1.0f / (float)nrun;
+  const float inv_nrun = __builtin_amdgcn_rcpf((float)nrun);
   uint32_t keep = 0;
   int nq = 0, thr = fg->iniTh;
   for (int pass = 0; pass < 2; pass++) {
@@ -787,7 +792,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
       int ysrc = y0 - 3 + turn * 7 + s;
       ysrc = ysrc < 0 ? -ysrc : ysrc;
       ysrc = ysrc >= h ? 2 * h - 2 - ysrc : ysrc;
-      const uint8_t *row = img + (size_t)ysrc * spitch + base;
+      const uint8_t *row = img + (uint32_t)(ysrc * spitch + base);  // uniform base + 32-bit lane offset
       d0[s] = *(const u32_unaligned *)(row);
       d1[s] = *(const u32_unaligned *)(row + 4);
       d2[s] = *(const u32_unaligned *)(row + 8);
@@ -832,7 +837,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
           }
           const uint32_t out = __builtin_amdgcn_perm(cl[1], cl[0], 0x0C0C0602u) |
                                (__builtin_amdgcn_perm(cl[3], cl[2], 0x0C0C0602u) << 16);
-          *(uint32_t *)(dst + (size_t)yo * L.pitch + x0) = out;
+          *(uint32_t *)(dst + (uint32_t)(yo * L.pitch + x0)) = out;
         }
       }
     }
