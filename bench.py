@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of ORB extract+match on MI355X (BASELINE.json metric, config C2).
 
-One STEP = one pass of the hot path over one batch of `--batch` (default 256) synthetic 640x480 gray frames that are
+One STEP = one pass of the hot path over one batch of `--batch` (default 512) synthetic 640x480 gray frames that are
 already resident in HBM: ORBextractor::operator() for every frame (pyramid, per-cell FAST, octree,
 orientation, 7x7 blur, rBRIEF-256; nFeatures=1000, 8 levels) + the brute-force Hamming best/second-best
 match of every frame against its predecessor (the inner search of ORBmatcher::SearchByBoW with one node).
@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-gather", action="store_true")

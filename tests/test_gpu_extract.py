@@ -240,16 +240,23 @@ def test_device_sort_replay_equals_std_sort():
         assert np.array_equal(got, want), (trial, n, nkeys)
 
 
-def test_large_batch_runs_as_sub_batches():
-    """Batches of >= 256 frames are cut into two sub-batches on separate stream pairs: results per frame are the
-    same as single-frame calls (checked against the oracle around the cut and at both ends)."""
+@pytest.mark.parametrize("nsub", [None, "2", "3"])
+def test_large_batch_and_sub_batches(nsub, monkeypatch):
+    """A 259-frame batch (32 x 8 + 3: the XCD block remap covers 256 frames, the tail keeps the plain mapping), as
+    one batch (default) and cut into 2 / 3 sub-batches on separate stream pairs (VSG_SUBBATCH, read when the handle
+    is created): results per frame are the same as single-frame calls (checked against the oracle around the cuts
+    and at both ends)."""
+    if nsub is None:
+        monkeypatch.delenv("VSG_SUBBATCH", raising=False)
+    else:
+        monkeypatch.setenv("VSG_SUBBATCH", nsub)
     B = 259
     imgs = np.stack([synth.sequence_frame(320, 240, 9, t % 40) for t in range(B)])
     ex = orb.ORBextractor(500, 1.2, 4, 20, 7, max_batch=B)
     ref = ol.OracleExtractor(500, 1.2, 4, 20, 7)
     outs = ex.extract_batch(imgs)
     assert len(outs) == B
-    for t in (0, 1, 128, 129, 130, 131, 257, 258):
+    for t in (0, 1, 86, 87, 128, 129, 130, 131, 173, 174, 255, 256, 257, 258):
         assert_same_output(outs[t], ref(imgs[t]), f"frame {t} of {B}")
     # frames with identical content give identical output wherever they sit in the batch
     for t in range(40, B):

@@ -207,9 +207,9 @@ static void harvest_timing(vsg_orb *h) {
   h->ev_pending = false;
   if (hipEventSynchronize(h->ev[5]) != hipSuccess || hipEventSynchronize(h->ev[7]) != hipSuccess) return;
   float ms;
-  // main chain: 0 start, 1 pyramid end, 8 fast begin, 2 fast end, 3 octree end, 4 slots end, 9 orient begin,
-  // 5 orient end; blur (own stream unless serialised): 6 begin, 7 end
-  const int pairs[kStages][2] = {{0, 1}, {8, 2}, {2, 3}, {6, 7}, {3, 4}, {9, 5}, {0, 5}};
+  // main chain: 0 start, 1 pyramid end, 8 fast begin, 2 fast end, 10 octree begin, 3 octree end, 4 slots end,
+  // 9 orient begin, 5 orient end; blur (own stream unless serialised, then between FAST and the octree): 6 begin, 7 end
+  const int pairs[kStages][2] = {{0, 1}, {8, 2}, {10, 3}, {6, 7}, {3, 4}, {9, 5}, {0, 5}};
   for (int i = 0; i < kStages; i++)
     if (hipEventElapsedTime(&ms, h->ev[pairs[i][0]], h->ev[pairs[i][1]]) == hipSuccess) h->acc_ms[i] += ms;
   h->acc_n++;
@@ -252,10 +252,11 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
                    PT.tabMax, nf);
   }
   if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
-  // The blur only needs the pyramid and runs on its own stream next to FAST -> octree -> slots.  Measured on
-  // MI355X the placement matters little (most kernels here are issue-bound, so concurrency mostly shares the
-  // CUs): released right after the pyramid is 1-2 % ahead of VSG_BLUR_LATE=1 with the default sub-batching.
-  static const bool blur_early = getenv("VSG_BLUR_LATE") == nullptr;
+  // The blur only needs the pyramid and runs on its own stream.  It is released AFTER FAST, beside the
+  // latency-bound octree (+ slots): FAST and the blur are both issue-bound, so running them side by side only
+  // shares the CUs, while the octree leaves most issue slots free.  Measured on MI355X (C2, one batch of 256):
+  // 254 k frames/s against 250 k with the blur released right after the pyramid (VSG_BLUR_EARLY=1).
+  static const bool blur_early = getenv("VSG_BLUR_EARLY") != nullptr && getenv("VSG_BLUR_LATE") == nullptr;
   if (!blur_early) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
     launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
@@ -272,6 +273,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
     launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
+  if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
   launch_octree(s, h->d_fg, cand, cand_count, nodeof, sel, sel_count, fg, h->G.maxQuota, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
   launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
@@ -292,10 +294,10 @@ static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, i
                             uint8_t *d_desc, int *d_counts, int capacity, hipStream_t s) {
   h->last_src0 = s0;
   const bool no_overlap = h->serialize;
-  // auto (VSG_SUBBATCH unset): two sub-batches once each half still fills the chip.  Measured on MI355X (C2): 256
-  // frames 210k -> 212k fps, 128 frames 190k -> 187k, so the cut is at 256; the gain was larger (4 %) while the
-  // octree was latency-bound.
-  int nsub = no_overlap ? 1 : h->nsub > 0 ? h->nsub : (nframes >= 256 ? 2 : 1);
+  // auto (VSG_SUBBATCH unset): ONE batch.  Sub-batches paid while the octree was a long latency-bound stage (+4 %,
+  // then +1 %); with the current kernels -- and whole frames pinned to one XCD's L2 by the block remap -- two
+  // sub-batches cost 2-4 % at 128-256 frames and nothing is gained at 512 (MI355X, C2-C4), so the cut stays a knob.
+  int nsub = no_overlap ? 1 : h->nsub > 0 ? h->nsub : 1;
   if (nsub > nframes) nsub = nframes;
   const bool tm = h->timing && nsub == 1;
   if (tm) harvest_timing(h);
