@@ -648,8 +648,10 @@ constexpr int kOctRegPts = VSG_OCT_K;  // candidates per thread held in register
 #endif
 constexpr int kOctThreads = VSG_OCT_NT;  // threads per (frame, level) octree
 
-// 4 waves per SIMD = 4 octrees per CU: the kernel is latency-bound, so residency is worth more than registers
-__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ cand,
+// 5 waves per SIMD = 5 octrees per CU (96 VGPRs, 10 dwords spilled off the hot paths): the kernel is latency-bound,
+// so residency is worth more than registers, and 96-register waves leave room for the blur waves that run beside it
+// (4 waves / 127 VGPRs: 0.167 ms per 512 frames and 256 k frames/s; 5: 0.160 ms and 260 k; 6: 255 k; 8: 0.185 ms)
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_octree(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ cand,
                                                 const int *__restrict__ cand_count, uint16_t *__restrict__ node_of,
                                                 uint32_t *__restrict__ sel, int *__restrict__ sel_count, int cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
