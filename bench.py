@@ -288,7 +288,7 @@ def main():
                     **({"valu_issue": valu} if valu else {}),
                     "launch_ms": round(timed[dom], 4), "bytes_per_launch": int(dom_bytes),
                     "timing": "HIP events per kernel, serialized pass of the same steps (stage_ms); the timed "
-                              "region itself overlaps streams and sub-batches",
+                              "region the blur runs beside the octree on a second stream",
                     "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                     # every stage against the same HBM roof: algorithmic bytes per launch / its duration
                     "stage_algorithmic_GBs": {k: round(stages[k] * B / (v * 1e-3) / 1e9, 1)
