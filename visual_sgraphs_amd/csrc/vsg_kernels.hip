@@ -404,6 +404,10 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0;
   const int nrun = (ng + kFastRun - 1) / kFastRun, nruns = nrun * vh;  // runs of kFastRun dwords per row
   const float inv_nrun = __builtin_amdgcn_rcpf((float)nrun);
+  // first run: its bit 0 is valid-region column cb0 >= -3; last run: `over` of its 4 * kFastRun columns lie beyond vw
+  const int cb0 = 4 * g0 - 3 - ox, over = 4 * (g0 + (nrun - 1) * kFastRun) - 3 - ox + 4 * kFastRun - vw;
+  const uint32_t first_mask = cb0 < 0 ? ~0u << (-cb0) : ~0u;
+  const uint32_t last_mask = over <= 0 ? ~0u : over >= 4 * kFastRun ? 0u : (1u << (4 * kFastRun - over)) - 1u;
   uint32_t keep = 0;
   int nq = 0, thr = fg->iniTh;
   for (int pass = 0; pass < 2; pass++) {
@@ -417,14 +421,13 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
       int r = 0, cb = 0;
       if (i < nruns) {
         r = div_small(i, inv_nrun);
-        const int g = g0 + (i - r * nrun) * kFastRun;
+        const int rr = i - r * nrun, g = g0 + rr * kFastRun;
         const uint8_t *t = &tile[(r + 3) * kTileP + 4 * g];
         m = fast_quick_run<kFastRun, kTileP>(t, thr);
         cb = 4 * g - 3 - ox;  // valid-region column of bit 0 of this run (>= -3)
-        // mask pixels outside [0, vw)
-        if (cb < 0) m &= ~0u << (-cb);
-        const int over = cb + 4 * kFastRun - vw;
-        if (over > 0) m &= over >= 4 * kFastRun ? 0u : (1u << (4 * kFastRun - over)) - 1u;
+        // pixels outside [0, vw) can only sit in the first and in the last run of a row: cell-uniform masks
+        if (rr == 0) m &= first_mask;
+        if (rr == nrun - 1) m &= last_mask;
       }
       const uint64_t hit = __ballot(m != 0);
       if (hit) {
