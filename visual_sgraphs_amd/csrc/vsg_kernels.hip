@@ -950,6 +950,13 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef VSG_OD_G
+#define VSG_OD_G 2
+#endif
+// keypoints a wavefront works through one after the other: amortises the workgroup prologue (pattern + disc tables
+// into LDS, one barrier).  2: 0.396 -> 0.386 ms per 512 frames; 4: no gain (fewer, longer workgroups)
+constexpr int kOdKpPerWave = VSG_OD_G;
+
 __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                      const FrameGeom *__restrict__ fg, Src0 s0,
                                                      const uint32_t *__restrict__ sel,
@@ -977,9 +984,13 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   const int lane = tid & 63;
   // everything derived from the keypoint index is wave-uniform: keep it in SGPRs so the per-level geometry comes
   // through the scalar cache in one round trip instead of a chain of dependent vector loads
-  const int g = __builtin_amdgcn_readfirstlane(blk.x * 4 + (tid >> 6));
-  if (g >= n) return;
   const int *level_start = &s_hdr[2];
+  uint8_t *patch = &s_patch[(tid >> 6) * (kPatchW * kPatchP)];
+#pragma unroll 1
+  for (int j = 0; j < kOdKpPerWave; j++) {
+  // the workgroup's keypoints: wave w takes blk.x * 4 * G + 4 * j + w  (adjacent keypoints run side by side)
+  const int g = __builtin_amdgcn_readfirstlane((blk.x * kOdKpPerWave + j) * 4 + (tid >> 6));
+  if (g >= n) break;
   int l = 0;
   while (g >= level_start[l + 1]) l++;
   l = __builtin_amdgcn_readfirstlane(l);
@@ -1022,7 +1033,6 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   brief_rotation(angle, &a, &b);
   // ---- descriptor.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38), so the 37x37 blurred
   // patch is staged in LDS with row-major (coalesced) byte loads; the 8 samples per lane are then LDS reads.
-  uint8_t *patch = &s_patch[(tid >> 6) * (kPatchW * kPatchP)];
   {
     // 37 rows x 10 (unaligned) dwords, 6 rows (60 lanes) per trip; gfx950 global loads accept any byte alignment
     constexpr int kDw = kPatchP / 4, kRows = 64 / kDw, kIt = (kPatchW + kRows - 1) / kRows;
@@ -1078,6 +1088,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
       kp.class_id = -1;
       kps[(size_t)frame * capacity + slot] = kp;
     }
+  }
+  // the next keypoint overwrites the patch: this wave's LDS reads above are issued (and, in order, completed) first
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1338,7 +1352,7 @@ void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, con
 void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                         const uint32_t *sel, const int *slots, const FrameHeader *hdr, const int8_t *pattern,
                         KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes) {
-  dim3 grid((fg.out_cap + 3) / 4, nframes), block(256);
+  dim3 grid((fg.out_cap + 4 * kOdKpPerWave - 1) / (4 * kOdKpPerWave), nframes), block(256);
   hipLaunchKernelGGL(k_orient_desc, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
                      counts, capacity);
 }
