@@ -83,7 +83,10 @@ int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t f
 /* Device-resident batched operator() for throughput pipelines and multi-GPU sharding:
  * d_gray, d_kps ([nframes][capacity]), d_desc ([nframes][capacity][32]) and d_counts ([nframes][2] =
  * {n, monoIndex}) are DEVICE pointers on the handle's device.  Work is enqueued asynchronously behind
- * `stream` (a hipStream_t, may be NULL = the handle's own stream) and completes in stream order.
+ * `stream` (a hipStream_t) and completes in stream order.  stream == NULL means the caller's NULL stream: the chain is
+ * ordered behind everything the NULL stream holds at entry and the NULL stream waits for it at exit, so
+ * producer -> extract -> vsg_hamming_block_best2_device(stream = NULL) sequences are ordered.  Level 0 is read in
+ * place: d_gray must stay alive until the work has completed (and for image_pyramid(0) / stereo read-back after it).
  * Descriptors stay resident for the matcher entry points. */
 int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes, size_t frame_stride, int rows,
                                  int cols, int stride, int lap0, int lap1, vsg_keypoint *d_kps, uint8_t *d_desc,
@@ -109,6 +112,12 @@ int vsg_orb_extract_batch_color(vsg_orb *h, const uint8_t *img, int channels, in
  * (w+38)x(h+38) buffer including the 19 px BORDER_REFLECT_101 frame (ORBextractor.cc:1186-1192). */
 int vsg_orb_level_size(vsg_orb *h, int level, int *w, int *ht);
 int vsg_orb_copy_pyramid_level(vsg_orb *h, int frame, int level, int with_border, uint8_t *dst, int dst_stride);
+
+/* All levels of mvImagePyramid of frame `frame` of the last call in ONE device-to-host copy, each WITH its 19 px
+ * border, packed back to back: level l starts at offsets[l] (nlevels entries) with a row stride of width + 38.  With
+ * dst == NULL (or dst_bytes too small) nothing is written and the byte count needed is returned; otherwise the bytes
+ * written.  This is what the adaptor's DownloadPyramid() uses. */
+int vsg_orb_copy_pyramid(vsg_orb *h, int frame, uint8_t *dst, size_t dst_bytes, size_t *offsets);
 
 /* Stage read-back of the last call, for stage-by-stage parity tests: the blurred level
  * (ORBextractor.cc:1129-1130), the FAST candidates (vToDistributeKeys, :868-873; unordered,
@@ -278,6 +287,179 @@ int vsg_search_for_initialization(int device, const uint8_t *desc1, const float 
                                   int n1, const int32_t *cand_off, const int32_t *cand_idx, const uint8_t *desc2,
                                   const float *angle2, int n2, float nnratio, int check_orientation,
                                   int32_t *matches12);
+
+
+/* ---- Threads, streams, staging ("re-entrant, thread-safe, stream per calling thread") ----------------
+ * Every matcher / grid / BoW / stereo / frame entry point runs on the CALLING THREAD's own non-blocking HIP stream and
+ * stages through that thread's pinned + device arenas, which only grow: no hipMalloc / hipFree / NULL-stream launch
+ * in steady state (a hipFree in LoopClosing's thread would otherwise stall Tracking's extractor streams).
+ * vsg_thread_release() frees the calling thread's streams and arenas (optional; call before the thread exits).
+ * vsg_thread_arena_growths(device) = number of arena (re)allocations so far on this thread (constant in steady state). */
+int vsg_thread_release(void);
+int vsg_thread_arena_growths(int device);
+
+/* Pin (hipHostRegister) caller memory once so that vsg_orb_submit_batch / vsg_orb_wait DMA straight from / into it
+ * instead of bouncing through the handle's staging buffers (cv::Mat::data of a reused frame buffer, the keypoint /
+ * descriptor arrays of a ring of Frames).  Unpinned memory keeps working everywhere, through a staging memcpy. */
+int vsg_host_register(void *ptr, size_t bytes);
+int vsg_host_unregister(void *ptr);
+
+/* ---- Asynchronous operator() batches (caller: Frame::ExtractORB, Frame.cc:555-563, in a throughput pipeline) -----
+ * vsg_orb_submit_batch enqueues H2D + the stage chain + the output export of one batch into one of the handle's
+ * vsg_orb_slots() (= 3) pipeline slots and returns at once with a ticket (>= 0); VSG_ERR_CAPACITY when every slot
+ * holds a batch that has not been waited for.  H2D of batch k+1 runs beside the kernels of batch k and the export of
+ * batch k-1 (three streams).  kps / desc ([nframes][capacity] records, host memory) must stay valid until the wait
+ * returns; if they are pinned (vsg_host_register) the device writes the n[i] records of every frame straight into
+ * them, otherwise they are filled from the slot's pinned staging inside vsg_orb_wait -- either way only n[i] records
+ * per frame cross PCIe, not `capacity`.  `gray` must stay valid until the wait returns if it is pinned; unpinned
+ * input is copied before submit returns.  vsg_orb_wait(ticket) blocks until that batch is complete and delivers n[]
+ * and mono_index[] (nframes entries each).  Tickets are waited for in submission order. */
+int vsg_orb_slots(const vsg_orb *h);
+int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t frame_stride, int rows, int cols,
+                         int stride, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc, int capacity);
+int vsg_orb_wait(vsg_orb *h, int ticket, int *n, int *mono_index);
+
+/* ---- Device-resident Frame / KeyFrame features (SURVEY 8b last row; Frame.h:280,290) ---------------------------
+ * A vsg_frame keeps what the searches read of one Frame or KeyFrame on the device between calls: the keypoints the
+ * grid indexes (mvKeysUn; mvKeys || mvKeysRight when Nleft != -1), mDescriptors, mvuRight and the 64 x 48 mGrid (+
+ * mGridRight) as CSR -- so that a search uploads only the projected positions and the map points' descriptors.
+ * A small host mirror of the keypoints serves the ordered host-side passes (rotation histogram, level ratio test).
+ * Frames are immutable after upload and may be searched concurrently from several threads. */
+typedef struct vsg_frame vsg_frame;
+int vsg_frame_create(int device, int capacity, vsg_frame **out);
+void vsg_frame_destroy(vsg_frame *f);
+/* Frame::Frame(...) after ExtractORB + UndistortKeyPoints: keys = mvKeysUn (Nleft == -1) or mvKeys followed by
+ * mvKeysRight (nleft = Nleft, Frame.cc:296); u_right = mvuRight (NULL: all -1); grid bounds mnMinX.. (Frame.cc:378).
+ * Builds mGrid / mGridRight exactly like AssignFeaturesToGrid (Frame.cc:521-553). */
+int vsg_frame_upload(vsg_frame *f, const vsg_keypoint *keys, const uint8_t *desc, const float *u_right, int n,
+                     int nleft, float min_x, float min_y, float max_x, float max_y);
+/* The same straight out of the extractor, device to device, for frame `index` of the handle's last
+ * vsg_orb_extract / _batch / _submit_batch call (no distortion: mvKeysUn = mvKeys, Frame.cc UndistortKeyPoints with
+ * mDistCoef == 0); the grid is built by a kernel.  The host mirror is filled from kps_host (the records the extract
+ * call delivered) -- nothing is downloaded. */
+int vsg_frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_keypoint *kps_host, int n, float min_x,
+                             float min_y, float max_x, float max_y);
+int vsg_frame_size(const vsg_frame *f);
+/* test / debug read-back of the device copy: grid CSR (cell_start[64*48+1], entries[n]) of the left (0) or right (1) grid */
+int vsg_frame_copy_grid(vsg_frame *f, int right, int32_t *cell_start, int32_t *entries);
+
+/* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel, bRight) (Frame.cc:802-868) / KeyFrame::GetFeaturesInArea
+ * (KeyFrame.cc:834-874; pass min_level = max_level = NULL) for nq windows on the resident grid; CSR out like
+ * vsg_grid_query.  Indices are grid-local (right grid: i - Nleft), exactly what the reference's vectors hold. */
+int vsg_frame_features_in_area(vsg_frame *f, const float *x, const float *y, const float *r, const int32_t *min_level,
+                               const int32_t *max_level, int right, int nq, int32_t *cand_off, int32_t *cand_idx,
+                               int cap);
+
+/* int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th, bFarPoints, thFarPoints)
+ * (ORBmatcher.h:46, ORBmatcher.cc:42-216), BOTH blocks (left :59-143, right camera :146-214 when F.Nleft != -1).
+ * One entry per map point that survives the caller-side tests (:50-57: in view, far points, isBad):
+ *   in_view / proj_x / proj_y / proj_xr / scale_level / view_cos   = mbTrackInView, mTrackProjX/Y, mTrackProjXR,
+ *   mnTrackScaleLevel, mTrackViewCos;  the *_r arrays (NULL when Nleft == -1) = the ...R members of the right camera;
+ *   mp_desc = pMP->GetDescriptor(); mp_observed = pMP->Observations() > 0.
+ * scale_factors = F.mvScaleFactors.  left_to_right / right_to_left = F.mvLeftToRightMatch / mvRightToLeftMatch
+ * (Nleft != -1).  train_blocked[i] = (F.mvpMapPoints[i] && Observations() > 0) on entry, updated in place;
+ * train_match[i] = index of the map point assigned to feature i (caller initialises to -1).  Returns nmatches. */
+int vsg_frame_search_by_projection(vsg_frame *F, int n_mp, const uint8_t *mp_desc, const uint8_t *mp_observed,
+                                   const uint8_t *in_view, const float *proj_x, const float *proj_y,
+                                   const float *proj_xr, const int32_t *scale_level, const float *view_cos,
+                                   const uint8_t *in_view_r, const float *proj_x_r, const float *proj_y_r,
+                                   const int32_t *scale_level_r, const float *view_cos_r, float th, float nnratio,
+                                   const float *scale_factors, int nlevels, const int32_t *left_to_right,
+                                   const int32_t *right_to_left, uint8_t *train_blocked, int32_t *train_match);
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono) (ORBmatcher.h:50,
+ * ORBmatcher.cc:1667-1878), both blocks (right camera :1786-1853 when CurrentFrame.Nleft != -1).  One entry per
+ * LastFrame map point that projects into the image (:1690-1711):  u, v = uv;  ur = uv(0) - mbf * invzc (stereo gate
+ * :1741-1747, used when Nleft == -1);  u_r, v_r = projection through Trl (:1788-1789; NULL when Nleft == -1);
+ * last_octave = nLastOctave;  last_angle = kpLF.angle;  mp_desc / mp_observed as above.  direction: 0 = neither,
+ * 1 = bForward, 2 = bBackward (:1683-1684) selects the level window of GetFeaturesInArea.  Returns nmatches after
+ * the rotation-consistency filter; a match dropped by it also loses its blocked flag (mvpMapPoints[i] = NULL, :1869). */
+int vsg_frame_search_by_projection_last(vsg_frame *cur, int n_q, const uint8_t *mp_desc, const uint8_t *mp_observed,
+                                        const float *u, const float *v, const float *ur, const float *u_r,
+                                        const float *v_r, const int32_t *last_octave, const float *last_angle,
+                                        float th, int direction, const float *scale_factors, int nlevels,
+                                        int check_orientation, uint8_t *train_blocked, int32_t *train_match);
+
+/* int ORBmatcher::SearchByProjection(KeyFrame *pKF, Sim3f &Scw, vpPoints, vpMatched, th, ratioHamming)
+ * (ORBmatcher.h:58, ORBmatcher.cc:430-528) and its twin that also records the source KeyFrame (ORBmatcher.h:62,
+ * .cc:530-641: the adaptor sets vpMatchedKF[i] = vpPointsKFs[matched[i]]).  One entry per point that passes the
+ * geometry (:446-487): u, v, radius = th * mvScaleFactors[nPredictedLevel], predicted_level.  matched[i] != -1 on
+ * entry = vpMatched[i] already set (skipped as a candidate, :501); on return matched[i] = query index for the new
+ * assignments (old entries keep their value).  Accept rule: bestDist <= TH_LOW * ratioHamming (:520).  Returns nmatches. */
+int vsg_frame_search_by_projection_sim3(vsg_frame *kf, int n_q, const uint8_t *mp_desc, const float *u, const float *v,
+                                        const float *radius, const int32_t *predicted_level, float ratio_hamming,
+                                        int32_t *matched);
+
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th,
+ * ORBdist) (ORBmatcher.h:54, ORBmatcher.cc:1880-2000).  One entry per KeyFrame map point that is not bad, not in
+ * sAlreadyFound and projects into the frame (:1905-1932): u, v, radius, predicted_level (window levels
+ * [level-1, level+1], :1934), kf_angle = pKF->mvKeysUn[i].angle.  occupied[i] = (CurrentFrame.mvpMapPoints[i] != NULL)
+ * on entry (:1946), updated in place incl. the rotation filter's reset (:1990); train_match as above. */
+int vsg_frame_search_by_projection_kf(vsg_frame *cur, int n_q, const uint8_t *mp_desc, const float *u, const float *v,
+                                      const float *radius, const int32_t *predicted_level, const float *kf_angle,
+                                      int orb_dist, int check_orientation, uint8_t *occupied, int32_t *train_match);
+
+/* int ORBmatcher::SearchBySim3(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12, S12, th) (ORBmatcher.h:76,
+ * ORBmatcher.cc:1448-1665).  Direction 1 (:1489-1565): for each KF1 feature i1 with a usable, not yet matched map
+ * point that projects into KF2: idx1[k] = i1, its descriptor, (u, v, radius, predicted level) in KF2; direction 2
+ * (:1568-1643) likewise from KF2 into KF1.  best-only scans from INT_MAX, accept <= TH_HIGH, then the agreement pass
+ * (:1646-1662): matches12[i1] = i2 where both directions agree, else -1.  n1 / n2 = feature counts of the two
+ * KeyFrames (matches12 has n1 entries).  Returns nFound. */
+int vsg_frame_search_by_sim3(vsg_frame *kf1, vsg_frame *kf2, int nq1, const int32_t *idx1, const uint8_t *desc1,
+                             const float *u1, const float *v1, const float *radius1, const int32_t *level1, int nq2,
+                             const int32_t *idx2, const uint8_t *desc2, const float *u2, const float *v2,
+                             const float *radius2, const int32_t *level2, int32_t *matches12);
+
+/* int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint*> &vpMapPoints, th, bRight) (ORBmatcher.h:84,
+ * ORBmatcher.cc:1148-1329): the search.  One entry per map point that passes :1176-1236: u, v, ur = u - bf * invz,
+ * radius, predicted_level.  Candidates: GetFeaturesInArea(u, v, radius, bRight), level window, then the chi-square
+ * gate on the reprojection error (:1267-1292: 7.8 with mvuRight >= 0, 5.99 without) with inv_level_sigma2 =
+ * pKF->mvInvLevelSigma2.  best_idx[k] (index into mDescriptors, i.e. + NLeft for bRight) / best_dist[k]; -1 / 256 when
+ * nothing qualifies.  A match is bestDist <= TH_LOW (:1308); the replace-vs-add decision on the MapPoint graph
+ * (:1310-1324) is vsg_fuse_decide below. Returns the number of entries with bestDist <= TH_LOW. */
+int vsg_frame_fuse(vsg_frame *kf, int n_q, const uint8_t *mp_desc, const float *u, const float *v, const float *ur,
+                   const float *radius, const int32_t *predicted_level, int right, const float *inv_level_sigma2,
+                   int nlevels, int32_t *best_idx, int32_t *best_dist);
+/* int ORBmatcher::Fuse(KeyFrame *pKF, Sim3f &Scw, vpPoints, th, vpReplacePoint) (ORBmatcher.h:87,
+ * ORBmatcher.cc:1331-1446): the search (scan from INT_MAX, level window only, no chi-square gate). */
+int vsg_frame_fuse_sim3(vsg_frame *kf, int n_q, const uint8_t *mp_desc, const float *u, const float *v,
+                        const float *radius, const int32_t *predicted_level, int32_t *best_idx, int32_t *best_dist);
+/* The ordered decision pass of both Fuse overloads on flattened state, for callers that keep map points as ids:
+ * slot_mp[i] = id of the map point in pKF->GetMapPoint(i) or -1 (updated in place as AddMapPoint /
+ * ReplaceMapPointMatch would); mp_obs[id] = Observations(), mp_bad[id] = isBad() (updated by Replace as
+ * MapPoint::Replace does for THIS keyframe: the survivor takes over the slot and the loser's observation count, the
+ * loser turns bad).  query_mp[k] = id of the k-th query's map point.  action[k]: 0 none (bestDist > TH_LOW),
+ * 1 AddObservation + AddMapPoint (:1321-1322), 2 pMP->Replace(pMPinKF) (:1315), 3 pMPinKF->Replace(pMP) (:1317),
+ * 4 counted but nothing done (pMPinKF is bad), 5 (sim3 form) vpReplacePoint[k] = pMPinKF (:1436).  sim3_form selects
+ * :1429-1444.  Returns nFused. */
+int vsg_fuse_decide(int n_q, const int32_t *query_mp, const int32_t *best_idx, const int32_t *best_dist, int sim3_form,
+                    int32_t *slot_mp, int n_slots, int32_t *mp_obs, uint8_t *mp_bad, int n_mp, int32_t *action,
+                    int32_t *other_mp);
+
+/* int ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.h:68,
+ * ORBmatcher.cc:643-756) with both frames resident: only vbPrevMatched (x, y per F1 keypoint) goes up;
+ * F2.GetFeaturesInArea(x, y, windowSize, 0, 0) (:663) runs on F2's resident grid for the level-0 keypoints of F1. */
+int vsg_frame_search_for_initialization(vsg_frame *f1, vsg_frame *f2, const float *prev_x, const float *prev_y,
+                                        int window_size, float nnratio, int check_orientation, int32_t *matches12);
+
+/* SearchByBoW(KeyFrame*, Frame&) / (KeyFrame*, KeyFrame*) (ORBmatcher.cc:226-428, 758-900) on resident descriptors:
+ * only the FeatureVectors and the validity flags go up.  Same outputs as vsg_search_by_bow_kf_f_stereo / _kf_kf. */
+int vsg_frame_search_by_bow_kf_f(vsg_frame *kf, const uint8_t *kf_valid, const int32_t *kf_node_id,
+                                 const int32_t *kf_off, const int32_t *kf_idx, int kf_nodes, vsg_frame *f,
+                                 const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
+                                 float nnratio, int check_orientation, int32_t *match_f);
+int vsg_frame_search_by_bow_kf_kf(vsg_frame *kf1, const uint8_t *valid1, const int32_t *node_id1, const int32_t *off1,
+                                  const int32_t *idx1, int nodes1, vsg_frame *kf2, const uint8_t *valid2,
+                                  const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                                  float nnratio, int check_orientation, int32_t *matches12);
+/* Frame::ComputeBoW (Frame.cc:882-889) on the resident descriptors; outputs as vsg_bow_transform. */
+int vsg_frame_bow_transform(vsg_vocab *voc, vsg_frame *f, int levelsup, int32_t *bow_ids, double *bow_vals,
+                            int bow_cap, int *n_bow, int32_t *fv_node, int32_t *fv_off, int32_t *fv_idx, int fv_cap,
+                            int *n_fv, int32_t *word_of, int32_t *node_of, double *weight_of);
+/* Frame::ComputeStereoMatches (Frame.cc:957-1127) on two resident feature sets (left / right eye of one stereo
+ * Frame, straight out of the two extractors): nothing but mvuRight / mvDepth crosses PCIe. */
+int vsg_frame_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, vsg_frame *fl, vsg_frame *fr,
+                             float mb, float mbf, float *u_right, float *depth);
 
 #ifdef __cplusplus
 }

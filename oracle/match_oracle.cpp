@@ -397,7 +397,8 @@ int or_search_by_projection_last(const uint8_t *qDesc, const float *qAngle, cons
     for (int i = 0; i < HISTO_LENGTH; i++) {
       if (i != ind1 && i != ind2 && i != ind3) {
         for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
-          trainMatch[rotHist[i][j]] = -1;
+          trainMatch[rotHist[i][j]] = -1;   // CurrentFrame.mvpMapPoints[...] = NULL (:1869):
+          trainBlocked[rotHist[i][j]] = 0;  // no map point any more, so the feature is free again
           nmatches--;
         }
       }

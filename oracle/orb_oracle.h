@@ -200,6 +200,47 @@ int or_search_for_initialization(const uint8_t *desc1, const float *angle1, cons
  * with one node and no greedy state): strict '<' scan order ties (Appendix B). */
 void or_block_best2(const uint8_t *a, int na, const uint8_t *b, int nb, int *best, int *second, int *argbest);
 
+/* ---- routine-level restatements on a flattened Frame / KeyFrame (routines_oracle.cpp): the functions follow the
+ * reference's loops from the point where a map point has been projected; see the comments there. ---- */
+typedef struct OrFrame OrFrame;
+OrFrame *or_frame_create(const OrKeyPoint *keys, const uint8_t *desc, const float *uRight, int N, int Nleft, float minX,
+                         float minY, float maxX, float maxY);
+void or_frame_destroy(OrFrame *f);
+int or_frame_grid(const OrFrame *f, int right, int *cell_start, int *entries);
+int or_frame_features_in_area(const OrFrame *f, float x, float y, float r, int minLevel, int maxLevel, int bRight,
+                              int kfForm, int *out, int cap);
+int or_frame_search_by_projection(const OrFrame *F, int nMP, const uint8_t *mpDesc, const uint8_t *mpObserved,
+                                  const uint8_t *mbTrackInView, const float *mTrackProjX, const float *mTrackProjY,
+                                  const float *mTrackProjXR, const int *mnTrackScaleLevel, const float *mTrackViewCos,
+                                  const uint8_t *mbTrackInViewR, const float *mTrackProjXR_r,
+                                  const float *mTrackProjYR_r, const int *mnTrackScaleLevelR,
+                                  const float *mTrackViewCosR, float th, float mfNNratio, const float *mvScaleFactors,
+                                  const int *mvLeftToRightMatch, const int *mvRightToLeftMatch, uint8_t *trainBlocked,
+                                  int *trainMatch);
+int or_frame_search_by_projection_last(const OrFrame *Cur, int nQ, const uint8_t *mpDesc, const uint8_t *mpObserved,
+                                       const float *u, const float *v, const float *ur, const float *uR,
+                                       const float *vR, const int *nLastOctave, const float *kpLFangle, float th,
+                                       int bForward, int bBackward, const float *mvScaleFactors, int mbCheckOrientation,
+                                       uint8_t *trainBlocked, int *trainMatch);
+int or_kf_search_by_projection_sim3(const OrFrame *pKF, int nQ, const uint8_t *mpDesc, const float *u, const float *v,
+                                    const float *radius, const int *nPredictedLevel, float ratioHamming, int *matched);
+int or_frame_search_by_projection_kf(const OrFrame *Cur, int nQ, const uint8_t *mpDesc, const float *u, const float *v,
+                                     const float *radius, const int *nPredictedLevel, const float *kfAngle, int ORBdist,
+                                     int mbCheckOrientation, uint8_t *occupied, int *trainMatch);
+int or_kf_search_by_sim3(const OrFrame *pKF1, const OrFrame *pKF2, int nq1, const int *idx1, const uint8_t *desc1,
+                         const float *u1, const float *v1, const float *radius1, const int *level1, int nq2,
+                         const int *idx2, const uint8_t *desc2, const float *u2, const float *v2, const float *radius2,
+                         const int *level2, int *matches12);
+int or_kf_fuse(const OrFrame *pKF, int nQ, const int *queryMP, const uint8_t *mpDesc, const float *u, const float *v,
+               const float *ur, const float *radius, const int *nPredictedLevel, int bRight,
+               const float *mvInvLevelSigma2, int *slotMP, int *mpObs, uint8_t *mpBad, int *bestIdx, int *bestDist,
+               int *action, int *other);
+int or_kf_fuse_sim3(const OrFrame *pKF, int nQ, const int *queryMP, const uint8_t *mpDesc, const float *u,
+                    const float *v, const float *radius, const int *nPredictedLevel, int *slotMP, int *mpObs,
+                    uint8_t *mpBad, int *bestIdx, int *bestDist, int *action, int *other);
+int or_frame_search_for_initialization(const OrFrame *F1, const OrFrame *F2, const float *prevX, const float *prevY,
+                                       int windowSize, float mfNNratio, int mbCheckOrientation, int *vnMatches12);
+
 #ifdef __cplusplus
 }
 #endif

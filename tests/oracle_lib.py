@@ -25,7 +25,7 @@ def _ptr(a, t):
 
 
 def build():
-    srcs = [ORACLE_DIR / n for n in ("orb_oracle.cpp", "match_oracle.cpp", "bow_oracle.cpp", "orb_oracle.h",
+    srcs = [ORACLE_DIR / n for n in ("orb_oracle.cpp", "match_oracle.cpp", "bow_oracle.cpp", "routines_oracle.cpp", "orb_oracle.h",
                                      "brief_pattern_data.inc")]
     if LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return
@@ -494,3 +494,183 @@ def distinctive_descriptors(desc, off):
     best = np.zeros(len(o) - 1, np.int32)
     lib().or_distinctive_descriptors(_ptr(d, _u8p), _ptr(o, _i32p), len(o) - 1, _ptr(best, _i32p))
     return best
+
+
+# ---------------------------------------------------------------- routine-level oracle (oracle/routines_oracle.cpp)
+def _rl():
+    L = lib()
+    if getattr(L, "_routines_bound", False):
+        return L
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.or_frame_create.restype = vp
+    L.or_frame_create.argtypes = [vp, _u8p, _f32p, ci, ci, cf, cf, cf, cf]
+    L.or_frame_destroy.argtypes = [vp]
+    L.or_frame_destroy.restype = None
+    L.or_frame_grid.argtypes = [vp, ci, _i32p, _i32p]
+    L.or_frame_features_in_area.argtypes = [vp, cf, cf, cf, ci, ci, ci, ci, _i32p, ci]
+    L.or_frame_search_by_projection.argtypes = [vp, ci, _u8p, _u8p, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, _u8p, _f32p,
+                                                _f32p, _i32p, _f32p, cf, cf, _f32p, _i32p, _i32p, _u8p, _i32p]
+    L.or_frame_search_by_projection_last.argtypes = [vp, ci, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p,
+                                                     _f32p, cf, ci, ci, _f32p, ci, _u8p, _i32p]
+    L.or_kf_search_by_projection_sim3.argtypes = [vp, ci, _u8p, _f32p, _f32p, _f32p, _i32p, cf, _i32p]
+    L.or_frame_search_by_projection_kf.argtypes = [vp, ci, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, ci, ci, _u8p, _i32p]
+    L.or_kf_search_by_sim3.argtypes = [vp, vp, ci, _i32p, _u8p, _f32p, _f32p, _f32p, _i32p, ci, _i32p, _u8p, _f32p,
+                                       _f32p, _f32p, _i32p, _i32p]
+    L.or_kf_fuse.argtypes = [vp, ci, _i32p, _u8p, _f32p, _f32p, _f32p, _f32p, _i32p, ci, _f32p, _i32p, _i32p, _u8p,
+                             _i32p, _i32p, _i32p, _i32p]
+    L.or_kf_fuse_sim3.argtypes = [vp, ci, _i32p, _u8p, _f32p, _f32p, _f32p, _i32p, _i32p, _i32p, _u8p, _i32p, _i32p,
+                                  _i32p, _i32p]
+    L.or_frame_search_for_initialization.argtypes = [vp, vp, _f32p, _f32p, ci, cf, ci, _i32p]
+    L._routines_bound = True
+    return L
+
+
+def _o(a, t, conv):
+    if a is None:
+        return None, None
+    x = conv(a)
+    return x, _ptr(x, t)
+
+
+class OracleFrame:
+    """Flattened Frame / KeyFrame of the routine-level oracle: keys = mvKeysUn (or mvKeys || mvKeysRight), desc,
+    mvuRight, Nleft, grid bounds."""
+
+    def __init__(self, kps, desc, bounds, u_right=None, nleft=-1):
+        self._L = _rl()
+        self.kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+        self.desc = _u8c(desc).reshape(-1, 32)
+        self.N, self.nleft = len(self.kps), int(nleft)
+        ur = _f32c(u_right) if u_right is not None else None
+        d = self.desc if len(self.desc) else np.zeros((1, 32), np.uint8)
+        self._h = self._L.or_frame_create(self.kps.ctypes.data_as(C.c_void_p), _ptr(d, _u8p),
+                                          _ptr(ur, _f32p) if ur is not None else None, self.N, self.nleft,
+                                          *[float(b) for b in bounds])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.or_frame_destroy(self._h)
+            self._h = None
+
+    def grid(self, right=False):
+        cs, en = np.zeros(64 * 48 + 1, np.int32), np.zeros(max(self.N, 1), np.int32)
+        ne = self._L.or_frame_grid(self._h, int(right), _ptr(cs, _i32p), _ptr(en, _i32p))
+        return cs, en[:ne]
+
+    def features_in_area(self, x, y, r, min_level=-1, max_level=-1, right=False, kf_form=False):
+        out = np.zeros(max(self.N, 1), np.int32)
+        n = self._L.or_frame_features_in_area(self._h, float(x), float(y), float(r), int(min_level), int(max_level),
+                                              int(right), int(kf_form), _ptr(out, _i32p), len(out))
+        return out[:n].copy()
+
+    def search_by_projection(self, mp, th, nnratio, scale_factors, train_blocked, left_to_right=None,
+                             right_to_left=None):
+        d = _u8c(mp["desc"]).reshape(-1, 32)
+        n = len(d)
+        obs, inv = _u8c(mp["observed"]), _u8c(mp["in_view"])
+        px, py, lvl, vc = _f32c(mp["proj_x"]), _f32c(mp["proj_y"]), _i32c(mp["scale_level"]), _f32c(mp["view_cos"])
+        pxr = _f32c(mp["proj_xr"]) if mp.get("proj_xr") is not None else np.zeros(max(n, 1), np.float32)
+        keep = []
+
+        def opt(key, conv, t):
+            if mp.get(key) is None:
+                return None
+            a = conv(mp[key])
+            keep.append(a)
+            return _ptr(a, t)
+        sf = _f32c(scale_factors)
+        ltr = _i32c(left_to_right) if left_to_right is not None else None
+        rtl = _i32c(right_to_left) if right_to_left is not None else None
+        tb = _u8c(train_blocked).copy()
+        tm = np.full(max(len(tb), 1), -1, np.int32)
+        nm = self._L.or_frame_search_by_projection(
+            self._h, n, _ptr(d, _u8p), _ptr(obs, _u8p), _ptr(inv, _u8p), _ptr(px, _f32p), _ptr(py, _f32p),
+            _ptr(pxr, _f32p), _ptr(lvl, _i32p), _ptr(vc, _f32p), opt("in_view_r", _u8c, _u8p),
+            opt("proj_x_r", _f32c, _f32p), opt("proj_y_r", _f32c, _f32p), opt("scale_level_r", _i32c, _i32p),
+            opt("view_cos_r", _f32c, _f32p), float(th), float(np.float32(nnratio)), _ptr(sf, _f32p),
+            _ptr(ltr, _i32p) if ltr is not None else None, _ptr(rtl, _i32p) if rtl is not None else None,
+            _ptr(tb, _u8p), _ptr(tm, _i32p))
+        return nm, tm[:len(tb)], tb
+
+    def search_by_projection_last(self, desc, observed, u, v, ur, last_octave, last_angle, th, direction,
+                                  scale_factors, check_ori, train_blocked, u_r=None, v_r=None):
+        d = _u8c(desc).reshape(-1, 32)
+        obs = _u8c(observed)
+        uu, vv, oc, an = _f32c(u), _f32c(v), _i32c(last_octave), _f32c(last_angle)
+        ur_ = _f32c(ur) if ur is not None else np.zeros(max(len(d), 1), np.float32)
+        ur2 = _f32c(u_r) if u_r is not None else None
+        vr2 = _f32c(v_r) if v_r is not None else None
+        sf = _f32c(scale_factors)
+        tb = _u8c(train_blocked).copy()
+        tm = np.full(max(len(tb), 1), -1, np.int32)
+        nm = self._L.or_frame_search_by_projection_last(
+            self._h, len(d), _ptr(d, _u8p), _ptr(obs, _u8p), _ptr(uu, _f32p), _ptr(vv, _f32p), _ptr(ur_, _f32p),
+            _ptr(ur2, _f32p) if ur2 is not None else None, _ptr(vr2, _f32p) if vr2 is not None else None,
+            _ptr(oc, _i32p), _ptr(an, _f32p), float(th), int(direction == 1), int(direction == 2), _ptr(sf, _f32p),
+            int(check_ori), _ptr(tb, _u8p), _ptr(tm, _i32p))
+        return nm, tm[:len(tb)], tb
+
+    def search_by_projection_sim3(self, desc, u, v, radius, level, ratio_hamming, matched):
+        d = _u8c(desc).reshape(-1, 32)
+        m = _i32c(matched).copy()
+        nm = self._L.or_kf_search_by_projection_sim3(self._h, len(d), _ptr(d, _u8p), _ptr(_f32c(u), _f32p),
+                                                     _ptr(_f32c(v), _f32p), _ptr(_f32c(radius), _f32p),
+                                                     _ptr(_i32c(level), _i32p), float(np.float32(ratio_hamming)),
+                                                     _ptr(m, _i32p))
+        return nm, m[:len(matched)]
+
+    def search_by_projection_kf(self, desc, u, v, radius, level, kf_angle, orb_dist, check_ori, occupied):
+        d = _u8c(desc).reshape(-1, 32)
+        oc = _u8c(occupied).copy()
+        tm = np.full(max(len(oc), 1), -1, np.int32)
+        nm = self._L.or_frame_search_by_projection_kf(self._h, len(d), _ptr(d, _u8p), _ptr(_f32c(u), _f32p),
+                                                      _ptr(_f32c(v), _f32p), _ptr(_f32c(radius), _f32p),
+                                                      _ptr(_i32c(level), _i32p), _ptr(_f32c(kf_angle), _f32p),
+                                                      int(orb_dist), int(check_ori), _ptr(oc, _u8p), _ptr(tm, _i32p))
+        return nm, tm[:len(occupied)], oc
+
+    def fuse(self, query_mp, desc, u, v, ur, radius, level, inv_sigma2, slot_mp, mp_obs, mp_bad, right=False):
+        d = _u8c(desc).reshape(-1, 32)
+        n = len(d)
+        sm, ob, bad = _i32c(slot_mp).copy(), _i32c(mp_obs).copy(), _u8c(mp_bad).copy()
+        bi, bd, act, oth = (np.zeros(max(n, 1), np.int32) for _ in range(4))
+        nf = self._L.or_kf_fuse(self._h, n, _ptr(_i32c(query_mp), _i32p), _ptr(d, _u8p), _ptr(_f32c(u), _f32p),
+                                _ptr(_f32c(v), _f32p), _ptr(_f32c(ur), _f32p), _ptr(_f32c(radius), _f32p),
+                                _ptr(_i32c(level), _i32p), int(right), _ptr(_f32c(inv_sigma2), _f32p), _ptr(sm, _i32p),
+                                _ptr(ob, _i32p), _ptr(bad, _u8p), _ptr(bi, _i32p), _ptr(bd, _i32p), _ptr(act, _i32p),
+                                _ptr(oth, _i32p))
+        return nf, bi[:n], bd[:n], act[:n], oth[:n], sm, ob, bad
+
+    def fuse_sim3(self, query_mp, desc, u, v, radius, level, slot_mp, mp_obs, mp_bad):
+        d = _u8c(desc).reshape(-1, 32)
+        n = len(d)
+        sm, ob, bad = _i32c(slot_mp).copy(), _i32c(mp_obs).copy(), _u8c(mp_bad).copy()
+        bi, bd, act, oth = (np.zeros(max(n, 1), np.int32) for _ in range(4))
+        nf = self._L.or_kf_fuse_sim3(self._h, n, _ptr(_i32c(query_mp), _i32p), _ptr(d, _u8p), _ptr(_f32c(u), _f32p),
+                                     _ptr(_f32c(v), _f32p), _ptr(_f32c(radius), _f32p), _ptr(_i32c(level), _i32p),
+                                     _ptr(sm, _i32p), _ptr(ob, _i32p), _ptr(bad, _u8p), _ptr(bi, _i32p), _ptr(bd, _i32p),
+                                     _ptr(act, _i32p), _ptr(oth, _i32p))
+        return nf, bi[:n], bd[:n], act[:n], oth[:n], sm, ob, bad
+
+    def search_for_initialization(self, f2, prev_x, prev_y, window_size, nnratio, check_ori):
+        out = np.full(max(self.N, 1), -1, np.int32)
+        nm = self._L.or_frame_search_for_initialization(self._h, f2._h, _ptr(_f32c(prev_x), _f32p),
+                                                        _ptr(_f32c(prev_y), _f32p), int(window_size),
+                                                        float(np.float32(nnratio)), int(check_ori), _ptr(out, _i32p))
+        return nm, out[:self.N]
+
+
+def search_by_sim3(kf1, kf2, q1, q2):
+    L = _rl()
+
+    def unpack(q):
+        d = _u8c(q["desc"]).reshape(-1, 32)
+        return (len(d), _i32c(q["idx"]), d if len(d) else np.zeros((1, 32), np.uint8), _f32c(q["u"]), _f32c(q["v"]),
+                _f32c(q["radius"]), _i32c(q["level"]))
+    a, b = unpack(q1), unpack(q2)
+    out = np.full(max(kf1.N, 1), -1, np.int32)
+    nf = L.or_kf_search_by_sim3(kf1._h, kf2._h, a[0], _ptr(a[1], _i32p), _ptr(a[2], _u8p), _ptr(a[3], _f32p),
+                                _ptr(a[4], _f32p), _ptr(a[5], _f32p), _ptr(a[6], _i32p), b[0], _ptr(b[1], _i32p),
+                                _ptr(b[2], _u8p), _ptr(b[3], _f32p), _ptr(b[4], _f32p), _ptr(b[5], _f32p),
+                                _ptr(b[6], _i32p), _ptr(out, _i32p))
+    return nf, out[:kf1.N]

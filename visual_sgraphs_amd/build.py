@@ -10,7 +10,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libvsg_orb.so"
-SOURCES = ["vsg_kernels.hip", "vsg_orb.hip", "vsg_match.hip", "vsg_grid.hip", "vsg_bow.hip"]
+SOURCES = ["vsg_kernels.hip", "vsg_orb.hip", "vsg_match.hip", "vsg_grid.hip", "vsg_bow.hip", "vsg_frame.hip", "vsg_ctx.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wno-unused-value",
          # MFMA results in VGPRs (the matcher's epilogue is VALU): no v_accvgpr_read per accumulator register

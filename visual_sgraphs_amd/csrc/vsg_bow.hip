@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "../../include/vsg_orb.h"
+#include "vsg_ctx.h"
+#include "vsg_frame_int.h"
 
 namespace {
 __global__ void k_bow_descend(const int *child_off, const int *child_list, const uint8_t *node_desc,
@@ -144,33 +146,49 @@ int vsg_vocab_info(const vsg_vocab *v, int *k, int *L, int *scoring, int *weight
   return VSG_OK;
 }
 
-int vsg_bow_transform(vsg_vocab *voc, const uint8_t *desc, int n, int levelsup, int32_t *bow_ids, double *bow_vals,
-                      int bow_cap, int *n_bow, int32_t *fv_node, int32_t *fv_off, int32_t *fv_idx, int fv_cap,
-                      int *n_fv, int32_t *word_of, int32_t *node_of, double *weight_of) {
+}  // extern "C" (vocabulary object)
+
+// tree descent on the calling thread's stream; d_desc = descriptors on the device (resident frame) or nullptr (host
+// descriptors are staged through the arena); per-feature word / node / weight come back through the pinned arena
+static int bow_descend(vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_desc, int n, int levelsup,
+                       const int **word, const int **node, const double **w) {
+  int rc = VSG_OK;
+  vsg::ThreadCtx *c = vsg::thread_ctx(voc->device, &rc);
+  if (!c) return rc;
+  vsg::Stage st;
+  const size_t oD = st.add(d_desc ? 0 : 32 * (size_t)n);
+  const size_t in_bytes = st.total;
+  const size_t oW = st.add(8 * (size_t)n), oWord = st.add(4 * (size_t)n), oNode = st.add(4 * (size_t)n);
+  rc = vsg::ctx_reserve(c, st.total, in_bytes + 64);
+  if (rc != VSG_OK) return rc;
+  if (!d_desc) {
+    memcpy(c->h_pin + oD, desc, 32 * (size_t)n);
+    B_TRY(hipMemcpyAsync(c->d_buf, c->h_pin, in_bytes, hipMemcpyHostToDevice, c->stream));
+    d_desc = c->d_buf + oD;
+  }
+  hipLaunchKernelGGL(k_bow_descend, dim3((n + 63) / 64), dim3(64), 0, c->stream, voc->d_child_off, voc->d_child_list,
+                     voc->d_desc, voc->d_weight, voc->d_word, d_desc, n, voc->L - levelsup, (int *)(c->d_pin + oWord),
+                     (int *)(c->d_pin + oNode), (double *)(c->d_pin + oW));
+  B_TRY(hipGetLastError());
+  B_TRY(hipStreamSynchronize(c->stream));
+  *word = (const int *)(c->h_pin + oWord);
+  *node = (const int *)(c->h_pin + oNode);
+  *w = (const double *)(c->h_pin + oW);
+  return VSG_OK;
+}
+
+static int bow_transform(vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_desc, int n, int levelsup,
+                         int32_t *bow_ids, double *bow_vals, int bow_cap, int *n_bow, int32_t *fv_node,
+                         int32_t *fv_off, int32_t *fv_idx, int fv_cap, int *n_fv, int32_t *word_of, int32_t *node_of,
+                         double *weight_of) {
   if (!voc || n < 0 || !n_bow || !n_fv || !fv_off) return VSG_ERR_INVALID;
   *n_bow = *n_fv = 0;
   fv_off[0] = 0;
   if (n == 0 || voc->nnodes <= 1) return VSG_OK;  // empty() vocabulary: v and fv stay empty (:1147-1150)
-  B_TRY(hipSetDevice(voc->device));
-  uint8_t *d_desc = nullptr;
-  int *d_word = nullptr, *d_node = nullptr;
-  double *d_w = nullptr;
-  std::vector<int> word((size_t)n), node((size_t)n);
-  std::vector<double> w((size_t)n);
-  hipError_t e = hipMalloc(&d_desc, 32 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&d_word, 4 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&d_node, 4 * (size_t)n);
-  if (e == hipSuccess) e = hipMalloc(&d_w, 8 * (size_t)n);
-  if (e == hipSuccess) e = hipMemcpy(d_desc, desc, 32 * (size_t)n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_bow_descend, dim3((n + 63) / 64), dim3(64), 0, 0, voc->d_child_off, voc->d_child_list,
-                       voc->d_desc, voc->d_weight, voc->d_word, d_desc, n, voc->L - levelsup, d_word, d_node, d_w);
-    e = hipMemcpy(word.data(), d_word, 4 * (size_t)n, hipMemcpyDeviceToHost);
-  }
-  if (e == hipSuccess) e = hipMemcpy(node.data(), d_node, 4 * (size_t)n, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(w.data(), d_w, 8 * (size_t)n, hipMemcpyDeviceToHost);
-  hipFree(d_desc), hipFree(d_word), hipFree(d_node), hipFree(d_w);
-  if (e != hipSuccess) return VSG_ERR_HIP;
+  const int *word = nullptr, *node = nullptr;
+  const double *w = nullptr;
+  int rc = bow_descend(voc, desc, d_desc, n, levelsup, &word, &node, &w);
+  if (rc != VSG_OK) return rc;
   // ---- BowVector / FeatureVector assembly in feature order (:1158-1206)
   std::map<unsigned, double> v;
   std::map<unsigned, std::vector<unsigned>> fv;
@@ -222,6 +240,26 @@ int vsg_bow_transform(vsg_vocab *voc, const uint8_t *desc, int n, int levelsup, 
     j++;
   }
   return (*n_bow > bow_cap || *n_fv > fv_cap) ? VSG_ERR_CAPACITY : VSG_OK;
+}
+
+
+extern "C" {
+
+int vsg_bow_transform(vsg_vocab *voc, const uint8_t *desc, int n, int levelsup, int32_t *bow_ids, double *bow_vals,
+                      int bow_cap, int *n_bow, int32_t *fv_node, int32_t *fv_off, int32_t *fv_idx, int fv_cap,
+                      int *n_fv, int32_t *word_of, int32_t *node_of, double *weight_of) {
+  if (n > 0 && !desc) return VSG_ERR_INVALID;
+  return bow_transform(voc, desc, nullptr, n, levelsup, bow_ids, bow_vals, bow_cap, n_bow, fv_node, fv_off, fv_idx,
+                       fv_cap, n_fv, word_of, node_of, weight_of);
+}
+
+// Frame::ComputeBoW (Frame.cc:882-889) on the descriptors of a resident frame: nothing goes up
+int vsg_frame_bow_transform(vsg_vocab *voc, vsg_frame *f, int levelsup, int32_t *bow_ids, double *bow_vals,
+                            int bow_cap, int *n_bow, int32_t *fv_node, int32_t *fv_off, int32_t *fv_idx, int fv_cap,
+                            int *n_fv, int32_t *word_of, int32_t *node_of, double *weight_of) {
+  if (!voc || !f || f->device != voc->device) return VSG_ERR_INVALID;
+  return bow_transform(voc, nullptr, f->d_desc, f->n, levelsup, bow_ids, bow_vals, bow_cap, n_bow, fv_node, fv_off,
+                       fv_idx, fv_cap, n_fv, word_of, node_of, weight_of);
 }
 
 }  // extern "C"

@@ -1,0 +1,118 @@
+// vsg_ctx.hip -- per-(host thread, device) streams and staging arenas (see vsg_ctx.h).
+#include "vsg_ctx.h"
+
+#include <mutex>
+#include <vector>
+
+#include "../../include/vsg_orb.h"
+
+namespace vsg {
+
+namespace {
+struct ThreadCtxSet {
+  std::vector<ThreadCtx *> by_device;  // index = device ordinal
+};
+thread_local ThreadCtxSet t_ctx;
+
+std::mutex g_lds_mutex;
+size_t g_lds_limit[8][kMaxDevices];  // zero-initialised: "64 KB default" is applied on read
+}  // namespace
+
+ThreadCtx *thread_ctx(int device, int *rc) {
+  if (rc) *rc = VSG_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    if (rc) *rc = VSG_ERR_NO_DEVICE;
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    if (rc) *rc = VSG_ERR_NO_DEVICE;
+    return nullptr;
+  }
+  if ((size_t)device < t_ctx.by_device.size() && t_ctx.by_device[device]) return t_ctx.by_device[device];
+  ThreadCtx *c = new ThreadCtx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    if (rc) *rc = VSG_ERR_HIP;
+    return nullptr;
+  }
+  if (t_ctx.by_device.size() <= (size_t)device) t_ctx.by_device.resize(device + 1, nullptr);
+  t_ctx.by_device[device] = c;
+  return c;
+}
+
+int ctx_reserve(ThreadCtx *c, size_t pinned_bytes, size_t device_bytes) {
+  if (!c) return VSG_ERR_INVALID;
+  if (pinned_bytes > c->pin_cap) {
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return VSG_ERR_HIP;
+    if (c->h_pin) hipHostFree(c->h_pin);
+    c->h_pin = c->d_pin = nullptr;
+    c->pin_cap = 0;
+    size_t cap = pinned_bytes + pinned_bytes / 2;
+    cap = (cap + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);
+    void *p = nullptr, *dp = nullptr;
+    // coherent (fine-grained) mapped host memory: kernel writes are visible to the host after the stream sync
+    if (hipHostMalloc(&p, cap, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return VSG_ERR_HIP;
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) {
+      hipHostFree(p);
+      return VSG_ERR_HIP;
+    }
+    c->h_pin = (uint8_t *)p;
+    c->d_pin = (uint8_t *)dp;
+    c->pin_cap = cap;
+    c->n_grow++;
+  }
+  if (device_bytes > c->dev_cap) {
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return VSG_ERR_HIP;
+    if (c->d_buf) hipFree(c->d_buf);
+    c->d_buf = nullptr;
+    c->dev_cap = 0;
+    size_t cap = device_bytes + device_bytes / 2;
+    cap = (cap + (1u << 16) - 1) & ~(size_t)((1u << 16) - 1);
+    void *p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) return VSG_ERR_HIP;
+    c->d_buf = (uint8_t *)p;
+    c->dev_cap = cap;
+    c->n_grow++;
+  }
+  return VSG_OK;
+}
+
+bool lds_limit_ensure(int slot, int device, const void *func, size_t bytes) {
+  if (bytes <= 64 * 1024) return true;
+  if (slot < 0 || slot >= 8 || device < 0 || device >= kMaxDevices) return false;
+  std::lock_guard<std::mutex> lk(g_lds_mutex);
+  if (bytes <= g_lds_limit[slot][device]) return true;
+  if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  g_lds_limit[slot][device] = bytes;
+  return true;
+}
+
+}  // namespace vsg
+
+extern "C" {
+
+int vsg_thread_release(void) {
+  using namespace vsg;
+  for (ThreadCtx *&c : t_ctx.by_device) {
+    if (!c) continue;
+    if (hipSetDevice(c->device) == hipSuccess) {
+      hipStreamSynchronize(c->stream);
+      if (c->h_pin) hipHostFree(c->h_pin);
+      if (c->d_buf) hipFree(c->d_buf);
+      hipStreamDestroy(c->stream);
+    }
+    delete c;
+    c = nullptr;
+  }
+  return VSG_OK;
+}
+
+int vsg_thread_arena_growths(int device) {
+  using namespace vsg;
+  if (device < 0 || (size_t)device >= t_ctx.by_device.size() || !t_ctx.by_device[device]) return 0;
+  return (int)t_ctx.by_device[device]->n_grow;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// vsg_frame_int.h -- internal layout of a device-resident Frame / KeyFrame feature set (include/vsg_orb.h: vsg_frame)
+// and the window-search launcher shared by vsg_frame.hip, vsg_match.hip, vsg_bow.hip and vsg_orb.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/vsg_orb.h"
+#include "vsg_common.h"
+#include "vsg_ctx.h"
+#include "vsg_walks.h"
+
+enum { kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows };  // FRAME_GRID_COLS / ROWS (Frame.h:49-50)
+
+// What the searches read of one Frame (Frame.h:280-290) or KeyFrame, resident on the device.
+struct vsg_frame {
+  int device = 0, capacity = 0;
+  int n = 0, nleft = -1;  // N, Nleft (right-camera features are [nleft, n))
+  bool has_uright = false;
+  float minX = 0, minY = 0, maxX = 0, maxY = 0, invW = 0, invH = 0;  // mnMinX.., mfGridElementWidthInv / HeightInv
+  uint8_t *d_block = nullptr;  // one allocation behind all of the pointers below
+  vsg::KeyPointPOD *d_kps = nullptr;
+  uint8_t *d_desc = nullptr;
+  float *d_uright = nullptr;
+  int *d_cell_start[2] = {nullptr, nullptr};  // [0] mGrid, [1] mGridRight: CSR over cells ix * 48 + iy
+  int *d_entries[2] = {nullptr, nullptr};
+  std::vector<vsg_keypoint> h_kps;  // host mirror (angle / octave for the ordered host passes)
+};
+
+namespace vsg {
+
+// device view of a frame, passed to kernels by value
+struct FrameDev {
+  const KeyPointPOD *kps;
+  const uint8_t *desc;
+  const float *uright;  // nullptr: every mvuRight is -1
+  const int *cell_start[2];
+  const int *entries[2];
+  int n, nleft;
+  float minX, minY, invW, invH;
+};
+FrameDev frame_dev(const vsg_frame *f);
+
+// One GetFeaturesInArea window + the static candidate filters of a search routine.
+struct WinQuery {
+  float x, y, r;    // Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel, bRight)   (Frame.cc:802-868)
+  int minL, maxL;   //   (-1, -1 = KeyFrame::GetFeaturesInArea, KeyFrame.cc:834-874)
+  int lo, hi;       // kpLevel < lo || kpLevel > hi -> skip (hi < 0: no such filter)       e.g. ORBmatcher.cc:506-509
+  float ur, gate;   // projected right coordinate + threshold of the stereo gates           e.g. ORBmatcher.cc:97-102
+  int flags;        // bit 0: bRight (mGridRight, indices + Nleft); bit 1: inactive query (empty list)
+  int pad0, pad1;
+};
+static_assert(sizeof(WinQuery) == 48, "WinQuery layout");
+
+enum { kWinList = 0, kWinBest = 1 };
+enum { kGateNone = 0, kGateUr = 1, kGateChi2 = 2 };
+
+// One window-search call on the calling thread's stream: begin() lays the pinned arena out and returns host pointers
+// for the caller to fill (queries, descriptors); launch() enqueues the kernel; finish() syncs and, for lists that
+// overflowed their stride, re-runs with a larger one.
+struct WindowCall {
+  ThreadCtx *c = nullptr;
+  int nq = 0, mode = kWinList, stride = 0;
+  size_t oQ = 0, oD = 0, oCnt = 0, oOut = 0;
+  bool with_desc = true;
+  // launch parameters remembered for the overflow re-run
+  const vsg_frame *frame = nullptr;
+  int gate_mode = kGateNone, best_init = 256;
+  float inv_sigma2[16] = {};
+  size_t base = 0;  // offset of this call's blocks inside the arena (several calls can share one arena)
+
+  int begin(int device, int nq, int mode, bool with_desc, size_t arena_base = 0, size_t arena_extra = 0);
+  WinQuery *queries() const { return (WinQuery *)(c->h_pin + base + oQ); }
+  uint8_t *desc() const { return c->h_pin + base + oD; }
+  int launch(const vsg_frame *f, int gate_mode, int best_init, const float *inv_sigma2, int nlevels,
+             const uint8_t *qdesc_dev = nullptr);  // qdesc_dev: query descriptors already on the device
+  int finish();  // hipStreamSynchronize + overflow handling
+  size_t bytes() const;
+  walk::CandView lists() const;
+  const int32_t *best() const { return (const int32_t *)(c->h_pin + base + oOut); }  // pairs {idx, dist}
+};
+
+// view of the handle's outputs of the last extract call (vsg_orb.hip)
+struct OrbOutputView {
+  const KeyPointPOD *d_kps = nullptr;  // frame `index`
+  const uint8_t *d_desc = nullptr;
+  const int *d_counts = nullptr;       // {n, monoIndex}
+  hipEvent_t done = nullptr;           // recorded after the last kernel of that call
+  int device = 0;
+};
+
+}  // namespace vsg
+
+int vsg_orb_output_view(vsg_orb *h, int index, vsg::OrbOutputView *v);

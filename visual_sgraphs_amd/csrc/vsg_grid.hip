@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/vsg_orb.h"
+#include "vsg_ctx.h"
 #include "vsg_math.h"
 
 namespace {
@@ -145,8 +146,12 @@ int vsg_grid_build(int device, const vsg_keypoint *kps, int n, float min_x, floa
   cell_start[kCells] = run;
   for (int i = 0; i < n; i++)
     if (cell_of[i] >= 0) entries[cnt[cell_of[i]]++] = i;  // insertion order == ascending keypoint index
-  hipError_t e = hipMalloc(&g->d_block, stage.size());
-  if (e == hipSuccess) e = hipMemcpy(g->d_block, stage.data(), stage.size(), hipMemcpyHostToDevice);
+  // a grid is an object with a lifetime (like the Frame it indexes): one allocation at build, none per query
+  int crc = VSG_OK;
+  vsg::ThreadCtx *c = vsg::thread_ctx(device, &crc);
+  hipError_t e = c ? hipMalloc(&g->d_block, stage.size()) : hipErrorInvalidDevice;
+  if (e == hipSuccess) e = hipMemcpyAsync(g->d_block, stage.data(), stage.size(), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   if (e != hipSuccess) {
     vsg_grid_destroy(g);
     return VSG_ERR_HIP;
@@ -161,42 +166,40 @@ int vsg_grid_build(int device, const vsg_keypoint *kps, int n, float min_x, floa
 int vsg_grid_query(vsg_grid *g, const float *x, const float *y, const float *r, const int32_t *min_level,
                    const int32_t *max_level, int nq, int32_t *cand_off, int32_t *cand_idx, int cap) {
   if (!g || !x || !y || !r || !cand_off || nq < 0 || cap < 0) return VSG_ERR_INVALID;
-  G_TRY(hipSetDevice(g->device));
+  int rc = VSG_OK;
+  vsg::ThreadCtx *c = vsg::thread_ctx(g->device, &rc);
+  if (!c) return rc;
   cand_off[0] = 0;
   if (nq == 0) return 0;
-  // one block up (x | y | r | minLevel | maxLevel), count -> offsets -> fill on the device without a host round
-  // trip in between, offsets and indices down
+  // queries up through the calling thread's pinned arena (read once by the kernels, straight over PCIe); count ->
+  // offsets -> fill on the device without a host round trip in between; offsets and indices come back the same way
   const size_t Q = (size_t)nq;
-  std::vector<uint8_t> stage(Q * 20);
-  memcpy(stage.data(), x, Q * 4);
-  memcpy(stage.data() + Q * 4, y, Q * 4);
-  memcpy(stage.data() + Q * 8, r, Q * 4);
-  if (min_level) memcpy(stage.data() + Q * 12, min_level, Q * 4);
-  if (max_level) memcpy(stage.data() + Q * 16, max_level, Q * 4);
-  const size_t oCnt = Q * 20, oOff = oCnt + Q * 4, oIdx = oOff + (Q + 1) * 4, total_bytes = oIdx + (size_t)cap * 4 + 4;
-  uint8_t *d = nullptr;
-  G_TRY(hipMalloc(&d, total_bytes));
-  int total = VSG_ERR_HIP;
-  hipError_t e = hipMemcpy(d, stage.data(), stage.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    const float *dx = (const float *)d, *dy = dx + Q, *dr = dy + Q;
-    const int *dlo = min_level ? (const int *)(d + Q * 12) : nullptr, *dhi = max_level ? (const int *)(d + Q * 16) : nullptr;
-    int *dcnt = (int *)(d + oCnt), *doff = (int *)(d + oOff), *didx = (int *)(d + oIdx);
-    hipLaunchKernelGGL(k_grid_query, dim3((nq + 63) / 64), dim3(64), 0, 0, g->d_kps, g->d_cell_start, g->d_entries,
-                       g->P, dx, dy, dr, dlo, dhi, nq, dcnt, (const int *)nullptr, (int *)nullptr, 0);
-    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(256), 0, 0, dcnt, nq, doff);
-    if (cand_idx && cap > 0)
-      hipLaunchKernelGGL(k_grid_query, dim3((nq + 63) / 64), dim3(64), 0, 0, g->d_kps, g->d_cell_start, g->d_entries,
-                         g->P, dx, dy, dr, dlo, dhi, nq, (int *)nullptr, doff, didx, cap);
-    e = hipMemcpy(cand_off, doff, (Q + 1) * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) {
-      total = cand_off[nq];
-      const int nw = total < cap ? total : cap;
-      if (cand_idx && nw > 0) e = hipMemcpy(cand_idx, didx, (size_t)nw * 4, hipMemcpyDeviceToHost);
-      if (e != hipSuccess) total = VSG_ERR_HIP;
-    }
-  }
-  hipFree(d);
+  vsg::Stage st;
+  const size_t oX = st.add(Q * 4), oY = st.add(Q * 4), oR = st.add(Q * 4), oLo = st.add(Q * 4), oHi = st.add(Q * 4),
+               oOff = st.add((Q + 1) * 4), oIdx = st.add((size_t)cap * 4 + 4);
+  rc = vsg::ctx_reserve(c, st.total, Q * 4 + 64);
+  if (rc != VSG_OK) return rc;
+  uint8_t *h = c->h_pin, *d = c->d_pin;
+  memcpy(h + oX, x, Q * 4);
+  memcpy(h + oY, y, Q * 4);
+  memcpy(h + oR, r, Q * 4);
+  if (min_level) memcpy(h + oLo, min_level, Q * 4);
+  if (max_level) memcpy(h + oHi, max_level, Q * 4);
+  const float *dx = (const float *)(d + oX), *dy = (const float *)(d + oY), *dr = (const float *)(d + oR);
+  const int *dlo = min_level ? (const int *)(d + oLo) : nullptr, *dhi = max_level ? (const int *)(d + oHi) : nullptr;
+  int *dcnt = (int *)c->d_buf, *doff = (int *)(d + oOff), *didx = (int *)(d + oIdx);
+  hipLaunchKernelGGL(k_grid_query, dim3((nq + 63) / 64), dim3(64), 0, c->stream, g->d_kps, g->d_cell_start, g->d_entries,
+                     g->P, dx, dy, dr, dlo, dhi, nq, dcnt, (const int *)nullptr, (int *)nullptr, 0);
+  hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(256), 0, c->stream, dcnt, nq, doff);
+  if (cand_idx && cap > 0)
+    hipLaunchKernelGGL(k_grid_query, dim3((nq + 63) / 64), dim3(64), 0, c->stream, g->d_kps, g->d_cell_start,
+                       g->d_entries, g->P, dx, dy, dr, dlo, dhi, nq, (int *)nullptr, doff, didx, cap);
+  G_TRY(hipGetLastError());
+  G_TRY(hipStreamSynchronize(c->stream));
+  memcpy(cand_off, h + oOff, (Q + 1) * 4);
+  const int total = cand_off[nq];
+  const int nw = total < cap ? total : cap;
+  if (cand_idx && nw > 0) memcpy(cand_idx, h + oIdx, (size_t)nw * 4);
   return total;
 }
 

@@ -12,6 +12,8 @@ void launch_stereo(hipStream_t s, const PyrView &pl, const PyrView &pr, float mb
 void launch_cvt_gray(hipStream_t s, const uint8_t *src, size_t sframe, int spitch, int channels, int rgb_order, int rows,
                      int cols, uint8_t *dst, size_t dframe, int dpitch, const int coeffs[3], int shift, int nframes);
 void launch_zero(hipStream_t s, int *p, int n);
+void launch_export(hipStream_t s, const KeyPointPOD *kps, const uint8_t *desc, const int *counts, int src_cap,
+                   void *h_kps, void *h_desc, int *h_counts, int dst_cap, int nframes);
 void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
                    const FrameGeom &fg, int level, int nframes);
 void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tile_tab, const Src0 &s0,

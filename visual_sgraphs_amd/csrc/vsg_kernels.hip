@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "vsg_common.h"
+#include "vsg_ctx.h"
 #include "vsg_geometry.h"
 #include "vsg_math.h"
 #include "vsg_octree_core.h"
@@ -1273,6 +1274,34 @@ void launch_cvt_gray(hipStream_t s, const uint8_t *src, size_t sframe, int spitc
                      rows, cols, dst, dframe, dpitch, coeffs[0], coeffs[1], coeffs[2], shift);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Output export of the host API (vsg_orb_submit_batch / vsg_orb_wait): frame f's n keypoint records and descriptors
+// go from the device outputs ([f][src_cap]) to PINNED HOST memory ([f][dst_cap]; the slot's staging or the caller's
+// own registered arrays) as coalesced dword stores over PCIe -- n rows per frame, not the capacity, and no DMA
+// descriptor per frame.  counts ({n, monoIndex} per frame) go along.
+__global__ __launch_bounds__(256) void k_export_outputs(const KeyPointPOD *__restrict__ kps, const uint8_t *__restrict__ desc,
+                                                        const int *__restrict__ counts, int src_cap,
+                                                        uint32_t *__restrict__ h_kps, uint32_t *__restrict__ h_desc,
+                                                        int *__restrict__ h_counts, int dst_cap) {
+  const int f = blockIdx.y;
+  int n = counts[2 * f];
+  if (blockIdx.x == 0 && threadIdx.x < 2) h_counts[2 * f + threadIdx.x] = counts[2 * f + threadIdx.x];
+  if (n > dst_cap) n = dst_cap;  // the host reports VSG_ERR_CAPACITY from the count
+  const uint32_t *sk = (const uint32_t *)(kps + (size_t)f * src_cap);
+  const uint32_t *sd = (const uint32_t *)(desc + (size_t)f * src_cap * 32);
+  uint32_t *dk = h_kps + (size_t)f * dst_cap * 7, *dd = h_desc + (size_t)f * dst_cap * 8;
+  const int nk = n * 7, nd = n * 8, stride = gridDim.x * 256;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nd; i += stride) {
+    dd[i] = sd[i];
+    if (i < nk) dk[i] = sk[i];
+  }
+}
+void launch_export(hipStream_t s, const KeyPointPOD *kps, const uint8_t *desc, const int *counts, int src_cap,
+                   void *h_kps, void *h_desc, int *h_counts, int dst_cap, int nframes) {
+  hipLaunchKernelGGL(k_export_outputs, dim3(4, nframes), dim3(256), 0, s, kps, desc, counts, src_cap, (uint32_t *)h_kps,
+                     (uint32_t *)h_desc, h_counts, dst_cap);
+}
+
 // per-call reset of the candidate / selection counters (a kernel rather than hipMemsetAsync so that it is
 // ordered like every other stage on the stream and the stage-timing events bracket real work)
 __global__ void k_zero(int *p, int n) {
@@ -1295,10 +1324,10 @@ void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sh
                     const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes) {
   const int a16 = (ldsA + 15) & ~15, ab16 = a16 + ((ldsB + 15) & ~15);
   const size_t lds = ab16 + tabMax * sizeof(Short4);
-  static size_t lds_limit = 64 * 1024;
-  if (lds > lds_limit &&
-      hipFuncSetAttribute((const void *)k_pyramid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-    lds_limit = lds;
+  // the raised limit is a per-DEVICE attribute of the function (vsg_ctx.h lds_limit_ensure)
+  int dev = 0;
+  hipGetDevice(&dev);
+  lds_limit_ensure(0, dev, (const void *)k_pyramid, lds);
   hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(kPyrThreads), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
                      d_tile_tab, s0, d_tiles, a16, ab16);
 }
@@ -1329,11 +1358,9 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   const size_t lds = octree::work_bytes(cap);
   // beyond 64 KB of dynamic LDS the launch needs the limit raised (quotas above ~1000 per level, e.g. a single
   // level holding every feature); gfx950 has 160 KB per workgroup
-  static size_t lds_limit = 64 * 1024;
-  if (lds > lds_limit) {
-    if (hipFuncSetAttribute((const void *)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-      lds_limit = lds;
-  }
+  int dev = 0;
+  hipGetDevice(&dev);
+  lds_limit_ensure(1, dev, (const void *)k_octree, lds);
   dim3 grid(fg.nlevels, nframes), block(kOctThreads);
   hipLaunchKernelGGL(k_octree, grid, block, lds, s, d_fg, cand, cand_count, node_of, sel, sel_count, cap);
 }

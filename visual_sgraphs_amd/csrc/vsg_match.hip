@@ -16,8 +16,13 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+
 #include "../../include/vsg_orb.h"
+#include "vsg_ctx.h"
+#include "vsg_frame_int.h"
 #include "vsg_math.h"
+#include "vsg_walks.h"
 
 namespace {
 
@@ -387,19 +392,22 @@ __global__ __launch_bounds__(256) void k_search_triangulation(const NodePair *pa
   }
 }
 
-// ---- windowed searches (SearchByProjection x5, SearchForInitialization, SearchBySim3, Fuse): every candidate
-// entry's Hamming distance in ONE data-parallel pass, dist[c] = |q_desc[q_of[c]] ^ t_desc[cand_idx[c]]|.  The walk over
-// the queries that follows is inherently sequential (a claimed feature blocks later queries) and touches a dozen
-// candidates per query: it runs on the host over these distances (below), like the reference's own loop -- the first
-// version walked the queries with a single wavefront on the device and took 1.3 ms for 1000 queries, 25x the CPU.
+// ---- windowed searches on HOST candidate lists (the caller ran GetFeaturesInArea itself): every candidate entry's
+// Hamming distance in ONE data-parallel pass, written as the packed entry the ordered host passes read
+// (vsg_walks.h: index | distance << 15 | octave << 24).  The walk over the queries that follows is inherently
+// sequential (a claimed feature blocks later queries) and touches a dozen candidates per query: it runs on the host
+// over these entries, like the reference's own loop -- the first version walked the queries with a single wavefront
+// on the device and took 1.3 ms for 1000 queries, 25x the CPU.  (Resident frames: k_window_search, vsg_frame.hip.)
 __global__ __launch_bounds__(256) void k_cand_dist(const uint8_t *qDesc, const int *qOf, const int *candIdx,
-                                                   const uint8_t *tDesc, int ncand, uint16_t *dist) {
+                                                   const uint8_t *tDesc, const uint8_t *tOct, int ncand,
+                                                   uint32_t *ent) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncand) return;
   uint4 a0, a1, b0, b1;
+  const int i = candIdx[c];
   load_desc(qDesc, qOf[c], a0, a1);
-  load_desc(tDesc, candIdx[c], b0, b1);
-  dist[c] = (uint16_t)hamming256(a0, a1, b0, b1);
+  load_desc(tDesc, i, b0, b1);
+  ent[c] = (uint32_t)i | ((uint32_t)hamming256(a0, a1, b0, b1) << 15) | ((uint32_t)(tOct ? tOct[i] & 15 : 0) << 24);
 }
 
 // ---- MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:380-415): one workgroup per map point.  The N x N
@@ -450,24 +458,9 @@ __global__ __launch_bounds__(128) void k_distinctive(const uint8_t *desc, const 
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-thread_local std::string g_merr;
-
-struct DevBuf {  // tiny RAII wrapper: device allocation + optional upload
-  void *p = nullptr;
-  ~DevBuf() {
-    if (p) hipFree(p);
-  }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4); }
-  hipError_t upload(const void *src, size_t bytes) {
-    hipError_t e = alloc(bytes);
-    if (e != hipSuccess || !bytes) return e;
-    return hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
-  }
-  template <class T>
-  T *as() {
-    return (T *)p;
-  }
-};
+// Every entry point runs on the calling thread's stream and stages through its arenas (vsg_ctx.h): inputs are laid
+// out in the pinned arena and go up in ONE DMA into the device arena (they are read many times by the kernels),
+// results come back through the pinned arena.  No allocation, no NULL-stream launch in steady state.
 
 #define M_TRY(expr)                      \
   do {                                   \
@@ -475,43 +468,14 @@ struct DevBuf {  // tiny RAII wrapper: device allocation + optional upload
     if (_e != hipSuccess) return VSG_ERR_HIP; \
   } while (0)
 
+using vsg::ThreadCtx;
+using vsg::Stage;
+namespace walk = vsg::walk;
+
 int use_device(int device) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return VSG_ERR_NO_DEVICE;
   return hipSetDevice(device) == hipSuccess ? VSG_OK : VSG_ERR_NO_DEVICE;
-}
-
-// rotation-consistency bin (e.g. ORBmatcher.cc:351-356)
-inline int rot_bin(float angle1, float angle2) {
-  const float factor = 1.0f / HISTO_LENGTH;
-  float rot = angle1 - angle2;
-  if (rot < 0.0) rot += 360.0f;
-  int bin = (int)std::round(rot * factor);
-  if (bin == HISTO_LENGTH) bin = 0;
-  return bin;
-}
-
-// ORBmatcher::ComputeThreeMaxima (ORBmatcher.cc:2002-2043)
-void three_maxima(const std::vector<int> *histo, int L, int &ind1, int &ind2, int &ind3) {
-  int max1 = 0, max2 = 0, max3 = 0;
-  for (int i = 0; i < L; i++) {
-    const int s = (int)histo[i].size();
-    if (s > max1) {
-      max3 = max2, max2 = max1, max1 = s;
-      ind3 = ind2, ind2 = ind1, ind1 = i;
-    } else if (s > max2) {
-      max3 = max2, max2 = s;
-      ind3 = ind2, ind2 = i;
-    } else if (s > max3) {
-      max3 = s, ind3 = i;
-    }
-  }
-  if (max2 < 0.1f * (float)max1) {
-    ind2 = -1;
-    ind3 = -1;
-  } else if (max3 < 0.1f * (float)max1) {
-    ind3 = -1;
-  }
 }
 
 // merge-join of two FeatureVectors (ORBmatcher.cc:247-405 loop skeleton incl. lower_bound jumps)
@@ -530,46 +494,128 @@ void join_nodes(const int *idA, const int *offA, int nA, const int *idB, const i
   }
 }
 
-// Distances of all candidate entries (device) for the windowed searches.  One staging buffer up, one array down.
-static int candidate_distances(int device, const uint8_t *q_desc, int n_q, const int32_t *cand_off,
-                               const int32_t *cand_idx, const uint8_t *t_desc, int n_t, std::vector<uint16_t> &dist) {
-  int rc = use_device(device);
-  if (rc != VSG_OK) return rc;
+// Packed candidate entries (vsg_walks.h) for host-provided CSR candidate lists.  On return *ent points into the
+// calling thread's pinned arena (valid until its next call).
+static int candidate_entries(int device, const uint8_t *q_desc, int n_q, const int32_t *cand_off,
+                             const int32_t *cand_idx, const uint8_t *t_desc, const int32_t *t_octave, int n_t,
+                             const uint32_t **ent) {
+  int rc = VSG_OK;
+  ThreadCtx *c = vsg::thread_ctx(device, &rc);
+  if (!c) return rc;
   const int ncand = cand_off[n_q];
-  dist.assign((size_t)ncand, 0);
+  *ent = nullptr;
   if (ncand == 0) return VSG_OK;
-  for (int c = 0; c < ncand; c++)
-    if (cand_idx[c] < 0 || cand_idx[c] >= n_t) return VSG_ERR_INVALID;
-  // [q_desc | t_desc | q_of | cand_idx] in one host block -> one H2D copy
-  const size_t oQ = 0, oT = oQ + (size_t)n_q * 32, oOf = oT + (size_t)n_t * 32, oIdx = oOf + (size_t)ncand * 4,
-               total = oIdx + (size_t)ncand * 4;
-  std::vector<uint8_t> stage(total);
-  memcpy(stage.data() + oQ, q_desc, (size_t)n_q * 32);
-  memcpy(stage.data() + oT, t_desc, (size_t)n_t * 32);
-  int32_t *qof = (int32_t *)(stage.data() + oOf);
+  if (n_t > 32767) return VSG_ERR_UNSUPPORTED;
+  for (int k = 0; k < ncand; k++)
+    if (cand_idx[k] < 0 || cand_idx[k] >= n_t) return VSG_ERR_INVALID;
+  Stage st;
+  const size_t oQ = st.add((size_t)n_q * 32), oT = st.add((size_t)n_t * 32), oOct = st.add(t_octave ? (size_t)n_t : 0),
+               oOf = st.add((size_t)ncand * 4), oIdx = st.add((size_t)ncand * 4);
+  const size_t in_bytes = st.total;
+  const size_t oEnt = st.add((size_t)ncand * 4);
+  rc = vsg::ctx_reserve(c, st.total, in_bytes);
+  if (rc != VSG_OK) return rc;
+  uint8_t *h = c->h_pin;
+  memcpy(h + oQ, q_desc, (size_t)n_q * 32);
+  memcpy(h + oT, t_desc, (size_t)n_t * 32);
+  if (t_octave)
+    for (int i = 0; i < n_t; i++) h[oOct + i] = (uint8_t)t_octave[i];
+  int32_t *qof = (int32_t *)(h + oOf);
   for (int q = 0; q < n_q; q++)
-    for (int c = cand_off[q]; c < cand_off[q + 1]; c++) qof[c] = q;
-  memcpy(stage.data() + oIdx, cand_idx, (size_t)ncand * 4);
-  DevBuf dIn, dDist;
-  M_TRY(dIn.upload(stage.data(), total));
-  M_TRY(dDist.alloc((size_t)ncand * 2));
-  const uint8_t *base = dIn.as<uint8_t>();
-  hipLaunchKernelGGL(k_cand_dist, dim3((ncand + 255) / 256), dim3(256), 0, 0, base + oQ, (const int *)(base + oOf),
-                     (const int *)(base + oIdx), base + oT, ncand, dDist.as<uint16_t>());
+    for (int k = cand_off[q]; k < cand_off[q + 1]; k++) qof[k] = q;
+  memcpy(h + oIdx, cand_idx, (size_t)ncand * 4);
+  M_TRY(hipMemcpyAsync(c->d_buf, h, in_bytes, hipMemcpyHostToDevice, c->stream));
+  const uint8_t *d = c->d_buf;
+  hipLaunchKernelGGL(k_cand_dist, dim3((ncand + 255) / 256), dim3(256), 0, c->stream, d + oQ, (const int *)(d + oOf),
+                     (const int *)(d + oIdx), d + oT, t_octave ? d + oOct : (const uint8_t *)nullptr, ncand,
+                     (uint32_t *)(c->d_pin + oEnt));
   M_TRY(hipGetLastError());
-  M_TRY(hipMemcpy(dist.data(), dDist.p, (size_t)ncand * 2, hipMemcpyDeviceToHost));
+  M_TRY(hipStreamSynchronize(c->stream));
+  *ent = (const uint32_t *)(h + oEnt);
   return VSG_OK;
 }
 
-// rotation-histogram filter shared by the searches: entries of the losing bins are handed to `drop`
-template <class Drop>
-static void filter_rotation(std::vector<int> (&rotHist)[HISTO_LENGTH], Drop drop) {
-  int ind1 = -1, ind2 = -1, ind3 = -1;
-  three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-  for (int i = 0; i < HISTO_LENGTH; i++) {
-    if (i == ind1 || i == ind2 || i == ind3) continue;
-    for (size_t j = 0; j < rotHist[i].size(); j++) drop(rotHist[i][j]);
+static walk::CandView csr_view(const uint32_t *ent, const int32_t *cand_off) {
+  walk::CandView cv;
+  cv.ent = ent;
+  cv.off = cand_off;
+  return cv;
+}
+
+// rotation-consistency filter of the BoW / triangulation searches: every match sits in exactly one bin
+template <class AngleA, class AngleB>
+static int bow_rotation_filter(int *out, int nOut, int mode, AngleA angleA, AngleB angleB, bool checkOri) {
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < nOut; i++) {
+    if (out[i] < 0) continue;
+    nmatches++;
+    if (checkOri) {
+      const int bin = mode == 0 ? walk::rot_bin(angleA(out[i]), angleB(i)) : walk::rot_bin(angleA(i), angleB(out[i]));
+      rotHist[bin].push_back(i);
+    }
   }
+  if (checkOri)
+    walk::filter_rotation(rotHist, [&](int i) {
+      out[i] = -1;
+      nmatches--;
+    });
+  return nmatches;
+}
+
+// SearchByBoW on descriptors that are either host arrays (descA/descB, staged) or already on the device (dDescA/dDescB)
+template <class AngleA, class AngleB>
+static int search_by_bow(int device, int mode, int nleftB, const uint8_t *descA, const uint8_t *dDescA, AngleA angleA,
+                         const uint8_t *validA, int nA, const int *idA, const int *offA, const int *idxA, int nodesA,
+                         const uint8_t *descB, const uint8_t *dDescB, AngleB angleB, const uint8_t *validB, int nB,
+                         const int *idB, const int *offB, const int *idxB, int nodesB, float nnratio, int checkOri,
+                         int *out) {
+  int rc = VSG_OK;
+  ThreadCtx *c = vsg::thread_ctx(device, &rc);
+  if (!c) return rc;
+  const int nOut = mode == 0 ? nB : nA;
+  for (int i = 0; i < nOut; i++) out[i] = -1;
+  std::vector<NodePair> pairs;
+  join_nodes(idA, offA, nodesA, idB, offB, nodesB, pairs);
+  if (pairs.empty() || nA == 0 || nB == 0) return 0;
+  const int nIdxA = offA[nodesA], nIdxB = offB[nodesB], npairs = (int)pairs.size();
+  Stage st;
+  const size_t oP = st.add(pairs.size() * sizeof(NodePair)), oVA = st.add((size_t)nA), oIA = st.add((size_t)nIdxA * 4),
+               oVB = st.add(mode == 1 ? (size_t)nB : 0), oIB = st.add((size_t)nIdxB * 4),
+               oDA = st.add(dDescA ? 0 : (size_t)nA * 32), oDB = st.add(dDescB ? 0 : (size_t)nB * 32);
+  const size_t in_bytes = st.total;
+  Stage dv;  // device-only scratch behind the inputs
+  dv.total = in_bytes;
+  const size_t oMA = dv.add((size_t)nA * 4), oMB = dv.add((size_t)nB * 4);
+  rc = vsg::ctx_reserve(c, in_bytes + (size_t)nOut * 4 + 64, dv.total);
+  if (rc != VSG_OK) return rc;
+  uint8_t *h = c->h_pin;
+  memcpy(h + oP, pairs.data(), pairs.size() * sizeof(NodePair));
+  memcpy(h + oVA, validA, (size_t)nA);
+  memcpy(h + oIA, idxA, (size_t)nIdxA * 4);
+  if (mode == 1) memcpy(h + oVB, validB, (size_t)nB);
+  memcpy(h + oIB, idxB, (size_t)nIdxB * 4);
+  if (!dDescA) memcpy(h + oDA, descA, (size_t)nA * 32);
+  if (!dDescB) memcpy(h + oDB, descB, (size_t)nB * 32);
+  M_TRY(hipMemcpyAsync(c->d_buf, h, in_bytes, hipMemcpyHostToDevice, c->stream));
+  uint8_t *d = c->d_buf;
+  int *dMA = (int *)(d + oMA), *dMB = (int *)(d + oMB);
+  if (mode == 0) {
+    M_TRY(hipMemsetAsync(dMB, 0xFF, (size_t)nB * 4, c->stream));  // -1
+  } else {
+    M_TRY(hipMemsetAsync(dMA, 0xFF, (size_t)nA * 4, c->stream));
+    M_TRY(hipMemsetAsync(dMB, 0, (size_t)nB * 4, c->stream));
+  }
+  hipLaunchKernelGGL(k_search_by_bow, dim3((npairs + 3) / 4), dim3(256), 0, c->stream, (const NodePair *)(d + oP), npairs,
+                     dDescA ? dDescA : d + oDA, d + oVA, (const int *)(d + oIA), dDescB ? dDescB : d + oDB, d + oVB,
+                     (const int *)(d + oIB), nnratio, mode, nleftB, dMA, dMB);
+  M_TRY(hipGetLastError());
+  int *hOut = (int *)(h + in_bytes);
+  M_TRY(hipMemcpyAsync(hOut, mode == 0 ? dMB : dMA, (size_t)nOut * 4, hipMemcpyDeviceToHost, c->stream));
+  M_TRY(hipStreamSynchronize(c->stream));
+  memcpy(out, hOut, (size_t)nOut * 4);
+  // rotation consistency (:407-425 / :879-897)
+  return bow_rotation_filter(out, nOut, mode, angleA, angleB, checkOri != 0);
 }
 
 }  // namespace
@@ -578,19 +624,30 @@ extern "C" {
 
 int vsg_hamming_pairs(int device, const uint8_t *a, int na, const uint8_t *b, int nb, const int32_t *ia,
                       const int32_t *ib, int npairs, int32_t *dist) {
-  if (!a || !b || !ia || !ib || !dist || npairs < 0) return VSG_ERR_INVALID;
-  int rc = use_device(device);
-  if (rc != VSG_OK) return rc;
+  if (!a || !b || !ia || !ib || !dist || npairs < 0 || na < 0 || nb < 0) return VSG_ERR_INVALID;
+  int rc = VSG_OK;
+  ThreadCtx *c = vsg::thread_ctx(device, &rc);
+  if (!c) return rc;
   if (npairs == 0) return VSG_OK;
-  DevBuf da, db, dia, dib, dd;
-  M_TRY(da.upload(a, (size_t)na * 32));
-  M_TRY(db.upload(b, (size_t)nb * 32));
-  M_TRY(dia.upload(ia, (size_t)npairs * 4));
-  M_TRY(dib.upload(ib, (size_t)npairs * 4));
-  M_TRY(dd.alloc((size_t)npairs * 4));
-  hipLaunchKernelGGL(k_hamming_pairs, dim3((npairs + 255) / 256), dim3(256), 0, 0, da.as<uint8_t>(), db.as<uint8_t>(),
-                     dia.as<int>(), dib.as<int>(), npairs, dd.as<int>());
-  M_TRY(hipMemcpy(dist, dd.p, (size_t)npairs * 4, hipMemcpyDeviceToHost));
+  Stage st;
+  const size_t oA = st.add((size_t)na * 32), oB = st.add((size_t)nb * 32), oIA = st.add((size_t)npairs * 4),
+               oIB = st.add((size_t)npairs * 4);
+  const size_t in_bytes = st.total;
+  const size_t oD = st.add((size_t)npairs * 4);
+  rc = vsg::ctx_reserve(c, st.total, in_bytes);
+  if (rc != VSG_OK) return rc;
+  uint8_t *h = c->h_pin;
+  memcpy(h + oA, a, (size_t)na * 32);
+  memcpy(h + oB, b, (size_t)nb * 32);
+  memcpy(h + oIA, ia, (size_t)npairs * 4);
+  memcpy(h + oIB, ib, (size_t)npairs * 4);
+  M_TRY(hipMemcpyAsync(c->d_buf, h, in_bytes, hipMemcpyHostToDevice, c->stream));
+  const uint8_t *d = c->d_buf;
+  hipLaunchKernelGGL(k_hamming_pairs, dim3((npairs + 255) / 256), dim3(256), 0, c->stream, d + oA, d + oB,
+                     (const int *)(d + oIA), (const int *)(d + oIB), npairs, (int *)(c->d_pin + oD));
+  M_TRY(hipGetLastError());
+  M_TRY(hipStreamSynchronize(c->stream));
+  memcpy(dist, h + oD, (size_t)npairs * 4);
   return VSG_OK;
 }
 
@@ -602,6 +659,8 @@ int vsg_hamming_block_best2_device(int device, const uint8_t *d_a, const uint8_t
   int rc = use_device(device);
   if (rc != VSG_OK) return rc;
   dim3 grid((max_rows + kBest2Rows - 1) / kBest2Rows, nblocks);
+  // stream == NULL is the caller's NULL stream (see vsg_orb_extract_batch_device for how the extractor orders itself
+  // against it)
   if (match_on_valu())
     hipLaunchKernelGGL(k_block_best2, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes,
                        d_counts_a, d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
@@ -615,89 +674,35 @@ int vsg_hamming_block_best2_device(int device, const uint8_t *d_a, const uint8_t
 int vsg_hamming_block_best2(int device, const uint8_t *a, int na, const uint8_t *b, int nb, int32_t *best,
                             int32_t *second, int32_t *argbest) {
   if (!a || !b || !best || !second || !argbest || na < 0 || nb < 0) return VSG_ERR_INVALID;
-  int rc = use_device(device);
-  if (rc != VSG_OK) return rc;
+  int rc = VSG_OK;
+  ThreadCtx *c = vsg::thread_ctx(device, &rc);
+  if (!c) return rc;
   if (na == 0) return VSG_OK;
-  DevBuf da, db, d1, d2, d3;
-  M_TRY(da.upload(a, (size_t)na * 32));
-  M_TRY(db.upload(b, (size_t)nb * 32));
-  M_TRY(d1.alloc((size_t)na * 4));
-  M_TRY(d2.alloc((size_t)na * 4));
-  M_TRY(d3.alloc((size_t)na * 4));
-  if (match_on_valu())
-    hipLaunchKernelGGL(k_block_best2, dim3((na + kBest2Rows - 1) / kBest2Rows, 1), dim3(256), 0, 0, da.as<uint8_t>(),
-                       db.as<uint8_t>(), (size_t)0, (const int *)nullptr, (const int *)nullptr, 0, na, nb, na,
-                       d1.as<int>(), d2.as<int>(), d3.as<int>());
-  else
-    hipLaunchKernelGGL(k_block_best2_mfma, dim3((na + kBest2Rows - 1) / kBest2Rows, 1), dim3(256), 0, 0,
-                       da.as<uint8_t>(), db.as<uint8_t>(), (size_t)0, (const int *)nullptr, (const int *)nullptr, 0, na,
-                       nb, na, d1.as<int>(), d2.as<int>(), d3.as<int>());
-  M_TRY(hipMemcpy(best, d1.p, (size_t)na * 4, hipMemcpyDeviceToHost));
-  M_TRY(hipMemcpy(second, d2.p, (size_t)na * 4, hipMemcpyDeviceToHost));
-  M_TRY(hipMemcpy(argbest, d3.p, (size_t)na * 4, hipMemcpyDeviceToHost));
-  return VSG_OK;
-}
-
-static int search_by_bow(int device, int mode, int nleftB, const uint8_t *descA, const float *angleA, const uint8_t *validA, int nA,
-                         const int *idA, const int *offA, const int *idxA, int nodesA, const uint8_t *descB,
-                         const float *angleB, const uint8_t *validB, int nB, const int *idB, const int *offB,
-                         const int *idxB, int nodesB, float nnratio, int checkOri, int *out) {
-  int rc = use_device(device);
+  Stage st;
+  const size_t oA = st.add((size_t)na * 32), oB = st.add((size_t)(nb > 0 ? nb : 1) * 32);
+  const size_t in_bytes = st.total;
+  const size_t o1 = st.add((size_t)na * 4), o2 = st.add((size_t)na * 4), o3 = st.add((size_t)na * 4);
+  rc = vsg::ctx_reserve(c, st.total, in_bytes);
   if (rc != VSG_OK) return rc;
-  const int nOut = mode == 0 ? nB : nA;
-  for (int i = 0; i < nOut; i++) out[i] = -1;
-  std::vector<NodePair> pairs;
-  join_nodes(idA, offA, nodesA, idB, offB, nodesB, pairs);
-  if (pairs.empty() || nA == 0 || nB == 0) return 0;
-  const int nIdxA = offA[nodesA], nIdxB = offB[nodesB];
-  DevBuf dPairs, dDescA, dValidA, dIdxA, dDescB, dValidB, dIdxB, dMatchA, dMatchB;
-  M_TRY(dPairs.upload(pairs.data(), pairs.size() * sizeof(NodePair)));
-  M_TRY(dDescA.upload(descA, (size_t)nA * 32));
-  M_TRY(dValidA.upload(validA, (size_t)nA));
-  M_TRY(dIdxA.upload(idxA, (size_t)nIdxA * 4));
-  M_TRY(dDescB.upload(descB, (size_t)nB * 32));
-  M_TRY(dIdxB.upload(idxB, (size_t)nIdxB * 4));
-  if (mode == 0) {
-    M_TRY(dMatchB.alloc((size_t)nB * 4));
-    M_TRY(hipMemset(dMatchB.p, 0xFF, (size_t)nB * 4));  // -1
-    M_TRY(dValidB.alloc(4));
-    M_TRY(dMatchA.alloc(4));
-  } else {
-    M_TRY(dValidB.upload(validB, (size_t)nB));
-    M_TRY(dMatchA.alloc((size_t)nA * 4));
-    M_TRY(hipMemset(dMatchA.p, 0xFF, (size_t)nA * 4));
-    M_TRY(dMatchB.alloc((size_t)nB * 4));
-    M_TRY(hipMemset(dMatchB.p, 0, (size_t)nB * 4));
-  }
-  const int npairs = (int)pairs.size();
-  hipLaunchKernelGGL(k_search_by_bow, dim3((npairs + 3) / 4), dim3(256), 0, 0, dPairs.as<NodePair>(), npairs,
-                     dDescA.as<uint8_t>(), dValidA.as<uint8_t>(), dIdxA.as<int>(), dDescB.as<uint8_t>(),
-                     dValidB.as<uint8_t>(), dIdxB.as<int>(), nnratio, mode, nleftB, dMatchA.as<int>(),
-                     dMatchB.as<int>());
-  M_TRY(hipMemcpy(out, mode == 0 ? dMatchB.p : dMatchA.p, (size_t)nOut * 4, hipMemcpyDeviceToHost));
-  // rotation consistency (:407-425 / :879-897): every match sits in exactly one bin
-  int nmatches = 0;
-  std::vector<int> rotHist[HISTO_LENGTH];
-  for (int i = 0; i < nOut; i++) {
-    if (out[i] < 0) continue;
-    nmatches++;
-    if (checkOri) {
-      const int bin = mode == 0 ? rot_bin(angleA[out[i]], angleB[i]) : rot_bin(angleA[i], angleB[out[i]]);
-      rotHist[bin].push_back(i);
-    }
-  }
-  if (checkOri) {
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-    for (int i = 0; i < HISTO_LENGTH; i++) {
-      if (i == ind1 || i == ind2 || i == ind3) continue;
-      for (size_t j = 0; j < rotHist[i].size(); j++) {
-        out[rotHist[i][j]] = -1;
-        nmatches--;
-      }
-    }
-  }
-  return nmatches;
+  uint8_t *h = c->h_pin;
+  memcpy(h + oA, a, (size_t)na * 32);
+  if (nb) memcpy(h + oB, b, (size_t)nb * 32);
+  M_TRY(hipMemcpyAsync(c->d_buf, h, in_bytes, hipMemcpyHostToDevice, c->stream));
+  const uint8_t *d = c->d_buf;
+  int *d1 = (int *)(c->d_pin + o1), *d2 = (int *)(c->d_pin + o2), *d3 = (int *)(c->d_pin + o3);
+  const dim3 grid((na + kBest2Rows - 1) / kBest2Rows, 1);
+  if (match_on_valu())
+    hipLaunchKernelGGL(k_block_best2, grid, dim3(256), 0, c->stream, d + oA, d + oB, (size_t)0, (const int *)nullptr,
+                       (const int *)nullptr, 0, na, nb, na, d1, d2, d3);
+  else
+    hipLaunchKernelGGL(k_block_best2_mfma, grid, dim3(256), 0, c->stream, d + oA, d + oB, (size_t)0,
+                       (const int *)nullptr, (const int *)nullptr, 0, na, nb, na, d1, d2, d3);
+  M_TRY(hipGetLastError());
+  M_TRY(hipStreamSynchronize(c->stream));
+  memcpy(best, h + o1, (size_t)na * 4);
+  memcpy(second, h + o2, (size_t)na * 4);
+  memcpy(argbest, h + o3, (size_t)na * 4);
+  return VSG_OK;
 }
 
 int vsg_search_for_triangulation(int device, const uint8_t *desc1, const float *angle1, const uint8_t *eligible1,
@@ -707,53 +712,50 @@ int vsg_search_for_triangulation(int device, const uint8_t *desc1, const float *
                                  const uint32_t *pair_ok, const int32_t *pair_off, int check_orientation,
                                  int32_t *matches12) {
   if (!matches12 || n1 < 0 || n2 < 0 || (pair_ok && !pair_off)) return VSG_ERR_INVALID;
-  int rc = use_device(device);
-  if (rc != VSG_OK) return rc;
+  int rc = VSG_OK;
+  ThreadCtx *c = vsg::thread_ctx(device, &rc);
+  if (!c) return rc;
   for (int i = 0; i < n1; i++) matches12[i] = -1;
   std::vector<NodePair> pairs;
   join_nodes(node_id1, off1, nodes1, node_id2, off2, nodes2, pairs);
   if (pairs.empty() || n1 == 0 || n2 == 0) return 0;
   const int npairs = (int)pairs.size();
-  DevBuf dPairs, dD1, dE1, dI1, dD2, dE2, dI2, dOk, dOff, dM;
-  M_TRY(dPairs.upload(pairs.data(), pairs.size() * sizeof(NodePair)));
-  M_TRY(dD1.upload(desc1, (size_t)n1 * 32));
-  M_TRY(dE1.upload(eligible1, (size_t)n1));
-  M_TRY(dI1.upload(idx1, (size_t)off1[nodes1] * 4));
-  M_TRY(dD2.upload(desc2, (size_t)n2 * 32));
-  M_TRY(dE2.upload(eligible2, (size_t)n2));
-  M_TRY(dI2.upload(idx2, (size_t)off2[nodes2] * 4));
+  const int nI1 = off1[nodes1], nI2 = off2[nodes2];
+  // bits of shared node s start at pair_off[s]; the last node ends at pair_off[npairs]
+  const size_t ok_words = pair_ok ? (size_t)(((long long)pair_off[npairs] + 31) / 32 + 1) : 0;
+  Stage st;
+  const size_t oP = st.add(pairs.size() * sizeof(NodePair)), oD1 = st.add((size_t)n1 * 32), oE1 = st.add((size_t)n1),
+               oI1 = st.add((size_t)nI1 * 4), oD2 = st.add((size_t)n2 * 32), oE2 = st.add((size_t)n2),
+               oI2 = st.add((size_t)nI2 * 4), oOk = st.add(ok_words * 4), oOff = st.add(pair_ok ? (size_t)(npairs + 1) * 4 : 0);
+  const size_t in_bytes = st.total;
+  const size_t oM = st.add((size_t)n1 * 4);
+  rc = vsg::ctx_reserve(c, st.total, st.total);
+  if (rc != VSG_OK) return rc;
+  uint8_t *h = c->h_pin;
+  memcpy(h + oP, pairs.data(), pairs.size() * sizeof(NodePair));
+  memcpy(h + oD1, desc1, (size_t)n1 * 32);
+  memcpy(h + oE1, eligible1, (size_t)n1);
+  memcpy(h + oI1, idx1, (size_t)nI1 * 4);
+  memcpy(h + oD2, desc2, (size_t)n2 * 32);
+  memcpy(h + oE2, eligible2, (size_t)n2);
+  memcpy(h + oI2, idx2, (size_t)nI2 * 4);
   if (pair_ok) {
-    // bits of shared node s start at pair_off[s]; the last node ends at pair_off[npairs]
-    const long long nbits = pair_off[npairs];
-    M_TRY(dOk.upload(pair_ok, (size_t)((nbits + 31) / 32 + 1) * 4));
-    M_TRY(dOff.upload(pair_off, (size_t)(npairs + 1) * 4));
+    memcpy(h + oOk, pair_ok, ok_words * 4);
+    memcpy(h + oOff, pair_off, (size_t)(npairs + 1) * 4);
   }
-  M_TRY(dM.alloc((size_t)n1 * 4));
-  M_TRY(hipMemset(dM.p, 0xFF, (size_t)n1 * 4));
-  hipLaunchKernelGGL(k_search_triangulation, dim3((npairs + 3) / 4), dim3(256), 0, 0, dPairs.as<NodePair>(), npairs,
-                     dD1.as<uint8_t>(), dE1.as<uint8_t>(), dI1.as<int>(), dD2.as<uint8_t>(), dE2.as<uint8_t>(),
-                     dI2.as<int>(), pair_ok ? dOk.as<uint32_t>() : (const uint32_t *)nullptr,
-                     pair_ok ? dOff.as<int>() : (const int *)nullptr, dM.as<int>());
-  M_TRY(hipMemcpy(matches12, dM.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-  int nmatches = 0;
-  std::vector<int> rotHist[HISTO_LENGTH];
-  for (int i = 0; i < n1; i++) {
-    if (matches12[i] < 0) continue;
-    nmatches++;
-    if (check_orientation) rotHist[rot_bin(angle1[i], angle2[matches12[i]])].push_back(i);
-  }
-  if (check_orientation) {
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
-    for (int i = 0; i < HISTO_LENGTH; i++) {
-      if (i == ind1 || i == ind2 || i == ind3) continue;
-      for (size_t j = 0; j < rotHist[i].size(); j++) {
-        matches12[rotHist[i][j]] = -1;
-        nmatches--;
-      }
-    }
-  }
-  return nmatches;
+  M_TRY(hipMemcpyAsync(c->d_buf, h, in_bytes, hipMemcpyHostToDevice, c->stream));
+  uint8_t *d = c->d_buf;
+  M_TRY(hipMemsetAsync(d + oM, 0xFF, (size_t)n1 * 4, c->stream));
+  hipLaunchKernelGGL(k_search_triangulation, dim3((npairs + 3) / 4), dim3(256), 0, c->stream, (const NodePair *)(d + oP),
+                     npairs, d + oD1, d + oE1, (const int *)(d + oI1), d + oD2, d + oE2, (const int *)(d + oI2),
+                     pair_ok ? (const uint32_t *)(d + oOk) : (const uint32_t *)nullptr,
+                     pair_ok ? (const int *)(d + oOff) : (const int *)nullptr, (int *)(d + oM));
+  M_TRY(hipGetLastError());
+  M_TRY(hipMemcpyAsync(h + oM, d + oM, (size_t)n1 * 4, hipMemcpyDeviceToHost, c->stream));
+  M_TRY(hipStreamSynchronize(c->stream));
+  memcpy(matches12, h + oM, (size_t)n1 * 4);
+  return bow_rotation_filter(matches12, n1, 1, [&](int i) { return angle1[i]; }, [&](int i) { return angle2[i]; },
+                             check_orientation != 0);
 }
 
 int vsg_search_by_bow_kf_f(int device, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid,
@@ -761,9 +763,9 @@ int vsg_search_by_bow_kf_f(int device, const uint8_t *kf_desc, const float *kf_a
                            int kf_nodes, const uint8_t *f_desc, const float *f_angle, int n_f,
                            const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
                            float nnratio, int check_orientation, int32_t *match_f) {
-  if (!match_f || n_kf < 0 || n_f < 0) return VSG_ERR_INVALID;
-  return search_by_bow(device, 0, -1, kf_desc, kf_angle, kf_valid, n_kf, kf_node_id, kf_off, kf_idx, kf_nodes, f_desc,
-                       f_angle, nullptr, n_f, f_node_id, f_off, f_idx, f_nodes, nnratio, check_orientation, match_f);
+  return vsg_search_by_bow_kf_f_stereo(device, kf_desc, kf_angle, kf_valid, n_kf, kf_node_id, kf_off, kf_idx, kf_nodes,
+                                       f_desc, f_angle, n_f, -1, f_node_id, f_off, f_idx, f_nodes, nnratio,
+                                       check_orientation, match_f);
 }
 
 int vsg_search_by_bow_kf_f_stereo(int device, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid,
@@ -772,9 +774,9 @@ int vsg_search_by_bow_kf_f_stereo(int device, const uint8_t *kf_desc, const floa
                                   const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
                                   float nnratio, int check_orientation, int32_t *match_f) {
   if (!match_f || n_kf < 0 || n_f < 0 || f_nleft < -1 || f_nleft > n_f) return VSG_ERR_INVALID;
-  return search_by_bow(device, 0, f_nleft, kf_desc, kf_angle, kf_valid, n_kf, kf_node_id, kf_off, kf_idx, kf_nodes,
-                       f_desc, f_angle, nullptr, n_f, f_node_id, f_off, f_idx, f_nodes, nnratio, check_orientation,
-                       match_f);
+  return search_by_bow(device, 0, f_nleft, kf_desc, nullptr, [&](int i) { return kf_angle[i]; }, kf_valid, n_kf,
+                       kf_node_id, kf_off, kf_idx, kf_nodes, f_desc, nullptr, [&](int i) { return f_angle[i]; }, nullptr,
+                       n_f, f_node_id, f_off, f_idx, f_nodes, nnratio, check_orientation, match_f);
 }
 
 int vsg_search_by_bow_kf_kf(int device, const uint8_t *desc1, const float *angle1, const uint8_t *valid1, int n1,
@@ -783,8 +785,32 @@ int vsg_search_by_bow_kf_kf(int device, const uint8_t *desc1, const float *angle
                             const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
                             float nnratio, int check_orientation, int32_t *matches12) {
   if (!matches12 || n1 < 0 || n2 < 0) return VSG_ERR_INVALID;
-  return search_by_bow(device, 1, -1, desc1, angle1, valid1, n1, node_id1, off1, idx1, nodes1, desc2, angle2, valid2, n2,
-                       node_id2, off2, idx2, nodes2, nnratio, check_orientation, matches12);
+  return search_by_bow(device, 1, -1, desc1, nullptr, [&](int i) { return angle1[i]; }, valid1, n1, node_id1, off1, idx1,
+                       nodes1, desc2, nullptr, [&](int i) { return angle2[i]; }, valid2, n2, node_id2, off2, idx2, nodes2,
+                       nnratio, check_orientation, matches12);
+}
+
+// the same two searches with both descriptor sets resident (vsg_frame): only FeatureVectors + flags go up
+int vsg_frame_search_by_bow_kf_f(vsg_frame *kf, const uint8_t *kf_valid, const int32_t *kf_node_id,
+                                 const int32_t *kf_off, const int32_t *kf_idx, int kf_nodes, vsg_frame *f,
+                                 const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
+                                 float nnratio, int check_orientation, int32_t *match_f) {
+  if (!kf || !f || !match_f || kf->device != f->device || !kf_valid) return VSG_ERR_INVALID;
+  const vsg_keypoint *ka = kf->h_kps.data(), *kb = f->h_kps.data();
+  return search_by_bow(kf->device, 0, f->nleft, nullptr, kf->d_desc, [&](int i) { return ka[i].angle; }, kf_valid, kf->n,
+                       kf_node_id, kf_off, kf_idx, kf_nodes, nullptr, f->d_desc, [&](int i) { return kb[i].angle; },
+                       nullptr, f->n, f_node_id, f_off, f_idx, f_nodes, nnratio, check_orientation, match_f);
+}
+
+int vsg_frame_search_by_bow_kf_kf(vsg_frame *kf1, const uint8_t *valid1, const int32_t *node_id1, const int32_t *off1,
+                                  const int32_t *idx1, int nodes1, vsg_frame *kf2, const uint8_t *valid2,
+                                  const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                                  float nnratio, int check_orientation, int32_t *matches12) {
+  if (!kf1 || !kf2 || !matches12 || kf1->device != kf2->device || !valid1 || !valid2) return VSG_ERR_INVALID;
+  const vsg_keypoint *ka = kf1->h_kps.data(), *kb = kf2->h_kps.data();
+  return search_by_bow(kf1->device, 1, -1, nullptr, kf1->d_desc, [&](int i) { return ka[i].angle; }, valid1, kf1->n,
+                       node_id1, off1, idx1, nodes1, nullptr, kf2->d_desc, [&](int i) { return kb[i].angle; }, valid2,
+                       kf2->n, node_id2, off2, idx2, nodes2, nnratio, check_orientation, matches12);
 }
 
 int vsg_search_by_projection_last(int device, const uint8_t *q_desc, const float *q_angle,
@@ -794,35 +820,12 @@ int vsg_search_by_projection_last(int device, const uint8_t *q_desc, const float
                                   int32_t *train_match) {
   if (!cand_off || !train_blocked || !train_match || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
   if (n_q == 0 || n_t == 0) return use_device(device) == VSG_OK ? 0 : VSG_ERR_NO_DEVICE;
-  std::vector<uint16_t> dist;
-  int rc = candidate_distances(device, q_desc, n_q, cand_off, cand_idx, t_desc, n_t, dist);
+  const uint32_t *ent = nullptr;
+  int rc = candidate_entries(device, q_desc, n_q, cand_off, cand_idx, t_desc, nullptr, n_t, &ent);
   if (rc != VSG_OK) return rc;
-  // ORBmatcher.cc:1686-1784 (left / mono block): best candidate only, strict '<' from 256
-  int nmatches = 0;
-  std::vector<int> rotHist[HISTO_LENGTH];
-  for (int q = 0; q < n_q; q++) {
-    int bestDist = 256, bestIdx2 = -1;
-    for (int c = cand_off[q]; c < cand_off[q + 1]; c++) {
-      const int i2 = cand_idx[c];
-      if (train_blocked[i2]) continue;  // mvpMapPoints[i2] with Observations() > 0
-      if (dist[c] < bestDist) {
-        bestDist = dist[c];
-        bestIdx2 = i2;
-      }
-    }
-    if (bestDist <= th_high && bestIdx2 >= 0) {
-      train_match[bestIdx2] = q;
-      train_blocked[bestIdx2] = query_blocks ? query_blocks[q] : 0;
-      nmatches++;
-      if (check_orientation) rotHist[rot_bin(q_angle[q], t_angle[bestIdx2])].push_back(bestIdx2);
-    }
-  }
-  if (check_orientation)  // :1855-1875
-    filter_rotation(rotHist, [&](int i2) {
-      train_match[i2] = -1;
-      nmatches--;
-    });
-  return nmatches;
+  // ORBmatcher.cc:1686-1784 (left / mono block) + the rotation filter :1855-1875
+  return walk::search_last(csr_view(ent, cand_off), n_q, -1, q_angle, query_blocks, [&](int i) { return t_angle[i]; },
+                           th_high, check_orientation != 0, train_blocked, train_match);
 }
 
 int vsg_search_by_projection_local(int device, const uint8_t *q_desc, const uint8_t *query_blocks, int n_q,
@@ -831,54 +834,39 @@ int vsg_search_by_projection_local(int device, const uint8_t *q_desc, const uint
                                    int32_t *train_match) {
   if (!cand_off || !train_blocked || !train_match || !t_octave || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
   if (n_q == 0 || n_t == 0) return use_device(device) == VSG_OK ? 0 : VSG_ERR_NO_DEVICE;
-  std::vector<uint16_t> dist;
-  int rc = candidate_distances(device, q_desc, n_q, cand_off, cand_idx, t_desc, n_t, dist);
+  const uint32_t *ent = nullptr;
+  int rc = candidate_entries(device, q_desc, n_q, cand_off, cand_idx, t_desc, t_octave, n_t, &ent);
   if (rc != VSG_OK) return rc;
-  // ORBmatcher.cc:48-144 (left block): best + second best with their pyramid levels
-  int nmatches = 0;
-  for (int q = 0; q < n_q; q++) {
-    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-    for (int c = cand_off[q]; c < cand_off[q + 1]; c++) {
-      const int idx = cand_idx[c];
-      if (train_blocked[idx]) continue;
-      const int d = dist[c];
-      if (d < bestDist) {
-        bestDist2 = bestDist;
-        bestDist = d;
-        bestLevel2 = bestLevel;
-        bestLevel = t_octave[idx];
-        bestIdx = idx;
-      } else if (d < bestDist2) {
-        bestLevel2 = t_octave[idx];
-        bestDist2 = d;
-      }
-    }
-    if (bestDist <= TH_HIGH && bestIdx >= 0) {  // :123
-      if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) continue;  // :125-126
-      if (bestLevel != bestLevel2 || (float)bestDist <= nnratio * (float)bestDist2) {         // :128
-        train_match[bestIdx] = q;
-        train_blocked[bestIdx] = query_blocks ? query_blocks[q] : 0;
-        nmatches++;
-      }
-    }
-  }
-  return nmatches;
+  // ORBmatcher.cc:48-144 (left block): every query is "in view"
+  std::vector<uint8_t> in_view((size_t)n_q, 1);
+  return walk::search_local(csr_view(ent, cand_off), n_q, -1, in_view.data(), nullptr, nullptr, query_blocks, nnratio,
+                            nullptr, nullptr, train_blocked, train_match);
 }
 
 int vsg_distinctive_descriptors(int device, const uint8_t *desc, const int32_t *off, int ngroups, int32_t *best) {
   if (!off || !best || ngroups < 0) return VSG_ERR_INVALID;
-  int rc = use_device(device);
-  if (rc != VSG_OK) return rc;
+  int rc = VSG_OK;
+  ThreadCtx *c = vsg::thread_ctx(device, &rc);
+  if (!c) return rc;
   if (ngroups == 0) return VSG_OK;
   for (int g = 0; g < ngroups; g++)
     if (off[g + 1] - off[g] > kDistinctMaxN) return VSG_ERR_UNSUPPORTED;
   const int n = off[ngroups];
-  DevBuf dD, dOff, dBest;
-  M_TRY(dD.upload(desc, (size_t)n * 32));
-  M_TRY(dOff.upload(off, (size_t)(ngroups + 1) * 4));
-  M_TRY(dBest.alloc((size_t)ngroups * 4));
-  hipLaunchKernelGGL(k_distinctive, dim3(ngroups), dim3(128), 0, 0, dD.as<uint8_t>(), dOff.as<int>(), dBest.as<int>());
-  M_TRY(hipMemcpy(best, dBest.p, (size_t)ngroups * 4, hipMemcpyDeviceToHost));
+  Stage st;
+  const size_t oD = st.add((size_t)n * 32), oOff = st.add((size_t)(ngroups + 1) * 4);
+  const size_t in_bytes = st.total;
+  const size_t oB = st.add((size_t)ngroups * 4);
+  rc = vsg::ctx_reserve(c, st.total, in_bytes);
+  if (rc != VSG_OK) return rc;
+  uint8_t *h = c->h_pin;
+  if (n) memcpy(h + oD, desc, (size_t)n * 32);
+  memcpy(h + oOff, off, (size_t)(ngroups + 1) * 4);
+  M_TRY(hipMemcpyAsync(c->d_buf, h, in_bytes, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_distinctive, dim3(ngroups), dim3(128), 0, c->stream, c->d_buf + oD, (const int *)(c->d_buf + oOff),
+                     (int *)(c->d_pin + oB));
+  M_TRY(hipGetLastError());
+  M_TRY(hipStreamSynchronize(c->stream));
+  memcpy(best, h + oB, (size_t)ngroups * 4);
   return VSG_OK;
 }
 
@@ -888,20 +876,15 @@ int vsg_search_window(int device, const uint8_t *q_desc, const uint8_t *query_bl
   if (!cand_off || !q_best_idx || !q_best_dist || n_q < 0 || n_t < 0) return VSG_ERR_INVALID;
   for (int q = 0; q < n_q; q++) q_best_idx[q] = -1, q_best_dist[q] = 256;
   if (n_q == 0 || n_t == 0) return use_device(device) == VSG_OK ? 0 : VSG_ERR_NO_DEVICE;
-  std::vector<uint16_t> dist;
-  int rc = candidate_distances(device, q_desc, n_q, cand_off, cand_idx, t_desc, n_t, dist);
+  const uint32_t *ent = nullptr;
+  int rc = candidate_entries(device, q_desc, n_q, cand_off, cand_idx, t_desc, nullptr, n_t, &ent);
   if (rc != VSG_OK) return rc;
+  const walk::CandView cv = csr_view(ent, cand_off);
   int nmatches = 0;
   for (int q = 0; q < n_q; q++) {
-    int bestDist = 256, bestIdx = -1;
-    for (int c = cand_off[q]; c < cand_off[q + 1]; c++) {
-      const int idx = cand_idx[c];
-      if (train_blocked && train_blocked[idx]) continue;
-      if (dist[c] < bestDist) {
-        bestDist = dist[c];
-        bestIdx = idx;
-      }
-    }
+    int bestDist, bestIdx;
+    walk::scan_best(cv.begin(q), cv.size(q), [&](int idx) { return train_blocked && train_blocked[idx]; }, 256, bestDist,
+                    bestIdx);
     q_best_idx[q] = bestIdx;
     q_best_dist[q] = bestDist;
     if (bestIdx >= 0 && bestDist <= th_high) {
@@ -920,51 +903,12 @@ int vsg_search_for_initialization(int device, const uint8_t *desc1, const float 
   if (!cand_off || !matches12 || !octave1 || n1 < 0 || n2 < 0) return VSG_ERR_INVALID;
   for (int i = 0; i < n1; i++) matches12[i] = -1;
   if (n1 == 0 || n2 == 0) return use_device(device) == VSG_OK ? 0 : VSG_ERR_NO_DEVICE;
-  std::vector<uint16_t> dist;
-  int rc = candidate_distances(device, desc1, n1, cand_off, cand_idx, desc2, n2, dist);
+  const uint32_t *ent = nullptr;
+  int rc = candidate_entries(device, desc1, n1, cand_off, cand_idx, desc2, nullptr, n2, &ent);
   if (rc != VSG_OK) return rc;
   // ORBmatcher.cc:643-756
-  int nmatches = 0;
-  std::vector<int> vMatchedDistance((size_t)n2, 0x7FFFFFFF), vnMatches21((size_t)n2, -1);
-  std::vector<int> rotHist[HISTO_LENGTH];
-  for (int i1 = 0; i1 < n1; i1++) {
-    if (octave1[i1] > 0) continue;  // :659-661
-    if (cand_off[i1] == cand_off[i1 + 1]) continue;
-    int bestDist = 0x7FFFFFFF, bestDist2 = 0x7FFFFFFF, bestIdx2 = -1;
-    for (int c = cand_off[i1]; c < cand_off[i1 + 1]; c++) {
-      const int i2 = cand_idx[c];
-      const int d = dist[c];
-      if (vMatchedDistance[i2] <= d) continue;  // :682
-      if (d < bestDist) {
-        bestDist2 = bestDist;
-        bestDist = d;
-        bestIdx2 = i2;
-      } else if (d < bestDist2) {
-        bestDist2 = d;
-      }
-    }
-    if (bestDist <= TH_LOW) {
-      if ((float)bestDist < (float)bestDist2 * nnratio) {  // :697-699
-        if (vnMatches21[bestIdx2] >= 0) {
-          matches12[vnMatches21[bestIdx2]] = -1;
-          nmatches--;
-        }
-        matches12[i1] = bestIdx2;
-        vnMatches21[bestIdx2] = i1;
-        vMatchedDistance[bestIdx2] = bestDist;
-        nmatches++;
-        if (check_orientation) rotHist[rot_bin(angle1[i1], angle2[bestIdx2])].push_back(i1);
-      }
-    }
-  }
-  if (check_orientation)  // :726-748
-    filter_rotation(rotHist, [&](int idx1) {
-      if (matches12[idx1] >= 0) {
-        matches12[idx1] = -1;
-        nmatches--;
-      }
-    });
-  return nmatches;
+  return walk::search_initialization(csr_view(ent, cand_off), n1, n2, octave1, [&](int i) { return angle1[i]; },
+                                     [&](int i) { return angle2[i]; }, nnratio, check_orientation != 0, matches12);
 }
 
 }  // extern "C"

@@ -17,6 +17,8 @@
 
 #include "../../include/vsg_orb.h"
 #include "vsg_common.h"
+#include "vsg_ctx.h"
+#include "vsg_frame_int.h"
 #include "vsg_geometry.h"
 #include "vsg_kernels.h"
 
@@ -40,7 +42,24 @@ static const int8_t kPattern[1024] = {
 
 static_assert(sizeof(KeyPointPOD) == 28 && sizeof(vsg_keypoint) == 28, "cv::KeyPoint layout");
 
-enum { kStages = 7, kEv = 12, kMaxSub = 8 };
+enum { kStages = 7, kEv = 12, kMaxSub = 8, kSlots = 3 };
+
+// One pipeline slot of the host API: level-0 staging and output records of ONE batch in flight, on the device and in
+// pinned host memory, plus the events that chain  H2D -> kernels -> export  across the three streams.
+struct Slot {
+  uint8_t *d_in = nullptr, *h_in = nullptr;  // [B][rows][in_pitch]
+  KeyPointPOD *d_kps = nullptr, *h_kps = nullptr;
+  uint8_t *d_desc = nullptr, *h_desc = nullptr;
+  int *d_counts = nullptr, *h_counts = nullptr;
+  hipEvent_t ev_in = nullptr, ev_done = nullptr, ev_out = nullptr;
+  bool allocated = false, busy = false;
+  int ticket = -1, nframes = 0;
+  // where vsg_orb_wait delivers (the caller's arrays); direct = the export kernel already wrote them
+  vsg_keypoint *out_kps = nullptr;
+  uint8_t *out_desc = nullptr;
+  int out_cap = 0;
+  bool direct = false;
+};
 
 struct vsg_orb {
   ExtractorTables T;
@@ -58,8 +77,21 @@ struct vsg_orb {
   int pyr_tiling = 0;                   // the tiling calibration found faster for a full batch of this geometry
   PyrTile *d_ptiles[kPyrTilings] = {};  // Geometry::pyr[i].tiles
   Short4 *d_ptab[kPyrTilings] = {};     // Geometry::pyr[i].tab
-  uint8_t *d_in = nullptr;  // level-0 staging for host images / unaligned device images, pitch in_pitch
+  uint8_t *d_in = nullptr;  // level-0 staging for unaligned / colour device images (device API), pitch in_pitch
   int in_pitch = 0;
+  Slot slot[kSlots];
+  int next_ticket = 0;
+  hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+  // outputs of the last enqueue (any entry point): where they are and when they are complete
+  const KeyPointPOD *last_kps = nullptr;
+  const uint8_t *last_desc = nullptr;
+  const int *last_counts = nullptr;
+  int last_cap = 0;
+  hipEvent_t ev_last = nullptr;    // recorded behind the last kernel of the last enqueue
+  bool have_last = false;
+  hipEvent_t ev_null_in = nullptr, ev_null_out = nullptr;  // ordering against the caller's NULL stream
+  uint8_t *d_scratch = nullptr;  // grows: colour upload of the host colour entry, bordered level of copy_level
+  size_t scratch_cap = 0;
   Src0 last_src0 = {nullptr, 0, 0};
   int8_t *d_pattern = nullptr;
   uint8_t *d_pyr = nullptr, *d_blur = nullptr;
@@ -68,14 +100,6 @@ struct vsg_orb {
   int *d_counts2 = nullptr;  // [2][B][kMaxLevels]: cand_count then sel_count
   int *d_flags = nullptr, *d_slots = nullptr;
   FrameHeader *d_hdr = nullptr;
-  KeyPointPOD *d_kps = nullptr;
-  uint8_t *d_desc = nullptr;
-  int *d_out_counts = nullptr;
-  // pinned host staging
-  uint8_t *h_in = nullptr;
-  KeyPointPOD *h_kps = nullptr;
-  uint8_t *h_desc = nullptr;
-  int *h_out_counts = nullptr;
   hipStream_t s_main = nullptr, s_blur = nullptr;
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_fork = nullptr;
   // sub-batch pipelining
@@ -94,6 +118,17 @@ struct vsg_orb {
 // dynamic LDS the fused pyramid may ask for (the launcher raises the 64 KB default limit; gfx950 has 160 KB)
 constexpr int kPyrLdsLimit = 150000;
 
+static void free_slot(Slot &S) {
+  hipFree(S.d_in), hipFree(S.d_kps), hipFree(S.d_desc), hipFree(S.d_counts);
+  hipHostFree(S.h_in), hipHostFree(S.h_kps), hipHostFree(S.h_desc), hipHostFree(S.h_counts);
+  S.d_in = S.h_in = nullptr;
+  S.d_kps = S.h_kps = nullptr;
+  S.d_desc = S.h_desc = nullptr;
+  S.d_counts = S.h_counts = nullptr;
+  S.allocated = S.busy = false;
+  S.ticket = -1;
+}
+
 static void free_image_buffers(vsg_orb *h) {
   hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in);
   for (int i = 0; i < kPyrTilings; i++) {
@@ -102,18 +137,65 @@ static void free_image_buffers(vsg_orb *h) {
   }
   hipFree(h->d_pyr), hipFree(h->d_blur), hipFree(h->d_cand), hipFree(h->d_sel), hipFree(h->d_nodeof);
   hipFree(h->d_counts2), hipFree(h->d_flags), hipFree(h->d_slots), hipFree(h->d_hdr);
-  hipFree(h->d_kps), hipFree(h->d_desc), hipFree(h->d_out_counts);
-  hipHostFree(h->h_in), hipHostFree(h->h_kps), hipHostFree(h->h_desc), hipHostFree(h->h_out_counts);
+  for (int i = 0; i < kSlots; i++) free_slot(h->slot[i]);
   h->d_fg = nullptr, h->d_tab = nullptr, h->d_cells = nullptr, h->d_in = nullptr;
   h->last_src0 = {nullptr, 0, 0};
+  h->have_last = false;
   h->d_pyr = h->d_blur = nullptr;
   h->d_cand = h->d_sel = nullptr;
   h->d_nodeof = nullptr;
   h->d_counts2 = h->d_flags = h->d_slots = nullptr;
   h->d_hdr = nullptr;
-  h->d_kps = nullptr, h->d_desc = nullptr, h->d_out_counts = nullptr;
-  h->h_in = nullptr, h->h_kps = nullptr, h->h_desc = nullptr, h->h_out_counts = nullptr;
   h->rows = h->cols = 0;
+}
+
+// every stream of the handle idle (before buffers are re-built or parameters change under running kernels)
+static int quiesce(vsg_orb *h) {
+  HIP_TRY(hipStreamSynchronize(h->s_h2d));
+  HIP_TRY(hipStreamSynchronize(h->s_main));
+  HIP_TRY(hipStreamSynchronize(h->s_blur));
+  HIP_TRY(hipStreamSynchronize(h->s_d2h));
+  if (h->have_last) HIP_TRY(hipEventSynchronize(h->ev_last));  // the last enqueue may sit on a caller stream
+  return VSG_OK;
+}
+
+// slot i's device + pinned buffers for the current geometry (slot 0 with the geometry, the others on first use)
+static int ensure_slot(vsg_orb *h, int i) {
+  Slot &S = h->slot[i];
+  if (S.allocated) return VSG_OK;
+  const FrameGeom &fg = h->G.fg;
+  const size_t B = (size_t)h->max_batch;
+  const size_t in_bytes = B * (size_t)h->rows * h->in_pitch + 64;
+  // outputs live in mapped pinned memory: the export kernel stores the records there straight from the device
+  const unsigned flags = hipHostMallocMapped | hipHostMallocPortable;
+  HIP_TRY(hipMalloc(&S.d_in, in_bytes));
+  HIP_TRY(hipHostMalloc(&S.h_in, in_bytes, hipHostMallocPortable));
+  HIP_TRY(hipMalloc(&S.d_kps, B * fg.out_cap * sizeof(KeyPointPOD)));
+  HIP_TRY(hipMalloc(&S.d_desc, B * fg.out_cap * 32));
+  HIP_TRY(hipMalloc(&S.d_counts, B * 2 * sizeof(int)));
+  HIP_TRY(hipHostMalloc(&S.h_kps, B * fg.out_cap * sizeof(KeyPointPOD), flags));
+  HIP_TRY(hipHostMalloc(&S.h_desc, B * fg.out_cap * 32, flags));
+  HIP_TRY(hipHostMalloc(&S.h_counts, B * 2 * sizeof(int), flags));
+  if (!S.ev_in) {
+    HIP_TRY(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&S.ev_out, hipEventDisableTiming));
+  }
+  S.allocated = true;
+  return VSG_OK;
+}
+
+static int ensure_scratch(vsg_orb *h, size_t bytes) {
+  if (bytes <= h->scratch_cap) return VSG_OK;
+  int rc = quiesce(h);
+  if (rc != VSG_OK) return rc;
+  hipFree(h->d_scratch);
+  h->d_scratch = nullptr;
+  h->scratch_cap = 0;
+  const size_t cap = bytes + bytes / 2;
+  HIP_TRY(hipMalloc(&h->d_scratch, cap));
+  h->scratch_cap = cap;
+  return VSG_OK;
 }
 
 // (re)build geometry + buffers for an image size
@@ -126,8 +208,8 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
     return VSG_ERR_UNSUPPORTED;
   }
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->s_main));
-  HIP_TRY(hipStreamSynchronize(h->s_blur));
+  rc = quiesce(h);
+  if (rc != VSG_OK) return rc;
   free_image_buffers(h);
   h->G = G;
   const FrameGeom &fg = h->G.fg;
@@ -159,17 +241,12 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   HIP_TRY(hipMalloc(&h->d_flags, B * fg.out_cap * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_slots, B * fg.out_cap * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_hdr, B * sizeof(FrameHeader)));
-  HIP_TRY(hipMalloc(&h->d_kps, B * fg.out_cap * sizeof(KeyPointPOD)));
-  HIP_TRY(hipMalloc(&h->d_desc, B * fg.out_cap * 32));
-  HIP_TRY(hipMalloc(&h->d_out_counts, B * 2 * sizeof(int)));
   h->in_pitch = (cols + 3) & ~3;
   HIP_TRY(hipMalloc(&h->d_in, B * (size_t)rows * h->in_pitch + 64));
-  HIP_TRY(hipHostMalloc(&h->h_in, B * (size_t)rows * h->in_pitch));
-  HIP_TRY(hipHostMalloc(&h->h_kps, B * fg.out_cap * sizeof(KeyPointPOD)));
-  HIP_TRY(hipHostMalloc(&h->h_desc, B * fg.out_cap * 32));
-  HIP_TRY(hipHostMalloc(&h->h_out_counts, B * 2 * sizeof(int)));
   h->rows = rows;
   h->cols = cols;
+  rc = ensure_slot(h, 0);
+  if (rc != VSG_OK) return rc;
   // Which pyramid tiling is faster depends on how the top level happens to divide (measured: 36 wins at 640x480,
   // 752x480 and 1920x1080, 32 at 1280x720), so both are timed once on a full batch of this geometry (the duration
   // does not depend on the pixel values; the staging buffer's content is used as it is).
@@ -323,8 +400,54 @@ static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, i
   }
   HIP_TRY(hipGetLastError());
   h->last_frames = nframes;
+  // where this call's results are and when they are complete (stage read-back, stereo, vsg_frame_from_extractor)
+  h->last_kps = d_kps, h->last_desc = d_desc, h->last_counts = d_counts, h->last_cap = capacity;
+  HIP_TRY(hipEventRecord(h->ev_last, s));
+  h->have_last = true;
   return VSG_OK;
 }
+
+// wait (on the host) for the last enqueue, whichever stream it went to
+static int wait_last(vsg_orb *h) {
+  if (h->have_last) HIP_TRY(hipEventSynchronize(h->ev_last));
+  HIP_TRY(hipStreamSynchronize(h->s_blur));
+  return VSG_OK;
+}
+
+// `stream` argument of the device entry points: NULL means the caller's NULL stream.  The chain runs on the handle's
+// own non-blocking stream, ordered behind everything the NULL stream holds at entry, and the NULL stream is made to
+// wait for it at exit -- so producer -> extract -> consumer sequences on the default stream are ordered.
+struct NullStreamBridge {
+  vsg_orb *h;
+  bool on;
+  hipStream_t s;
+  NullStreamBridge(vsg_orb *h_, void *stream) : h(h_), on(stream == nullptr), s(stream ? (hipStream_t)stream : h_->s_main) {}
+  int enter() {
+    if (!on) return VSG_OK;
+    HIP_TRY(hipEventRecord(h->ev_null_in, nullptr));
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_null_in, 0));
+    return VSG_OK;
+  }
+  int leave() {
+    if (!on) return VSG_OK;
+    HIP_TRY(hipEventRecord(h->ev_null_out, s));
+    HIP_TRY(hipStreamWaitEvent(nullptr, h->ev_null_out, 0));
+    return VSG_OK;
+  }
+};
+
+static bool host_pinned(const void *p, void **dev_alias) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory: not an error
+    return false;
+  }
+  if (a.type != hipMemoryTypeHost) return false;
+  if (dev_alias) *dev_alias = a.devicePointer;
+  return true;
+}
+
+
 
 extern "C" {
 
@@ -337,6 +460,17 @@ int vsg_device_count(void) {
     return VSG_ERR_NO_DEVICE;
   }
   return n;
+}
+
+int vsg_host_register(void *ptr, size_t bytes) {
+  if (!ptr || !bytes) return VSG_ERR_INVALID;
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+  return VSG_OK;
+}
+int vsg_host_unregister(void *ptr) {
+  if (!ptr) return VSG_ERR_INVALID;
+  HIP_TRY(hipHostUnregister(ptr));
+  return VSG_OK;
 }
 
 int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device,
@@ -359,8 +493,13 @@ int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fa
   }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&h->s_blur, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_null_in, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_null_out, hipEventDisableTiming) != hipSuccess ||
       hipMalloc(&h->d_pattern, 1024) != hipSuccess ||
       hipMemcpy(h->d_pattern, kPattern, 1024, hipMemcpyHostToDevice) != hipSuccess) {
     set_err("HIP initialisation failed");
@@ -389,10 +528,14 @@ int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fa
 void vsg_orb_destroy(vsg_orb *h) {
   if (!h) return;
   hipSetDevice(h->device);
-  if (h->s_main) hipStreamSynchronize(h->s_main);
-  if (h->s_blur) hipStreamSynchronize(h->s_blur);
+  if (h->s_main) quiesce(h);
   free_image_buffers(h);
   hipFree(h->d_pattern);
+  hipFree(h->d_scratch);
+  for (int i = 0; i < kSlots; i++) {
+    Slot &S = h->slot[i];
+    if (S.ev_in) hipEventDestroy(S.ev_in), hipEventDestroy(S.ev_done), hipEventDestroy(S.ev_out);
+  }
   for (int i = 0; i < kEv; i++)
     if (h->ev[i]) hipEventDestroy(h->ev[i]);
   for (int j = 0; j < kMaxSub; j++) {
@@ -405,8 +548,13 @@ void vsg_orb_destroy(vsg_orb *h) {
   if (h->ev_fork) hipEventDestroy(h->ev_fork);
   if (h->ev_pyr) hipEventDestroy(h->ev_pyr);
   if (h->ev_blur) hipEventDestroy(h->ev_blur);
+  if (h->ev_last) hipEventDestroy(h->ev_last);
+  if (h->ev_null_in) hipEventDestroy(h->ev_null_in);
+  if (h->ev_null_out) hipEventDestroy(h->ev_null_out);
   if (h->s_main) hipStreamDestroy(h->s_main);
   if (h->s_blur) hipStreamDestroy(h->s_blur);
+  if (h->s_h2d) hipStreamDestroy(h->s_h2d);
+  if (h->s_d2h) hipStreamDestroy(h->s_d2h);
   delete h;
 }
 
@@ -434,10 +582,11 @@ int vsg_orb_set_blur_taps(vsg_orb *h, const uint16_t taps[7]) {
   }
   if (tsum > 257) return VSG_ERR_UNSUPPORTED;  // keeps the 8.8 row sums within 16 bits (no saturation anywhere)
   memcpy(h->taps, taps, sizeof(h->taps));
-  if (h->rows) {  // refresh the device copy of the geometry
+  if (h->rows) {  // refresh the device copy of the geometry -- never under running kernels
     for (int k = 0; k < 7; k++) h->G.fg.taps[k] = taps[k];
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(hipStreamSynchronize(h->s_main));
+    int rc = quiesce(h);
+    if (rc != VSG_OK) return rc;
     HIP_TRY(hipMemcpy(h->d_fg, &h->G.fg, sizeof(FrameGeom), hipMemcpyHostToDevice));
   }
   return VSG_OK;
@@ -450,34 +599,6 @@ int vsg_orb_capacity(vsg_orb *h, int rows, int cols) {
   if (rc != VSG_OK) return rc;
   return h->G.fg.out_cap;
 }
-
-}  // extern "C"
-
-// D2H of the handle's own output buffers + copy into the caller's [nframes][capacity] arrays
-static int fetch_outputs(vsg_orb *h, int nframes, vsg_keypoint *kps, uint8_t *desc, int capacity, int *n,
-                         int *mono_index, hipStream_t s) {
-  const FrameGeom &fg = h->G.fg;
-  HIP_TRY(hipMemcpyAsync(h->h_out_counts, h->d_out_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h->h_kps, h->d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h->h_desc, h->d_desc, (size_t)nframes * fg.out_cap * 32, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  int status = VSG_OK;
-  for (int f = 0; f < nframes; f++) {
-    const int nf = h->h_out_counts[2 * f];
-    n[f] = nf;
-    mono_index[f] = h->h_out_counts[2 * f + 1];
-    if (nf > capacity) {
-      set_err("caller capacity too small for the extracted keypoints");
-      status = VSG_ERR_CAPACITY;
-      continue;
-    }
-    if (nf > 0 && kps) memcpy(kps + (size_t)f * capacity, h->h_kps + (size_t)f * fg.out_cap, (size_t)nf * sizeof(KeyPointPOD));
-    if (nf > 0 && desc) memcpy(desc + (size_t)f * capacity * 32, h->h_desc + (size_t)f * fg.out_cap * 32, (size_t)nf * 32);
-  }
-  return status;
-}
-
-extern "C" {
 
 int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes, size_t frame_stride, int rows,
                                  int cols, int stride, int lap0, int lap1, vsg_keypoint *d_kps, uint8_t *d_desc,
@@ -492,7 +613,10 @@ int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes,
     set_err("capacity below vsg_orb_capacity()");
     return VSG_ERR_CAPACITY;
   }
-  hipStream_t s = stream ? (hipStream_t)stream : h->s_main;
+  NullStreamBridge br(h, stream);
+  rc = br.enter();
+  if (rc != VSG_OK) return rc;
+  hipStream_t s = br.s;
   Src0 s0;
   if (((uintptr_t)d_gray & 3) == 0 && (stride & 3) == 0 && (frame_stride & 3) == 0) {
     s0 = {d_gray, frame_stride, stride};  // level 0 is read in place: no ingest copy
@@ -502,7 +626,9 @@ int vsg_orb_extract_batch_device(vsg_orb *h, const uint8_t *d_gray, int nframes,
                                stride, cols, rows, hipMemcpyDeviceToDevice, s));
     s0 = {h->d_in, (size_t)rows * h->in_pitch, h->in_pitch};
   }
-  return enqueue_pipeline(h, s0, nframes, lap0, lap1, (KeyPointPOD *)d_kps, d_desc, d_counts, capacity, s);
+  rc = enqueue_pipeline(h, s0, nframes, lap0, lap1, (KeyPointPOD *)d_kps, d_desc, d_counts, capacity, s);
+  if (rc != VSG_OK) return rc;
+  return br.leave();
 }
 
 int vsg_orb_set_gray_coeffs(vsg_orb *h, const int coeffs[3], int shift) {
@@ -524,12 +650,141 @@ int vsg_orb_extract_batch_device_color(vsg_orb *h, const uint8_t *d_img, int cha
   int rc = ensure_geometry(h, rows, cols);
   if (rc != VSG_OK) return rc;
   if (capacity < h->G.fg.out_cap) return VSG_ERR_CAPACITY;
-  hipStream_t s = stream ? (hipStream_t)stream : h->s_main;
+  NullStreamBridge br(h, stream);
+  rc = br.enter();
+  if (rc != VSG_OK) return rc;
+  hipStream_t s = br.s;
   // cvtColor of Tracking::GrabImage* straight into the gray level-0 staging buffer
   launch_cvt_gray(s, d_img, frame_stride, stride, channels, rgb_order, rows, cols, h->d_in,
                   (size_t)rows * h->in_pitch, h->in_pitch, h->gray_coeffs, h->gray_shift, nframes);
   const Src0 s0 = {h->d_in, (size_t)rows * h->in_pitch, h->in_pitch};
-  return enqueue_pipeline(h, s0, nframes, lap0, lap1, (KeyPointPOD *)d_kps, d_desc, d_counts, capacity, s);
+  rc = enqueue_pipeline(h, s0, nframes, lap0, lap1, (KeyPointPOD *)d_kps, d_desc, d_counts, capacity, s);
+  if (rc != VSG_OK) return rc;
+  return br.leave();
+}
+
+// ---- host API: submit / wait over the pipeline slots ---------------------------------------------------------
+
+int vsg_orb_slots(const vsg_orb *h) { return h ? kSlots : VSG_ERR_INVALID; }
+
+// kernels of the chain + export for slot S, behind its ev_in; `color`: the slot's d_in holds interleaved colour frames
+// in d_scratch instead (host colour entry)
+static int submit_tail(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc,
+                       int capacity) {
+  const FrameGeom &fg = h->G.fg;
+  const Src0 s0 = {S.d_in, (size_t)h->rows * h->in_pitch, h->in_pitch};
+  int rc = enqueue_pipeline(h, s0, nframes, lap0, lap1, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, h->s_main);
+  if (rc != VSG_OK) return rc;
+  HIP_TRY(hipEventRecord(S.ev_done, h->s_main));
+  HIP_TRY(hipStreamWaitEvent(h->s_d2h, S.ev_done, 0));
+  // export: n records per frame, written by the device into pinned host memory -- the caller's own arrays when they
+  // are pinned (no copy left for vsg_orb_wait), the slot's staging otherwise
+  void *dk = nullptr, *dd = nullptr;
+  S.direct = kps && desc && capacity > 0 && host_pinned(kps, &dk) && host_pinned(desc, &dd) && dk && dd;
+  S.out_kps = kps, S.out_desc = desc, S.out_cap = capacity;
+  static const bool dma_out = getenv("VSG_D2H_DMA") != nullptr;  // A/B switch: copy-engine D2H of out_cap-sized buffers
+  if (dma_out) {
+    S.direct = false;
+    HIP_TRY(hipMemcpyAsync(S.h_counts, S.d_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, h->s_d2h));
+    HIP_TRY(hipMemcpyAsync(S.h_kps, S.d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, h->s_d2h));
+    HIP_TRY(hipMemcpyAsync(S.h_desc, S.d_desc, (size_t)nframes * fg.out_cap * 32, hipMemcpyDeviceToHost, h->s_d2h));
+  } else if (S.direct) {
+    launch_export(h->s_d2h, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, dk, dd, S.h_counts, capacity, nframes);
+  } else {
+    launch_export(h->s_d2h, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, S.h_kps, S.h_desc, S.h_counts, fg.out_cap, nframes);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(S.ev_out, h->s_d2h));
+  S.busy = true;
+  S.nframes = nframes;
+  S.ticket = h->next_ticket++;
+  return S.ticket;
+}
+
+static int acquire_slot(vsg_orb *h, Slot **out) {
+  const int i = h->next_ticket % kSlots;
+  Slot &S = h->slot[i];
+  if (S.busy) {
+    set_err("every pipeline slot holds a batch that has not been waited for (vsg_orb_wait)");
+    return VSG_ERR_CAPACITY;
+  }
+  int rc = ensure_slot(h, i);
+  if (rc != VSG_OK) return rc;
+  *out = &S;
+  return VSG_OK;
+}
+
+int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t frame_stride, int rows, int cols,
+                         int stride, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc, int capacity) {
+  if (!h || nframes < 1 || nframes > h->max_batch) return VSG_ERR_INVALID;
+  if (!gray || rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = ensure_geometry(h, rows, cols);
+  if (rc != VSG_OK) return rc;
+  Slot *Sp = nullptr;
+  rc = acquire_slot(h, &Sp);
+  if (rc != VSG_OK) return rc;
+  Slot &S = *Sp;
+  const int ip = h->in_pitch;
+  const size_t fbytes = (size_t)rows * ip;
+  const bool packed = stride == ip && (nframes == 1 || frame_stride == fbytes);
+  if (host_pinned(gray, nullptr)) {
+    // pinned caller memory: DMA straight from it (one descriptor for a packed batch, one 2-D copy per frame otherwise)
+    if (packed) {
+      HIP_TRY(hipMemcpyAsync(S.d_in, gray, fbytes * nframes, hipMemcpyHostToDevice, h->s_h2d));
+    } else {
+      for (int f = 0; f < nframes; f++)
+        HIP_TRY(hipMemcpy2DAsync(S.d_in + f * fbytes, ip, gray + (size_t)f * frame_stride, stride, cols, rows,
+                                 hipMemcpyHostToDevice, h->s_h2d));
+    }
+  } else {
+    // pageable memory: bounce through the slot's pinned staging in chunks, so that the copy engine works on chunk
+    // i while the host copies chunk i + 1
+    const int chunk = 8;
+    for (int f0 = 0; f0 < nframes; f0 += chunk) {
+      const int nf = nframes - f0 < chunk ? nframes - f0 : chunk;
+      for (int f = f0; f < f0 + nf; f++) {
+        uint8_t *dst = S.h_in + f * fbytes;
+        const uint8_t *src = gray + (size_t)f * frame_stride;
+        if (stride == ip)
+          memcpy(dst, src, fbytes);
+        else
+          for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * ip, src + (size_t)y * stride, (size_t)cols);
+      }
+      HIP_TRY(hipMemcpyAsync(S.d_in + f0 * fbytes, S.h_in + f0 * fbytes, fbytes * nf, hipMemcpyHostToDevice, h->s_h2d));
+    }
+  }
+  HIP_TRY(hipEventRecord(S.ev_in, h->s_h2d));
+  HIP_TRY(hipStreamWaitEvent(h->s_main, S.ev_in, 0));
+  return submit_tail(h, S, nframes, lap0, lap1, kps, desc, capacity);
+}
+
+int vsg_orb_wait(vsg_orb *h, int ticket, int *n, int *mono_index) {
+  if (!h || ticket < 0 || !n || !mono_index) return VSG_ERR_INVALID;
+  Slot &S = h->slot[ticket % kSlots];
+  if (!S.busy || S.ticket != ticket) {
+    set_err("unknown ticket (already waited for, or never submitted)");
+    return VSG_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventSynchronize(S.ev_out));
+  S.busy = false;
+  const FrameGeom &fg = h->G.fg;
+  int status = VSG_OK;
+  for (int f = 0; f < S.nframes; f++) {
+    const int nf = S.h_counts[2 * f];
+    n[f] = nf;
+    mono_index[f] = S.h_counts[2 * f + 1];
+    if (nf > S.out_cap && (S.out_kps || S.out_desc)) {
+      set_err("caller capacity too small for the extracted keypoints");
+      status = VSG_ERR_CAPACITY;
+      continue;
+    }
+    if (S.direct || nf <= 0) continue;
+    if (S.out_kps) memcpy(S.out_kps + (size_t)f * S.out_cap, S.h_kps + (size_t)f * fg.out_cap, (size_t)nf * sizeof(KeyPointPOD));
+    if (S.out_desc) memcpy(S.out_desc + (size_t)f * S.out_cap * 32, S.h_desc + (size_t)f * fg.out_cap * 32, (size_t)nf * 32);
+  }
+  return status;
 }
 
 int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t frame_stride, int rows, int cols,
@@ -537,25 +792,9 @@ int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t f
                           int *mono_index) {
   if (!h || nframes < 1 || nframes > h->max_batch || !n || !mono_index) return VSG_ERR_INVALID;
   if (!gray || rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
-  HIP_TRY(hipSetDevice(h->device));
-  int rc = ensure_geometry(h, rows, cols);
-  if (rc != VSG_OK) return rc;
-  const FrameGeom &fg = h->G.fg;
-  hipStream_t s = h->s_main;
-  const int ip = h->in_pitch;
-  for (int f = 0; f < nframes; f++) {
-    uint8_t *dst = h->h_in + (size_t)f * rows * ip;
-    const uint8_t *src = gray + (size_t)f * frame_stride;
-    if (stride == ip)
-      memcpy(dst, src, (size_t)rows * ip);
-    else
-      for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * ip, src + (size_t)y * stride, (size_t)cols);
-  }
-  HIP_TRY(hipMemcpyAsync(h->d_in, h->h_in, (size_t)nframes * rows * ip, hipMemcpyHostToDevice, s));  // one DMA
-  const Src0 s0 = {h->d_in, (size_t)rows * ip, ip};
-  rc = enqueue_pipeline(h, s0, nframes, lap0, lap1, h->d_kps, h->d_desc, h->d_out_counts, fg.out_cap, s);
-  if (rc != VSG_OK) return rc;
-  return fetch_outputs(h, nframes, kps, desc, capacity, n, mono_index, s);
+  const int t = vsg_orb_submit_batch(h, gray, nframes, frame_stride, rows, cols, stride, lap0, lap1, kps, desc, capacity);
+  if (t < 0) return t;
+  return vsg_orb_wait(h, t, n, mono_index);
 }
 
 int vsg_orb_extract_batch_color(vsg_orb *h, const uint8_t *img, int channels, int rgb_order, int nframes,
@@ -567,25 +806,26 @@ int vsg_orb_extract_batch_color(vsg_orb *h, const uint8_t *img, int channels, in
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_geometry(h, rows, cols);
   if (rc != VSG_OK) return rc;
-  const FrameGeom &fg = h->G.fg;
-  hipStream_t s = h->s_main;
   const size_t row_bytes = (size_t)cols * channels, frame_bytes = row_bytes * rows;
-  uint8_t *d_color = nullptr;
-  HIP_TRY(hipMalloc(&d_color, frame_bytes * nframes));
-  hipError_t e = hipSuccess;
-  for (int f = 0; f < nframes && e == hipSuccess; f++)
-    e = hipMemcpy2DAsync(d_color + f * frame_bytes, row_bytes, img + (size_t)f * frame_stride, stride, row_bytes, rows,
-                         hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) {
-    rc = vsg_orb_extract_batch_device_color(h, d_color, channels, rgb_order, nframes, frame_bytes, rows, cols,
-                                            (int)row_bytes, lap0, lap1, (vsg_keypoint *)h->d_kps, h->d_desc,
-                                            h->d_out_counts, fg.out_cap, s);
-    if (rc == VSG_OK) rc = fetch_outputs(h, nframes, kps, desc, capacity, n, mono_index, s);
-  }
-  hipStreamSynchronize(s);
-  hipFree(d_color);
-  HIP_TRY(e);
-  return rc;
+  rc = ensure_scratch(h, frame_bytes * nframes);  // grows once; no allocation per call
+  if (rc != VSG_OK) return rc;
+  Slot *Sp = nullptr;
+  rc = acquire_slot(h, &Sp);
+  if (rc != VSG_OK) return rc;
+  Slot &S = *Sp;
+  // the scratch buffer is shared by consecutive colour batches: the previous batch's conversion must be done
+  HIP_TRY(hipStreamSynchronize(h->s_h2d));
+  for (int f = 0; f < nframes; f++)
+    HIP_TRY(hipMemcpy2DAsync(h->d_scratch + f * frame_bytes, row_bytes, img + (size_t)f * frame_stride, stride, row_bytes,
+                             rows, hipMemcpyHostToDevice, h->s_h2d));
+  // cvtColor of Tracking::GrabImage* into the slot's gray level-0 staging, on the upload stream
+  launch_cvt_gray(h->s_h2d, h->d_scratch, frame_bytes, (int)row_bytes, channels, rgb_order, rows, cols, S.d_in,
+                  (size_t)rows * h->in_pitch, h->in_pitch, h->gray_coeffs, h->gray_shift, nframes);
+  HIP_TRY(hipEventRecord(S.ev_in, h->s_h2d));
+  HIP_TRY(hipStreamWaitEvent(h->s_main, S.ev_in, 0));
+  const int t = submit_tail(h, S, nframes, lap0, lap1, kps, desc, capacity);
+  if (t < 0) return t;
+  return vsg_orb_wait(h, t, n, mono_index);
 }
 
 int vsg_orb_extract(vsg_orb *h, const uint8_t *gray, int rows, int cols, int stride, int lap0, int lap1,
@@ -607,6 +847,9 @@ int vsg_orb_level_size(vsg_orb *h, int level, int *w, int *ht) {
   return VSG_OK;
 }
 
+// Stage read-back of the LAST call.  Level 0 lives in the buffer that call read it from: the slot's staging for the
+// host entry points, the CALLER's device buffer for vsg_orb_extract_batch_device -- which must therefore still be
+// alive (image_pyramid(0), vsg_stereo_matches).
 static int copy_level(vsg_orb *h, const uint8_t *base, int frame, int level, int with_border, uint8_t *dst,
                       int dst_stride) {
   if (!h || !h->rows || !dst || level < 0 || level >= h->T.nlevels || frame < 0 || frame >= h->max_batch)
@@ -621,20 +864,18 @@ static int copy_level(vsg_orb *h, const uint8_t *base, int frame, int level, int
     img = h->last_src0.base + (size_t)frame * h->last_src0.frame_stride;
     ipitch = h->last_src0.pitch;
   }
-  HIP_TRY(hipStreamSynchronize(h->s_main));
-  HIP_TRY(hipStreamSynchronize(h->s_blur));
+  int rc = wait_last(h);
+  if (rc != VSG_OK) return rc;
   if (!with_border) {
     HIP_TRY(hipMemcpy2D(dst, dst_stride, img, ipitch, L.w, L.h, hipMemcpyDeviceToHost));
     return VSG_OK;
   }
   const int b = kEdgeThreshold, bw = L.w + 2 * b, bh = L.h + 2 * b;
-  uint8_t *tmp = nullptr;
-  HIP_TRY(hipMalloc(&tmp, (size_t)bw * bh));
-  launch_border_copy(h->s_main, img, L.w, L.h, ipitch, tmp, bw, b);
-  hipError_t e = hipStreamSynchronize(h->s_main);
-  if (e == hipSuccess) e = hipMemcpy2D(dst, dst_stride, tmp, bw, bw, bh, hipMemcpyDeviceToHost);
-  hipFree(tmp);
-  HIP_TRY(e);
+  rc = ensure_scratch(h, (size_t)bw * bh);
+  if (rc != VSG_OK) return rc;
+  launch_border_copy(h->s_main, img, L.w, L.h, ipitch, h->d_scratch, bw, b);
+  HIP_TRY(hipMemcpy2DAsync(dst, dst_stride, h->d_scratch, bw, bw, bh, hipMemcpyDeviceToHost, h->s_main));
+  HIP_TRY(hipStreamSynchronize(h->s_main));
   return VSG_OK;
 }
 
@@ -645,11 +886,46 @@ int vsg_orb_copy_blurred_level(vsg_orb *h, int frame, int level, uint8_t *dst, i
   return copy_level(h, h ? h->d_blur : nullptr, frame, level, 0, dst, dst_stride);
 }
 
+// One D2H for mvImagePyramid (ORBextractor.h:93) of frame `frame`: every level WITH its 19 px REFLECT_101 border,
+// packed back to back into dst (level l at offsets[l], row stride = level width + 38).  Frame::ComputeStereoMatches
+// (Frame.cc:964,1054-1069) is the only host reader.  Returns the bytes written, or the bytes needed when dst is NULL
+// or dst_bytes is too small (nothing is written then).
+int vsg_orb_copy_pyramid(vsg_orb *h, int frame, uint8_t *dst, size_t dst_bytes, size_t *offsets) {
+  if (!h || !h->rows || frame < 0 || frame >= h->max_batch) return VSG_ERR_INVALID;
+  const FrameGeom &fg = h->G.fg;
+  const int b = kEdgeThreshold;
+  size_t total = 0;
+  for (int l = 0; l < fg.nlevels; l++) {
+    if (offsets) offsets[l] = total;
+    total += (size_t)(fg.lv[l].w + 2 * b) * (fg.lv[l].h + 2 * b);
+  }
+  if (total > 0x7FFFFFFFu) return VSG_ERR_UNSUPPORTED;
+  if (!dst || dst_bytes < total) return (int)total;
+  if (!h->last_src0.base) return VSG_ERR_INVALID;
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = wait_last(h);
+  if (rc != VSG_OK) return rc;
+  rc = ensure_scratch(h, total);
+  if (rc != VSG_OK) return rc;
+  size_t off = 0;
+  for (int l = 0; l < fg.nlevels; l++) {
+    const LevelGeom &L = fg.lv[l];
+    const uint8_t *img = l == 0 ? h->last_src0.base + (size_t)frame * h->last_src0.frame_stride
+                                : h->d_pyr + (size_t)frame * fg.pyr_frame_bytes + L.img_off;
+    launch_border_copy(h->s_main, img, L.w, L.h, l == 0 ? h->last_src0.pitch : L.pitch, h->d_scratch + off, L.w + 2 * b, b);
+    off += (size_t)(L.w + 2 * b) * (L.h + 2 * b);
+  }
+  HIP_TRY(hipMemcpyAsync(dst, h->d_scratch, total, hipMemcpyDeviceToHost, h->s_main));
+  HIP_TRY(hipStreamSynchronize(h->s_main));
+  return (int)total;
+}
+
 static int copy_list(vsg_orb *h, const uint32_t *list, size_t frame_elems, int off, int lcap, const int *counts,
                      int frame, int level, uint32_t *dst, int cap) {
   if (!h || !h->rows || level < 0 || level >= h->T.nlevels || frame < 0 || frame >= h->max_batch) return VSG_ERR_INVALID;
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->s_main));
+  int rc = wait_last(h);
+  if (rc != VSG_OK) return rc;
   int n = 0;
   HIP_TRY(hipMemcpy(&n, counts + frame * kMaxLevels + level, sizeof(int), hipMemcpyDeviceToHost));
   if (n > lcap) n = lcap;
@@ -670,6 +946,8 @@ int vsg_orb_copy_selected(vsg_orb *h, int frame, int level, uint32_t *dst, int c
                    h->d_counts2 + (size_t)h->max_batch * kMaxLevels, frame, level, dst, cap);
 }
 
+}  // extern "C"
+
 static int pyr_view(vsg_orb *h, int frame, PyrView &v) {
   if (!h || !h->rows || frame < 0 || frame >= h->max_batch || !h->last_src0.base) return VSG_ERR_INVALID;
   const FrameGeom &fg = h->G.fg;
@@ -688,46 +966,18 @@ static int pyr_view(vsg_orb *h, int frame, PyrView &v) {
   return VSG_OK;
 }
 
-int vsg_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const vsg_keypoint *kps_l,
-                       const uint8_t *desc_l, int n_l, const vsg_keypoint *kps_r, const uint8_t *desc_r, int n_r,
-                       float mb, float mbf, float *u_right, float *depth) {
-  if (!hl || !hr || !u_right || !depth || n_l < 0 || n_r < 0 || hl->device != hr->device) return VSG_ERR_INVALID;
-  for (int i = 0; i < n_l; i++) u_right[i] = -1.0f, depth[i] = -1.0f;
-  if (n_l == 0 || n_r == 0) return 0;
-  PyrView pl, pr;
-  int rc = pyr_view(hl, frame_l, pl);
-  if (rc == VSG_OK) rc = pyr_view(hr, frame_r, pr);
-  if (rc != VSG_OK) return rc;
-  HIP_TRY(hipSetDevice(hl->device));
-  HIP_TRY(hipStreamSynchronize(hl->s_main));
-  HIP_TRY(hipStreamSynchronize(hr->s_main));
-  KeyPointPOD *dkl = nullptr, *dkr = nullptr;
-  uint8_t *ddl = nullptr, *ddr = nullptr;
-  float *du = nullptr, *dd = nullptr;
-  int *ds = nullptr;
-  hipError_t e = hipMalloc(&dkl, sizeof(KeyPointPOD) * n_l);
-  if (e == hipSuccess) e = hipMalloc(&dkr, sizeof(KeyPointPOD) * n_r);
-  if (e == hipSuccess) e = hipMalloc(&ddl, 32 * (size_t)n_l);
-  if (e == hipSuccess) e = hipMalloc(&ddr, 32 * (size_t)n_r);
-  if (e == hipSuccess) e = hipMalloc(&du, 4 * (size_t)n_l);
-  if (e == hipSuccess) e = hipMalloc(&dd, 4 * (size_t)n_l);
-  if (e == hipSuccess) e = hipMalloc(&ds, 4 * (size_t)n_l);
-  if (e == hipSuccess) e = hipMemcpy(dkl, kps_l, sizeof(KeyPointPOD) * n_l, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(dkr, kps_r, sizeof(KeyPointPOD) * n_r, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(ddl, desc_l, 32 * (size_t)n_l, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(ddr, desc_r, 32 * (size_t)n_r, hipMemcpyHostToDevice);
-  std::vector<int> sad((size_t)n_l, -1);
-  if (e == hipSuccess) {
-    launch_stereo(hl->s_main, pl, pr, mb, mbf, hl->T.scale.data(), hl->T.invScale.data(), hl->T.nlevels, dkl, ddl, n_l,
-                  dkr, ddr, n_r, du, dd, ds);
-    e = hipStreamSynchronize(hl->s_main);
-  }
-  if (e == hipSuccess) e = hipMemcpy(u_right, du, 4 * (size_t)n_l, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(depth, dd, 4 * (size_t)n_l, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(sad.data(), ds, 4 * (size_t)n_l, hipMemcpyDeviceToHost);
-  hipFree(dkl), hipFree(dkr), hipFree(ddl), hipFree(ddr), hipFree(du), hipFree(dd), hipFree(ds);
-  HIP_TRY(e);
-  // median-based outlier cut (Frame.cc:1113-1126)
+int vsg_orb_output_view(vsg_orb *h, int index, OrbOutputView *v) {
+  if (!h || !v || !h->have_last || index < 0 || index >= h->last_frames) return VSG_ERR_INVALID;
+  v->d_kps = h->last_kps + (size_t)index * h->last_cap;
+  v->d_desc = h->last_desc + (size_t)index * h->last_cap * 32;
+  v->d_counts = h->last_counts + 2 * index;
+  v->done = h->ev_last;
+  v->device = h->device;
+  return VSG_OK;
+}
+
+// median-based outlier cut of Frame::ComputeStereoMatches (Frame.cc:1113-1126)
+static int stereo_median_cut(const int *sad, int n_l, float *u_right, float *depth) {
   std::vector<std::pair<int, int>> vDistIdx;
   for (int i = 0; i < n_l; i++)
     if (sad[i] >= 0) vDistIdx.push_back(std::pair<int, int>(sad[i], i));
@@ -743,6 +993,77 @@ int vsg_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const
     kept--;
   }
   return kept;
+}
+
+// Frame::ComputeStereoMatches on device-resident keypoints / descriptors: one launch on the calling thread's stream,
+// results through its pinned arena.  d_kps* / d_desc* are device pointers.
+static int stereo_run(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const KeyPointPOD *dkl, const uint8_t *ddl,
+                      int n_l, const KeyPointPOD *dkr, const uint8_t *ddr, int n_r, float mb, float mbf, ThreadCtx *c,
+                      size_t out_off, float *u_right, float *depth) {
+  PyrView pl, pr;
+  int rc = pyr_view(hl, frame_l, pl);
+  if (rc == VSG_OK) rc = pyr_view(hr, frame_r, pr);
+  if (rc != VSG_OK) return rc;
+  // both extractors' last enqueues must be complete before their pyramids are read
+  if (hl->have_last) HIP_TRY(hipStreamWaitEvent(c->stream, hl->ev_last, 0));
+  if (hr->have_last) HIP_TRY(hipStreamWaitEvent(c->stream, hr->ev_last, 0));
+  const size_t N = (size_t)n_l;
+  float *du = (float *)(c->d_pin + out_off), *dd = du + N;
+  int *ds = (int *)(dd + N);
+  launch_stereo(c->stream, pl, pr, mb, mbf, hl->T.scale.data(), hl->T.invScale.data(), hl->T.nlevels, dkl, ddl, n_l, dkr,
+                ddr, n_r, du, dd, ds);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const float *hu = (const float *)(c->h_pin + out_off), *hd = hu + N;
+  const int *hs = (const int *)(hd + N);
+  memcpy(u_right, hu, N * 4);
+  memcpy(depth, hd, N * 4);
+  return stereo_median_cut(hs, n_l, u_right, depth);
+}
+
+extern "C" {
+
+int vsg_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const vsg_keypoint *kps_l,
+                       const uint8_t *desc_l, int n_l, const vsg_keypoint *kps_r, const uint8_t *desc_r, int n_r,
+                       float mb, float mbf, float *u_right, float *depth) {
+  if (!hl || !hr || !u_right || !depth || n_l < 0 || n_r < 0 || hl->device != hr->device) return VSG_ERR_INVALID;
+  for (int i = 0; i < n_l; i++) u_right[i] = -1.0f, depth[i] = -1.0f;
+  if (n_l == 0 || n_r == 0) return 0;
+  int rc = VSG_OK;
+  ThreadCtx *c = thread_ctx(hl->device, &rc);
+  if (!c) return rc;
+  // keypoints and descriptors of both eyes go up through the pinned arena (one DMA into the device arena)
+  Stage st;
+  const size_t oKL = st.add(sizeof(KeyPointPOD) * n_l), oKR = st.add(sizeof(KeyPointPOD) * n_r);
+  const size_t oDL = st.add(32 * (size_t)n_l), oDR = st.add(32 * (size_t)n_r);
+  const size_t in_bytes = st.total;
+  const size_t oOut = st.add(12 * (size_t)n_l);
+  rc = ctx_reserve(c, st.total, in_bytes);
+  if (rc != VSG_OK) return rc;
+  memcpy(c->h_pin + oKL, kps_l, sizeof(KeyPointPOD) * n_l);
+  memcpy(c->h_pin + oKR, kps_r, sizeof(KeyPointPOD) * n_r);
+  memcpy(c->h_pin + oDL, desc_l, 32 * (size_t)n_l);
+  memcpy(c->h_pin + oDR, desc_r, 32 * (size_t)n_r);
+  HIP_TRY(hipMemcpyAsync(c->d_buf, c->h_pin, in_bytes, hipMemcpyHostToDevice, c->stream));
+  return stereo_run(hl, frame_l, hr, frame_r, (const KeyPointPOD *)(c->d_buf + oKL), c->d_buf + oDL, n_l,
+                    (const KeyPointPOD *)(c->d_buf + oKR), c->d_buf + oDR, n_r, mb, mbf, c, oOut, u_right, depth);
+}
+
+int vsg_frame_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, vsg_frame *fl, vsg_frame *fr,
+                             float mb, float mbf, float *u_right, float *depth) {
+  if (!hl || !hr || !fl || !fr || !u_right || !depth || hl->device != hr->device || fl->device != hl->device ||
+      fr->device != hl->device)
+    return VSG_ERR_INVALID;
+  const int n_l = fl->n, n_r = fr->n;
+  for (int i = 0; i < n_l; i++) u_right[i] = -1.0f, depth[i] = -1.0f;
+  if (n_l == 0 || n_r == 0) return 0;
+  int rc = VSG_OK;
+  ThreadCtx *c = thread_ctx(hl->device, &rc);
+  if (!c) return rc;
+  rc = ctx_reserve(c, 12 * (size_t)n_l + 64, 0);
+  if (rc != VSG_OK) return rc;
+  return stereo_run(hl, frame_l, hr, frame_r, fl->d_kps, fl->d_desc, n_l, fr->d_kps, fr->d_desc, n_r, mb, mbf, c, 0,
+                    u_right, depth);
 }
 
 int vsg_orb_set_serialize(vsg_orb *h, int serialize) {
@@ -762,22 +1083,19 @@ int vsg_orb_enable_timing(vsg_orb *h, int enable) {
 
 int vsg_debug_device_sort(int device, uint64_t *items, int n) {
   if (!items || n < 0 || n > 2048) return VSG_ERR_INVALID;
-  if (vsg_device_count() <= device || device < 0) return VSG_ERR_NO_DEVICE;
-  if (n == 0) return VSG_OK;
-  HIP_TRY(hipSetDevice(device));
-  uint64_t *d = nullptr;
-  HIP_TRY(hipMalloc(&d, sizeof(uint64_t) * n));
-  hipError_t e = hipMemcpy(d, items, sizeof(uint64_t) * n, hipMemcpyHostToDevice);
-  if (e == hipSuccess) {
-    launch_debug_sort(nullptr, d, n);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpy(items, d, sizeof(uint64_t) * n, hipMemcpyDeviceToHost);
-  hipFree(d);
-  if (e != hipSuccess) {
-    set_err(std::string("vsg_debug_device_sort: ") + hipGetErrorString(e));
-    return VSG_ERR_HIP;
-  }
+  if (n == 0) return vsg_device_count() > device && device >= 0 ? VSG_OK : VSG_ERR_NO_DEVICE;
+  int rc = VSG_OK;
+  ThreadCtx *c = thread_ctx(device, &rc);
+  if (!c) return rc;
+  rc = ctx_reserve(c, sizeof(uint64_t) * n, sizeof(uint64_t) * n);
+  if (rc != VSG_OK) return rc;
+  memcpy(c->h_pin, items, sizeof(uint64_t) * n);
+  HIP_TRY(hipMemcpyAsync(c->d_buf, c->h_pin, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream));
+  launch_debug_sort(c->stream, (uint64_t *)c->d_buf, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(c->h_pin, c->d_buf, sizeof(uint64_t) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  memcpy(items, c->h_pin, sizeof(uint64_t) * n);
   return VSG_OK;
 }
 

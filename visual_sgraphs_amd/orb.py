@@ -42,6 +42,15 @@ EXPORTS = [
     "vsg_orb_extract_batch_device_color", "vsg_orb_extract_batch_color", "vsg_vocab_load", "vsg_vocab_destroy",
     "vsg_vocab_info", "vsg_bow_transform", "vsg_distinctive_descriptors", "vsg_debug_device_sort",
     "vsg_search_for_triangulation", "vsg_search_by_bow_kf_f_stereo",
+    # round 2: threads / staging, async host pipeline, device-resident frames, routine-level searches
+    "vsg_thread_release", "vsg_thread_arena_growths", "vsg_host_register", "vsg_host_unregister", "vsg_orb_slots",
+    "vsg_orb_submit_batch", "vsg_orb_wait", "vsg_orb_copy_pyramid", "vsg_frame_create", "vsg_frame_destroy",
+    "vsg_frame_upload", "vsg_frame_from_extractor", "vsg_frame_size", "vsg_frame_copy_grid",
+    "vsg_frame_features_in_area", "vsg_frame_search_by_projection", "vsg_frame_search_by_projection_last",
+    "vsg_frame_search_by_projection_sim3", "vsg_frame_search_by_projection_kf", "vsg_frame_search_by_sim3",
+    "vsg_frame_fuse", "vsg_frame_fuse_sim3", "vsg_fuse_decide", "vsg_frame_search_for_initialization",
+    "vsg_frame_search_by_bow_kf_f", "vsg_frame_search_by_bow_kf_kf", "vsg_frame_bow_transform",
+    "vsg_frame_stereo_matches",
 ]
 
 
@@ -139,6 +148,43 @@ def load_library():
     L.vsg_grid_destroy.argtypes = [C.c_void_p]
     L.vsg_grid_destroy.restype = None
     L.vsg_grid_query.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _i32p, _i32p, C.c_int, _i32p, _i32p, C.c_int]
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.vsg_thread_arena_growths.argtypes = [ci]
+    L.vsg_host_register.argtypes = [vp, C.c_size_t]
+    L.vsg_host_unregister.argtypes = [vp]
+    L.vsg_orb_slots.argtypes = [vp]
+    L.vsg_orb_submit_batch.argtypes = [vp, vp, ci, C.c_size_t, ci, ci, ci, ci, ci, vp, vp, ci]
+    L.vsg_orb_wait.argtypes = [vp, ci, _i32p, _i32p]
+    L.vsg_orb_copy_pyramid.argtypes = [vp, ci, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.vsg_frame_create.argtypes = [ci, ci, C.POINTER(vp)]
+    L.vsg_frame_destroy.argtypes = [vp]
+    L.vsg_frame_destroy.restype = None
+    L.vsg_frame_upload.argtypes = [vp, vp, _u8p, _f32p, ci, ci, cf, cf, cf, cf]
+    L.vsg_frame_from_extractor.argtypes = [vp, vp, ci, vp, ci, cf, cf, cf, cf]
+    L.vsg_frame_size.argtypes = [vp]
+    L.vsg_frame_copy_grid.argtypes = [vp, ci, _i32p, _i32p]
+    L.vsg_frame_features_in_area.argtypes = [vp, _f32p, _f32p, _f32p, _i32p, _i32p, ci, ci, _i32p, _i32p, ci]
+    L.vsg_frame_search_by_projection.argtypes = [vp, ci, _u8p, _u8p, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, _u8p,
+                                                 _f32p, _f32p, _i32p, _f32p, cf, cf, _f32p, ci, _i32p, _i32p, _u8p,
+                                                 _i32p]
+    L.vsg_frame_search_by_projection_last.argtypes = [vp, ci, _u8p, _u8p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p,
+                                                      _f32p, cf, ci, _f32p, ci, ci, _u8p, _i32p]
+    L.vsg_frame_search_by_projection_sim3.argtypes = [vp, ci, _u8p, _f32p, _f32p, _f32p, _i32p, cf, _i32p]
+    L.vsg_frame_search_by_projection_kf.argtypes = [vp, ci, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, ci, ci, _u8p,
+                                                    _i32p]
+    L.vsg_frame_search_by_sim3.argtypes = [vp, vp, ci, _i32p, _u8p, _f32p, _f32p, _f32p, _i32p, ci, _i32p, _u8p, _f32p,
+                                           _f32p, _f32p, _i32p, _i32p]
+    L.vsg_frame_fuse.argtypes = [vp, ci, _u8p, _f32p, _f32p, _f32p, _f32p, _i32p, ci, _f32p, ci, _i32p, _i32p]
+    L.vsg_frame_fuse_sim3.argtypes = [vp, ci, _u8p, _f32p, _f32p, _f32p, _i32p, _i32p, _i32p]
+    L.vsg_fuse_decide.argtypes = [ci, _i32p, _i32p, _i32p, ci, _i32p, ci, _i32p, _u8p, ci, _i32p, _i32p]
+    L.vsg_frame_search_for_initialization.argtypes = [vp, vp, _f32p, _f32p, ci, cf, ci, _i32p]
+    L.vsg_frame_search_by_bow_kf_f.argtypes = [vp, _u8p, _i32p, _i32p, _i32p, ci, vp, _i32p, _i32p, _i32p, ci, cf, ci,
+                                               _i32p]
+    L.vsg_frame_search_by_bow_kf_kf.argtypes = [vp, _u8p, _i32p, _i32p, _i32p, ci, vp, _u8p, _i32p, _i32p, _i32p, ci,
+                                                cf, ci, _i32p]
+    L.vsg_frame_bow_transform.argtypes = [vp, vp, ci, _i32p, _f64p, ci, _i32p, _i32p, _i32p, _i32p, ci, _i32p, _i32p,
+                                          _i32p, _f64p]
+    L.vsg_frame_stereo_matches.argtypes = [vp, ci, vp, ci, vp, vp, cf, cf, _f32p, _f32p]
     _lib = L
     return L
 
@@ -278,6 +324,46 @@ class ORBextractor:
         self._shape = (rows, cols)
         return [(int(mono[i]), kps[i, :n[i]].copy(), desc[i, :n[i]].copy()) for i in range(B)]
 
+    # ---- asynchronous host pipeline (vsg_orb_submit_batch / vsg_orb_wait)
+    def slots(self):
+        return self._L.vsg_orb_slots(self._h)
+
+    def submit_batch(self, images, kps_out, desc_out, vLappingArea=(0, 0)):
+        """images [B,H,W] uint8 (pinned via `pin()` => DMA straight from it), kps_out [B,cap] KP_DTYPE, desc_out
+        [B,cap,32] uint8 (pinned => the device writes them directly).  Returns a ticket for wait()."""
+        assert images.dtype == np.uint8 and images.ndim == 3 and images.strides[2] == 1
+        B, rows, cols = images.shape
+        cap = kps_out.shape[1]
+        assert kps_out.dtype == KP_DTYPE and kps_out.flags.c_contiguous and desc_out.flags.c_contiguous
+        t = _check(self._L.vsg_orb_submit_batch(self._h, C.c_void_p(images.ctypes.data), B, images.strides[0], rows, cols,
+                                                images.strides[1], int(vLappingArea[0]), int(vLappingArea[1]),
+                                                C.c_void_p(kps_out.ctypes.data), C.c_void_p(desc_out.ctypes.data), cap),
+                   "vsg_orb_submit_batch")
+        self._shape = (rows, cols)
+        self._inflight = getattr(self, "_inflight", {})
+        self._inflight[t] = (B, images, kps_out, desc_out)  # keep the buffers alive until the wait
+        return t
+
+    def wait(self, ticket):
+        """Blocks until the batch of `ticket` is complete.  Returns (n[B], monoIndex[B])."""
+        B = self._inflight[ticket][0]
+        n, mono = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        _check(self._L.vsg_orb_wait(self._h, int(ticket), _p(n, _i32p), _p(mono, _i32p)), "vsg_orb_wait")
+        del self._inflight[ticket]
+        return n, mono
+
+    def copy_pyramid(self, frame=0):
+        """mvImagePyramid of one frame in ONE D2H: list of bordered levels ((h+38) x (w+38) uint8 views)."""
+        offs = (C.c_size_t * self.nlevels)()
+        need = _check(self._L.vsg_orb_copy_pyramid(self._h, frame, None, 0, offs), "vsg_orb_copy_pyramid")
+        buf = np.zeros(need, np.uint8)
+        _check(self._L.vsg_orb_copy_pyramid(self._h, frame, _p(buf, _u8p), need, offs), "vsg_orb_copy_pyramid")
+        out = []
+        for l in range(self.nlevels):
+            w, h = self.level_size(l)
+            out.append(buf[offs[l]:offs[l] + (w + 38) * (h + 38)].reshape(h + 38, w + 38))
+        return out
+
     def extract_batch_device(self, d_gray, nframes, frame_stride, rows, cols, stride, d_kps, d_desc, d_counts, capacity,
                              vLappingArea=(0, 0), stream=None):
         """Raw device-pointer entry (ints / torch .data_ptr()); asynchronous on `stream`."""
@@ -384,14 +470,18 @@ class ORBmatcher:
 
     @staticmethod
     def DescriptorDistance(a, b, device=0):
-        """ORBmatcher::DescriptorDistance for one pair (or row-wise for [n,32] arrays)."""
+        """ORBmatcher::DescriptorDistance (ORBmatcher.cc:2047-2063).  One pair is eight popcounts: host arithmetic
+        (a kernel launch would cost four orders of magnitude more); [n,32] arrays go row-wise through the device."""
+        if np.ndim(a) == 1:
+            x = np.bitwise_xor(_u8(a), _u8(b))
+            return int(np.unpackbits(x).sum())
         a2, b2 = np.atleast_2d(_u8(a)), np.atleast_2d(_u8(b))
         n = len(a2)
         idx = np.arange(n, dtype=np.int32)
         out = np.zeros(n, np.int32)
         _check(load_library().vsg_hamming_pairs(device, _p(a2, _u8p), n, _p(b2, _u8p), len(b2), _p(idx, _i32p),
                                                 _p(idx, _i32p), n, _p(out, _i32p)), "vsg_hamming_pairs")
-        return int(out[0]) if np.ndim(a) == 1 else out
+        return out
 
     def hamming_pairs(self, a, b, ia, ib):
         a, b, ia, ib = _u8(a), _u8(b), _i32(ia), _i32(ib)
@@ -616,3 +706,272 @@ def ComputeDistinctiveDescriptors(desc, off, device=0):
     _check(load_library().vsg_distinctive_descriptors(int(device), _p(d, _u8p), _p(o, _i32p), len(o) - 1,
                                                       _p(best, _i32p)), "vsg_distinctive_descriptors")
     return best[:len(o) - 1]
+
+
+def pin(array):
+    """hipHostRegister a numpy array (vsg_host_register): extraction DMAs straight from / into pinned memory."""
+    a = np.ascontiguousarray(array)
+    _check(load_library().vsg_host_register(C.c_void_p(a.ctypes.data), a.nbytes), "vsg_host_register")
+    return a
+
+
+def unpin(array):
+    _check(load_library().vsg_host_unregister(C.c_void_p(array.ctypes.data)), "vsg_host_unregister")
+
+
+def thread_arena_growths(device=0):
+    return load_library().vsg_thread_arena_growths(int(device))
+
+
+def _opt(a, t, conv):
+    return (None, None) if a is None else (lambda x: (x, _p(x, t)))(conv(a))
+
+
+class Frame:
+    """What the searches read of a VS_GRAPHS::Frame / KeyFrame, resident on the device (include/vsg_orb.h: vsg_frame):
+    mvKeysUn (or mvKeys || mvKeysRight with Nleft), mDescriptors, mvuRight, mGrid / mGridRight (Frame.h:280-290)."""
+
+    def __init__(self, capacity, device=0):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        self.device = int(device)
+        _check(self._L.vsg_frame_create(self.device, int(capacity), C.byref(self._h)), "vsg_frame_create")
+        self.kps = np.zeros(0, KP_DTYPE)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.vsg_frame_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def N(self):
+        return self._L.vsg_frame_size(self._h)
+
+    def upload(self, kps, desc, bounds, u_right=None, nleft=-1):
+        """bounds = (mnMinX, mnMinY, mnMaxX, mnMaxY)."""
+        k = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+        d = _u8(desc).reshape(-1, 32)
+        assert len(k) == len(d)
+        ur = _f32(u_right) if u_right is not None else None
+        _check(self._L.vsg_frame_upload(self._h, k.ctypes.data_as(C.c_void_p), _p(d, _u8p) if len(d) else None,
+                                        _p(ur, _f32p) if ur is not None else None, len(k), int(nleft),
+                                        *[float(b) for b in bounds]), "vsg_frame_upload")
+        self.kps, self.nleft = k, int(nleft)
+        return self
+
+    def from_extractor(self, ex, index, kps, bounds):
+        """Device-to-device from frame `index` of the extractor's last call; kps = the records that call returned."""
+        k = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+        _check(self._L.vsg_frame_from_extractor(self._h, ex.handle, int(index), k.ctypes.data_as(C.c_void_p), len(k),
+                                                *[float(b) for b in bounds]), "vsg_frame_from_extractor")
+        self.kps, self.nleft = k, -1
+        return self
+
+    def grid(self, right=False):
+        cs, en = np.zeros(64 * 48 + 1, np.int32), np.zeros(max(self.N, 1), np.int32)
+        ne = _check(self._L.vsg_frame_copy_grid(self._h, int(right), _p(cs, _i32p), _p(en, _i32p)), "vsg_frame_copy_grid")
+        return cs, en[:ne]
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=None, maxLevel=None, bRight=False):
+        x, y, r = _f32(np.atleast_1d(x)), _f32(np.atleast_1d(y)), _f32(np.atleast_1d(r))
+        nq = len(x)
+        lo = _i32(np.atleast_1d(minLevel)) if minLevel is not None else None
+        hi = _i32(np.atleast_1d(maxLevel)) if maxLevel is not None else None
+        off = np.zeros(nq + 1, np.int32)
+        cap = max(1, 64 * nq)
+        while True:
+            idx = np.zeros(cap, np.int32)
+            total = _check(self._L.vsg_frame_features_in_area(
+                self._h, _p(x, _f32p), _p(y, _f32p), _p(r, _f32p), _p(lo, _i32p) if lo is not None else None,
+                _p(hi, _i32p) if hi is not None else None, int(bRight), nq, _p(off, _i32p), _p(idx, _i32p), cap),
+                "vsg_frame_features_in_area")
+            if total <= cap:
+                return off, idx[:total]
+            cap = total
+
+    # ---- ORBmatcher::SearchByProjection(Frame &F, vpMapPoints, th, ...)  (ORBmatcher.cc:42-216)
+    def SearchByProjection(self, mp, th, nnratio, scale_factors, train_blocked, left_to_right=None, right_to_left=None):
+        """mp: dict of per-map-point arrays (desc, observed, in_view, proj_x, proj_y, proj_xr, scale_level, view_cos
+        and, for Nleft != -1, in_view_r, proj_x_r, proj_y_r, scale_level_r, view_cos_r).
+        Returns (nmatches, train_match, train_blocked)."""
+        d = _u8(mp["desc"]).reshape(-1, 32)
+        n = len(d)
+        obs, inv = _u8(mp["observed"]), _u8(mp["in_view"])
+        px, py, lvl, vc = _f32(mp["proj_x"]), _f32(mp["proj_y"]), _i32(mp["scale_level"]), _f32(mp["view_cos"])
+        pxr = _f32(mp["proj_xr"]) if mp.get("proj_xr") is not None else None
+        R = {}
+        for key, conv, t in (("in_view_r", _u8, _u8p), ("proj_x_r", _f32, _f32p), ("proj_y_r", _f32, _f32p),
+                             ("scale_level_r", _i32, _i32p), ("view_cos_r", _f32, _f32p)):
+            R[key] = conv(mp[key]) if mp.get(key) is not None else None
+        sf = _f32(scale_factors)
+        ltr = _i32(left_to_right) if left_to_right is not None else None
+        rtl = _i32(right_to_left) if right_to_left is not None else None
+        tb = _u8(train_blocked).copy()
+        tm = np.full(max(len(tb), 1), -1, np.int32)
+
+        def o(a, t):
+            return _p(a, t) if a is not None else None
+        nm = _check(self._L.vsg_frame_search_by_projection(
+            self._h, n, _p(d, _u8p), _p(obs, _u8p), _p(inv, _u8p), _p(px, _f32p), _p(py, _f32p), o(pxr, _f32p),
+            _p(lvl, _i32p), _p(vc, _f32p), o(R["in_view_r"], _u8p), o(R["proj_x_r"], _f32p), o(R["proj_y_r"], _f32p),
+            o(R["scale_level_r"], _i32p), o(R["view_cos_r"], _f32p), float(th), float(np.float32(nnratio)), _p(sf, _f32p),
+            len(scale_factors), o(ltr, _i32p), o(rtl, _i32p), _p(tb, _u8p), _p(tm, _i32p)),
+            "vsg_frame_search_by_projection")
+        return nm, tm[:len(tb)], tb
+
+    # ---- SearchByProjection(CurrentFrame, LastFrame, th, bMono)  (ORBmatcher.cc:1667-1878)
+    def SearchByProjection_Last(self, desc, observed, u, v, ur, last_octave, last_angle, th, direction, scale_factors,
+                                check_orientation, train_blocked, u_r=None, v_r=None):
+        d = _u8(desc).reshape(-1, 32)
+        obs = _u8(observed)
+        uu, vv, oc, an = _f32(u), _f32(v), _i32(last_octave), _f32(last_angle)
+        ur_ = _f32(ur) if ur is not None else None
+        ur2, vr2 = (_f32(u_r), _f32(v_r)) if u_r is not None else (None, None)
+        sf = _f32(scale_factors)
+        tb = _u8(train_blocked).copy()
+        tm = np.full(max(len(tb), 1), -1, np.int32)
+        nm = _check(self._L.vsg_frame_search_by_projection_last(
+            self._h, len(d), _p(d, _u8p), _p(obs, _u8p), _p(uu, _f32p), _p(vv, _f32p),
+            _p(ur_, _f32p) if ur_ is not None else None, _p(ur2, _f32p) if ur2 is not None else None,
+            _p(vr2, _f32p) if vr2 is not None else None, _p(oc, _i32p), _p(an, _f32p), float(th), int(direction),
+            _p(sf, _f32p), len(scale_factors), int(check_orientation), _p(tb, _u8p), _p(tm, _i32p)),
+            "vsg_frame_search_by_projection_last")
+        return nm, tm[:len(tb)], tb
+
+    # ---- SearchByProjection(KeyFrame*, Sim3, vpPoints, vpMatched, th, ratioHamming)  (ORBmatcher.cc:430-641)
+    def SearchByProjection_Sim3(self, desc, u, v, radius, predicted_level, ratio_hamming, matched):
+        d = _u8(desc).reshape(-1, 32)
+        m = _i32(matched).copy()
+        nm = _check(self._L.vsg_frame_search_by_projection_sim3(
+            self._h, len(d), _p(d, _u8p), _p(_f32(u), _f32p), _p(_f32(v), _f32p), _p(_f32(radius), _f32p),
+            _p(_i32(predicted_level), _i32p), float(np.float32(ratio_hamming)), _p(m, _i32p)),
+            "vsg_frame_search_by_projection_sim3")
+        return nm, m[:len(matched)]
+
+    # ---- SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)  (ORBmatcher.cc:1880-2000)
+    def SearchByProjection_KF(self, desc, u, v, radius, predicted_level, kf_angle, orb_dist, check_orientation, occupied):
+        d = _u8(desc).reshape(-1, 32)
+        oc = _u8(occupied).copy()
+        tm = np.full(max(len(oc), 1), -1, np.int32)
+        nm = _check(self._L.vsg_frame_search_by_projection_kf(
+            self._h, len(d), _p(d, _u8p), _p(_f32(u), _f32p), _p(_f32(v), _f32p), _p(_f32(radius), _f32p),
+            _p(_i32(predicted_level), _i32p), _p(_f32(kf_angle), _f32p), int(orb_dist), int(check_orientation),
+            _p(oc, _u8p), _p(tm, _i32p)), "vsg_frame_search_by_projection_kf")
+        return nm, tm[:len(occupied)], oc
+
+    # ---- Fuse x2 (ORBmatcher.cc:1148-1446): the search part
+    def Fuse(self, desc, u, v, ur, radius, predicted_level, inv_level_sigma2, right=False):
+        d = _u8(desc).reshape(-1, 32)
+        bi, bd = np.zeros(max(len(d), 1), np.int32), np.zeros(max(len(d), 1), np.int32)
+        s2 = _f32(inv_level_sigma2)
+        nf = _check(self._L.vsg_frame_fuse(self._h, len(d), _p(d, _u8p), _p(_f32(u), _f32p), _p(_f32(v), _f32p),
+                                           _p(_f32(ur), _f32p), _p(_f32(radius), _f32p),
+                                           _p(_i32(predicted_level), _i32p), int(right), _p(s2, _f32p),
+                                           len(inv_level_sigma2), _p(bi, _i32p), _p(bd, _i32p)), "vsg_frame_fuse")
+        return nf, bi[:len(d)], bd[:len(d)]
+
+    def Fuse_Sim3(self, desc, u, v, radius, predicted_level):
+        d = _u8(desc).reshape(-1, 32)
+        bi, bd = np.zeros(max(len(d), 1), np.int32), np.zeros(max(len(d), 1), np.int32)
+        nf = _check(self._L.vsg_frame_fuse_sim3(self._h, len(d), _p(d, _u8p), _p(_f32(u), _f32p), _p(_f32(v), _f32p),
+                                                _p(_f32(radius), _f32p), _p(_i32(predicted_level), _i32p),
+                                                _p(bi, _i32p), _p(bd, _i32p)), "vsg_frame_fuse_sim3")
+        return nf, bi[:len(d)], bd[:len(d)]
+
+    def SearchForInitialization(self, f2, prev_x, prev_y, window_size, nnratio, check_orientation):
+        """self = F1, f2 = F2 (both resident)."""
+        out = np.full(max(self.N, 1), -1, np.int32)
+        nm = _check(self._L.vsg_frame_search_for_initialization(
+            self._h, f2.handle, _p(_f32(prev_x), _f32p), _p(_f32(prev_y), _f32p), int(window_size),
+            float(np.float32(nnratio)), int(check_orientation), _p(out, _i32p)), "vsg_frame_search_for_initialization")
+        return nm, out[:self.N]
+
+    def SearchByBoW_KF_F(self, kf_valid, kf_fv, f, f_fv, nnratio, check_orientation):
+        """self = KeyFrame, f = Frame (both resident).  Returns (nmatches, matchF)."""
+        kv = _u8(kf_valid)
+        kn, ko, ki = (_i32(x) for x in kf_fv)
+        fn, fo, fi = (_i32(x) for x in f_fv)
+        out = np.full(max(f.N, 1), -1, np.int32)
+        nm = _check(self._L.vsg_frame_search_by_bow_kf_f(
+            self._h, _p(kv, _u8p), _p(kn, _i32p), _p(ko, _i32p), _p(ki, _i32p), len(kf_fv[0]), f.handle, _p(fn, _i32p),
+            _p(fo, _i32p), _p(fi, _i32p), len(f_fv[0]), float(np.float32(nnratio)), int(check_orientation),
+            _p(out, _i32p)), "vsg_frame_search_by_bow_kf_f")
+        return nm, out[:f.N]
+
+    def SearchByBoW_KF_KF(self, valid1, fv1, kf2, valid2, fv2, nnratio, check_orientation):
+        v1, v2 = _u8(valid1), _u8(valid2)
+        n1, o1, i1 = (_i32(x) for x in fv1)
+        n2, o2, i2 = (_i32(x) for x in fv2)
+        out = np.full(max(self.N, 1), -1, np.int32)
+        nm = _check(self._L.vsg_frame_search_by_bow_kf_kf(
+            self._h, _p(v1, _u8p), _p(n1, _i32p), _p(o1, _i32p), _p(i1, _i32p), len(fv1[0]), kf2.handle, _p(v2, _u8p),
+            _p(n2, _i32p), _p(o2, _i32p), _p(i2, _i32p), len(fv2[0]), float(np.float32(nnratio)),
+            int(check_orientation), _p(out, _i32p)), "vsg_frame_search_by_bow_kf_kf")
+        return nm, out[:self.N]
+
+    def ComputeBoW(self, voc, levelsup=4):
+        """Frame::ComputeBoW on the resident descriptors; same dict as ORBVocabulary.transform."""
+        n = self.N
+        cap = n + 1
+        bi, bv = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        fn, fo, fi = np.zeros(cap, np.int32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+        w_of, n_of, wt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+        nb, nf = C.c_int32(), C.c_int32()
+        f64p = C.POINTER(C.c_double)
+        _check(self._L.vsg_frame_bow_transform(voc._h, self._h, int(levelsup), _p(bi, _i32p), _p(bv, f64p), cap,
+                                               C.byref(nb), _p(fn, _i32p), _p(fo, _i32p), _p(fi, _i32p), cap,
+                                               C.byref(nf), _p(w_of, _i32p), _p(n_of, _i32p), _p(wt, f64p)),
+               "vsg_frame_bow_transform")
+        return dict(bow_ids=bi[:nb.value].copy(), bow_vals=bv[:nb.value].copy(),
+                    fv=(fn[:nf.value].copy(), fo[:nf.value + 1].copy(), fi[:fo[nf.value]].copy()),
+                    word=w_of[:n].copy(), node=n_of[:n].copy(), weight=wt[:n].copy())
+
+
+def SearchBySim3(kf1, kf2, q1, q2):
+    """ORBmatcher::SearchBySim3 (ORBmatcher.cc:1448-1665) on two resident KeyFrames.  q1 / q2: dicts with idx, desc,
+    u, v, radius, level of the points projected KF1 -> KF2 and KF2 -> KF1.  Returns (nFound, matches12)."""
+    L = load_library()
+
+    def unpack(q):
+        d = _u8(q["desc"]).reshape(-1, 32)
+        return (len(d), _i32(q["idx"]), d if len(d) else np.zeros((1, 32), np.uint8), _f32(q["u"]), _f32(q["v"]),
+                _f32(q["radius"]), _i32(q["level"]))
+    a, b = unpack(q1), unpack(q2)
+    out = np.full(max(kf1.N, 1), -1, np.int32)
+    nf = _check(L.vsg_frame_search_by_sim3(
+        kf1.handle, kf2.handle, a[0], _p(a[1], _i32p), _p(a[2], _u8p), _p(a[3], _f32p), _p(a[4], _f32p), _p(a[5], _f32p),
+        _p(a[6], _i32p), b[0], _p(b[1], _i32p), _p(b[2], _u8p), _p(b[3], _f32p), _p(b[4], _f32p), _p(b[5], _f32p),
+        _p(b[6], _i32p), _p(out, _i32p)), "vsg_frame_search_by_sim3")
+    return nf, out[:kf1.N]
+
+
+def fuse_decide(query_mp, best_idx, best_dist, sim3_form, slot_mp, mp_obs, mp_bad):
+    """The ordered replace-vs-add pass of Fuse (ORBmatcher.cc:1308-1327, :1429-1444) on flattened map-point ids.
+    Returns (nFused, action, other_mp, slot_mp, mp_obs, mp_bad) -- the three state arrays are updated copies."""
+    qm, bi, bd = _i32(query_mp), _i32(best_idx), _i32(best_dist)
+    sm, ob, bad = _i32(slot_mp).copy(), _i32(mp_obs).copy(), _u8(mp_bad).copy()
+    act, oth = np.zeros(max(len(qm), 1), np.int32), np.zeros(max(len(qm), 1), np.int32)
+    nf = _check(load_library().vsg_fuse_decide(len(query_mp), _p(qm, _i32p), _p(bi, _i32p), _p(bd, _i32p),
+                                               int(sim3_form), _p(sm, _i32p), len(slot_mp), _p(ob, _i32p),
+                                               _p(bad, _u8p), len(mp_obs), _p(act, _i32p), _p(oth, _i32p)),
+                "vsg_fuse_decide")
+    return nf, act[:len(query_mp)], oth[:len(query_mp)], sm, ob, bad
+
+
+def ComputeStereoMatches_resident(ex_left, frame_l, ex_right, frame_r, fl, fr, mb, mbf):
+    """Frame::ComputeStereoMatches on two resident feature sets (vsg_frame_stereo_matches)."""
+    ur, dep = np.zeros(max(fl.N, 1), np.float32), np.zeros(max(fl.N, 1), np.float32)
+    _check(load_library().vsg_frame_stereo_matches(ex_left.handle, int(frame_l), ex_right.handle, int(frame_r),
+                                                   fl.handle, fr.handle, float(mb), float(mbf), _p(ur, _f32p),
+                                                   _p(dep, _f32p)), "vsg_frame_stereo_matches")
+    return ur[:fl.N], dep[:fl.N]
