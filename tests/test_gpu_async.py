@@ -1,0 +1,150 @@
+"""GPU tests of the asynchronous host pipeline (vsg_orb_submit_batch / vsg_orb_wait), pinned caller memory, the
+NULL-stream ordering of the device entry points and the one-copy pyramid read-back."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from visual_sgraphs_amd import orb, synth
+
+pytestmark = pytest.mark.gpu
+
+W, H, NF = 320, 240, 500
+
+
+def _frames(seed, n):
+    return np.stack([synth.sequence_frame(W, H, seed, t) for t in range(n)])
+
+
+def _oracle(frames):
+    ref = ol.OracleExtractor(NF, 1.2, 8, 20, 7)
+    return [ref(f) for f in frames]
+
+
+def _check(frames, kps, desc, n, mono):
+    for f, (rm, rk, rd) in enumerate(_oracle(frames)):
+        assert n[f] == len(rk) and mono[f] == rm
+        assert kps[f, :n[f]].tobytes() == rk.tobytes() and np.array_equal(desc[f, :n[f]], rd)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_submit_wait_three_batches_in_flight(pinned):
+    B = 4
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    assert ex.slots() == 3
+    batches = [_frames(20 + i, B) for i in range(5)]
+    outs = [(np.zeros((B, cap), orb.KP_DTYPE), np.zeros((B, cap, 32), np.uint8)) for _ in batches]
+    if pinned:
+        batches = [orb.pin(b) for b in batches]
+        outs = [(orb.pin(k), orb.pin(d)) for k, d in outs]
+    tickets = [ex.submit_batch(batches[i], *outs[i]) for i in range(3)]
+    with pytest.raises(orb.VsgError) as e:  # every slot holds an un-waited batch
+        ex.submit_batch(batches[3], *outs[3])
+    assert e.value.code == -2
+    res = [ex.wait(tickets[0])]
+    tickets.append(ex.submit_batch(batches[3], *outs[3]))  # the freed slot is reused while 1 and 2 are in flight
+    res.append(ex.wait(tickets[1]))
+    tickets.append(ex.submit_batch(batches[4], *outs[4]))
+    res += [ex.wait(t) for t in tickets[2:]]
+    for i in range(5):
+        _check(batches[i], outs[i][0], outs[i][1], *res[i])
+    with pytest.raises(orb.VsgError):
+        ex._inflight[tickets[0]] = (B, None, None, None)
+        ex.wait(tickets[0])  # a ticket can be waited for once
+    if pinned:
+        for b, (k, d) in zip(batches, outs):
+            orb.unpin(b), orb.unpin(k), orb.unpin(d)
+
+
+def test_blocking_calls_ride_the_same_pipeline():
+    """vsg_orb_extract / _batch = submit + wait; strided (non-packed) input rows and a sub-view of a larger image."""
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=2)
+    big = np.zeros((2, H + 7, W + 13), np.uint8)
+    fr = _frames(31, 2)
+    big[:, 3:3 + H, 5:5 + W] = fr
+    view = big[:, 3:3 + H, 5:5 + W]  # row stride W + 13, frame stride (H + 7) * (W + 13)
+    cap = ex.capacity(H, W)
+    kps, desc = np.zeros((2, cap), orb.KP_DTYPE), np.zeros((2, cap, 32), np.uint8)
+    t = ex.submit_batch(view, kps, desc)
+    n, mono = ex.wait(t)
+    _check(fr, kps, desc, n, mono)
+    for f, (rm, rk, rd) in zip(fr, _oracle(fr)):
+        m, k, d = ex(f)
+        assert m == rm and k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+
+
+def test_export_writes_only_n_records():
+    """D2H is sized by n: rows beyond n[f] of the caller's arrays are left untouched."""
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=2)
+    fr = _frames(41, 2)
+    fr[1] //= 8  # low contrast: far fewer keypoints than the capacity
+    fr[1] += 100
+    cap = ex.capacity(H, W)
+    for pinned in (False, True):
+        kps = np.zeros((2, cap), orb.KP_DTYPE)
+        desc = np.full((2, cap, 32), 0xAB, np.uint8)
+        if pinned:
+            kps, desc = orb.pin(kps), orb.pin(desc)
+        n, mono = ex.wait(ex.submit_batch(fr, kps, desc))
+        _check(fr, kps, desc, n, mono)
+        assert n[1] < cap - 8
+        for f in range(2):
+            assert np.all(desc[f, n[f]:] == 0xAB)
+        if pinned:
+            orb.unpin(kps), orb.unpin(desc)
+
+
+def test_null_stream_calls_are_ordered():
+    """extract_batch_device(stream = NULL) then block_best2_device(stream = NULL) behind a producer on the
+    NULL stream -- all three must be ordered without any explicit synchronisation by the caller."""
+    import ctypes as C
+
+    import torch
+    dev = torch.device("cuda", 0)
+    B = 4
+    fr = _frames(51, B)
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    L = orb.load_library()
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    best, second, arg = (torch.zeros((B - 1, cap), dtype=torch.int32, device=dev) for _ in range(3))
+    src = torch.from_numpy(fr).to(dev)
+    for rep in range(3):
+        junk = torch.randn(4096, 4096, device=dev)
+        for _ in range(4):
+            junk = junk @ junk  # keeps the NULL stream busy so that the producer below finishes late
+        d_gray = (src.to(torch.int16) + int(rep) - int(rep)).to(torch.uint8)  # producer on the NULL stream
+        ex.extract_batch_device(d_gray.data_ptr(), B, H * W, H, W, W, d_kps.data_ptr(), d_desc.data_ptr(),
+                                d_counts.data_ptr(), cap, (0, 0), None)
+        rc = L.vsg_hamming_block_best2_device(0, C.c_void_p(d_desc[1].data_ptr()), C.c_void_p(d_desc[0].data_ptr()),
+                                              cap * 32, C.c_void_p(d_counts[1].data_ptr()),
+                                              C.c_void_p(d_counts[0].data_ptr()), 2, B - 1, cap,
+                                              C.c_void_p(best.data_ptr()), C.c_void_p(second.data_ptr()),
+                                              C.c_void_p(arg.data_ptr()), None)
+        assert rc == 0
+        counts = d_counts.cpu().numpy()  # a NULL-stream copy: ordered behind both
+        kps, desc = d_kps.cpu().numpy(), d_desc.cpu().numpy()
+        ref = _oracle(fr)
+        for f, (rm, rk, rd) in enumerate(ref):
+            n = counts[f, 0]
+            assert n == len(rk) and kps[f, :n].tobytes() == rk.tobytes() and np.array_equal(desc[f, :n], rd)
+        for f in range(B - 1):
+            rb, rs, ra = ol.block_best2(ref[f + 1][2], ref[f][2])
+            n = len(rb)
+            assert np.array_equal(best[f, :n].cpu().numpy(), rb) and np.array_equal(arg[f, :n].cpu().numpy(), ra)
+        d_desc.zero_(), d_counts.zero_()
+
+
+def test_copy_pyramid_is_one_transfer_and_equals_per_level_copies():
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=2)
+    fr = _frames(61, 2)
+    ex.extract_batch(fr)
+    ref = ol.OracleExtractor(NF, 1.2, 8, 20, 7)
+    for f in range(2):
+        ref(fr[f])
+        levels = ex.copy_pyramid(f)
+        for l, lv in enumerate(levels):
+            assert np.array_equal(lv, ref.pyramid_level(l, with_border=True))
+            assert np.array_equal(lv, ex.image_pyramid(l, frame=f, with_border=True))

@@ -72,6 +72,31 @@ def debug_device_sort(items, device=0):
     return a
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64; libvsg_orb.so links the system one under the same soname.  Whichever
+    is loaded first serves both, and torch only finds its GPUs through its own copy -- so when torch is installed its
+    copy is loaded here, by path and without importing torch, before libvsg_orb.so resolves the soname.  One HIP
+    runtime per process then holds no matter whether `import torch` or this module comes first (streams and device
+    pointers are handed between the two, bench.py)."""
+    import importlib.util
+    import os
+    import sys
+    if "torch" in sys.modules or os.environ.get("VSG_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if not spec or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen libvsg_orb.so (built in-tree by visual_sgraphs_amd.build).  Fails loudly if it is missing."""
     global _lib
@@ -80,6 +105,7 @@ def load_library():
     if not LIB_PATH.exists():
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -m visual_sgraphs_amd.build` "
                            "(the ORB front-end has no CPU fallback)")
+    _share_torch_hip_runtime()
     L = C.CDLL(str(LIB_PATH))
     L.vsg_last_error.restype = C.c_char_p
     L.vsg_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
