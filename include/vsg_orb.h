@@ -297,6 +297,9 @@ int vsg_search_for_initialization(int device, const uint8_t *desc1, const float 
  * vsg_thread_arena_growths(device) = number of arena (re)allocations so far on this thread (constant in steady state). */
 int vsg_thread_release(void);
 int vsg_thread_arena_growths(int device);
+/* debug: wall time in microseconds of the calling thread's last vsg_frame_* window search -- {filling the pinned
+ * arena, the launch call, the stream synchronisation (kernel + PCIe), the whole entry point} */
+int vsg_debug_call_profile(float us[4]);
 
 /* Pin (hipHostRegister) caller memory once so that vsg_orb_submit_batch / vsg_orb_wait DMA straight from / into it
  * instead of bouncing through the handle's staging buffers (cv::Mat::data of a reused frame buffer, the keypoint /

@@ -40,7 +40,7 @@ def u_right_for(kps, rng, frac=0.6):
     return ur
 
 
-def projections(rng, src_kps, shift=(3.0, 2.0), noise=1.5, n_far=20, bounds=BOUNDS):
+def projections(rng, src_kps, shift=(-3.0, -2.0), noise=1.5, n_far=20, bounds=BOUNDS):
     """(u, v) of the source keypoints in the target frame + a few points far from any feature / outside the image."""
     n = len(src_kps)
     u = src_kps["x"] + np.float32(shift[0]) + rng.normal(0, noise, n).astype(np.float32)
@@ -83,7 +83,7 @@ def local_map_scenario(seed, stereo2=False):
               view_cos=rng.choice(np.array([0.9, 0.9985, 0.9999], np.float32), n))
     ltr = rtl = None
     if stereo2:
-        ur2, vr2 = projections(rng, src_k, shift=(3.0 + 8.0, 2.0))
+        ur2, vr2 = projections(rng, src_k, shift=(-3.0 + 8.0, -2.0))
         lvl_r = np.clip(src_k["octave"] + rng.integers(-1, 2, n), 0, 7).astype(np.int32)
         lvl_r[rng.random(n) < 0.05] = -1
         mp.update(in_view_r=(rng.random(n) < 0.7).astype(np.uint8), proj_x_r=ur2, proj_y_r=vr2, scale_level_r=lvl_r,
@@ -121,7 +121,7 @@ def last_frame_scenario(seed, stereo2=False):
                direction=int(rng.integers(0, 3)), blocked=(rng.random(len(keys)) < 0.1).astype(np.uint8), u_r=None,
                v_r=None)
     if stereo2:
-        out["u_r"], out["v_r"] = projections(rng, src_k, shift=(3.0 + 8.0, 2.0))
+        out["u_r"], out["v_r"] = projections(rng, src_k, shift=(-3.0 + 8.0, -2.0))
     return out
 
 

@@ -151,7 +151,7 @@ def test_search_by_sim3_two_directions_and_agreement(seed):
         lvl = np.clip(src_k["octave"][idx] + rng.integers(-1, 2, len(idx)), 0, 7).astype(np.int32)
         return dict(idx=idx, desc=sc.noisy_desc(rng, src_d[idx], 6), u=u, v=v,
                     radius=(np.float32(7.5) * sc.SCALE_FACTORS[lvl]).astype(np.float32), level=lvl)
-    q1, q2 = direction(k1, d1, (3.0, 2.0)), direction(k2, d2, (-3.0, -2.0))
+    q1, q2 = direction(k1, d1, (-3.0, -2.0)), direction(k2, d2, (3.0, 2.0))
     got = orb.SearchBySim3(f1, f2, q1, q2)
     ref = ol.search_by_sim3(o1, o2, q1, q2)
     assert ref[0] > 30 and got[0] == ref[0] and np.array_equal(got[1], ref[1])
@@ -238,7 +238,8 @@ def test_bow_chain_on_resident_frames(seed):
 def test_stereo_matches_resident():
     exl, exr = orb.ORBextractor(1200, 1.2, 8, 20, 7), orb.ORBextractor(1200, 1.2, 8, 20, 7)
     rl, rr = ol.OracleExtractor(1200, 1.2, 8, 20, 7), ol.OracleExtractor(1200, 1.2, 8, 20, 7)
-    L_, R_ = synth.sequence_frame(752, 480, 8, 2), synth.sequence_frame(752, 480, 8, 0)
+    from test_gpu_stereo import rectified_pair
+    L_, R_ = rectified_pair(752, 480, 77, 17)
     (_, kl, dl), (_, kr, dr) = exl(L_), exr(R_)
     rl(L_), rr(R_)
     b = (0.0, 0.0, 752.0, 480.0)

@@ -27,6 +27,10 @@ struct ThreadCtx {
   uint8_t *d_buf = nullptr;  // device scratch arena
   size_t dev_cap = 0;
   unsigned long n_grow = 0;  // arena (re)allocations so far: constant in steady state (tests assert it)
+  // monotonically increasing device counter from which the waves of k_window_search reserve their output segments;
+  // the host tracks its value (never reset: no memset per call)
+  uint32_t *d_counter = nullptr;
+  uint32_t counter_base = 0;
 };
 
 // The calling thread's context on `device` (created on first use).  nullptr + VSG_ERR_* in *rc on failure.

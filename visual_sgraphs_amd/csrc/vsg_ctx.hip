@@ -32,7 +32,8 @@ ThreadCtx *thread_ctx(int device, int *rc) {
   if ((size_t)device < t_ctx.by_device.size() && t_ctx.by_device[device]) return t_ctx.by_device[device];
   ThreadCtx *c = new ThreadCtx();
   c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void **)&c->d_counter, 256) != hipSuccess || hipMemset(c->d_counter, 0, 256) != hipSuccess) {
     delete c;
     if (rc) *rc = VSG_ERR_HIP;
     return nullptr;
@@ -101,6 +102,7 @@ int vsg_thread_release(void) {
       hipStreamSynchronize(c->stream);
       if (c->h_pin) hipHostFree(c->h_pin);
       if (c->d_buf) hipFree(c->d_buf);
+      if (c->d_counter) hipFree(c->d_counter);
       hipStreamDestroy(c->stream);
     }
     delete c;

@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+#include <time.h>
+
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -26,7 +29,7 @@ using namespace vsg;
 
 namespace {
 
-enum { VSG_RETRY = -100 };  // internal: candidate lists overflowed their stride; the entry point runs again
+enum { VSG_RETRY = -100 };  // internal: candidate lists overflowed the compact array; the entry point runs again
 
 __device__ __forceinline__ int wave_incl_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1
@@ -39,35 +42,36 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 }
 
 struct WinLaunch {
-  int nq, mode, gate_mode, best_init, stride;
+  int nq, mode, gate_mode, best_init, cap;
+  uint32_t counter_base;
   float inv_sigma2[16];
 };
 
-// ---- Frame::AssignFeaturesToGrid (Frame.cc:521-553) for keypoints [i0, i0 + n) -> CSR (cell_start, entries) with
-// entries = keypoint index - i0 in ascending order inside every cell (= the push_back order of the reference).
-// One workgroup: cells in LDS, per-cell counts by LDS atomics, one block scan, and a stable rank
-// (#{j < i : cell_j == cell_i}) per keypoint -- the j loop reads one LDS address per iteration wave-wide (broadcast).
+// ---- Frame::AssignFeaturesToGrid (Frame.cc:521-553) for keypoints [i0, i0 + n) -> CSR (cell_start, ent) with the
+// entries of every cell in ascending keypoint order (= the push_back order of the reference), index = i - i0.
+// One workgroup: per-cell counts by LDS atomics, one block scan, an unordered atomic append, then every cell's
+// (handful of) entries are put in index order by the thread that owns the cell.
 __global__ __launch_bounds__(1024) void k_frame_grid_build(const KeyPointPOD *__restrict__ kps, int i0, int n,
                                                             float minX, float minY, float invW, float invH,
-                                                            int *__restrict__ cell_start, int *__restrict__ entries) {
-  extern __shared__ __attribute__((aligned(16))) int16_t s_cell[];
+                                                            int *__restrict__ cell_start, GridEnt *__restrict__ ent) {
   __shared__ int s_cnt[kGridCells + 1];
+  __shared__ int s_fill[kGridCells];
   __shared__ int s_wtot[16];
   const int tid = threadIdx.x;
   for (int c = tid; c <= kGridCells; c += 1024) s_cnt[c] = 0;
   __syncthreads();
-  for (int i = tid; i < n; i += 1024) {
-    const KeyPointPOD kp = kps[i0 + i];
-    // PosInGrid (Frame.cc:870-880): round() = half away from zero
+  // PosInGrid (Frame.cc:870-880): round() = half away from zero
+  auto cell_of = [&](const KeyPointPOD &kp) -> int {
     const int px = (int)roundf(fmul(fsub(kp.x, minX), invW));
     const int py = (int)roundf(fmul(fsub(kp.y, minY), invH));
-    const bool in = !(px < 0 || px >= kGridCols || py < 0 || py >= kGridRows);
-    s_cell[i] = in ? (int16_t)(px * kGridRows + py) : (int16_t)-1;
-    if (in) atomicAdd(&s_cnt[px * kGridRows + py], 1);
+    return (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? -1 : px * kGridRows + py;
+  };
+  for (int i = tid; i < n; i += 1024) {
+    const int c = cell_of(kps[i0 + i]);
+    if (c >= 0) atomicAdd(&s_cnt[c], 1);
   }
   __syncthreads();
-  // exclusive scan of the 3072 counts: 3 cells per thread
-  {
+  {  // exclusive scan of the 3072 counts: 3 cells per thread
     const int c0 = tid * 3;
     const int a = s_cnt[c0], b = s_cnt[c0 + 1], c = s_cnt[c0 + 2];
     const int s = a + b + c;
@@ -78,77 +82,95 @@ __global__ __launch_bounds__(1024) void k_frame_grid_build(const KeyPointPOD *__
     for (int w = 0; w < (tid >> 6); w++) base += s_wtot[w];
     const int start = base + incl - s;
     __syncthreads();
-    s_cnt[c0] = start;
-    s_cnt[c0 + 1] = start + a;
-    s_cnt[c0 + 2] = start + a + b;
+    s_cnt[c0] = start, s_cnt[c0 + 1] = start + a, s_cnt[c0 + 2] = start + a + b;
+    s_fill[c0] = start, s_fill[c0 + 1] = start + a, s_fill[c0 + 2] = start + a + b;
     if (tid == 1023) s_cnt[kGridCells] = start + s;
   }
   __syncthreads();
   for (int c = tid; c <= kGridCells; c += 1024) cell_start[c] = s_cnt[c];
   for (int i = tid; i < n; i += 1024) {
-    const int c = s_cell[i];
+    const KeyPointPOD kp = kps[i0 + i];
+    const int c = cell_of(kp);
     if (c < 0) continue;
-    int rank = 0;
-    for (int j = 0; j < i; j++) rank += s_cell[j] == c;
-    entries[s_cnt[c] + rank] = i;
+    const int slot = atomicAdd(&s_fill[c], 1);
+    ent[slot] = {kp.x, kp.y, (uint32_t)i | ((uint32_t)(kp.octave & 0xFFFF) << 16)};
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int c = tid; c < kGridCells; c += 1024) {  // insertion sort by index: cells hold a few entries
+    const int e0 = s_cnt[c], e1 = s_cnt[c + 1];
+    for (int a = e0 + 1; a < e1; a++) {
+      const GridEnt v = ent[a];
+      int b = a - 1;
+      while (b >= e0 && (ent[b].io & 0xFFFFu) > (v.io & 0xFFFFu)) {
+        ent[b + 1] = ent[b];
+        b--;
+      }
+      ent[b + 1] = v;
+    }
   }
 }
 
 // ---- the window search (see the file header).  4 queries per 256-thread workgroup, one per wavefront.
+// List mode: every query owns an inline slot of kInline entries (one 64-byte line) in the output array, so that the
+// host's ordered pass streams through memory; a window with more candidates reserves a segment of the overflow area
+// behind the slots with ONE atomic on a never-reset device counter (the host knows its value) and writes its whole
+// list there.  {start, length} per query say where the list is.  Best mode: first minimum over the candidates.
+// Completion is the stream's: a variant whose last workgroup stamped a pinned flag for the host to spin on needed a
+// system-scope fence per wave and took 32 us instead of 13 (MI355X, 1004 queries).
+enum { kInline = 16 };
+
 __global__ __launch_bounds__(256) void k_window_search(FrameDev F, const WinQuery *__restrict__ Q,
                                                        const uint8_t *__restrict__ qdesc, WinLaunch W,
-                                                       int *__restrict__ cnt, uint32_t *__restrict__ ent,
-                                                       int *__restrict__ best) {
+                                                       int *__restrict__ off, int *__restrict__ cnt,
+                                                       uint32_t *__restrict__ out, int *__restrict__ best,
+                                                       uint32_t *__restrict__ counter) {
   const int lane = threadIdx.x & 63;
   const int q = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  if (q >= W.nq) return;
-  const WinQuery wq = Q[q];
-  uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (qdesc) {
-    const uint32_t *p = (const uint32_t *)(qdesc + (size_t)q * 32);
+  if (q < W.nq) {
+    const WinQuery wq = Q[q];
+    uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (qdesc) {
+      const uint32_t *p = (const uint32_t *)(qdesc + (size_t)q * 32);
 #pragma unroll
-    for (int k = 0; k < 8; k++) qd[k] = p[k];
-  }
-  int count = 0;  // candidates so far (wave-uniform)
-  uint32_t bestKey = 0xFFFFFFFFu;
-  int bestIdx = -1;
-  const int right = wq.flags & 1;
-  const int *cs = F.cell_start[right], *en = F.entries[right];
-  const int koff = right ? F.nleft : 0;
-  const float x = wq.x, y = wq.y, r = wq.r;
-  // (int)floor((x - mnMinX - factorX) * mfGridElementWidthInv) etc. (Frame.cc:810-832): float arithmetic
-  const int nMinCellX = max(0, (int)floorf(fmul(fsub(fsub(x, F.minX), r), F.invW)));
-  const int nMaxCellX = min(kGridCols - 1, (int)ceilf(fmul(fadd(fsub(x, F.minX), r), F.invW)));
-  const int nMinCellY = max(0, (int)floorf(fmul(fsub(fsub(y, F.minY), r), F.invH)));
-  const int nMaxCellY = min(kGridRows - 1, (int)ceilf(fmul(fadd(fsub(y, F.minY), r), F.invH)));
-  const bool active = !(wq.flags & 2) && nMinCellX < kGridCols && nMaxCellX >= 0 && nMinCellY < kGridRows &&
-                      nMaxCellY >= 0 && nMaxCellX >= nMinCellX && nMaxCellY >= nMinCellY;
-  if (active) {
-    const int ncy = nMaxCellY - nMinCellY + 1, ncell = (nMaxCellX - nMinCellX + 1) * ncy;
+      for (int k = 0; k < 8; k++) qd[k] = p[k];
+    }
+    const int right = wq.flags & 1;
+    const int *cs = F.cell_start[right];
+    const GridEnt *en = F.ent[right];
+    const int koff = right ? F.nleft : 0;
+    const float x = wq.x, y = wq.y, r = wq.r;
+    // (int)floor((x - mnMinX - factorX) * mfGridElementWidthInv) etc. (Frame.cc:810-832): float arithmetic
+    const int nMinCellX = max(0, (int)floorf(fmul(fsub(fsub(x, F.minX), r), F.invW)));
+    const int nMaxCellX = min(kGridCols - 1, (int)ceilf(fmul(fadd(fsub(x, F.minX), r), F.invW)));
+    const int nMinCellY = max(0, (int)floorf(fmul(fsub(fsub(y, F.minY), r), F.invH)));
+    const int nMaxCellY = min(kGridRows - 1, (int)ceilf(fmul(fadd(fsub(y, F.minY), r), F.invH)));
+    const bool active = !(wq.flags & 2) && nMinCellX < kGridCols && nMaxCellX >= 0 && nMinCellY < kGridRows &&
+                        nMaxCellY >= 0 && nMaxCellX >= nMinCellX && nMaxCellY >= nMinCellY;
+    const int ncy = active ? nMaxCellY - nMinCellY + 1 : 1, ncell = active ? (nMaxCellX - nMinCellX + 1) * ncy : 0;
     const bool bCheckLevels = (wq.minL > 0) || (wq.maxL >= 0);
-    // does keypoint i (grid-local index) survive GetFeaturesInArea and the routine's static gates?
-    auto pass = [&](int i, int &oct) -> bool {
-      const KeyPointPOD kp = F.kps[i + koff];
-      oct = kp.octave;
+    // does this grid entry survive GetFeaturesInArea and the routine's static gates?
+    auto pass = [&](const GridEnt &g) -> bool {
+      const int oct = (int)(int16_t)(g.io >> 16);
       if (bCheckLevels) {
-        if (kp.octave < wq.minL) return false;
-        if (wq.maxL >= 0 && kp.octave > wq.maxL) return false;
+        if (oct < wq.minL) return false;
+        if (wq.maxL >= 0 && oct > wq.maxL) return false;
       }
-      const float distx = fsub(kp.x, x), disty = fsub(kp.y, y);
+      const float distx = fsub(g.x, x), disty = fsub(g.y, y);
       if (!(fabsf(distx) < r && fabsf(disty) < r)) return false;
-      if (wq.hi >= 0 && (kp.octave < wq.lo || kp.octave > wq.hi)) return false;
+      if (wq.hi >= 0 && (oct < wq.lo || oct > wq.hi)) return false;
       if (W.gate_mode == kGateUr) {
         // F.Nleft == -1 && F.mvuRight[idx] > 0: er = fabs(ur - mvuRight[idx]); er > gate -> skip
         // (ORBmatcher.cc:97-102, 1741-1747)
         if (F.uright && F.nleft == -1) {
-          const float uR = F.uright[i];
+          const float uR = F.uright[g.io & 0xFFFFu];
           if (uR > 0 && fabsf(fsub(wq.ur, uR)) > wq.gate) return false;
         }
       } else if (W.gate_mode == kGateChi2) {
         // Fuse (ORBmatcher.cc:1267-1292): reprojection error against the keypoint, chi-square at the keypoint's level
-        const float uR = F.uright ? F.uright[i] : -1.0f;
-        const float ex = fsub(x, kp.x), ey = fsub(y, kp.y);
-        const float inv = W.inv_sigma2[kp.octave & 15];
+        const float uR = F.uright ? F.uright[g.io & 0xFFFFu] : -1.0f;
+        const float ex = fsub(x, g.x), ey = fsub(y, g.y);
+        const float inv = W.inv_sigma2[oct & 15];
         if (uR >= 0) {
           const float er = fsub(wq.ur, uR);
           const float e2 = fadd(fadd(fmul(ex, ex), fmul(ey, ey)), fmul(er, er));
@@ -160,65 +182,123 @@ __global__ __launch_bounds__(256) void k_window_search(FrameDev F, const WinQuer
       }
       return true;
     };
-    for (int c0 = 0; c0 < ncell; c0 += 64) {
-      const int c = c0 + lane;
-      int e0 = 0, e1 = 0;
-      if (c < ncell) {
-        const int cx = c / ncy, cy = c - cx * ncy;
-        const int cell = (nMinCellX + cx) * kGridRows + nMinCellY + cy;
-        e0 = cs[cell];
-        e1 = cs[cell + 1];
-      }
-      int mine = 0, oct;
-      for (int e = e0; e < e1; e++) mine += pass(en[e], oct) ? 1 : 0;
-      const int incl = wave_incl_scan(mine);
-      const int tot = __builtin_amdgcn_readlane(incl, 63);
-      if (tot == 0) continue;
-      int pos = count + incl - mine;
-      for (int e = e0; e < e1 && mine > 0; e++) {
-        const int i = en[e];
-        if (!pass(i, oct)) continue;
-        int dist = 0;
-        if (qdesc) {
-          const uint4 *d = (const uint4 *)(F.desc + (size_t)(i + koff) * 32);
-          const uint4 b0 = d[0], b1 = d[1];
-          dist = __popc(qd[0] ^ b0.x) + __popc(qd[1] ^ b0.y) + __popc(qd[2] ^ b0.z) + __popc(qd[3] ^ b0.w) +
-                 __popc(qd[4] ^ b1.x) + __popc(qd[5] ^ b1.y) + __popc(qd[6] ^ b1.z) + __popc(qd[7] ^ b1.w);
+    uint32_t bestKey = 0xFFFFFFFFu;
+    int bestIdx = -1;
+    // One walk over the window in the reference's candidate order (cells ix outer / iy inner = ascending lane, entries
+    // in cell order).  `emit(pos, i, dist, oct)` receives every surviving candidate with its list position.
+    auto walk_window = [&](auto emit) -> int {
+      int count = 0;
+      for (int c0 = 0; c0 < ncell; c0 += 64) {
+        const int c = c0 + lane;
+        int e0 = 0, e1 = 0;
+        if (c < ncell) {
+          const int cx = c / ncy, cy = c - cx * ncy;
+          const int cell = (nMinCellX + cx) * kGridRows + nMinCellY + cy;
+          e0 = cs[cell];
+          e1 = cs[cell + 1];
         }
-        if (W.mode == kWinList) {
-          if (pos < W.stride) ent[(size_t)q * W.stride + pos] = (uint32_t)i | ((uint32_t)dist << 15) | ((uint32_t)(oct & 15) << 24);
-        } else if (dist < W.best_init) {
+        // the filter runs once per entry: survivors are remembered as a bit mask (cells hold a handful of entries;
+        // a chunk with a cell of more than 32 falls back to filtering twice)
+        const bool big = __ballot(e1 - e0 > 32) != 0;
+        uint32_t mask = 0;
+        int mine = 0;
+        if (!big) {
+          for (int e = e0; e < e1; e++)
+            if (pass(en[e])) mask |= 1u << (e - e0);
+          mine = __popc(mask);
+        } else {
+          for (int e = e0; e < e1; e++) mine += pass(en[e]) ? 1 : 0;
+        }
+        const int incl = wave_incl_scan(mine);
+        const int tot = __builtin_amdgcn_readlane(incl, 63);
+        if (tot == 0) continue;
+        int pos = count + incl - mine;
+        auto one = [&](int e) {
+          const GridEnt g = en[e];
+          const int i = (int)(g.io & 0xFFFFu);
+          int dist = 0;
+          if (qdesc) {
+            const uint4 *d = (const uint4 *)(F.desc + (size_t)(i + koff) * 32);
+            const uint4 b0 = d[0], b1 = d[1];
+            dist = __popc(qd[0] ^ b0.x) + __popc(qd[1] ^ b0.y) + __popc(qd[2] ^ b0.z) + __popc(qd[3] ^ b0.w) +
+                   __popc(qd[4] ^ b1.x) + __popc(qd[5] ^ b1.y) + __popc(qd[6] ^ b1.z) + __popc(qd[7] ^ b1.w);
+          }
+          emit(pos, i, dist, (int)((g.io >> 16) & 15u));
+          pos++;
+        };
+        if (!big) {
+          while (mask) {
+            one(e0 + __builtin_ctz(mask));
+            mask &= mask - 1;
+          }
+        } else {
+          for (int e = e0; e < e1; e++)
+            if (pass(en[e])) one(e);
+        }
+        count += tot;
+      }
+      return count;
+    };
+    if (W.mode == kWinList) {
+      uint32_t *slot = out + (size_t)q * kInline;
+      const int total = walk_window([&](int pos, int i, int dist, int oct) {
+        if (pos < kInline) slot[pos] = (uint32_t)i | ((uint32_t)dist << 15) | ((uint32_t)oct << 24);
+      });
+      int start = q * kInline;
+      if (total > kInline) {  // the whole list goes to the overflow area
+        int base = 0;
+        if (lane == 0) base = (int)(atomicAdd(counter, (uint32_t)total) - W.counter_base);
+        base = __builtin_amdgcn_readfirstlane(base);
+        start = W.nq * kInline + base;
+        uint32_t *seg = out + start;
+        const int room = W.cap - base;
+        walk_window([&](int pos, int i, int dist, int oct) {
+          if (pos < room) seg[pos] = (uint32_t)i | ((uint32_t)dist << 15) | ((uint32_t)oct << 24);
+        });
+      }
+      if (lane == 0) {
+        off[q] = start;
+        cnt[q] = total;
+      }
+    } else {
+      walk_window([&](int pos, int i, int dist, int) {
+        if (dist < W.best_init) {
           const uint32_t key = ((uint32_t)dist << 16) | (uint32_t)pos;  // first minimum in candidate order
           if (key < bestKey) {
             bestKey = key;
             bestIdx = i;
           }
         }
-        pos++;
-      }
-      count += tot;
-    }
-  }
-  if (W.mode == kWinList) {
-    if (lane == 0) cnt[q] = count;
-  } else {
-    uint32_t k = bestKey;
+      });
+      uint32_t k = bestKey;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) k = min(k, __shfl_xor(k, d));
-    const uint64_t owner = __ballot(bestKey == k && bestIdx >= 0);
-    int idx = -1, dist = W.best_init;
-    if (k != 0xFFFFFFFFu && owner) {
-      idx = __builtin_amdgcn_readlane(bestIdx, __builtin_ctzll(owner));
-      dist = (int)(k >> 16);
-    }
-    if (lane == 0) {
-      best[2 * q] = idx < 0 ? -1 : idx + koff;  // index into mDescriptors (ORBmatcher.cc:1294-1295: idx += NLeft)
-      best[2 * q + 1] = dist;
+      for (int d = 32; d >= 1; d >>= 1) k = min(k, __shfl_xor(k, d));
+      const uint64_t owner = __ballot(bestKey == k && bestIdx >= 0);
+      int idx = -1, dist = W.best_init;
+      if (k != 0xFFFFFFFFu && owner) {
+        idx = __builtin_amdgcn_readlane(bestIdx, __builtin_ctzll(owner));
+        dist = (int)(k >> 16);
+      }
+      if (lane == 0) {
+        best[2 * q] = idx < 0 ? -1 : idx + koff;  // index into mDescriptors (ORBmatcher.cc:1294-1295: idx += NLeft)
+        best[2 * q + 1] = dist;
+      }
     }
   }
 }
 
-thread_local int t_stride_hint = 64;
+thread_local int t_cap_hint = 0;  // entries per query the compact candidate array is sized for (sticky, grows)
+
+// where the last window call of this thread spent its wall time (vsg_debug_call_profile): a handful of clock reads
+struct CallProf {
+  double t0 = 0, fill = 0, launch = 0, sync = 0, total = 0;
+};
+thread_local CallProf t_prof;
+inline double now_us() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
 
 }  // namespace
 
@@ -231,7 +311,7 @@ FrameDev frame_dev(const vsg_frame *f) {
   d.uright = f->has_uright ? f->d_uright : nullptr;
   for (int g = 0; g < 2; g++) {
     d.cell_start[g] = f->d_cell_start[g];
-    d.entries[g] = f->d_entries[g];
+    d.ent[g] = f->d_ent[g];
   }
   d.n = f->n;
   d.nleft = f->nleft;
@@ -241,57 +321,67 @@ FrameDev frame_dev(const vsg_frame *f) {
 
 int WindowCall::begin(int device, int nq_, int mode_, bool with_desc_, size_t arena_base, size_t arena_extra) {
   int rc = VSG_OK;
+  if (arena_base == 0) t_prof.t0 = now_us();
   c = thread_ctx(device, &rc);
   if (!c) return rc;
   nq = nq_, mode = mode_, with_desc = with_desc_, base = arena_base;
-  stride = mode == kWinList ? t_stride_hint : 0;
-  Stage st;
   const size_t Q = (size_t)(nq > 0 ? nq : 1);
+  if (t_cap_hint < 4) t_cap_hint = 4;
+  cap = mode == kWinList ? (int)(Q * (size_t)t_cap_hint) : 0;  // entries of the overflow area behind the inline slots
+  Stage st;
   oQ = st.add(Q * sizeof(WinQuery));
   oD = st.add(with_desc ? Q * 32 : 0);
+  oOff = st.add(mode == kWinList ? Q * 4 : 0);
   oCnt = st.add(mode == kWinList ? Q * 4 : 0);
-  oOut = st.add(mode == kWinList ? Q * (size_t)stride * 4 : Q * 8);
+  oOut = st.add(mode == kWinList ? (Q * kInline + (size_t)cap) * 4 : Q * 8);
   return ctx_reserve(c, base + st.total + arena_extra, 0);
 }
 
 size_t WindowCall::bytes() const {
   const size_t Q = (size_t)(nq > 0 ? nq : 1);
-  return oOut + (((mode == kWinList ? Q * (size_t)stride * 4 : Q * 8) + 63) & ~(size_t)63);
+  return oOut + (((mode == kWinList ? (Q * kInline + (size_t)cap) * 4 : Q * 8) + 63) & ~(size_t)63);
 }
 
 int WindowCall::launch(const vsg_frame *f, int gate_mode_, int best_init_, const float *inv_sigma2_, int nlevels,
                        const uint8_t *qdesc_dev) {
   frame = f;
   gate_mode = gate_mode_, best_init = best_init_;
-  WinLaunch W;
-  W.nq = nq, W.mode = mode, W.gate_mode = gate_mode, W.best_init = best_init, W.stride = stride;
-  for (int l = 0; l < 16; l++) W.inv_sigma2[l] = (inv_sigma2_ && l < nlevels) ? inv_sigma2_[l] : 0.f;
+  const double tl = now_us();
+  if (base == 0) t_prof.fill = tl - t_prof.t0;
   if (nq <= 0) return VSG_OK;
+  WinLaunch W;
+  W.nq = nq, W.mode = mode, W.gate_mode = gate_mode, W.best_init = best_init, W.cap = cap;
+  W.counter_base = c->counter_base;
+  for (int l = 0; l < 16; l++) W.inv_sigma2[l] = (inv_sigma2_ && l < nlevels) ? inv_sigma2_[l] : 0.f;
   uint8_t *d = c->d_pin + base;
   hipLaunchKernelGGL(k_window_search, dim3((nq + 3) / 4), dim3(256), 0, c->stream, frame_dev(f),
-                     (const WinQuery *)(d + oQ), qdesc_dev ? qdesc_dev : with_desc ? (const uint8_t *)(d + oD) : (const uint8_t *)nullptr, W,
-                     (int *)(d + oCnt), (uint32_t *)(d + oOut), (int *)(d + oOut));
+                     (const WinQuery *)(d + oQ),
+                     qdesc_dev ? qdesc_dev : with_desc ? (const uint8_t *)(d + oD) : (const uint8_t *)nullptr, W,
+                     (int *)(d + oOff), (int *)(d + oCnt), (uint32_t *)(d + oOut), (int *)(d + oOut), c->d_counter);
+  t_prof.launch = now_us() - tl;
   return hipGetLastError() == hipSuccess ? VSG_OK : VSG_ERR_HIP;
 }
 
 int WindowCall::finish() {
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return VSG_ERR_HIP;
+  const double ts = now_us();
+  if (nq > 0 && hipStreamSynchronize(c->stream) != hipSuccess) return VSG_ERR_HIP;
+  t_prof.sync = now_us() - ts;
   if (mode != kWinList) return VSG_OK;
   const int32_t *cn = (const int32_t *)(c->h_pin + base + oCnt);
-  int mx = 0;
-  for (int q = 0; q < nq; q++) mx = cn[q] > mx ? cn[q] : mx;
-  if (mx <= stride) return VSG_OK;
-  int s = stride;
-  while (s < mx) s *= 2;
-  t_stride_hint = s;  // sticky: the next calls of this thread start with room for windows like this one
+  long long total = 0;  // entries of the lists that went to the overflow area = what the waves added to the counter
+  for (int q = 0; q < nq; q++) total += cn[q] > kInline ? cn[q] : 0;
+  c->counter_base += (uint32_t)total;
+  if (total <= cap) return VSG_OK;
+  const long long per = (2 * total + nq - 1) / (nq > 0 ? nq : 1);
+  t_cap_hint = (int)(per > t_cap_hint ? per : 2 * t_cap_hint);  // sticky: room for windows like these from now on
   return VSG_RETRY;
 }
 
 walk::CandView WindowCall::lists() const {
   walk::CandView cv;
   cv.ent = (const uint32_t *)(c->h_pin + base + oOut);
+  cv.off = (const int32_t *)(c->h_pin + base + oOff);
   cv.cnt = (const int32_t *)(c->h_pin + base + oCnt);
-  cv.stride = stride;
   return cv;
 }
 
@@ -314,9 +404,9 @@ struct FrameLayout {
     oD = st.add(C * 32);
     oU = st.add(C * 4);
     oCS0 = st.add((kGridCells + 1) * 4);
-    oE0 = st.add(C * 4);
+    oE0 = st.add(C * sizeof(GridEnt));
     oCS1 = st.add((kGridCells + 1) * 4);
-    oE1 = st.add(C * 4);
+    oE1 = st.add(C * sizeof(GridEnt));
     total = st.total;
   }
 };
@@ -324,7 +414,7 @@ struct FrameLayout {
 // Frame::AssignFeaturesToGrid (Frame.cc:521-553) on the host for keys [i0, i0 + n): stable bucket fill with the
 // reference's float operations (PosInGrid, Frame.cc:870-880; libm round = half away from zero)
 void host_grid(const vsg_keypoint *kps, int i0, int n, float minX, float minY, float invW, float invH, int *cell_start,
-               int *entries) {
+               GridEnt *ent) {
   std::vector<int16_t> cell_of((size_t)n + 1);
   std::vector<int> cnt(kGridCells, 0);
   for (int i = 0; i < n; i++) {
@@ -342,7 +432,10 @@ void host_grid(const vsg_keypoint *kps, int i0, int n, float minX, float minY, f
   }
   cell_start[kGridCells] = run;
   for (int i = 0; i < n; i++)
-    if (cell_of[i] >= 0) entries[cnt[cell_of[i]]++] = i;  // insertion order == ascending keypoint index
+    if (cell_of[i] >= 0) {  // insertion order == ascending keypoint index
+      const vsg_keypoint &k = kps[i0 + i];
+      ent[cnt[cell_of[i]]++] = {k.x, k.y, (uint32_t)i | ((uint32_t)(k.octave & 0xFFFF) << 16)};
+    }
 }
 
 int frame_check(const vsg_frame *f) { return f && f->d_block ? VSG_OK : VSG_ERR_INVALID; }
@@ -359,7 +452,10 @@ template <class Body>
 int with_retry(Body body) {
   for (int attempt = 0; attempt < 8; attempt++) {
     const int rc = body();
-    if (rc != VSG_RETRY) return rc;
+    if (rc != VSG_RETRY) {
+      t_prof.total = now_us() - t_prof.t0;
+      return rc;
+    }
   }
   return VSG_ERR_CAPACITY;
 }
@@ -372,6 +468,14 @@ inline float radius_by_viewing_cos(float viewCos) {  // ORBmatcher::RadiusByView
 }  // namespace
 
 extern "C" {
+
+// debug: wall time (microseconds) of the calling thread's last windowed search: filling the pinned arena, the kernel
+// launch call, the wait for completion (= kernel + PCIe), and the whole entry point (the rest is the ordered host pass)
+int vsg_debug_call_profile(float us[4]) {
+  if (!us) return VSG_ERR_INVALID;
+  us[0] = (float)t_prof.fill, us[1] = (float)t_prof.launch, us[2] = (float)t_prof.sync, us[3] = (float)t_prof.total;
+  return VSG_OK;
+}
 
 int vsg_frame_create(int device, int capacity, vsg_frame **out) {
   if (!out || capacity < 1 || capacity > 32767) return VSG_ERR_INVALID;
@@ -391,9 +495,9 @@ int vsg_frame_create(int device, int capacity, vsg_frame **out) {
   f->d_desc = f->d_block + L.oD;
   f->d_uright = (float *)(f->d_block + L.oU);
   f->d_cell_start[0] = (int *)(f->d_block + L.oCS0);
-  f->d_entries[0] = (int *)(f->d_block + L.oE0);
+  f->d_ent[0] = (GridEnt *)(f->d_block + L.oE0);
   f->d_cell_start[1] = (int *)(f->d_block + L.oCS1);
-  f->d_entries[1] = (int *)(f->d_block + L.oE1);
+  f->d_ent[1] = (GridEnt *)(f->d_block + L.oE1);
   *out = f;
   return VSG_OK;
 }
@@ -426,12 +530,14 @@ int vsg_frame_upload(vsg_frame *f, const vsg_keypoint *keys, const uint8_t *desc
   if (n) memcpy(h + L.oD, desc, (size_t)n * 32);
   if (u_right && n) memcpy(h + L.oU, u_right, (size_t)n * 4);
   const int nl = nleft == -1 ? n : nleft;
-  host_grid(keys, 0, nl, f->minX, f->minY, f->invW, f->invH, (int *)(h + L.oCS0), (int *)(h + L.oE0));
+  host_grid(keys, 0, nl, f->minX, f->minY, f->invW, f->invH, (int *)(h + L.oCS0), (GridEnt *)(h + L.oE0));
   if (nleft != -1)
-    host_grid(keys, nleft, n - nleft, f->minX, f->minY, f->invW, f->invH, (int *)(h + L.oCS1), (int *)(h + L.oE1));
+    host_grid(keys, nleft, n - nleft, f->minX, f->minY, f->invW, f->invH, (int *)(h + L.oCS1), (GridEnt *)(h + L.oE1));
   else
     memset(h + L.oCS1, 0, (kGridCells + 1) * 4);
-  F_TRY(hipMemcpyAsync(f->d_block, h, L.total, hipMemcpyHostToDevice, c->stream));
+  // only the used part of every block travels: [keys | desc | uright | grid] are contiguous up to the right grid
+  const size_t used = nleft != -1 ? L.oE1 + (size_t)(n - nleft + 1) * sizeof(GridEnt) : L.oCS1 + (kGridCells + 1) * 4;
+  F_TRY(hipMemcpyAsync(f->d_block, h, used, hipMemcpyHostToDevice, c->stream));
   F_TRY(hipStreamSynchronize(c->stream));  // the frame may be searched from any thread from now on
   return VSG_OK;
 }
@@ -453,10 +559,10 @@ int vsg_frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_keyp
     F_TRY(hipMemcpyAsync(f->d_kps, v.d_kps, (size_t)n * sizeof(KeyPointPOD), hipMemcpyDeviceToDevice, c->stream));
     F_TRY(hipMemcpyAsync(f->d_desc, v.d_desc, (size_t)n * 32, hipMemcpyDeviceToDevice, c->stream));
   }
-  const size_t lds = ((size_t)n * 2 + 31) & ~(size_t)15;
-  if (!lds_limit_ensure(2, f->device, (const void *)k_frame_grid_build, lds)) return VSG_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(k_frame_grid_build, dim3(1), dim3(1024), lds, c->stream, f->d_kps, 0, n, f->minX, f->minY, f->invW,
-                     f->invH, f->d_cell_start[0], f->d_entries[0]);
+  // the grid is built from the keypoints where they already are (the extractor's output), beside the two copies
+  hipLaunchKernelGGL(k_frame_grid_build, dim3(1), dim3(1024), 0, c->stream, v.d_kps, 0, n, f->minX, f->minY, f->invW,
+                     f->invH, f->d_cell_start[0], f->d_ent[0]);
+  F_TRY(hipGetLastError());
   F_TRY(hipMemsetAsync(f->d_cell_start[1], 0, (kGridCells + 1) * 4, c->stream));
   F_TRY(hipStreamSynchronize(c->stream));
   return VSG_OK;
@@ -467,12 +573,17 @@ int vsg_frame_copy_grid(vsg_frame *f, int right, int32_t *cell_start, int32_t *e
   int rc = VSG_OK;
   ThreadCtx *c = thread_ctx(f->device, &rc);
   if (!c) return rc;
-  F_TRY(hipMemcpyAsync(cell_start, f->d_cell_start[right], (kGridCells + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+  rc = ctx_reserve(c, (kGridCells + 1) * 4 + (size_t)(f->capacity + 1) * sizeof(GridEnt) + 128, 0);
+  if (rc != VSG_OK) return rc;
+  int *hcs = (int *)c->h_pin;
+  GridEnt *he = (GridEnt *)(c->h_pin + (((kGridCells + 1) * 4 + 63) & ~63));
+  F_TRY(hipMemcpyAsync(hcs, f->d_cell_start[right], (kGridCells + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+  F_TRY(hipMemcpyAsync(he, f->d_ent[right], (size_t)f->capacity * sizeof(GridEnt), hipMemcpyDeviceToHost, c->stream));
   F_TRY(hipStreamSynchronize(c->stream));
-  const int ne = cell_start[kGridCells];
+  memcpy(cell_start, hcs, (kGridCells + 1) * 4);
+  const int ne = hcs[kGridCells];
   if (ne < 0 || ne > f->capacity) return VSG_ERR_HIP;
-  if (ne) F_TRY(hipMemcpyAsync(entries, f->d_entries[right], (size_t)ne * 4, hipMemcpyDeviceToHost, c->stream));
-  F_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < ne; i++) entries[i] = (int)(he[i].io & 0xFFFFu);
   return ne;
 }
 

@@ -13,6 +13,15 @@
 
 enum { kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows };  // FRAME_GRID_COLS / ROWS (Frame.h:49-50)
 
+namespace vsg {
+// One entry of a grid cell's vector (mGrid[ix][iy][j], Frame.h:290) with the keypoint fields GetFeaturesInArea tests
+// stored inline: a window walk reads cell_start -> entries and never chases the keypoint array.
+struct GridEnt {
+  float x, y;   // kpUn.pt
+  uint32_t io;  // feature index (grid-local) | octave << 16
+};
+}  // namespace vsg
+
 // What the searches read of one Frame (Frame.h:280-290) or KeyFrame, resident on the device.
 struct vsg_frame {
   int device = 0, capacity = 0;
@@ -24,7 +33,7 @@ struct vsg_frame {
   uint8_t *d_desc = nullptr;
   float *d_uright = nullptr;
   int *d_cell_start[2] = {nullptr, nullptr};  // [0] mGrid, [1] mGridRight: CSR over cells ix * 48 + iy
-  int *d_entries[2] = {nullptr, nullptr};
+  vsg::GridEnt *d_ent[2] = {nullptr, nullptr};
   std::vector<vsg_keypoint> h_kps;  // host mirror (angle / octave for the ordered host passes)
 };
 
@@ -36,7 +45,7 @@ struct FrameDev {
   const uint8_t *desc;
   const float *uright;  // nullptr: every mvuRight is -1
   const int *cell_start[2];
-  const int *entries[2];
+  const GridEnt *ent[2];
   int n, nleft;
   float minX, minY, invW, invH;
 };
@@ -61,8 +70,8 @@ enum { kGateNone = 0, kGateUr = 1, kGateChi2 = 2 };
 // overflowed their stride, re-runs with a larger one.
 struct WindowCall {
   ThreadCtx *c = nullptr;
-  int nq = 0, mode = kWinList, stride = 0;
-  size_t oQ = 0, oD = 0, oCnt = 0, oOut = 0;
+  int nq = 0, mode = kWinList, cap = 0;  // cap: entries the compact candidate array holds (list mode)
+  size_t oQ = 0, oD = 0, oOff = 0, oCnt = 0, oOut = 0;
   bool with_desc = true;
   // launch parameters remembered for the overflow re-run
   const vsg_frame *frame = nullptr;
@@ -75,7 +84,7 @@ struct WindowCall {
   uint8_t *desc() const { return c->h_pin + base + oD; }
   int launch(const vsg_frame *f, int gate_mode, int best_init, const float *inv_sigma2, int nlevels,
              const uint8_t *qdesc_dev = nullptr);  // qdesc_dev: query descriptors already on the device
-  int finish();  // hipStreamSynchronize + overflow handling
+  int finish();  // completion (pinned flag written by the kernel's last wave, or the stream) + overflow handling
   size_t bytes() const;
   walk::CandView lists() const;
   const int32_t *best() const { return (const int32_t *)(c->h_pin + base + oOut); }  // pairs {idx, dist}

@@ -21,14 +21,18 @@ inline int ent_idx(uint32_t e) { return (int)(e & 0x7FFFu); }
 inline int ent_dist(uint32_t e) { return (int)((e >> 15) & 0x1FFu); }
 inline int ent_oct(uint32_t e) { return (int)((e >> 24) & 0xFu); }
 
-// Per-query candidate lists, either CSR (off != nullptr) or fixed stride (cnt + stride).
+// Per-query candidate lists: CSR (off[nq + 1], cnt == nullptr) or segments (off[q] = start, cnt[q] = length -- what
+// the device writes: every query reserves its segment of one compact array, in no particular order).
 struct CandView {
   const uint32_t *ent = nullptr;
-  const int32_t *off = nullptr;  // CSR offsets [nq + 1]
-  const int32_t *cnt = nullptr;  // fixed-stride form: entries of q at ent + q * stride, cnt[q] of them
-  int stride = 0;
-  const uint32_t *begin(int q) const { return off ? ent + off[q] : ent + (size_t)q * stride; }
-  int size(int q) const { return off ? off[q + 1] - off[q] : cnt[q]; }
+  const int32_t *off = nullptr;
+  const int32_t *cnt = nullptr;
+  const uint32_t *begin(int q) const { return ent + off[q]; }
+  int size(int q) const { return cnt ? cnt[q] : off[q + 1] - off[q]; }
+  // the device has just written these lists: every line is a miss; ask for the list of a later query early
+  void prefetch(int q, int nq) const {
+    if (q < nq) __builtin_prefetch(ent + off[q]);
+  }
 };
 
 // rotation-consistency bin (e.g. ORBmatcher.cc:351-356, 1771-1777)
@@ -85,7 +89,10 @@ inline int search_last(const CandView &cv, int nq, int nleft, const float *q_ang
                        int32_t *train_match) {
   int nmatches = 0;
   std::vector<int> rotHist[HISTO_LENGTH];
+  const int nall = nleft != -1 ? 2 * nq : nq;
   for (int q = 0; q < nq; q++) {
+    cv.prefetch(q + 8, nall);
+    if (nleft != -1) cv.prefetch(nq + q + 8, nall);
     const int n = cv.size(q);
     if (n == 0) continue;  // vIndices2.empty() (:1727) -- skips the right block of this map point as well
     const uint32_t *e = cv.begin(q);
@@ -166,7 +173,10 @@ inline int search_local(const CandView &cv, int n_mp, int nleft, const uint8_t *
                         const int32_t *left_to_right, const int32_t *right_to_left, uint8_t *train_blocked,
                         int32_t *train_match) {
   int nmatches = 0;
+  const int nall = nleft != -1 ? 2 * n_mp : n_mp;
   for (int q = 0; q < n_mp; q++) {
+    cv.prefetch(q + 8, nall);
+    if (nleft != -1) cv.prefetch(n_mp + q + 8, nall);
     const bool inR = nleft != -1 && in_view_r && in_view_r[q];
     if (!in_view[q] && !inR) continue;  // :50-51
     const uint8_t blocks = mp_observed ? mp_observed[q] : 0;
@@ -231,6 +241,7 @@ inline void scan_best(const uint32_t *e, int n, Taken taken, int init, int &best
 inline int search_sim3_projection(const CandView &cv, int nq, float ratio_hamming, int32_t *matched) {
   int nmatches = 0;
   for (int q = 0; q < nq; q++) {
+    cv.prefetch(q + 8, nq);
     const int n = cv.size(q);
     if (n == 0) continue;  // :487-488
     int bestDist, bestIdx;
@@ -250,6 +261,7 @@ inline int search_kf_projection(const CandView &cv, int nq, const float *kf_angl
   int nmatches = 0;
   std::vector<int> rotHist[HISTO_LENGTH];
   for (int q = 0; q < nq; q++) {
+    cv.prefetch(q + 8, nq);
     const int n = cv.size(q);
     if (n == 0) continue;  // :1936-1937
     int bestDist, bestIdx2;
@@ -278,6 +290,7 @@ inline int search_initialization(const CandView &cv, int n1, int n2, const int32
   std::vector<int> vMatchedDistance((size_t)n2, 0x7FFFFFFF), vnMatches21((size_t)n2, -1);
   std::vector<int> rotHist[HISTO_LENGTH];
   for (int i1 = 0; i1 < n1; i1++) {
+    cv.prefetch(i1 + 8, n1);
     if (octave1 && octave1[i1] > 0) continue;  // :659-661
     const int n = cv.size(i1);
     if (n == 0) continue;

@@ -43,7 +43,7 @@ EXPORTS = [
     "vsg_vocab_info", "vsg_bow_transform", "vsg_distinctive_descriptors", "vsg_debug_device_sort",
     "vsg_search_for_triangulation", "vsg_search_by_bow_kf_f_stereo",
     # round 2: threads / staging, async host pipeline, device-resident frames, routine-level searches
-    "vsg_thread_release", "vsg_thread_arena_growths", "vsg_host_register", "vsg_host_unregister", "vsg_orb_slots",
+    "vsg_thread_release", "vsg_thread_arena_growths", "vsg_debug_call_profile", "vsg_host_register", "vsg_host_unregister", "vsg_orb_slots",
     "vsg_orb_submit_batch", "vsg_orb_wait", "vsg_orb_copy_pyramid", "vsg_frame_create", "vsg_frame_destroy",
     "vsg_frame_upload", "vsg_frame_from_extractor", "vsg_frame_size", "vsg_frame_copy_grid",
     "vsg_frame_features_in_area", "vsg_frame_search_by_projection", "vsg_frame_search_by_projection_last",
