@@ -77,6 +77,103 @@ def cpu_baseline(w, h, nfeatures, frames, budget_s, threads):
     return ol.bench_throughput(np.stack(frames), nfeatures, threads, budget_s, do_match=True)
 
 
+def host_api_leg(W, H, nfeat, device, batch=64, seconds=1.5):
+    """Throughput THROUGH the drop-in boundary: host uint8 frames in, keypoint / descriptor records out
+    (vsg_orb_submit_batch / vsg_orb_wait, three batches in flight), with pinned (vsg_host_register) and with pageable
+    caller memory, and the latency of one blocking single-frame operator().  PCIe-inclusive: never `value`."""
+    from visual_sgraphs_amd import orb, synth
+    ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, device=device, max_batch=batch)
+    cap = ex.capacity(H, W)
+    nslot = ex.slots()
+    ring_in = [np.stack([synth.sequence_frame(W, H, 2000 + r, t) for t in range(batch)]) for r in range(nslot)]
+    out = {"batch": batch, "slots": nslot}
+    for mode in ("pinned", "pageable"):
+        ins = [orb.pin(a) for a in ring_in] if mode == "pinned" else ring_in
+        outs = [(np.zeros((batch, cap), orb.KP_DTYPE), np.zeros((batch, cap, 32), np.uint8)) for _ in range(nslot)]
+        if mode == "pinned":
+            outs = [(orb.pin(k), orb.pin(d)) for k, d in outs]
+        tickets, done, k = [], 0, 0
+        t_end = None
+        t0 = time.perf_counter()
+        warm = 2 * nslot
+        while True:
+            if k == warm:
+                t0 = time.perf_counter()
+                t_end = t0 + seconds
+            tickets.append(ex.submit_batch(ins[k % nslot], *outs[k % nslot]))
+            k += 1
+            if len(tickets) == nslot:
+                n, _ = ex.wait(tickets.pop(0))
+                done += 1
+            if t_end is not None and time.perf_counter() >= t_end:
+                break
+        while tickets:
+            n, _ = ex.wait(tickets.pop(0))
+            done += 1
+        dt = time.perf_counter() - t0
+        out[f"{mode}_frames_per_s"] = round((k - warm) * batch / dt, 1)
+        out[f"{mode}_keypoints_last_frame"] = int(n[-1])
+        if mode == "pinned":
+            for a in ins:
+                orb.unpin(a)
+            for kk, dd in outs:
+                orb.unpin(kk), orb.unpin(dd)
+    img = ring_in[0][0]
+    for _ in range(20):
+        ex(img)
+    t0 = time.perf_counter()
+    reps = 200
+    for _ in range(reps):
+        ex(img)
+    out["single_frame_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+    out["note"] = ("host memory in, host memory out through vsg_orb_submit_batch / vsg_orb_wait (H2D, kernels and the "
+                   "n-sized export of three batches overlap); PCIe-inclusive, not `value`")
+    return out
+
+
+def matcher_latency_leg():
+    """Per-call latency of the per-frame ORBmatcher entry points on device-resident frames, from plain C++
+    (tools/abi_latency.cpp), next to the CPU oracle's routine on one host thread."""
+    import subprocess
+    exe = ROOT / "tools" / "_bin" / "abi_latency"
+    if not exe.exists():
+        return {"error": "tools/_bin/abi_latency not built (make -C tools)"}
+    try:
+        r = subprocess.run([str(exe), "300"], capture_output=True, text=True, timeout=120)
+        if r.returncode != 0:
+            return {"error": r.stderr.strip()[-300:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
+
+
+def device_rate(workload, batch, steps, device):
+    """Device-resident extract-only rate of another BASELINE config (a claim the driver cannot see otherwise)."""
+    import torch
+    from visual_sgraphs_amd import orb, synth
+    W, H, nfeat = WORKLOADS[workload]
+    dev = torch.device("cuda", device)
+    ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, device=device, max_batch=batch)
+    cap = ex.capacity(H, W)
+    frames = np.stack([synth.sequence_frame(W, H, 3000, t) for t in range(min(batch, 16))])
+    frames = np.concatenate([frames] * ((batch + len(frames) - 1) // len(frames)))[:batch]
+    d_gray = torch.from_numpy(frames).to(dev)
+    d_kps = torch.zeros((batch, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((batch, cap, 32), dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros((batch, 2), dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    for i in range(steps + 3):
+        if i == 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        ex.extract_batch_device(d_gray.data_ptr(), batch, H * W, H, W, W, d_kps.data_ptr(), d_desc.data_ptr(),
+                                d_counts.data_ptr(), cap, (0, 0), st.cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": f"{workload}: {W}x{H}, nFeatures={nfeat}, extract only", "frames_per_step": batch,
+            "frames_per_s": round(batch * steps / dt, 1), "keypoints_per_frame": round(float(d_counts[:, 0].float().mean()), 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +188,8 @@ def main():
                          "kernels of batch k+1, two record buffers in flight)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget per CPU baseline leg (0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs outside the timed region (host API, matcher latency, C4 rate)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo for dry runs")
     ap.add_argument("--one-device", action="store_true",
                     help="dry run of the multi-rank path on a single GPU: every rank uses device 0 (needs gloo)")
@@ -334,6 +433,19 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
     }
     out.update(extra)
+    if world == 1 and not args.no_extras:
+        # claims the driver cannot otherwise see, each behind a short budget, all OUTSIDE the timed region
+        del d_gray, d_kps, d_desc, d_best, d_second, d_arg
+        torch.cuda.empty_cache()
+        try:
+            out["host_api"] = host_api_leg(W, H, nfeat, local_rank)
+        except Exception as e:  # noqa: BLE001
+            out["host_api"] = {"error": str(e)}
+        out["matcher_latency"] = matcher_latency_leg()
+        try:
+            out["other_configs"] = [device_rate("C4", 128, 10, local_rank)]
+        except Exception as e:  # noqa: BLE001
+            out["other_configs"] = {"error": str(e)}
     print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

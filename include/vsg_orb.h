@@ -464,6 +464,37 @@ int vsg_frame_bow_transform(vsg_vocab *voc, vsg_frame *f, int levelsup, int32_t 
 int vsg_frame_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, vsg_frame *fl, vsg_frame *fr,
                              float mb, float mbf, float *u_right, float *depth);
 
+/* ---- Frame sharding over the GPUs of one node (one process per GPU) -------------------------------
+ * The reference has no distributed layer.  Extraction shards by frame (or camera stream) with no collective; the
+ * neighbour's features that matching frame t against t-1 needs travel as fixed-capacity per-frame records
+ *   { int32 n, int32 monoIndex, pad to 16 | KeyPoint[cap] (padded to 16) | uint8 desc[cap][32] | pad to 64 }
+ * in ONE ncclAllGather (RCCL over xGMI) per batch, enqueued on the caller's stream.  RCCL is loaded on first use
+ * (dlopen); VSG_ERR_UNSUPPORTED when it is not available.
+ *   vsg_shard_unique_id   rank 0 creates the 128-byte ncclUniqueId; the caller hands it to every rank (MPI, a file,
+ *                         torch.distributed.broadcast, ...)
+ *   vsg_shard_create      ncclCommInitRank + the send / receive record buffers for `frames_per_rank` frames per batch
+ *   vsg_shard_all_gather  packs this rank's batch (the device outputs of vsg_orb_extract_batch_device: d_counts
+ *                         [nframes][2], d_kps / d_desc [nframes][src_capacity]) and all-gathers; asynchronous on `stream`
+ *   vsg_shard_record      device pointers of frame `frame` of rank `rank` in the gathered block: they can be passed
+ *                         straight to vsg_hamming_block_best2_device / vsg_frame_* (valid until the next all-gather)
+ *   vsg_shard_frame_owner / vsg_shard_stream_owner   the partition: frame f -> rank f mod world; camera stream s of
+ *                         n_streams -> rank s (world <= n_streams: s mod world), a stream's frames round-robin over the
+ *                         ranks {s, s + n_streams, ...} when there are more ranks than streams (4 cameras on 8 GPUs) */
+typedef struct vsg_shard vsg_shard;
+const char *vsg_shard_last_error(void);
+size_t vsg_shard_record_bytes(int capacity);
+size_t vsg_shard_record_desc_offset(int capacity);
+int vsg_shard_frame_owner(int frame, int world);
+int vsg_shard_stream_owner(int stream, int n_streams, int world, int frame);
+int vsg_shard_unique_id(uint8_t id[128]);
+int vsg_shard_create(int device, int rank, int world, const uint8_t id[128], int capacity, int frames_per_rank,
+                     vsg_shard **out);
+void vsg_shard_destroy(vsg_shard *s);
+int vsg_shard_all_gather(vsg_shard *s, const int *d_counts, const vsg_keypoint *d_kps, const uint8_t *d_desc,
+                         int src_capacity, int nframes, void *stream);
+int vsg_shard_record(vsg_shard *s, int rank, int frame, const int **d_counts, const vsg_keypoint **d_kps,
+                     const uint8_t **d_desc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@
 // and a `mvImagePyramid` refresh for Frame::ComputeStereoMatches (Frame.cc:964,1054-1069).
 // See INTEGRATION.md for the three-line change in Tracking.cc / Frame.cc that swaps the extractor.
 #pragma once
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -85,20 +86,32 @@ class ORBextractor {
       desc.rowRange(0, n).copyTo(_descriptors);
     return mono;
   }
-  // Refresh mvImagePyramid[level] (bordered buffer + ROI view, as ComputePyramid leaves it) on demand;
-  // only the stereo matcher reads it.
-  void DownloadPyramid() {
+  // Refresh mvImagePyramid (bordered buffers + ROI views, as ComputePyramid leaves them) on demand; only the stereo
+  // matcher reads it (Frame.cc:964,1054-1069).  ONE device-to-host copy for all levels into a buffer that is reused
+  // from call to call; the cv::Mat headers point into it (no allocation, no per-level transfer).
+  void DownloadPyramid(int frame = 0) {
+    std::vector<size_t> off(nlevels_);
+    const int need = vsg_orb_copy_pyramid(h_, frame, nullptr, 0, off.data());
+    if (need < 0) CV_Error(cv::Error::StsError, vsg_last_error());
+    if (pyr_host_.size() < (size_t)need) pyr_host_.resize((size_t)need);
+    if (vsg_orb_copy_pyramid(h_, frame, pyr_host_.data(), pyr_host_.size(), off.data()) < 0)
+      CV_Error(cv::Error::StsError, vsg_last_error());
     for (int l = 0; l < nlevels_; l++) {
       int w = 0, h = 0;
       vsg_orb_level_size(h_, l, &w, &h);
-      cv::Mat temp(h + 38, w + 38, CV_8UC1);
-      vsg_orb_copy_pyramid_level(h_, 0, l, 1, temp.data, (int)temp.step);
+      cv::Mat temp(h + 38, w + 38, CV_8UC1, pyr_host_.data() + off[l], (size_t)(w + 38));
       mvImagePyramid[l] = temp(cv::Rect(19, 19, w, h));
     }
   }
   std::vector<cv::Mat> mvImagePyramid;  // ORBextractor.h:93
 #endif
 
+  // keypoint capacity per frame for images of this size (>= nfeatures + 3 * nlevels)
+  int capacity(int rows, int cols) const {
+    const int cap = vsg_orb_capacity(h_, rows, cols);
+    if (cap < 0) throw std::runtime_error(std::string("vsg_orb_capacity: ") + vsg_last_error());
+    return cap;
+  }
   int GetLevels() const { return nlevels_; }
   float GetScaleFactor() const { return scaleFactor_; }
   std::vector<float> GetScaleFactors() const { return scale_; }
@@ -112,15 +125,23 @@ class ORBextractor {
   int nlevels_;
   float scaleFactor_;
   std::vector<float> scale_, inv_scale_, sigma2_, inv_sigma2_;
+#ifdef VSG_WITH_OPENCV
+  std::vector<uint8_t> pyr_host_;  // backing store of mvImagePyramid
+#endif
 };
 
-// static int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)  (ORBmatcher.h:40)
-inline int DescriptorDistance(const uint8_t *a, const uint8_t *b, int device = 0) {
-  const int32_t zero = 0;
-  int32_t d = -1;
-  int rc = vsg_hamming_pairs(device, a, 1, b, 1, &zero, &zero, 1, &d);
-  if (rc != VSG_OK) throw std::runtime_error("vsg_hamming_pairs failed");
-  return d;
+// static int ORBmatcher::DescriptorDistance(const cv::Mat &a, const cv::Mat &b)  (ORBmatcher.h:40, .cc:2047-2063).
+// One pair is eight 32-bit popcounts: host arithmetic (a kernel launch costs four orders of magnitude more); bulk
+// distances go through vsg_hamming_pairs / the search entry points.
+inline int DescriptorDistance(const uint8_t *a, const uint8_t *b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t x, y;
+    std::memcpy(&x, a + 4 * i, 4);
+    std::memcpy(&y, b + 4 * i, 4);
+    dist += __builtin_popcount(x ^ y);
+  }
+  return dist;
 }
 
 inline void check(int rc, const char *what) {
@@ -230,9 +251,7 @@ class ORBmatcher {
   explicit ORBmatcher(float nnratio = 0.6f, bool checkOri = true, int device = 0)
       : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device) {}
 
-  static int DescriptorDistance(const uint8_t *a, const uint8_t *b, int device = 0) {
-    return vsg::DescriptorDistance(a, b, device);
-  }
+  static int DescriptorDistance(const uint8_t *a, const uint8_t *b) { return vsg::DescriptorDistance(a, b); }
 
   // SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches)  (ORBmatcher.cc:226-428)
   // kfValid[i] = (vpMapPointsKF[i] && !isBad()); matchF[iF] = KF feature index or -1.
@@ -383,6 +402,197 @@ inline std::vector<int32_t> ComputeDistinctiveDescriptors(const uint8_t *desc, c
   if (!best.empty()) check(vsg_distinctive_descriptors(device, desc, off.data(), (int)best.size(), best.data()),
                            "vsg_distinctive_descriptors");
   return best;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Device-resident features of a Frame / KeyFrame (include/vsg_orb.h: vsg_frame): what the searches read -- mvKeysUn
+// (or mvKeys || mvKeysRight with Nleft), mDescriptors, mvuRight, mGrid / mGridRight (Frame.h:280-290) -- stays on the
+// GPU between calls.  A maintainer adds one `std::shared_ptr<vsg::ResidentFrame> mpResident` to Frame and KeyFrame
+// (KeyFrame's constructor copies the pointer from the Frame it is built from, like it copies mGrid, KeyFrame.cc:37-60)
+// and fills it at the end of the Frame constructors, after UndistortKeyPoints / ComputeStereo* / AssignFeaturesToGrid.
+class ResidentFrame {
+ public:
+  explicit ResidentFrame(int capacity, int device = 0) {
+    check(vsg_frame_create(device, capacity, &f_), "vsg_frame_create");
+  }
+  ~ResidentFrame() { vsg_frame_destroy(f_); }
+  ResidentFrame(const ResidentFrame &) = delete;
+  ResidentFrame &operator=(const ResidentFrame &) = delete;
+  // keys = mvKeysUn (Nleft == -1) or mvKeys followed by mvKeysRight; uRight = mvuRight.data() or nullptr
+  void Upload(const vsg_keypoint *keys, const uint8_t *desc, const float *uRight, int N, int Nleft, float mnMinX,
+              float mnMinY, float mnMaxX, float mnMaxY) {
+    check(vsg_frame_upload(f_, keys, desc, uRight, N, Nleft, mnMinX, mnMinY, mnMaxX, mnMaxY), "vsg_frame_upload");
+  }
+  // straight out of the extractor that just ran (no distortion: mvKeysUn == mvKeys)
+  void FromExtractor(const ORBextractor &ex, const std::vector<vsg_keypoint> &keys, float mnMinX, float mnMinY,
+                     float mnMaxX, float mnMaxY, int index = 0) {
+    check(vsg_frame_from_extractor(f_, ex.handle(), index, keys.data(), (int)keys.size(), mnMinX, mnMinY, mnMaxX, mnMaxY),
+          "vsg_frame_from_extractor");
+  }
+  int N() const { return vsg_frame_size(f_); }
+  vsg_frame *handle() const { return f_; }
+
+  // Frame::GetFeaturesInArea / KeyFrame::GetFeaturesInArea for many windows at once
+  Candidates GetFeaturesInArea(const float *x, const float *y, const float *r, const int32_t *minLevel,
+                               const int32_t *maxLevel, int nq, bool bRight = false) const {
+    Candidates c;
+    c.off.resize(nq + 1);
+    c.idx.resize(32 * (size_t)nq + 64);
+    int total = vsg_frame_features_in_area(f_, x, y, r, minLevel, maxLevel, bRight, nq, c.off.data(), c.idx.data(),
+                                           (int)c.idx.size());
+    check(total, "vsg_frame_features_in_area");
+    if (total > (int)c.idx.size()) {
+      c.idx.resize(total);
+      check(vsg_frame_features_in_area(f_, x, y, r, minLevel, maxLevel, bRight, nq, c.off.data(), c.idx.data(), total),
+            "vsg_frame_features_in_area");
+    }
+    c.idx.resize(total);
+    return c;
+  }
+
+ private:
+  vsg_frame *f_ = nullptr;
+};
+
+// Projected map points as the routines' geometry code leaves them (one entry per point that passed the routine's
+// visibility / distance tests); see include/vsg_orb.h for which members each search reads.
+struct ProjectedPoints {
+  std::vector<uint8_t> desc;       // n x 32: pMP->GetDescriptor()
+  std::vector<uint8_t> observed;   // pMP->Observations() > 0
+  std::vector<float> u, v, ur;     // projection (ur = u - mbf * invz where the routine uses it)
+  std::vector<float> radius;       // th * mvScaleFactors[level]
+  std::vector<int32_t> level;      // nPredictedLevel / nLastOctave
+  std::vector<float> angle;        // keypoint angle of the source feature (rotation check)
+  std::vector<float> uR, vR;       // right-camera projection (Nleft != -1)
+  int n() const { return (int)level.size(); }
+};
+
+// The remaining ORBmatcher searches on resident frames (ORBmatcher.h:44-87).  Outputs are feature -> query-index maps;
+// the maintainer's glue writes the MapPoint* assignments back.
+class ResidentMatcher {
+ public:
+  static const int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;
+  explicit ResidentMatcher(float nnratio = 0.6f, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+  // SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)  (ORBmatcher.cc:1667-1878)
+  // direction: 0 neither, 1 bForward, 2 bBackward.  trainBlocked[i] = mvpMapPoints[i] && Observations() > 0 (in/out).
+  int SearchByProjection(ResidentFrame &CurrentFrame, const ProjectedPoints &last, float th, int direction,
+                         const std::vector<float> &mvScaleFactors, std::vector<uint8_t> &trainBlocked,
+                         std::vector<int32_t> &trainMatch) const {
+    trainMatch.assign(CurrentFrame.N(), -1);
+    trainBlocked.resize(CurrentFrame.N(), 0);
+    int rc = vsg_frame_search_by_projection_last(
+        CurrentFrame.handle(), last.n(), last.desc.data(), last.observed.data(), last.u.data(), last.v.data(),
+        last.ur.empty() ? nullptr : last.ur.data(), last.uR.empty() ? nullptr : last.uR.data(),
+        last.vR.empty() ? nullptr : last.vR.data(), last.level.data(), last.angle.data(), th, direction,
+        mvScaleFactors.data(), (int)mvScaleFactors.size(), mbCheckOrientation, trainBlocked.data(), trainMatch.data());
+    check(rc, "vsg_frame_search_by_projection_last");
+    return rc;
+  }
+
+  // SearchByProjection(KeyFrame *pKF, Sim3f &Scw, vpPoints, vpMatched, th, ratioHamming)  (ORBmatcher.cc:430-528) and
+  // its twin with vpPointsKFs / vpMatchedKF (:530-641): matched[i] != -1 = vpMatched[i] is set; new entries = query index
+  int SearchByProjection(ResidentFrame &pKF, const ProjectedPoints &pts, float ratioHamming,
+                         std::vector<int32_t> &matched) const {
+    matched.resize(pKF.N(), -1);
+    int rc = vsg_frame_search_by_projection_sim3(pKF.handle(), pts.n(), pts.desc.data(), pts.u.data(), pts.v.data(),
+                                                 pts.radius.data(), pts.level.data(), ratioHamming, matched.data());
+    check(rc, "vsg_frame_search_by_projection_sim3");
+    return rc;
+  }
+
+  // SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist)  (ORBmatcher.cc:1880-2000)
+  int SearchByProjection(ResidentFrame &CurrentFrame, const ProjectedPoints &kfPoints, int ORBdist,
+                         std::vector<uint8_t> &occupied, std::vector<int32_t> &trainMatch) const {
+    trainMatch.assign(CurrentFrame.N(), -1);
+    occupied.resize(CurrentFrame.N(), 0);
+    int rc = vsg_frame_search_by_projection_kf(CurrentFrame.handle(), kfPoints.n(), kfPoints.desc.data(),
+                                               kfPoints.u.data(), kfPoints.v.data(), kfPoints.radius.data(),
+                                               kfPoints.level.data(), kfPoints.angle.data(), ORBdist,
+                                               mbCheckOrientation, occupied.data(), trainMatch.data());
+    check(rc, "vsg_frame_search_by_projection_kf");
+    return rc;
+  }
+
+  // SearchBySim3(pKF1, pKF2, vpMatches12, S12, th)  (ORBmatcher.cc:1448-1665): idx1 / idx2 = feature index of every
+  // projected point in its own KeyFrame; matches12[i1] = i2 where both directions agree
+  int SearchBySim3(ResidentFrame &pKF1, ResidentFrame &pKF2, const std::vector<int32_t> &idx1,
+                   const ProjectedPoints &into2, const std::vector<int32_t> &idx2, const ProjectedPoints &into1,
+                   std::vector<int32_t> &matches12) const {
+    matches12.assign(pKF1.N(), -1);
+    int rc = vsg_frame_search_by_sim3(pKF1.handle(), pKF2.handle(), into2.n(), idx1.data(), into2.desc.data(),
+                                      into2.u.data(), into2.v.data(), into2.radius.data(), into2.level.data(), into1.n(),
+                                      idx2.data(), into1.desc.data(), into1.u.data(), into1.v.data(),
+                                      into1.radius.data(), into1.level.data(), matches12.data());
+    check(rc, "vsg_frame_search_by_sim3");
+    return rc;
+  }
+
+  // Fuse(pKF, vpMapPoints, th, bRight)  (ORBmatcher.cc:1148-1329): the search; bestIdx / bestDist per point.  The
+  // caller then walks the points in order and does Replace / AddObservation on its MapPoint graph for those with
+  // bestDist <= TH_LOW (:1308-1327) -- or hands flattened ids to vsg_fuse_decide.
+  int Fuse(ResidentFrame &pKF, const ProjectedPoints &pts, bool bRight, const std::vector<float> &mvInvLevelSigma2,
+           std::vector<int32_t> &bestIdx, std::vector<int32_t> &bestDist) const {
+    bestIdx.assign(pts.n(), -1);
+    bestDist.assign(pts.n(), 256);
+    int rc = vsg_frame_fuse(pKF.handle(), pts.n(), pts.desc.data(), pts.u.data(), pts.v.data(), pts.ur.data(),
+                            pts.radius.data(), pts.level.data(), bRight, mvInvLevelSigma2.data(),
+                            (int)mvInvLevelSigma2.size(), bestIdx.data(), bestDist.data());
+    check(rc, "vsg_frame_fuse");
+    return rc;
+  }
+  // Fuse(pKF, Scw, vpPoints, th, vpReplacePoint)  (ORBmatcher.cc:1331-1446)
+  int Fuse(ResidentFrame &pKF, const ProjectedPoints &pts, std::vector<int32_t> &bestIdx,
+           std::vector<int32_t> &bestDist) const {
+    bestIdx.assign(pts.n(), -1);
+    bestDist.assign(pts.n(), 0x7FFFFFFF);
+    int rc = vsg_frame_fuse_sim3(pKF.handle(), pts.n(), pts.desc.data(), pts.u.data(), pts.v.data(), pts.radius.data(),
+                                 pts.level.data(), bestIdx.data(), bestDist.data());
+    check(rc, "vsg_frame_fuse_sim3");
+    return rc;
+  }
+
+  // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)  (ORBmatcher.cc:643-756)
+  int SearchForInitialization(ResidentFrame &F1, ResidentFrame &F2, const std::vector<float> &prevX,
+                              const std::vector<float> &prevY, int windowSize, std::vector<int32_t> &vnMatches12) const {
+    vnMatches12.assign(F1.N(), -1);
+    int rc = vsg_frame_search_for_initialization(F1.handle(), F2.handle(), prevX.data(), prevY.data(), windowSize,
+                                                 mfNNratio, mbCheckOrientation, vnMatches12.data());
+    check(rc, "vsg_frame_search_for_initialization");
+    return rc;
+  }
+
+  // SearchByBoW(KeyFrame*, Frame&) / (KeyFrame*, KeyFrame*)  (ORBmatcher.cc:226-428, 758-900) on resident descriptors
+  int SearchByBoW(ResidentFrame &pKF, const uint8_t *kfValid, const FeatureVectorCSR &kfFeatVec, ResidentFrame &F,
+                  const FeatureVectorCSR &fFeatVec, std::vector<int32_t> &matchF) const {
+    matchF.assign(F.N(), -1);
+    int rc = vsg_frame_search_by_bow_kf_f(pKF.handle(), kfValid, kfFeatVec.node.data(), kfFeatVec.off.data(),
+                                          kfFeatVec.idx.data(), kfFeatVec.nodes(), F.handle(), fFeatVec.node.data(),
+                                          fFeatVec.off.data(), fFeatVec.idx.data(), fFeatVec.nodes(), mfNNratio,
+                                          mbCheckOrientation, matchF.data());
+    check(rc, "vsg_frame_search_by_bow_kf_f");
+    return rc;
+  }
+
+ protected:
+  float mfNNratio;
+  bool mbCheckOrientation;
+};
+
+// Asynchronous operator() batches over the handle's pipeline slots (vsg_orb_submit_batch / vsg_orb_wait): H2D of
+// batch k+1 beside the kernels of batch k beside the export of batch k-1.  Pin the buffers once with
+// vsg_host_register for zero-copy staging.
+inline int SubmitBatch(const ORBextractor &ex, const uint8_t *gray, int nframes, size_t frameStride, int rows, int cols,
+                       int stride, const std::vector<int> &vLappingArea, vsg_keypoint *kps, uint8_t *desc,
+                       int capacity) {
+  int t = vsg_orb_submit_batch(ex.handle(), gray, nframes, frameStride, rows, cols, stride, vLappingArea.at(0),
+                               vLappingArea.at(1), kps, desc, capacity);
+  check(t, "vsg_orb_submit_batch");
+  return t;
+}
+inline void WaitBatch(const ORBextractor &ex, int ticket, std::vector<int> &n, std::vector<int> &monoIndex) {
+  check(vsg_orb_wait(ex.handle(), ticket, n.data(), monoIndex.data()), "vsg_orb_wait");
 }
 
 }  // namespace vsg

@@ -86,8 +86,29 @@ int main(int argc, char **argv) {
 
     const int d01 = vsg::ORBmatcher::DescriptorDistance(desc[0].data(), desc[1].data());
 
+    // ---- the resident path: frame 1 straight out of the extractor (it ran last), frame 0 uploaded from the host
+    vsg::ResidentFrame R0(ex.capacity(H, W)), R1(ex.capacity(H, W));
+    R1.FromExtractor(ex, kps[1], 0.f, 0.f, (float)W, (float)H);
+    R0.Upload(kps[0].data(), desc[0].data(), nullptr, (int)kps[0].size(), -1, 0.f, 0.f, (float)W, (float)H);
+    vsg::ProjectedPoints P;
+    for (auto &k : kps[0]) {
+      P.u.push_back(k.x - 3.0f), P.v.push_back(k.y - 2.0f), P.level.push_back(k.octave), P.angle.push_back(k.angle);
+      P.radius.push_back(10.0f * scale[k.octave]), P.observed.push_back(1);
+    }
+    P.desc = desc[0];
+    P.ur = P.u;
+    vsg::ResidentMatcher rm(0.7f, true);
+    std::vector<uint8_t> rBlocked;
+    std::vector<int32_t> rLast, rSim3(kps[1].size(), -1), rFuseIdx, rFuseDist, rInit;
+    const int nlast = rm.SearchByProjection(R1, P, 15.0f, 0, scale, rBlocked, rLast);
+    const int nsim3 = rm.SearchByProjection(R1, P, 1.0f, rSim3);
+    const int nfuse = rm.Fuse(R1, P, false, ex.GetInverseScaleSigmaSquares(), rFuseIdx, rFuseDist);
+    std::vector<float> px, py;
+    for (auto &k : kps[0]) px.push_back(k.x), py.push_back(k.y);
+    const int nrinit = rm.SearchForInitialization(R0, R1, px, py, 100, rInit);
+
     std::ofstream f(argv[2], std::ios::binary);
-    std::vector<int32_t> head{mono[0], mono[1], nwin, nbow, ninit, d01, ntri};
+    std::vector<int32_t> head{mono[0], mono[1], nwin, nbow, ninit, d01, ntri, nlast, nsim3, nfuse, nrinit};
     dump(f, head);
     for (int t = 0; t < 2; ++t) dump(f, kps[t]), dump(f, desc[t]);
     dump(f, cand.off), dump(f, cand.idx), dump(f, bestIdx), dump(f, bestDist), dump(f, trainMatch), dump(f, matchF);
@@ -97,6 +118,7 @@ int main(int argc, char **argv) {
     for (auto &kv : bow[1]) bow_ids.push_back((int32_t)kv.first), bow_vals.push_back(kv.second);
     dump(f, bow_ids), dump(f, bow_vals);
     dump(f, tri_flat);
+    dump(f, rLast), dump(f, rSim3), dump(f, rFuseIdx), dump(f, rFuseDist), dump(f, rInit);
     printf("OK %zu %zu win=%d bow=%d init=%d\n", kps[0].size(), kps[1].size(), nwin, nbow, ninit);
     return 0;
   } catch (const std::exception &e) {

@@ -85,3 +85,36 @@ def test_cpp_adaptor_full_surface_compiles(lib):
         pytest.skip("a GPU is present")
     r = subprocess.run([str(d / "adaptor_check"), "/dev/null", "/dev/null"], capture_output=True, text=True)
     assert r.returncode == 3 and "no CPU fallback" in r.stdout
+
+
+def test_adaptor_opencv_branch_compiles(tmp_path):
+    """The VSG_WITH_OPENCV branch of the adaptor (the reference's exact operator() signature, mvImagePyramid,
+    DownloadPyramid) is type-checked with the reference's language standard against a DECLARATION-ONLY header of the
+    OpenCV names it touches (tests/_adaptor/cv_decl: not OpenCV, never linked or run).  OpenCV itself is absent from
+    this image, so behaviour against a real cv::Mat stays unverified (INTEGRATION.md)."""
+    import subprocess
+    src = tmp_path / "cvchk.cpp"
+    src.write_text('#define VSG_WITH_OPENCV\n#include "vsg_orb_adaptor.hpp"\n'
+                   'int use(vsg::ORBextractor &e, cv::InputArray img, std::vector<cv::KeyPoint> &k, cv::OutputArray d,'
+                   ' std::vector<int> &lap) { int m = e(img, img, k, d, lap); e.DownloadPyramid(); '
+                   'return m + (int)e.mvImagePyramid.size(); }\n')
+    subprocess.check_call(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Werror", "-I", str(ROOT / "include"), "-I",
+                           str(ROOT / "tests" / "_adaptor" / "cv_decl"), str(src)])
+
+
+def test_stream_to_rank_honours_more_ranks_than_streams():
+    from visual_sgraphs_amd import sharding
+    # C5: 4 camera streams on 8 GPUs = 2 ranks per stream, alternating frames (SURVEY 8e)
+    seen = {}
+    for s in range(4):
+        for f in range(6):
+            r = sharding.stream_to_rank(s, 4, 8, f)
+            assert 0 <= r < 8 and r % 4 == s
+            seen.setdefault(r, []).append((s, f))
+    assert sorted(seen) == list(range(8)) and all(len(v) == 3 for v in seen.values())
+    # fewer or as many ranks as streams: stream s -> rank s % world, every frame
+    assert [sharding.stream_to_rank(s, 4, 4, 9) for s in range(4)] == [0, 1, 2, 3]
+    assert [sharding.stream_to_rank(s, 4, 2, 1) for s in range(4)] == [0, 1, 0, 1]
+    # a world that is not a multiple of the stream count: the spare ranks share the first streams
+    ranks = {sharding.stream_to_rank(s, 4, 6, f) for s in range(4) for f in range(4)}
+    assert ranks == set(range(6))

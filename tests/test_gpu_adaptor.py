@@ -33,6 +33,8 @@ def _read(path):
         out[k] = take(np.int32)
     out["bow_vals"] = take(np.float64)
     out["tri"] = take(np.int32).reshape(-1, 2)
+    for k in ("r_last", "r_sim3", "r_fuse_idx", "r_fuse_dist", "r_init"):
+        out[k] = take(np.int32)
     assert pos == len(raw)
     return out
 
@@ -112,3 +114,22 @@ def test_cpp_adaptor_end_to_end_equals_oracle(tmp_path):
     ni, m12 = ol.search_for_initialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"], 0.7, True)
     assert int(got["head"][4]) == ni and np.array_equal(got["init12"], m12)
     assert int(got["head"][5]) == ol.descriptor_distance(d0[0], d1[0])
+
+    # ---- resident path (vsg::ResidentFrame / ResidentMatcher) vs the routine-level oracle
+    b = (0.0, 0.0, 640.0, 480.0)
+    o0, o1 = ol.OracleFrame(k0, d0, b), ol.OracleFrame(k1, d1, b)
+    u, v = (k0["x"] - np.float32(3)).astype(np.float32), (k0["y"] - np.float32(2)).astype(np.float32)
+    octv, ang = k0["octave"].astype(np.int32), k0["angle"].astype(np.float32)
+    ones, zeros = np.ones(len(k0), np.uint8), np.zeros(len(k1), np.uint8)
+    nl, tm, _ = o1.search_by_projection_last(d0, ones, u, v, None, octv, ang, 15.0, 0, scale, True, zeros)
+    assert int(got["head"][7]) == nl > 300 and np.array_equal(got["r_last"], tm)
+    rad = (np.float32(10) * scale[octv]).astype(np.float32)
+    ns, m = o1.search_by_projection_sim3(d0, u, v, rad, octv, 1.0, np.full(len(k1), -1, np.int32))
+    assert int(got["head"][8]) == ns > 300 and np.array_equal(got["r_sim3"], m)
+    inv2 = ref.tables()["inv_sigma2"]
+    z = np.zeros(len(k0) + len(k1), np.int32)
+    r = o1.fuse(np.arange(len(k0)), d0, u, v, u, rad, octv, inv2, np.full(len(k1), -1, np.int32), z, z.astype(np.uint8))
+    assert int(got["head"][9]) == r[0] > 100
+    assert np.array_equal(got["r_fuse_idx"], r[1]) and np.array_equal(got["r_fuse_dist"], r[2])
+    ni2, mi = o0.search_for_initialization(o1, k0["x"], k0["y"], 100, 0.7, True)
+    assert int(got["head"][10]) == ni2 > 50 and np.array_equal(got["r_init"], mi)

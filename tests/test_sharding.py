@@ -85,3 +85,102 @@ def test_single_process_gather_is_identity():
     sharding.all_gather_records(recv, send)
     c, k, d = sharding.unpack_records(recv, 10)
     assert torch.equal(c, counts) and torch.equal(k, kps) and torch.equal(d, desc)
+
+
+def test_record_layout_matches_the_c_abi():
+    from visual_sgraphs_amd import orb
+    L = orb.load_library()
+    for cap in (1, 40, 1024, 1274, 2024):
+        assert sharding.record_bytes(cap) == L.vsg_shard_record_bytes(cap)
+        assert sharding.desc_offset(cap) == L.vsg_shard_record_desc_offset(cap)
+        assert sharding.desc_offset(cap) % 16 == 0 and sharding.record_bytes(cap) % 64 == 0
+    for s in range(4):
+        for f in range(5):
+            for w in (1, 2, 4, 6, 8):
+                assert sharding.stream_to_rank(s, 4, w, f) == L.vsg_shard_stream_owner(s, 4, w, f)
+
+
+def test_chunk_partition_and_predecessors():
+    for world in (1, 2, 3, 8):
+        seen = sum((sharding.chunk_frames(64, r, world) for r in range(world)), [])
+        assert seen == list(range(64))
+        for r in range(world):
+            pr, off = sharding.predecessor_of_first(r, world)
+            first = sharding.chunk_frames(64, r, world)[0]
+            want = first - 1 if first > 0 else 64 - 1  # the previous batch's last frame for the very first one
+            assert sharding.chunk_frames(64, pr, world)[-1] == want and off == (0 if r > 0 else -1)
+
+
+def _seq_worker(rank, world, port, n_frames, q):
+    """Each rank extracts its contiguous chunk of ONE global sequence (CPU oracle standing in for the device),
+    all-gathers the records and matches its first frame against the gathered last frame of its predecessor rank;
+    every other frame is matched locally.  The union must equal the single-process sequence bit for bit."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import oracle_lib as ol
+    from visual_sgraphs_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = sharding.chunk_frames(n_frames, rank, world)
+    ex = ol.OracleExtractor(300, 1.2, 4, 20, 7)
+    cap = 300 + 3 * 4 + 16
+    B = len(mine)
+    counts = torch.zeros((B, 2), dtype=torch.int32)
+    kps = torch.zeros((B, cap, 28), dtype=torch.uint8)
+    desc = torch.zeros((B, cap, 32), dtype=torch.uint8)
+    local = []
+    for i, t in enumerate(mine):
+        mono, k, d = ex(synth.sequence_frame(160, 120, 9, t))
+        local.append(d)
+        counts[i, 0], counts[i, 1] = len(k), mono
+        kps[i, :len(k)] = torch.from_numpy(k.view(np.uint8).reshape(len(k), 28))
+        desc[i, :len(k)] = torch.from_numpy(d)
+    rec = sharding.record_bytes(cap)
+    send = torch.zeros((B, rec), dtype=torch.uint8)
+    recv = torch.zeros((world * B, rec), dtype=torch.uint8)
+    sharding.pack_records(send, counts, kps, desc)
+    sharding.all_gather_records(recv, send)
+    c, _, d = sharding.unpack_records(recv, cap)
+    out = {}
+    for i, t in enumerate(mine):
+        if i > 0:
+            prev = local[i - 1]
+        elif rank > 0:
+            pr, _ = sharding.predecessor_of_first(rank, world)
+            row = pr * B + (B - 1)
+            prev = d[row, :int(c[row, 0])].numpy()
+        else:
+            continue  # frame 0 has no predecessor in a single batch
+        out[t] = [a.tolist() for a in ol.block_best2(local[i], prev)]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cross_rank_boundary_match_equals_single_process_sequence():
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import oracle_lib as ol
+    from visual_sgraphs_amd import synth
+    n_frames, world = 6, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_seq_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    [p.start() for p in procs]
+    got = {}
+    for _ in range(world):
+        got.update(q.get(timeout=180)[1])
+    [p.join(timeout=60) for p in procs]
+    ex = ol.OracleExtractor(300, 1.2, 4, 20, 7)
+    descs = [ex(synth.sequence_frame(160, 120, 9, t))[2] for t in range(n_frames)]
+    assert sorted(got) == list(range(1, n_frames))
+    for t in range(1, n_frames):
+        want = [a.tolist() for a in ol.block_best2(descs[t], descs[t - 1])]
+        assert got[t] == want, t

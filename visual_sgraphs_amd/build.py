@@ -10,7 +10,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libvsg_orb.so"
-SOURCES = ["vsg_kernels.hip", "vsg_orb.hip", "vsg_match.hip", "vsg_grid.hip", "vsg_bow.hip", "vsg_frame.hip", "vsg_ctx.hip"]
+SOURCES = ["vsg_kernels.hip", "vsg_orb.hip", "vsg_match.hip", "vsg_grid.hip", "vsg_bow.hip", "vsg_frame.hip", "vsg_ctx.hip", "vsg_shard.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wno-unused-value",
          # MFMA results in VGPRs (the matcher's epilogue is VALU): no v_accvgpr_read per accumulator register
@@ -35,7 +35,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", str(LIB)] + [str(CSRC / s) for s in SOURCES]
+    cmd = [_hipcc()] + FLAGS + ["-o", str(LIB)] + [str(CSRC / s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=str(CSRC))

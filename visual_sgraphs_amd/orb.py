@@ -51,6 +51,9 @@ EXPORTS = [
     "vsg_frame_fuse", "vsg_frame_fuse_sim3", "vsg_fuse_decide", "vsg_frame_search_for_initialization",
     "vsg_frame_search_by_bow_kf_f", "vsg_frame_search_by_bow_kf_kf", "vsg_frame_bow_transform",
     "vsg_frame_stereo_matches",
+    "vsg_shard_last_error", "vsg_shard_record_bytes", "vsg_shard_record_desc_offset", "vsg_shard_frame_owner",
+    "vsg_shard_stream_owner", "vsg_shard_unique_id", "vsg_shard_create", "vsg_shard_destroy", "vsg_shard_all_gather",
+    "vsg_shard_record",
 ]
 
 
@@ -211,6 +214,19 @@ def load_library():
     L.vsg_frame_bow_transform.argtypes = [vp, vp, ci, _i32p, _f64p, ci, _i32p, _i32p, _i32p, _i32p, ci, _i32p, _i32p,
                                           _i32p, _f64p]
     L.vsg_frame_stereo_matches.argtypes = [vp, ci, vp, ci, vp, vp, cf, cf, _f32p, _f32p]
+    L.vsg_shard_last_error.restype = C.c_char_p
+    L.vsg_shard_record_bytes.restype = C.c_size_t
+    L.vsg_shard_record_bytes.argtypes = [ci]
+    L.vsg_shard_record_desc_offset.restype = C.c_size_t
+    L.vsg_shard_record_desc_offset.argtypes = [ci]
+    L.vsg_shard_frame_owner.argtypes = [ci, ci]
+    L.vsg_shard_stream_owner.argtypes = [ci, ci, ci, ci]
+    L.vsg_shard_unique_id.argtypes = [_u8p]
+    L.vsg_shard_create.argtypes = [ci, ci, ci, _u8p, ci, ci, C.POINTER(vp)]
+    L.vsg_shard_destroy.argtypes = [vp]
+    L.vsg_shard_destroy.restype = None
+    L.vsg_shard_all_gather.argtypes = [vp, vp, vp, vp, ci, ci, vp]
+    L.vsg_shard_record.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     _lib = L
     return L
 
