@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs outside the timed region (host API, matcher latency, C4 rate)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo for dry runs")
+    ap.add_argument("--torch-gather", action="store_true",
+                    help="exchange the records through torch.distributed instead of the library's own RCCL communicator")
     ap.add_argument("--one-device", action="store_true",
                     help="dry run of the multi-rank path on a single GPU: every rank uses device 0 (needs gloo)")
     args = ap.parse_args()
@@ -221,10 +223,14 @@ def main():
     ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, device=local_rank, max_batch=B)
     cap = ex.capacity(H, W)
 
-    # synthetic frames: every rank gets its own sequence; consecutive frames are translated copies (matchable)
-    frames = np.stack([synth.sequence_frame(W, H, 1000 + rank, t) for t in range(B)])
+    # synthetic frames: ONE global sequence per step, dealt to the ranks in contiguous chunks (sharding.chunk_frames):
+    # rank r owns frames [r * B, (r + 1) * B); consecutive frames are translated copies (matchable), also across the
+    # chunk boundary -- the predecessor of a rank's first frame is the LAST frame of rank r - 1, which only the record
+    # exchange can deliver (for rank 0: the last rank's last frame of the previous step)
+    t_first = rank * B
+    frames = np.stack([synth.sequence_frame(W, H, 1000, t_first + t) for t in range(B)])
     d_gray = torch.from_numpy(frames).to(dev)
-    # output records: slot 0 keeps the previous batch's last frame so every frame has a predecessor to match
+    # output records: slot 0 keeps the previous batch's last frame so every frame has a predecessor to match (N = 1)
     d_kps = torch.zeros((B + 1, cap, 28), dtype=torch.uint8, device=dev)
     d_desc = torch.zeros((B + 1, cap, 32), dtype=torch.uint8, device=dev)
     d_counts = torch.zeros((B + 1, 2), dtype=torch.int32, device=dev)
@@ -232,69 +238,132 @@ def main():
     d_second = torch.zeros_like(d_best)
     d_arg = torch.zeros_like(d_best)
     from visual_sgraphs_amd import sharding
-    if distributed and not args.no_gather:
-        # one fixed-capacity record block per frame: {n, monoIndex} + keypoints + descriptors
-        rec_bytes = sharding.record_bytes(cap)
-        # two buffer pairs: the all-gather of batch k is still in flight while batch k+1 is packed
-        send = [torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
-        recv = [torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev) for _ in range(2)]
-    pending = [None, None]
-    step_no = [0]
-    async_gather = distributed and args.dist_backend == "nccl" and not args.sync_gather
-    gather_mode = [async_gather]
     L = orb.load_library()
     import ctypes as C
-    # All work of a step is ordered on ONE explicit (non-default) HIP stream: torch copies, the extractor's stage
-    # chain, the match kernel and the RCCL all-gather.  (Passing torch's default stream handle -- 0 -- would make the
-    # C ABI fall back to the handle's own stream and un-order the match kernel from the extraction.)
+    # All kernels of a step are ordered on ONE explicit (non-default) HIP stream: torch copies, the extractor's stage
+    # chain, the match kernels.  The record exchange runs on a second stream, under the NEXT step's kernels.
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
+    exchange = distributed and not args.no_gather
+    comm, comm_kind = None, None
+    if exchange:
+        cstream = torch.cuda.Stream(device=dev)
+        rec_bytes = sharding.record_bytes(cap)
+        od = sharding.desc_offset(cap)
+        if args.dist_backend == "nccl" and not args.one_device and not args.torch_gather:
+            try:  # the library's own RCCL communicator (C ABI: vsg_shard_*)
+                comm = sharding.ShardComm(local_rank, rank, world, cap, B)
+                comm_kind = "C ABI vsg_shard_* (ncclAllGather)"
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] vsg_shard_create failed ({e}); using torch.distributed for the exchange", file=sys.stderr)
+        if comm is None:
+            comm_kind = f"torch.distributed {args.dist_backend} all_gather_into_tensor"
+            send = torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev)
+            recv = torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev)
+        # boundary state: this rank's first frame of the previous step, and (rank 0) the last rank's last frame
+        d_first_desc = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
+        d_first_cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+        d_tail_desc = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
+        d_tail_cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+        d_bbest, d_bsecond, d_barg = (torch.zeros((1, cap), dtype=torch.int32, device=dev) for _ in range(3))
+        ev_extracted, ev_consumed, ev_gathered = (torch.cuda.Event() for _ in range(3))
+        state = {"steps": 0}
+        pred_rank = rank - 1 if rank > 0 else world - 1
 
     match_events = []
 
+    def best2(a_desc, b_desc, a_cnt, b_cnt, nblocks, stride_bytes, best, second, arg):
+        rc = L.vsg_hamming_block_best2_device(local_rank, C.c_void_p(a_desc), C.c_void_p(b_desc), stride_bytes,
+                                              C.c_void_p(a_cnt), C.c_void_p(b_cnt), 2, nblocks, cap,
+                                              C.c_void_p(best), C.c_void_p(second), C.c_void_p(arg), C.c_void_p(stream))
+        assert rc == 0, rc
+
+    def gathered_record(r, f):
+        """(counts, desc) device pointers of frame f of rank r in the last completed exchange"""
+        if comm is not None:
+            c, _, d = comm.record(r, f)
+            return c, d
+        row = recv[r * B + f]
+        return row.data_ptr(), row.data_ptr() + od
+
     def step(time_match=False):
-        # carry the last frame of the previous batch into slot 0
-        d_desc[0].copy_(d_desc[B])
-        d_counts[0].copy_(d_counts[B])
+        if not exchange:
+            # N = 1: carry the last frame of the previous batch into slot 0
+            d_desc[0].copy_(d_desc[B])
+            d_counts[0].copy_(d_counts[B])
         ex.extract_batch_device(d_gray.data_ptr(), B, H * W, H, W, W, d_kps[1].data_ptr(), d_desc[1].data_ptr(),
                                 d_counts[1].data_ptr(), cap, (0, 0), stream)
+        if exchange:
+            ev_extracted.record(tstream)
         if not args.no_match:
             if time_match:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(tstream)
-            rc = L.vsg_hamming_block_best2_device(local_rank, C.c_void_p(d_desc[1].data_ptr()),
-                                                  C.c_void_p(d_desc[0].data_ptr()), cap * 32,
-                                                  C.c_void_p(d_counts[1].data_ptr()), C.c_void_p(d_counts[0].data_ptr()),
-                                                  2, B, cap, C.c_void_p(d_best.data_ptr()),
-                                                  C.c_void_p(d_second.data_ptr()), C.c_void_p(d_arg.data_ptr()),
-                                                  C.c_void_p(stream))
-            assert rc == 0, rc
+            if not exchange:
+                best2(d_desc[1].data_ptr(), d_desc[0].data_ptr(), d_counts[1].data_ptr(), d_counts[0].data_ptr(), B,
+                      cap * 32, d_best.data_ptr(), d_second.data_ptr(), d_arg.data_ptr())
+            else:
+                # frames 1 .. B-1 against their local predecessors
+                if B > 1:
+                    best2(d_desc[2].data_ptr(), d_desc[1].data_ptr(), d_counts[2].data_ptr(), d_counts[1].data_ptr(),
+                          B - 1, cap * 32, d_best[1].data_ptr(), d_second[1].data_ptr(), d_arg[1].data_ptr())
+                # the previous step's first frame against its predecessor on the neighbour rank, from the records
+                # that step's all-gather delivered (the exchange of step k runs under the kernels of step k + 1)
+                if state["steps"] > 0:
+                    tstream.wait_event(ev_gathered)
+                    if rank > 0:
+                        pc, pd = gathered_record(pred_rank, B - 1)
+                    else:
+                        pc, pd = d_tail_cnt.data_ptr(), d_tail_desc.data_ptr()
+                    best2(d_first_desc.data_ptr(), pd, d_first_cnt.data_ptr(), pc, 1, 0, d_bbest.data_ptr(),
+                          d_bsecond.data_ptr(), d_barg.data_ptr())
+                    if rank == 0:  # keep the last rank's last frame for the NEXT boundary match
+                        tc, td = gathered_record(world - 1, B - 1)
+                        L_memcpy(d_tail_cnt.data_ptr(), tc, 8)
+                        L_memcpy(d_tail_desc.data_ptr(), td, cap * 32)
+                d_first_desc.copy_(d_desc[1])
+                d_first_cnt.copy_(d_counts[1])
+                ev_consumed.record(tstream)
             if time_match:
                 e1.record(tstream)
                 match_events.append((e0, e1))
-        if distributed and not args.no_gather:
-            slot = step_no[0] & 1
-            step_no[0] += 1
-            if pending[slot] is not None:  # the exchange that used this buffer pair two steps ago
-                pending[slot].wait()
-                pending[slot] = None
-            sharding.pack_records(send[slot], d_counts[1:], d_kps[1:], d_desc[1:])
+        if exchange:
+            if args.no_match:
+                ev_consumed.record(tstream)
+            with torch.cuda.stream(cstream):
+                cstream.wait_event(ev_extracted)  # this step's records exist
+                cstream.wait_event(ev_consumed)   # the previous exchange's records have been read
+                if comm is not None:
+                    comm.all_gather(d_counts[1].data_ptr(), d_kps[1].data_ptr(), d_desc[1].data_ptr(), cap, B,
+                                    cstream.cuda_stream)
+                else:
+                    sharding.pack_records(send, d_counts[1:], d_kps[1:], d_desc[1:])
+                    w = sharding.all_gather_records(recv, send, async_op=args.dist_backend == "nccl")
+                    if w is not None:
+                        w.wait()  # stream-level: cstream waits for the collective, the host does not block
+                ev_gathered.record(cstream)
+            state["steps"] += 1
+            if args.sync_gather:
+                tstream.wait_event(ev_gathered)
+
+    def L_memcpy(dst, src, nbytes):
+        """device-to-device copy of raw pointers on the compute stream"""
+        rc = hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3, C.c_void_p(stream))
+        assert rc == 0, rc
+
+    hip = None
+    if exchange:
+        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
             try:
-                pending[slot] = sharding.all_gather_records(recv[slot], send[slot], async_op=gather_mode[0])
-            except Exception as e:  # a backend without async support: fall back to the blocking exchange
-                if not gather_mode[0]:
-                    raise
-                print(f"[bench] async all-gather unavailable ({e}); using the blocking form", file=sys.stderr)
-                gather_mode[0] = False
-                pending[slot] = sharding.all_gather_records(recv[slot], send[slot], async_op=False)
+                hip = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        assert hip is not None, "HIP runtime not found by name"
 
     def barrier():
-        for i in range(2):  # every exchange belongs to the region it was issued in
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -350,6 +419,15 @@ def main():
             n = int(counts[B, 0])
             ok &= np.array_equal(d_best[B - 1, :n].cpu().numpy(), rb) and np.array_equal(d_arg[B - 1, :n].cpu().numpy(), ra)
             ok &= np.array_equal(d_second[B - 1, :n].cpu().numpy(), rs)
+            if exchange and K + Wu >= 3:
+                # the boundary match: rank 0's first frame against the LAST frame of the last rank, which only the
+                # record exchange delivered -- the oracle extracts that remote frame itself
+                _, _, rd_first = ref(frames[0])
+                _, _, rd_pred = ref(synth.sequence_frame(W, H, 1000, world * B - 1))
+                rb, rs, ra = ol.block_best2(rd_first, rd_pred)
+                n = len(rb)
+                ok &= np.array_equal(d_bbest[0, :n].cpu().numpy(), rb) and np.array_equal(d_barg[0, :n].cpu().numpy(), ra)
+                ok &= np.array_equal(d_bsecond[0, :n].cpu().numpy(), rs)
         parity = bool(ok)
 
     if rank != 0:
@@ -424,10 +502,10 @@ def main():
         "config": {"workload": f"{args.workload}: {W}x{H} gray, nFeatures={nfeat}, 8 levels, scale 1.2, FAST 20/7, "
                                f"extract{'' if args.no_match else ' + brute-force Hamming best2 match vs previous frame'}",
                    "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded x{world}"
-                   + (f", {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} all-gather of "
-                      "keypoint/descriptor records per step"
-                      + (" (overlapped with the next batch's kernels)" if async_gather else "")
-                      if distributed and not args.no_gather else ""),
+                   + (f", contiguous chunks of one sequence per step; all-gather of keypoint/descriptor records per "
+                      f"step via {comm_kind} on a second stream under the next step's kernels; every rank's first "
+                      "frame is matched against the gathered last frame of the previous rank"
+                      if exchange else ""),
                    "keypoints_per_frame": round(n_kp, 1), "inputs": "resident in HBM"},
         "parity": {"bit_exact_vs_oracle": parity, "checked_frames": [0, B - 1]},
         "roofline": roofline, "cpu_baseline": cpu,
