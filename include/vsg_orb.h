@@ -128,6 +128,11 @@ int vsg_orb_copy_selected(vsg_orb *h, int frame, int level, uint32_t *dst, int c
 
 /* Average device time per stage of the last N timed calls (HIP events on the handle's streams).
  * names: "pyramid","fast","octree","blur","slots","orient_desc","total".  Returns number of stages. */
+/* Tracing: VSG_ROCTX=1 in the environment wraps the stage chain and the entry points in roctx ranges for
+ * rocprofv3 --marker-trace.  vsg_orb_time_stats is the REGISTER_TIMES analogue (Settings.h:23): mean / std in ms of
+ * the host wall time of the blocking operator() calls so far ("ORB Extraction" in Tracking::PrintTimeStats,
+ * Tracking.cc:291-330; Frame::mTimeORB_Ext, Frame.cc:126-137).  Returns the number of calls; reset != 0 clears. */
+int vsg_orb_time_stats(vsg_orb *h, double *mean_ms, double *std_ms, int reset);
 int vsg_orb_enable_timing(vsg_orb *h, int enable);
 /* serialize != 0: enqueue every kernel on one stream (no blur overlap), so that stage timings and rocprof kernel
  * durations are free of interference from concurrent kernels.  Results are identical either way. */

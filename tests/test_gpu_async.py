@@ -148,3 +148,50 @@ def test_copy_pyramid_is_one_transfer_and_equals_per_level_copies():
         for l, lv in enumerate(levels):
             assert np.array_equal(lv, ref.pyramid_level(l, with_border=True))
             assert np.array_equal(lv, ex.image_pyramid(l, frame=f, with_border=True))
+
+
+def test_two_handles_two_host_threads_large_lds_and_time_stats():
+    """Frame.cc:129-132: left / right extractors run concurrently on two host threads.  A level quota above ~1000
+    needs more than 64 KB of dynamic LDS in the octree: the raised limit is tracked per device under a mutex
+    (vsg_ctx.h lds_limit_ensure), so two handles racing through their first launch both get it."""
+    import threading
+    img = synth.frame(640, 480, 5)
+    want = ol.OracleExtractor(3000, 1.2, 2, 20, 7)(img)
+    outs, errs = [None, None], []
+
+    def run(i):
+        try:
+            ex = orb.ORBextractor(3000, 1.2, 2, 20, 7)  # ~1640 features on level 0
+            for _ in range(3):
+                outs[i] = ex(img)
+            n, mean, sd = ex.time_stats()
+            assert n == 3 and mean > 0 and sd >= 0
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for o in outs:
+        assert o[0] == want[0] and o[1].tobytes() == want[1].tobytes() and np.array_equal(o[2], want[2])
+
+
+def test_two_handles_on_two_devices():
+    """C5 pinning: one process driving two GPUs.  hipFuncSetAttribute is per device, so the large-LDS launches must
+    work on the second device too."""
+    if orb.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    img = synth.frame(640, 480, 5)
+    want = ol.OracleExtractor(3000, 1.2, 2, 20, 7)(img)
+    for dev in (0, 1, 0):
+        ex = orb.ORBextractor(3000, 1.2, 2, 20, 7, device=dev)
+        o = ex(img)
+        assert o[0] == want[0] and o[1].tobytes() == want[1].tobytes() and np.array_equal(o[2], want[2])
+    s = __import__("scenarios")
+    k = s.kf_projection_scenario(1)
+    f1 = orb.Frame(len(k["keys"]), device=1).upload(k["keys"], k["desc"], s.BOUNDS)
+    o = ol.OracleFrame(k["keys"], k["desc"], s.BOUNDS)
+    m0 = np.full(len(k["keys"]), -1, np.int32)
+    got = f1.SearchByProjection_Sim3(k["q_desc"], k["u"], k["v"], k["radius"], k["level"], 1.0, m0)
+    ref = o.search_by_projection_sim3(k["q_desc"], k["u"], k["v"], k["radius"], k["level"], 1.0, m0)
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1])

@@ -150,7 +150,172 @@ def case_window(rng):
     return ok, ("window", w, h, nf, seq, th, ratio, ori)
 
 
-CASES = {"window": case_window, "batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow}
+def _rand_frame_pair(rng, stereo2):
+    """(keys, desc, nleft, u_right, bounds) of a random target frame + (k0, d0) of the source frame it is searched from"""
+    w, h = int(rng.integers(300, 800)), int(rng.integers(240, 600))
+    nf = int(rng.integers(100, 1500))
+    seq = int(rng.integers(0, 1 << 16))
+    ref = ol.OracleExtractor(nf, 1.2, 8, 20, 7)
+    _, k0, d0 = ref(synth.sequence_frame(w, h, seq, 0))
+    _, k1, d1 = ref(synth.sequence_frame(w, h, seq, 1))
+    bounds = (float(rng.choice([0.0, -7.5])), float(rng.choice([0.0, -3.25])), float(w), float(h))
+    if stereo2:
+        _, k2, d2 = ref(synth.sequence_frame(w, h, seq, 2))
+        keys, desc, nleft, ur = np.concatenate([k1, k2]), np.concatenate([d1, d2]), len(k1), None
+    else:
+        keys, desc, nleft = k1, d1, -1
+        ur = np.where(rng.random(len(k1)) < 0.5, k1["x"] - rng.uniform(1, 30, len(k1)), -1).astype(np.float32)
+        if rng.random() < 0.3:
+            ur = None
+    return keys, desc, nleft, ur, bounds, k0, d0
+
+
+def case_resident(rng):
+    """Device-resident frames: every routine-level search against the routine-level oracle, random geometry state."""
+    import scenarios as sc
+    stereo2 = bool(rng.integers(0, 2))
+    keys, desc, nleft, ur, bounds, k0, d0 = _rand_frame_pair(rng, stereo2)
+    n = len(k0)
+    if n == 0 or len(keys) == 0:
+        return True, ("resident-empty",)
+    f = orb.Frame(len(keys)).upload(keys, desc, bounds, ur, nleft)
+    o = ol.OracleFrame(keys, desc, bounds, ur, nleft)
+    sf, inv2 = sc.SCALE_FACTORS, sc.INV_SIGMA2
+    u = (k0["x"] - 3 + rng.normal(0, 2, n)).astype(np.float32)
+    v = (k0["y"] - 2 + rng.normal(0, 2, n)).astype(np.float32)
+    qd = sc.noisy_desc(rng, d0, int(rng.integers(0, 20)))
+    lvl = np.clip(k0["octave"] + rng.integers(-1, 2, n), 0, 7).astype(np.int32)
+    obs = (rng.random(n) < 0.7).astype(np.uint8)
+    blocked = (rng.random(len(keys)) < 0.15).astype(np.uint8)
+    th = float(rng.choice([1.0, 3.0, 7.0, 15.0]))
+    ori = bool(rng.integers(0, 2))
+    which = int(rng.integers(0, 6))
+    tag = ("resident", which, stereo2, len(keys), n, th, ori)
+    if which == 0:  # SearchByProjection(F, vpMapPoints)
+        mp = dict(desc=qd, observed=obs, in_view=(rng.random(n) < 0.9).astype(np.uint8), proj_x=u, proj_y=v,
+                  proj_xr=(u - rng.uniform(1, 30, n)).astype(np.float32), scale_level=lvl,
+                  view_cos=rng.choice(np.array([0.9, 0.9985], np.float32), n))
+        ltr = rtl = None
+        if stereo2:
+            lr = lvl.copy()
+            lr[rng.random(n) < 0.05] = -1
+            mp.update(in_view_r=(rng.random(n) < 0.7).astype(np.uint8), proj_x_r=(u + 8).astype(np.float32), proj_y_r=v,
+                      scale_level_r=lr, view_cos_r=rng.choice(np.array([0.9, 0.9999], np.float32), n))
+            nr = len(keys) - nleft
+            ltr, rtl = np.full(nleft, -1, np.int32), np.full(nr, -1, np.int32)
+            m = min(nleft, nr) // 3
+            a = rng.choice(min(nleft, nr), m, replace=False)
+            b = rng.permutation(a)
+            ltr[a], rtl[b] = b, a
+        ratio = float(rng.choice([0.6, 0.8, 0.9]))
+        g = f.SearchByProjection(mp, th, ratio, sf, blocked, ltr, rtl)
+        r = o.search_by_projection(mp, th, ratio, sf, blocked, ltr, rtl)
+    elif which == 1:  # SearchByProjection(CurrentFrame, LastFrame)
+        d = int(rng.integers(0, 3))
+        args = (qd, obs, u, v, (u - rng.uniform(1, 30, n)).astype(np.float32), k0["octave"].astype(np.int32),
+                k0["angle"].astype(np.float32), th, d, sf, ori, blocked)
+        kw = dict(u_r=(u + 8).astype(np.float32), v_r=v) if stereo2 else {}
+        g, r = f.SearchByProjection_Last(*args, **kw), o.search_by_projection_last(*args, **kw)
+    elif which == 2 and not stereo2:  # SearchByProjection(KF, Sim3) / (Frame, KF)
+        rad = (np.float32(th) * sf[lvl]).astype(np.float32)
+        matched = np.where(rng.random(len(keys)) < 0.15, 99999, -1).astype(np.int32)
+        ratio = float(rng.choice([0.5, 1.0, 1.5]))
+        g1, r1 = f.SearchByProjection_Sim3(qd, u, v, rad, lvl, ratio, matched), o.search_by_projection_sim3(qd, u, v, rad, lvl, ratio, matched)
+        od = int(rng.choice([50, 64, 100]))
+        g2 = f.SearchByProjection_KF(qd, u, v, rad, lvl, k0["angle"], od, ori, blocked)
+        r2 = o.search_by_projection_kf(qd, u, v, rad, lvl, k0["angle"], od, ori, blocked)
+        g, r = (g1[0] + g2[0], g1[1], g2[1], g2[2]), (r1[0] + r2[0], r1[1], r2[1], r2[2])
+    elif which == 3:  # Fuse x2 (bRight on fisheye-stereo frames)
+        rad = (np.float32(th) * sf[lvl]).astype(np.float32)
+        right = stereo2 and bool(rng.integers(0, 2))
+        ur_q = (u - rng.uniform(1, 30, n)).astype(np.float32)
+        nfu, bi, bd = f.Fuse(qd, u, v, ur_q, rad, lvl, inv2, right=right)
+        nk = len(keys)
+        slot = np.where(rng.random(nk) < 0.5, n + np.arange(nk), -1).astype(np.int32)
+        mobs = rng.integers(1, 6, n + nk).astype(np.int32)
+        bad = (rng.random(n + nk) < 0.1).astype(np.uint8)
+        qmp = np.arange(n, dtype=np.int32)
+        rr = o.fuse(qmp, qd, u, v, ur_q, rad, lvl, inv2, slot, mobs, bad, right=right)
+        dd = orb.fuse_decide(qmp, bi, bd, False, slot, mobs, bad)
+        g = (nfu, bi, bd, dd[1], dd[3])
+        r = (rr[0], rr[1], rr[2], rr[3], rr[5])
+        if not stereo2:
+            nf2, bi2, bd2 = f.Fuse_Sim3(qd, u, v, rad, lvl)
+            r2 = o.fuse_sim3(qmp, qd, u, v, rad, lvl, slot, mobs, bad)
+            g, r = g + (nf2, bi2, bd2), r + (r2[0], r2[1], r2[2])
+    elif which == 4 and not stereo2:  # SearchBySim3 + SearchForInitialization (two resident frames)
+        f0, o0 = orb.Frame(n).upload(k0, d0, bounds), ol.OracleFrame(k0, d0, bounds)
+        i1 = np.sort(rng.choice(n, max(1, n // 2), replace=False)).astype(np.int32)
+        q1 = dict(idx=i1, desc=qd[i1], u=u[i1], v=v[i1], radius=(np.float32(th) * sf[lvl[i1]]).astype(np.float32), level=lvl[i1])
+        n1 = len(keys)
+        i2 = np.sort(rng.choice(n1, max(1, n1 // 2), replace=False)).astype(np.int32)
+        l2 = keys["octave"][i2].astype(np.int32)
+        q2 = dict(idx=i2, desc=desc[i2], u=(keys["x"][i2] + 3).astype(np.float32), v=(keys["y"][i2] + 2).astype(np.float32),
+                  radius=(np.float32(th) * sf[l2]).astype(np.float32), level=l2)
+        g1, r1 = orb.SearchBySim3(f0, f, q1, q2), ol.search_by_sim3(o0, o, q1, q2)
+        ws = int(rng.choice([20, 100]))
+        g2 = f0.SearchForInitialization(f, k0["x"], k0["y"], ws, 0.9, ori)
+        r2 = o0.search_for_initialization(o, k0["x"], k0["y"], ws, 0.9, ori)
+        g, r = (g1[0] + g2[0], g1[1], g2[1]), (r1[0] + r2[0], r1[1], r2[1])
+    else:  # windows only, Frame and KeyFrame forms, both grids
+        nq = min(n, 400)
+        rr_ = rng.uniform(0.5, 120, nq).astype(np.float32)
+        lo, hi = rng.integers(-1, 8, nq).astype(np.int32), rng.integers(-1, 8, nq).astype(np.int32)
+        right = stereo2 and bool(rng.integers(0, 2))
+        off, idx = f.GetFeaturesInArea(u[:nq], v[:nq], rr_, lo, hi, bRight=right)
+        want = [o.features_in_area(u[q], v[q], rr_[q], lo[q], hi[q], right) for q in range(nq)]
+        g = (len(idx), off, idx)
+        r = (sum(len(x) for x in want), np.concatenate([[0], np.cumsum([len(x) for x in want])]).astype(np.int32),
+             np.concatenate(want).astype(np.int32) if want else np.zeros(0, np.int32))
+    ok = g[0] == r[0] and all(np.array_equal(x, y) for x, y in zip(g[1:], r[1:]))
+    return ok, tag
+
+
+def case_async(rng):
+    """vsg_orb_submit_batch / vsg_orb_wait with random batch sizes, strides, pinned / pageable buffers, lapping areas."""
+    w, h, nf, sc_, nl, ini, mn = geometry(rng)
+    B = int(rng.integers(1, 6))
+    ex = orb.ORBextractor(nf, sc_, nl, ini, mn, max_batch=B)
+    ref = ol.OracleExtractor(nf, sc_, nl, ini, mn)
+    cap = ex.capacity(h, w)
+    lap = (int(rng.integers(-10, w)), int(rng.integers(-10, w + 50)))
+    pinned = bool(rng.integers(0, 2))
+    nb = int(rng.integers(1, 6))
+    tickets, bufs = [], []
+    ok = True
+    for k in range(nb):
+        b = int(rng.integers(1, B + 1))
+        pad = int(rng.integers(0, 9))
+        big = np.zeros((b, h, w + pad), np.uint8)
+        imgs = np.stack([synth.frame(w, h, int(rng.integers(0, 1 << 20))) for _ in range(b)])
+        big[:, :, :w] = imgs
+        view = big[:, :, :w]
+        kps, desc = np.zeros((b, cap), orb.KP_DTYPE), np.zeros((b, cap, 32), np.uint8)
+        if pinned:
+            big, kps, desc = orb.pin(big), orb.pin(kps), orb.pin(desc)
+            view = big[:, :, :w]
+        if len(tickets) == ex.slots():
+            ok &= _finish(ex, ref, tickets.pop(0), bufs.pop(0), lap, pinned)
+        tickets.append(ex.submit_batch(view, kps, desc, lap))
+        bufs.append((imgs, big, kps, desc))
+    while tickets:
+        ok &= _finish(ex, ref, tickets.pop(0), bufs.pop(0), lap, pinned)
+    return ok, ("async", w, h, nf, sc_, nl, B, nb, pinned, lap)
+
+
+def _finish(ex, ref, ticket, buf, lap, pinned):
+    imgs, big, kps, desc = buf
+    n, mono = ex.wait(ticket)
+    ok = True
+    for i in range(len(imgs)):
+        rm, rk, rd = ref(imgs[i], lap)
+        ok &= n[i] == len(rk) and mono[i] == rm and kps[i, :n[i]].tobytes() == rk.tobytes() and np.array_equal(desc[i, :n[i]], rd)
+    if pinned:
+        orb.unpin(big), orb.unpin(kps), orb.unpin(desc)
+    return bool(ok)
+
+
+CASES = {"resident": case_resident, "async": case_async, "window": case_window, "batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow}
 
 
 def main():

@@ -49,6 +49,16 @@ struct Stage {
   }
 };
 
+// roctx ranges around stages and entry points (the REGISTER_TIMES analogue for profilers: SURVEY 5 "tracing";
+// orb_slam3/include/Settings.h:23).  Off unless VSG_ROCTX=1 (one getenv at first use); the marker library
+// (librocprofiler-sdk-roctx / libroctx64) is loaded lazily, so nothing depends on it.
+void range_push(const char *name);
+void range_pop();
+struct Range {
+  explicit Range(const char *name) { range_push(name); }
+  ~Range() { range_pop(); }
+};
+
 // Device attributes that are per DEVICE, not per process (hipFuncSetAttribute of a >64 KB dynamic-LDS kernel): callers
 // remember the limit they raised per device ordinal under this mutex-protected table.
 enum { kMaxDevices = 64 };

@@ -1,6 +1,9 @@
 // vsg_ctx.hip -- per-(host thread, device) streams and staging arenas (see vsg_ctx.h).
 #include "vsg_ctx.h"
 
+#include <dlfcn.h>
+#include <stdlib.h>
+
 #include <mutex>
 #include <vector>
 
@@ -78,6 +81,42 @@ int ctx_reserve(ThreadCtx *c, size_t pinned_bytes, size_t device_bytes) {
     c->n_grow++;
   }
   return VSG_OK;
+}
+
+namespace {
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  bool on = false;
+};
+Roctx g_roctx;
+std::once_flag g_roctx_once;
+const Roctx &roctx() {
+  std::call_once(g_roctx_once, [] {
+    const char *e = getenv("VSG_ROCTX");
+    if (!e || !*e || *e == '0') return;
+    for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void *lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) continue;
+      g_roctx.push = (int (*)(const char *))dlsym(lib, "roctxRangePushA");
+      g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
+      if (g_roctx.push && g_roctx.pop) {
+        g_roctx.on = true;
+        return;
+      }
+    }
+  });
+  return g_roctx;
+}
+}  // namespace
+
+void range_push(const char *name) {
+  const Roctx &r = roctx();
+  if (r.on) r.push(name);
+}
+void range_pop() {
+  const Roctx &r = roctx();
+  if (r.on) r.pop();
 }
 
 bool lds_limit_ensure(int slot, int device, const void *func, size_t bytes) {

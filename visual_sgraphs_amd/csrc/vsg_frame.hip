@@ -321,6 +321,7 @@ FrameDev frame_dev(const vsg_frame *f) {
 
 int WindowCall::begin(int device, int nq_, int mode_, bool with_desc_, size_t arena_base, size_t arena_extra) {
   int rc = VSG_OK;
+  range_push("ORBmatcher window search");
   if (arena_base == 0) t_prof.t0 = now_us();
   c = thread_ctx(device, &rc);
   if (!c) return rc;
@@ -366,6 +367,7 @@ int WindowCall::finish() {
   const double ts = now_us();
   if (nq > 0 && hipStreamSynchronize(c->stream) != hipSuccess) return VSG_ERR_HIP;
   t_prof.sync = now_us() - ts;
+  range_pop();
   if (mode != kWinList) return VSG_OK;
   const int32_t *cn = (const int32_t *)(c->h_pin + base + oCnt);
   long long total = 0;  // entries of the lists that went to the overflow area = what the waves added to the counter

@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -107,6 +109,9 @@ struct vsg_orb {
   bool serialize = false;  // every kernel on one stream (per-kernel timing without interference)
   hipStream_t sub_s[kMaxSub] = {}, sub_b[kMaxSub] = {};
   hipEvent_t sub_ev_pyr[kMaxSub] = {}, sub_ev_blur[kMaxSub] = {}, sub_ev_done[kMaxSub] = {};
+  // host wall time of the blocking operator() calls (REGISTER_TIMES analogue: Frame::mTimeORB_Ext, Frame.cc:126-137)
+  double host_ms_sum = 0, host_ms_sq = 0;
+  long host_calls = 0;
   // timing
   bool timing = false;
   hipEvent_t ev[kEv] = {};
@@ -307,6 +312,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   int *sel_count = h->d_counts2 + ((size_t)h->max_batch + F) * kMaxLevels;
   int *flags = h->d_flags + F * fg.out_cap, *slots = h->d_slots + F * fg.out_cap;
   FrameHeader *hdr = h->d_hdr + F;
+  Range r_all("vsg_orb: enqueue stage chain");
   if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
   static const bool per_level = getenv("VSG_PYR_PER_LEVEL") != nullptr;  // A/B switch: 7 chained launches
   // tiling: the coarser one when it still gives the chip enough workgroups and leaves three of them per CU
@@ -321,6 +327,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
     else if (P0.ok && P0.lds_bytes() <= kPyrLdsLimit)
       ti = 0;
   }
+  range_push("ComputePyramid");
   if (ti < 0) {
     for (int l = 1; l < fg.nlevels; l++) launch_resize(s, pyr, h->d_fg, h->d_tab, s0, fg, l, nf);
   } else {
@@ -328,6 +335,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
     launch_pyramid(s, pyr, h->d_fg, h->d_ptab[ti], s0, h->d_ptiles[ti], (int)PT.tiles.size(), PT.ldsA, PT.ldsB,
                    PT.tabMax, nf);
   }
+  range_pop();
   if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
   // The blur only needs the pyramid and runs on its own stream.  It is released AFTER FAST, beside the
   // latency-bound octree (+ slots): FAST and the blur are both issue-bound, so running them side by side only
@@ -351,6 +359,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
   if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
+  Range r_tail("DistributeOctTree + slots + IC_Angle / rBRIEF");
   launch_octree(s, h->d_fg, cand, cand_count, nodeof, sel, sel_count, fg, h->G.maxQuota, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
   launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
@@ -792,9 +801,26 @@ int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t f
                           int *mono_index) {
   if (!h || nframes < 1 || nframes > h->max_batch || !n || !mono_index) return VSG_ERR_INVALID;
   if (!gray || rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
+  Range r("ORBextractor::operator() [blocking batch]");
+  const auto t0 = std::chrono::steady_clock::now();
   const int t = vsg_orb_submit_batch(h, gray, nframes, frame_stride, rows, cols, stride, lap0, lap1, kps, desc, capacity);
   if (t < 0) return t;
-  return vsg_orb_wait(h, t, n, mono_index);
+  const int rc = vsg_orb_wait(h, t, n, mono_index);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  h->host_ms_sum += ms, h->host_ms_sq += ms * ms, h->host_calls++;
+  return rc;
+}
+
+// "ORB Extraction" mean / std in ms over the blocking operator() calls so far, as Tracking::PrintTimeStats reports it
+// under REGISTER_TIMES (Tracking.cc:291-330, Settings.h:23).  Returns the number of calls; reset != 0 clears.
+int vsg_orb_time_stats(vsg_orb *h, double *mean_ms, double *std_ms, int reset) {
+  if (!h) return VSG_ERR_INVALID;
+  const long n = h->host_calls;
+  const double mean = n ? h->host_ms_sum / n : 0.0;
+  if (mean_ms) *mean_ms = mean;
+  if (std_ms) *std_ms = n > 1 ? std::sqrt(std::max(0.0, (h->host_ms_sq - n * mean * mean) / (n - 1))) : 0.0;
+  if (reset) h->host_ms_sum = h->host_ms_sq = 0, h->host_calls = 0;
+  return (int)n;
 }
 
 int vsg_orb_extract_batch_color(vsg_orb *h, const uint8_t *img, int channels, int rgb_order, int nframes,

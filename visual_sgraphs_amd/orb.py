@@ -13,8 +13,12 @@ from pathlib import Path
 
 import numpy as np
 
+import os
+
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libvsg_orb.so"
+# VSG_LIB=<path> loads an experimental build instead of the in-tree library (A/B scripts under tools/): the in-tree
+# file is never overwritten, so later runs cannot silently pick up a variant
+LIB_PATH = Path(os.environ["VSG_LIB"]) if os.environ.get("VSG_LIB") else _PKG / "libvsg_orb.so"
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -43,7 +47,7 @@ EXPORTS = [
     "vsg_vocab_info", "vsg_bow_transform", "vsg_distinctive_descriptors", "vsg_debug_device_sort",
     "vsg_search_for_triangulation", "vsg_search_by_bow_kf_f_stereo",
     # round 2: threads / staging, async host pipeline, device-resident frames, routine-level searches
-    "vsg_thread_release", "vsg_thread_arena_growths", "vsg_debug_call_profile", "vsg_host_register", "vsg_host_unregister", "vsg_orb_slots",
+    "vsg_thread_release", "vsg_thread_arena_growths", "vsg_debug_call_profile", "vsg_orb_time_stats", "vsg_host_register", "vsg_host_unregister", "vsg_orb_slots",
     "vsg_orb_submit_batch", "vsg_orb_wait", "vsg_orb_copy_pyramid", "vsg_frame_create", "vsg_frame_destroy",
     "vsg_frame_upload", "vsg_frame_from_extractor", "vsg_frame_size", "vsg_frame_copy_grid",
     "vsg_frame_features_in_area", "vsg_frame_search_by_projection", "vsg_frame_search_by_projection_last",
@@ -179,6 +183,7 @@ def load_library():
     L.vsg_grid_query.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _i32p, _i32p, C.c_int, _i32p, _i32p, C.c_int]
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.vsg_thread_arena_growths.argtypes = [ci]
+    L.vsg_orb_time_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), ci]
     L.vsg_host_register.argtypes = [vp, C.c_size_t]
     L.vsg_host_unregister.argtypes = [vp]
     L.vsg_orb_slots.argtypes = [vp]
@@ -484,6 +489,12 @@ class ORBextractor:
         buf = np.zeros(cap, np.uint32)
         n = _check(self._L.vsg_orb_copy_selected(self._h, frame, level, _p(buf, _u32p), cap), "vsg_orb_copy_selected")
         return self._unpack(buf[:n])
+
+    def time_stats(self, reset=False):
+        """REGISTER_TIMES analogue: (calls, mean_ms, std_ms) of the blocking operator() calls so far."""
+        m, sd = C.c_double(), C.c_double()
+        n = _check(self._L.vsg_orb_time_stats(self._h, C.byref(m), C.byref(sd), int(reset)), "vsg_orb_time_stats")
+        return n, m.value, sd.value
 
     def set_serialize(self, on=True):
         _check(self._L.vsg_orb_set_serialize(self._h, int(on)), "vsg_orb_set_serialize")
