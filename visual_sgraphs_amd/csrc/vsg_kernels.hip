@@ -861,8 +861,6 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
                                                int lap1) {
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int lstart[kMaxLevels + 1];
-  enum { kSortKeys = 4096 };
-  __shared__ uint32_t s_key[kSortKeys];
   const int frame = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) {
     int s = 0;
@@ -901,32 +899,6 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
     hdr[frame].n = n;
     hdr[frame].mono = n - T;
     for (int l = 0; l <= kMaxLevels; l++) hdr[frame].level_start[l] = lstart[l];
-  }
-  // WORK ORDER of orient+desc (the order of the RESULTS is fixed by sl[], the order of the work is free): inside a
-  // level the keypoints are visited by 16-row band, then by x, so that the wavefronts that run side by side read
-  // neighbouring patches -- the octree's list order is spatially incoherent and made every L2 pull every patch line
-  // again (PMC fetch of k_orient_desc 490 MB per 512 C2 frames for 31 MB of algorithmic traffic).  fl[] has served
-  // its purpose as scan scratch and becomes the permutation: fl[j] = keypoint handled by work item j.
-  __syncthreads();
-  if (n <= kSortKeys) {
-    for (int i = tid; i < n; i += 256) {
-      int l = 0;
-      while (i >= lstart[l + 1]) l++;
-      const uint32_t c = sel[(size_t)frame * fg->sel_frame + fg->lv[l].sel_off + (i - lstart[l])];
-      // (band, x, index in the level): unique keys, so a rank is one compare per other keypoint of the level
-      s_key[i] = ((uint32_t)(VSG_CAND_Y(c) >> 4) << 24) | ((uint32_t)VSG_CAND_X(c) << 12) | (uint32_t)(i - lstart[l]);
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-      int l = 0;
-      while (i >= lstart[l + 1]) l++;
-      const uint32_t k = s_key[i];
-      int rank = lstart[l];
-      for (int j = lstart[l]; j < lstart[l + 1]; j++) rank += s_key[j] < k;
-      fl[rank] = i;
-    }
-  } else {
-    for (int i = tid; i < n; i += 256) fl[i] = i;
   }
 }
 
@@ -988,7 +960,7 @@ constexpr int kOdKpPerWave = VSG_OD_G;
 
 __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                      const FrameGeom *__restrict__ fg, Src0 s0,
-                                                     const uint32_t *__restrict__ sel, const int *__restrict__ perm,
+                                                     const uint32_t *__restrict__ sel,
                                                      const int *__restrict__ slots, const FrameHeader *__restrict__ hdr,
                                                      const int8_t *__restrict__ pattern, KeyPointPOD *__restrict__ kps,
                                                      uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity) {
@@ -1018,10 +990,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
 #pragma unroll 1
   for (int j = 0; j < kOdKpPerWave; j++) {
   // the workgroup's keypoints: wave w takes blk.x * 4 * G + 4 * j + w  (adjacent keypoints run side by side)
-  const int gw = __builtin_amdgcn_readfirstlane((blk.x * kOdKpPerWave + j) * 4 + (tid >> 6));
-  if (gw >= n) break;
-  // work item gw handles keypoint g (spatial work order, k_slots); everything below is indexed by g
-  const int g = __builtin_amdgcn_readfirstlane(perm[(size_t)frame * fg->out_cap + gw]);
+  const int g = __builtin_amdgcn_readfirstlane((blk.x * kOdKpPerWave + j) * 4 + (tid >> 6));
+  if (g >= n) break;
   int l = 0;
   while (g >= level_start[l + 1]) l++;
   l = __builtin_amdgcn_readfirstlane(l);
@@ -1407,11 +1377,10 @@ void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, con
   hipLaunchKernelGGL(k_slots, dim3(nframes), dim3(256), 0, s, d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1);
 }
 void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
-                        const uint32_t *sel, const int *perm, const int *slots, const FrameHeader *hdr,
-                        const int8_t *pattern, KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity,
-                        const FrameGeom &fg, int nframes) {
+                        const uint32_t *sel, const int *slots, const FrameHeader *hdr, const int8_t *pattern,
+                        KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes) {
   dim3 grid((fg.out_cap + 4 * kOdKpPerWave - 1) / (4 * kOdKpPerWave), nframes), block(256);
-  hipLaunchKernelGGL(k_orient_desc, grid, block, 0, s, pyr, blur, d_fg, s0, sel, perm, slots, hdr, pattern, kps, desc,
+  hipLaunchKernelGGL(k_orient_desc, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
                      counts, capacity);
 }
 void launch_border_copy(hipStream_t s, const uint8_t *img, int w, int h, int pitch, uint8_t *dst, int dpitch, int b) {

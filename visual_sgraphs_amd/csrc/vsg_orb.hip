@@ -366,7 +366,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
   HIP_TRY(hipStreamWaitEvent(s, ev_blur, 0));
   if (tm) HIP_TRY(hipEventRecord(h->ev[9], s));
-  launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, flags /* = work order after k_slots */, slots, hdr, h->d_pattern, d_kps + F * capacity,
+  launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, slots, hdr, h->d_pattern, d_kps + F * capacity,
                      d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[5], s));
   return VSG_OK;
