@@ -446,8 +446,16 @@ def main():
         dom_bytes = stages.get(dom, 0) * B  # algorithmic bytes one launch (batch of B frames) moves
         ach = dom_bytes / (timed[dom] * 1e-3) / 1e9 if timed[dom] > 0 else 0.0
         traffic, valu = None, None
-        try:  # PMC-derived HBM bytes / VALU instructions per launch of that kernel, collected offline (profiles/)
-            tr = json.load(open(ROOT / "profiles" / "traffic_r01.json")).get(f"{args.workload}/{B}", {}).get(dom)
+        stage_traffic = {}
+        try:  # PMC-derived HBM bytes / VALU instructions per launch of every kernel, collected offline (profiles/)
+            doc = {}
+            for name in ("traffic_r02.json", "traffic_r01.json"):
+                if (ROOT / "profiles" / name).exists():
+                    doc = json.load(open(ROOT / "profiles" / name))
+                    traffic_source = f"profiles/{name}"
+                    break
+            per_stage = doc.get(f"{args.workload}/{B}", {})
+            tr = per_stage.get(dom)
             if tr:
                 traffic = tr["fetch_bytes"] + tr["write_bytes"]
                 if tr.get("valu_insts") and timed[dom] > 0:
@@ -458,11 +466,20 @@ def main():
                             "busy_frac_range": [round(min(1.0, tr["valu_insts"] * 2.3 / simd_cycles), 3),
                                                 round(min(1.0, tr["valu_insts"] * 4.2 / simd_cycles), 3)],
                             "source": "SQ_INSTS_VALU (profiles/), issue cycles from profiles/r01_c_ubench_valu_rates.txt"}
-        except (OSError, ValueError):
+            # PMC traffic over algorithmic bytes per stage: well above 1 = wasted re-reads (the first thing to fix)
+            for k, v in per_stage.items():
+                if k in stages and stages[k] > 0 and "fetch_bytes" in v:
+                    stage_traffic[k] = {"pmc_bytes": v["fetch_bytes"] + v.get("write_bytes", 0),
+                                        "algorithmic_bytes": int(stages[k] * B),
+                                        "ratio": round((v["fetch_bytes"] + v.get("write_bytes", 0)) / (stages[k] * B), 2)}
+            if stage_traffic:
+                stage_traffic["_source"] = traffic_source + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except (OSError, ValueError, KeyError):
             pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     **({"valu_issue": valu} if valu else {}),
+                    **({"stage_traffic_vs_algorithmic": stage_traffic} if stage_traffic else {}),
                     "launch_ms": round(timed[dom], 4), "bytes_per_launch": int(dom_bytes),
                     "timing": "HIP events per kernel, serialized pass of the same steps (stage_ms); the timed "
                               "region the blur runs beside the octree on a second stream",
