@@ -195,3 +195,43 @@ def test_two_handles_on_two_devices():
     got = f1.SearchByProjection_Sim3(k["q_desc"], k["u"], k["v"], k["radius"], k["level"], 1.0, m0)
     ref = o.search_by_projection_sim3(k["q_desc"], k["u"], k["v"], k["radius"], k["level"], 1.0, m0)
     assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
+
+
+def test_c5_four_camera_streams_pinned_to_devices():
+    """Config C5 (rs_d435i_rgbd_inertial: 4 concurrent 640x480 streams, nFeatures 1250): one extractor handle + one
+    host thread per camera stream, each pinned to the device sharding.stream_to_rank gives it (all four land on the
+    devices that exist: with one GPU on device 0, with 4-8 GPUs on distinct ones), frames of every stream in order,
+    consecutive frames of a stream matched on the device that holds both."""
+    import threading
+    from visual_sgraphs_amd import sharding
+    ndev = orb.device_count()
+    n_streams, n_frames = 4, 3
+    seqs = [[synth.sequence_frame(640, 480, 900 + s, t) for t in range(n_frames)] for s in range(n_streams)]
+    ref = ol.OracleExtractor(1250, 1.2, 8, 20, 7)
+    want = [[ref(f) for f in seq] for seq in seqs]
+    got, errs = [[None] * n_frames for _ in range(n_streams)], []
+
+    def camera(s):
+        try:
+            dev = sharding.stream_to_rank(s, n_streams, min(ndev, n_streams))
+            ex = orb.ORBextractor(1250, 1.2, 8, 20, 7, device=dev)
+            m = orb.ORBmatcher(0.7, True, device=dev)
+            prev = None
+            for t, img in enumerate(seqs[s]):
+                mono, k, d = ex(img)
+                best = m.block_best2(d, prev)[0] if prev is not None else None
+                got[s][t] = (mono, k, d, best)
+                prev = d
+        except Exception as e:  # noqa: BLE001
+            errs.append((s, e))
+    ts = [threading.Thread(target=camera, args=(s,)) for s in range(n_streams)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for s in range(n_streams):
+        for t in range(n_frames):
+            mono, k, d, best = got[s][t]
+            rm, rk, rd = want[s][t]
+            assert mono == rm and k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+            if t > 0:
+                assert np.array_equal(best, ol.block_best2(rd, want[s][t - 1][2])[0])
