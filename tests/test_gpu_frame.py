@@ -299,3 +299,69 @@ def test_concurrent_host_threads_share_frames():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errors, errors
+
+
+# ---------------------------------------------------------------------------------------------- edge cases
+def test_empty_frames_zero_queries_and_wild_coordinates():
+    k, d = sc.features(1, 1)
+    f, o = _frame(k, d), ol.OracleFrame(k, d, sc.BOUNDS)
+    empty = orb.Frame(8).upload(np.zeros(0, orb.KP_DTYPE), np.zeros((0, 32), np.uint8), sc.BOUNDS)
+    z = np.zeros(0, np.float32)
+    zi = np.zeros(0, np.int32)
+    zd = np.zeros((0, 32), np.uint8)
+    # no queries
+    n, m = f.SearchByProjection_Sim3(zd, z, z, z, zi, 1.0, np.full(len(k), -1, np.int32))
+    assert n == 0 and np.all(m == -1)
+    assert f.Fuse_Sim3(zd, z, z, z, zi)[0] == 0
+    # queries against a frame without features
+    q = sc.kf_projection_scenario(1)
+    n, m = empty.SearchByProjection_Sim3(q["q_desc"], q["u"], q["v"], q["radius"], q["level"], 1.0, np.zeros(0, np.int32))
+    assert n == 0
+    nf, bi, bd = empty.Fuse_Sim3(q["q_desc"], q["u"], q["v"], q["radius"], q["level"])
+    assert nf == 0 and np.all(bi == -1) and np.all(bd == 0x7FFFFFFF)
+    assert empty.SearchForInitialization(f, z, z, 100, 0.9, True)[0] == 0
+    # NaN / infinite / huge coordinates and radii: empty windows on both sides, like the reference's int conversions
+    wild = np.array([np.nan, np.inf, -np.inf, 1e12, -1e12, 3e38, 50.0, 50.0, 50.0], np.float32)
+    rad = np.array([10, 10, 10, 10, 10, 10, np.nan, np.inf, 1e30], np.float32)
+    lv = np.zeros(len(wild), np.int32)
+    off, idx = f.GetFeaturesInArea(wild, np.full(len(wild), 60.0, np.float32), rad)
+    for i in range(len(wild)):
+        assert np.array_equal(idx[off[i]:off[i + 1]], o.features_in_area(wild[i], 60.0, rad[i], kf_form=True)), i
+    qd = np.tile(d[:1], (len(wild), 1))
+    got = f.SearchByProjection_Sim3(qd, wild, np.full(len(wild), 60.0, np.float32), rad, lv + 3, 1.0,
+                                    np.full(len(k), -1, np.int32))
+    ref = o.search_by_projection_sim3(qd, wild, np.full(len(wild), 60.0, np.float32), rad, lv + 3, 1.0,
+                                      np.full(len(k), -1, np.int32))
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
+
+
+def test_every_keypoint_in_one_cell_and_outside_the_grid():
+    """All features in a single grid cell (a cell with far more than 32 entries takes the kernel's fallback path) and
+    features that PosInGrid rejects (undistorted coordinates outside the bounds, Frame.cc:877-878)."""
+    rng = np.random.default_rng(3)
+    n = 300
+    k = np.zeros(n, orb.KP_DTYPE)
+    k["x"] = rng.uniform(100.0, 104.0, n)
+    k["y"] = rng.uniform(100.0, 104.0, n)
+    k["octave"] = rng.integers(0, 4, n)
+    k["x"][:20] = rng.uniform(-50, -10, 20)  # outside the grid: never indexed
+    k["y"][20:40] = rng.uniform(300, 400, 20)
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    f, o = _frame(k, d), ol.OracleFrame(k, d, sc.BOUNDS)
+    for right in (False,):
+        cs, en = f.grid(right)
+        ocs, oen = o.grid(right)
+        assert np.array_equal(cs, ocs) and np.array_equal(en, oen) and len(en) == n - 40
+    q = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    u = rng.uniform(90, 115, 64).astype(np.float32)
+    v = rng.uniform(90, 115, 64).astype(np.float32)
+    r = rng.uniform(1, 30, 64).astype(np.float32)
+    lvl = rng.integers(0, 4, 64).astype(np.int32)
+    m0 = np.full(n, -1, np.int32)
+    got = f.SearchByProjection_Sim3(q, u, v, r, lvl, 5.0, m0)
+    ref = o.search_by_projection_sim3(q, u, v, r, lvl, 5.0, m0)
+    assert ref[0] > 5 and got[0] == ref[0] and np.array_equal(got[1], ref[1])
+    off, idx = f.GetFeaturesInArea(u, v, r)
+    assert max(np.diff(off)) > 64  # lists longer than the inline slot and than 32 entries per cell
+    for i in range(64):
+        assert np.array_equal(idx[off[i]:off[i + 1]], o.features_in_area(u[i], v[i], r[i], kf_form=True))

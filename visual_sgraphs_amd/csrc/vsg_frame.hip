@@ -62,8 +62,8 @@ __global__ __launch_bounds__(1024) void k_frame_grid_build(const KeyPointPOD *__
   __syncthreads();
   // PosInGrid (Frame.cc:870-880): round() = half away from zero
   auto cell_of = [&](const KeyPointPOD &kp) -> int {
-    const int px = (int)roundf(fmul(fsub(kp.x, minX), invW));
-    const int py = (int)roundf(fmul(fsub(kp.y, minY), invH));
+    const int px = cvt_int_x86(roundf(fmul(fsub(kp.x, minX), invW)));
+    const int py = cvt_int_x86(roundf(fmul(fsub(kp.y, minY), invH)));
     return (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? -1 : px * kGridRows + py;
   };
   for (int i = tid; i < n; i += 1024) {
@@ -141,10 +141,11 @@ __global__ __launch_bounds__(256) void k_window_search(FrameDev F, const WinQuer
     const int koff = right ? F.nleft : 0;
     const float x = wq.x, y = wq.y, r = wq.r;
     // (int)floor((x - mnMinX - factorX) * mfGridElementWidthInv) etc. (Frame.cc:810-832): float arithmetic
-    const int nMinCellX = max(0, (int)floorf(fmul(fsub(fsub(x, F.minX), r), F.invW)));
-    const int nMaxCellX = min(kGridCols - 1, (int)ceilf(fmul(fadd(fsub(x, F.minX), r), F.invW)));
-    const int nMinCellY = max(0, (int)floorf(fmul(fsub(fsub(y, F.minY), r), F.invH)));
-    const int nMaxCellY = min(kGridRows - 1, (int)ceilf(fmul(fadd(fsub(y, F.minY), r), F.invH)));
+    // (the int conversions behave like the reference's x86 build for NaN / out-of-range values: cvt_int_x86)
+    const int nMinCellX = max(0, cvt_int_x86(floorf(fmul(fsub(fsub(x, F.minX), r), F.invW))));
+    const int nMaxCellX = min(kGridCols - 1, cvt_int_x86(ceilf(fmul(fadd(fsub(x, F.minX), r), F.invW))));
+    const int nMinCellY = max(0, cvt_int_x86(floorf(fmul(fsub(fsub(y, F.minY), r), F.invH))));
+    const int nMaxCellY = min(kGridRows - 1, cvt_int_x86(ceilf(fmul(fadd(fsub(y, F.minY), r), F.invH))));
     const bool active = !(wq.flags & 2) && nMinCellX < kGridCols && nMaxCellX >= 0 && nMinCellY < kGridRows &&
                         nMaxCellY >= 0 && nMaxCellX >= nMinCellX && nMaxCellY >= nMinCellY;
     const int ncy = active ? nMaxCellY - nMinCellY + 1 : 1, ncell = active ? (nMaxCellX - nMinCellX + 1) * ncy : 0;
@@ -420,8 +421,8 @@ void host_grid(const vsg_keypoint *kps, int i0, int n, float minX, float minY, f
   std::vector<int16_t> cell_of((size_t)n + 1);
   std::vector<int> cnt(kGridCells, 0);
   for (int i = 0; i < n; i++) {
-    const int px = (int)roundf(fmul(fsub(kps[i0 + i].x, minX), invW));
-    const int py = (int)roundf(fmul(fsub(kps[i0 + i].y, minY), invH));
+    const int px = cvt_int_x86(roundf(fmul(fsub(kps[i0 + i].x, minX), invW)));
+    const int py = cvt_int_x86(roundf(fmul(fsub(kps[i0 + i].y, minY), invH)));
     const bool in = !(px < 0 || px >= kGridCols || py < 0 || py >= kGridRows);
     cell_of[i] = in ? (int16_t)(px * kGridRows + py) : (int16_t)-1;
     if (in) cnt[px * kGridRows + py]++;

@@ -57,10 +57,10 @@ __global__ void k_grid_query(const vsg_keypoint *kps, const int *cell_start, con
   int n = 0;
   const int out0 = cand_off ? cand_off[q] : 0;
   // (int)floor((x - mnMinX - factorX) * mfGridElementWidthInv) etc. (Frame.cc:810-832)
-  const int nMinCellX = max(0, (int)floorf(vsg::fmul(vsg::fsub(vsg::fsub(x, P.minX), r), P.invW)));
-  const int nMaxCellX = min(kCols - 1, (int)ceilf(vsg::fmul(vsg::fadd(vsg::fsub(x, P.minX), r), P.invW)));
-  const int nMinCellY = max(0, (int)floorf(vsg::fmul(vsg::fsub(vsg::fsub(y, P.minY), r), P.invH)));
-  const int nMaxCellY = min(kRows - 1, (int)ceilf(vsg::fmul(vsg::fadd(vsg::fsub(y, P.minY), r), P.invH)));
+  const int nMinCellX = max(0, vsg::cvt_int_x86(floorf(vsg::fmul(vsg::fsub(vsg::fsub(x, P.minX), r), P.invW))));
+  const int nMaxCellX = min(kCols - 1, vsg::cvt_int_x86(ceilf(vsg::fmul(vsg::fadd(vsg::fsub(x, P.minX), r), P.invW))));
+  const int nMinCellY = max(0, vsg::cvt_int_x86(floorf(vsg::fmul(vsg::fsub(vsg::fsub(y, P.minY), r), P.invH))));
+  const int nMaxCellY = min(kRows - 1, vsg::cvt_int_x86(ceilf(vsg::fmul(vsg::fadd(vsg::fsub(y, P.minY), r), P.invH))));
   if (nMinCellX < kCols && nMaxCellX >= 0 && nMinCellY < kRows && nMaxCellY >= 0) {
     const bool bCheckLevels = (lo > 0) || (hi >= 0);
     for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
@@ -131,8 +131,8 @@ int vsg_grid_build(int device, const vsg_keypoint *kps, int n, float min_x, floa
   std::vector<int16_t> cell_of((size_t)n + 1);
   std::vector<int> cnt(kCells, 0);
   for (int i = 0; i < n; i++) {
-    const int px = (int)roundf(vsg::fmul(vsg::fsub(kps[i].x, g->P.minX), g->P.invW));
-    const int py = (int)roundf(vsg::fmul(vsg::fsub(kps[i].y, g->P.minY), g->P.invH));
+    const int px = vsg::cvt_int_x86(roundf(vsg::fmul(vsg::fsub(kps[i].x, g->P.minX), g->P.invW)));
+    const int py = vsg::cvt_int_x86(roundf(vsg::fmul(vsg::fsub(kps[i].y, g->P.minY), g->P.invH)));
     const bool in = !(px < 0 || px >= kCols || py < 0 || py >= kRows);
     cell_of[i] = in ? (int16_t)(px * kRows + py) : (int16_t)-1;
     if (in) cnt[px * kRows + py]++;

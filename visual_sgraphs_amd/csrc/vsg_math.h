@@ -20,6 +20,13 @@
 
 namespace vsg {
 
+// (int)f as the reference's x86-64 build computes it (cvttss2si): truncation, and the "integer indefinite" value
+// 0x80000000 for NaN and for anything outside [-2^31, 2^31) -- gfx950's v_cvt_i32_f32 saturates instead (and turns
+// NaN into 0), which would change which grid cells a window with a wild coordinate or radius covers (Frame.cc:810-832).
+VSG_HD int cvt_int_x86(float f) {
+  return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : (int)0x80000000;
+}
+
 // ---- non-contracting float / double primitives
 #if defined(__HIP_DEVICE_COMPILE__)
 VSG_HD float fmul(float a, float b) { return __fmul_rn(a, b); }
