@@ -812,7 +812,8 @@ int vsg_frame_search_by_sim3(vsg_frame *kf1, vsg_frame *kf2, int nq1, const int3
   rc = a.launch(kf2, kGateNone, 0x7FFFFFFF, nullptr, 0);
   if (rc == VSG_OK) rc = b.launch(kf1, kGateNone, 0x7FFFFFFF, nullptr, 0);
   if (rc != VSG_OK) return rc;
-  rc = b.finish();
+  rc = a.finish();  // one of the two directions may be empty: each waits for the stream it launched on
+  if (rc == VSG_OK) rc = b.finish();
   if (rc != VSG_OK) return rc;
   std::vector<int> vnMatch1((size_t)N1, -1), vnMatch2((size_t)N2, -1);
   const int32_t *ba = a.best(), *bb = b.best();

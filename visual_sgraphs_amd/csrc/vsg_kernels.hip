@@ -769,6 +769,10 @@ __global__ __launch_bounds__(256) void k_debug_sort(uint64_t *items, int n) {
 // (one 32-bit store) from 7 v_mad_u32_u24 per pixel.  Adjacent lanes own adjacent column groups, so every
 // wave-level load/store is one contiguous 256-byte row segment.
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));  // gfx950 global dword loads need no alignment
+// The level-0 pointer comes out of a by-value kernel-argument struct (Src0), which the compiler types as a FLAT
+// pointer; an align-1 flat load is split into four byte loads before address-space inference turns it global.
+// Loads through this type say "global" up front and stay one dword instruction.
+typedef __attribute__((address_space(1))) const u32_unaligned u32_global_unaligned;
 
 __device__ __forceinline__ int reflect101(int p, int len) {
   while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
@@ -1055,7 +1059,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
       // rows past v = 15 (it = 3, row = 7) are masked by the weights; re-read the previous row so the address stays
       // inside the image
       const int back = (it == 3 && row == 7) ? 1 : 0;
-      px[it] = *(const u32_unaligned *)(ptr + (ptrdiff_t)(8 * it - back) * upitch);
+      px[it] = *(const u32_global_unaligned *)(ptr + (ptrdiff_t)(8 * it - back) * upitch);
     }
 #pragma unroll
     for (int it = 0; it < 4; it++) {
