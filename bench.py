@@ -258,6 +258,12 @@ def main():
                 comm_kind = "C ABI vsg_shard_* (ncclAllGather)"
             except Exception as e:  # noqa: BLE001
                 print(f"[bench] vsg_shard_create failed ({e}); using torch.distributed for the exchange", file=sys.stderr)
+            # every rank must take the same path: one rank falling back alone would leave the others in a collective
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
         if comm is None:
             comm_kind = f"torch.distributed {args.dist_backend} all_gather_into_tensor"
             send = torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev)
