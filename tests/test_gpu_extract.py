@@ -66,6 +66,28 @@ def test_stage_by_stage_parity(w, h, nf, nl, seed, div):
         assert np.any(want[1]["response"] < 20)  # the fallback branch really ran
 
 
+def _reference_configs():
+    """every (image size, ORBextractor.*) tuple of the reference's settings files (tests/golden/make_reference_configs.py)"""
+    import json
+    cases = json.loads((Path(__file__).parent / "golden" / "reference_configs.json").read_text())["cases"]
+    return [tuple(c["params"][k] for k in ("w", "h", "nFeatures", "scaleFactor", "nLevels", "iniThFAST", "minThFAST"))
+            for c in cases]
+
+
+@pytest.mark.parametrize("w,h,nf,sf,nl,ini,mn", _reference_configs())
+def test_every_reference_configuration(w, h, nf, sf, nl, ini, mn):
+    """The 16 distinct extractor configurations of the reference's 49 settings files (EuRoC, KITTI, TUM, TUM-VI,
+    RealSense D435i / T265, ...): single frame and a 3-frame batch, operator() output bit for bit."""
+    ref = ol.OracleExtractor(nf, sf, nl, ini, mn)
+    ex = orb.ORBextractor(nf, sf, nl, ini, mn, max_batch=3)
+    seed = (w * 31 + h * 17 + nf + ini) % 1000
+    imgs = [synth.frame(w, h, seed + i, amplitude_div=1 if i < 2 else 6) for i in range(3)]
+    wants = [ref(im) for im in imgs]
+    assert_same_output(ex(imgs[0]), wants[0], f"{w}x{h}/{nf}/{nl}/{ini}")
+    for got, want in zip(ex.extract_batch(np.stack(imgs)), wants):
+        assert_same_output(got, want, f"batch {w}x{h}/{nf}/{nl}/{ini}")
+
+
 def test_pyramid_with_border_matches_mvImagePyramid():
     img = synth.frame(320, 240, 12)
     ref = ol.OracleExtractor(500, 1.2, 4, 20, 7)

@@ -76,6 +76,33 @@ def test_geometry_matches_oracle(hc, w, h, nf, nl):
         assert info["pitch"] % 64 == 0 and info["pitch"] >= info["w"]
 
 
+def _reference_configs():
+    """every (image size, ORBextractor.*) tuple of the reference's settings files (tests/golden/make_reference_configs.py)"""
+    import json
+    from pathlib import Path
+    cases = json.loads((Path(__file__).parent / "golden" / "reference_configs.json").read_text())["cases"]
+    return [tuple(c["params"][k] for k in ("w", "h", "nFeatures", "scaleFactor", "nLevels", "iniThFAST", "minThFAST"))
+            for c in cases]
+
+
+@pytest.mark.parametrize("w,h,nf,sf,nl,ini,mn", _reference_configs())
+def test_geometry_matches_oracle_for_every_reference_config(hc, w, h, nf, sf, nl, ini, mn):
+    assert hc.hc_build(nf, sf, nl, ini, mn, h, w) == 0
+    e = ol.OracleExtractor(nf, sf, nl, ini, mn)
+    e(synth.constant_frame(w, h))
+    t = e.tables()
+    sc, inv = np.zeros(nl, np.float32), np.zeros(nl, np.float32)
+    q, um = np.zeros(nl, np.int32), np.zeros(16, np.int32)
+    hc.hc_tables(sc.ctypes.data_as(C.POINTER(C.c_float)), inv.ctypes.data_as(C.POINTER(C.c_float)),
+                 q.ctypes.data_as(_i32p), um.ctypes.data_as(_i32p))
+    assert np.array_equal(sc, t["scale"]) and np.array_equal(inv, t["inv_scale"])
+    assert np.array_equal(q, t["features_per_level"]) and int(q.sum()) == nf
+    for l in range(nl):
+        info = level_info(hc, l)
+        assert (info["w"], info["h"]) == e.level_size(l)
+        assert info["quota"] == t["features_per_level"][l]
+
+
 def test_geometry_known_answers_c2(hc):
     assert hc.hc_build(1000, 1.2, 8, 20, 7, 480, 640) == 0
     cells = [(17, 12, 36, 38), (14, 10, 36, 37), (11, 8, 38, 38), (9, 7, 38, 36), (7, 5, 40, 40), (6, 4, 38, 41),
