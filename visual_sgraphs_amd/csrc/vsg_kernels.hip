@@ -773,6 +773,13 @@ typedef uint32_t u32_unaligned __attribute__((aligned(1)));  // gfx950 global dw
 // pointer; an align-1 flat load is split into four byte loads before address-space inference turns it global.
 // Loads through this type say "global" up front and stay one dword instruction.
 typedef __attribute__((address_space(1))) const u32_unaligned u32_global_unaligned;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x2 u32x2_unaligned __attribute__((aligned(1)));
+typedef __attribute__((address_space(1))) const u32x2_unaligned u64_global_unaligned;
+typedef u32x2 u32x2_4aligned __attribute__((aligned(4)));
+typedef __attribute__((address_space(1))) const u32x2_4aligned u64_global_4aligned;
+typedef __attribute__((address_space(1))) const uint32_t u32_global;
 
 __device__ __forceinline__ int reflect101(int p, int len) {
   while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
@@ -951,30 +958,31 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 enum { kPatchR = 18, kPatchW = 2 * kPatchR + 1, kPatchP = 40 };  // rBRIEF patch radius / width / LDS row pitch
 
-// Disc membership of the IC_Angle patch in the lane layout used below: lane = 32 * hh + (u + 15); bit `it` of entry
-// `lane` says that pixel (u, v = 2 * it + hh - 15) lies inside the 749-px patch (|u| <= umax[|v|], ORBextractor.cc:454-469).
-// IC_Angle lane layout: 8 rows x 8 dword columns per load instruction (lane = 8 * row + column), 4 instructions
-// cover the 31 x 31 patch (rows 8 * it + row - 15, pixels u = 4 * column + b - 15).  Per (it, lane) the table
-// holds byte weights for the lane's 4 pixels: wp = 1 inside the 749-px disc (|u| <= umax[|v|],
+// IC_Angle lane layout: 16 rows x 4 (unaligned) qwords per load instruction (lane = 4 * row + column), 2 instructions
+// cover the 31 x 31 patch (rows 16 * it + row - 15, pixels u = 8 * column + 4 * half + b - 15).  Per (it, lane, half)
+// the table holds byte weights for the 4 pixels of that dword: wp = 1 inside the 749-px disc (|u| <= umax[|v|],
 // ORBextractor.cc:454-469), wu = (u + 15) inside, else 0 -- so  sum p = udot4(px, wp)  and
-// sum (u + 15) p = udot4(px, wu).
-struct alignas(8) DiscTable {
-  uint32_t w[4][64][2];
+// sum (u + 15) p = udot4(px, wu).  (tools/ubench_tcp.hip: the L1 moves this patch fastest as qwords, 4 lanes per
+// row -- 82 cycles per CU against 106 for dwords, 8 lanes per row -- and that layout does not care about the byte
+// alignment of the patch origin.)
+struct alignas(16) DiscTable {
+  uint32_t w[2][64][4];  // [it][lane] = {wp(half 0), wu(half 0), wp(half 1), wu(half 1)}
 };
 constexpr DiscTable make_disc_table() {
   DiscTable t{};
-  for (int it = 0; it < 4; it++)
+  for (int it = 0; it < 2; it++)
     for (int lane = 0; lane < 64; lane++) {
-      const int v = 8 * it + (lane >> 3) - kHalfPatch, av = v < 0 ? -v : v;
-      for (int b = 0; b < 4; b++) {
-        const int u = 4 * (lane & 7) + b - kHalfPatch, au = u < 0 ? -u : u;
-        if (v > kHalfPatch || u > kHalfPatch) continue;
-        const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * (av & 15))) & 15);  // umax[|v|]
-        if (au <= um) {
-          t.w[it][lane][0] |= 1u << (8 * b);
-          t.w[it][lane][1] |= (uint32_t)(u + kHalfPatch) << (8 * b);
+      const int v = 16 * it + (lane >> 2) - kHalfPatch, av = v < 0 ? -v : v;
+      for (int h = 0; h < 2; h++)
+        for (int b = 0; b < 4; b++) {
+          const int u = 8 * (lane & 3) + 4 * h + b - kHalfPatch, au = u < 0 ? -u : u;
+          if (v > kHalfPatch || u > kHalfPatch) continue;
+          const int um = (int)((0x3689ABCDDEEEFFFFull >> (4 * (av & 15))) & 15);  // umax[|v|]
+          if (au <= um) {
+            t.w[it][lane][2 * h + 0] |= 1u << (8 * b);
+            t.w[it][lane][2 * h + 1] |= (uint32_t)(u + kHalfPatch) << (8 * b);
+          }
         }
-      }
     }
   return t;
 }
@@ -1010,10 +1018,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   __shared__ f32x4 patf[256];            // test k: (x0, y0, x1, y1) of bit_pattern_31_ as floats
   __shared__ int s_hdr[kMaxLevels + 3];  // n, mono, level_start[0..kMaxLevels]
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchW * kPatchP];
-  __shared__ uint2 s_ic[4 * 64];  // c_disc, one 8-byte entry per (it, lane)
+  __shared__ u32x4 s_ic[2 * 64];  // c_disc, one 16-byte entry per (it, lane)
   const BlockXY blk = frame_major_block();
   const int frame = blk.y, tid = threadIdx.x;
-  s_ic[tid] = ((const uint2 *)c_disc.w)[tid];
+  if (tid < 128) s_ic[tid] = ((const u32x4 *)c_disc.w)[tid];
   {
     const uint32_t pw = ((const uint32_t *)pattern)[tid];
     patf[tid] = (f32x4){(float)(int8_t)pw, (float)(int8_t)(pw >> 8), (float)(int8_t)(pw >> 16), (float)(int8_t)(pw >> 24)};
@@ -1046,29 +1054,26 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   const size_t foff = (size_t)frame * fg->pyr_frame_bytes + L.img_off;
   int upitch;
   const uint8_t *unblurred = level_ptr(fg, s0, pyr, frame, l, upitch);
-  // ---- IC_Angle: the kernel is bound by the number of vector-memory instructions (each one walks 64 lane
-  // addresses), so the 31 x 31 patch is read as dwords -- 8 rows x 8 (unaligned) dwords per instruction, 4
-  // instructions instead of 16 byte loads -- and the disc mask / column weights are v_dot4_u32_u8 operands.
+  // ---- IC_Angle: 16 rows x 4 (unaligned) qwords per load instruction, 2 instructions per patch; the disc mask and
+  // the column weights are v_dot4_u32_u8 operands.  The row past v = 15 (it = 1, row = 15) is masked by the weights;
+  // those lanes re-read row 30 so the address stays inside the image.
   int m10 = 0, m01 = 0;
   {
-    const int row = lane >> 3, col = lane & 7;
-    const uint8_t *ptr = unblurred + (ptrdiff_t)(cy + row - kHalfPatch) * upitch + (cx - kHalfPatch) + 4 * col;
-    uint32_t px[4];
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      // rows past v = 15 (it = 3, row = 7) are masked by the weights; re-read the previous row so the address stays
-      // inside the image
-      const int back = (it == 3 && row == 7) ? 1 : 0;
-      px[it] = *(const u32_global_unaligned *)(ptr + (ptrdiff_t)(8 * it - back) * upitch);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const uint2 w = s_ic[it * 64 + lane];
-      const int sp = (int)__builtin_amdgcn_udot4(px[it], w.x, 0u, false);  // sum of the pixels inside the disc
-      const int su = (int)__builtin_amdgcn_udot4(px[it], w.y, 0u, false);  // sum of (u + 15) * pixel
-      m10 += su - kHalfPatch * sp;
-      m01 += (8 * it + row - kHalfPatch) * sp;
-    }
+    const int row = lane >> 2, col = lane & 3;
+    const uint8_t *ptr = unblurred + (ptrdiff_t)(cy - kHalfPatch) * upitch + (cx - kHalfPatch) + 8 * col;
+    const u32x2 p0 = *(const u64_global_unaligned *)(ptr + (ptrdiff_t)row * upitch);
+    const u32x2 p1 = *(const u64_global_unaligned *)(ptr + (ptrdiff_t)min(row + 16, 2 * kHalfPatch) * upitch);
+    const u32x4 w0 = s_ic[lane], w1 = s_ic[64 + lane];
+    // S = sum p, U = sum (u + 15) p over the lane's 2 x 8 pixels;  v = 16 it + row - 15
+    const uint32_t s0p = __builtin_amdgcn_udot4(p0.y, w0.z, __builtin_amdgcn_udot4(p0.x, w0.x, 0u, false), false);
+    const uint32_t s1p = __builtin_amdgcn_udot4(p1.y, w1.z, __builtin_amdgcn_udot4(p1.x, w1.x, 0u, false), false);
+    uint32_t su = __builtin_amdgcn_udot4(p0.x, w0.y, 0u, false);
+    su = __builtin_amdgcn_udot4(p0.y, w0.w, su, false);
+    su = __builtin_amdgcn_udot4(p1.x, w1.y, su, false);
+    su = __builtin_amdgcn_udot4(p1.y, w1.w, su, false);
+    const int S = (int)(s0p + s1p);
+    m10 = (int)su - kHalfPatch * S;
+    m01 = (row - kHalfPatch) * S + 16 * (int)s1p;
   }
   m10 = wave_sum_i32(m10);
   m01 = wave_sum_i32(m01);
@@ -1078,23 +1083,35 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   // ---- descriptor.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38), so the 37x37 blurred
   // patch is staged in LDS with row-major (coalesced) byte loads; the 8 samples per lane are then LDS reads.
   {
-    // 37 rows x 10 (unaligned) dwords, 6 rows (60 lanes) per trip; gfx950 global loads accept any byte alignment
-    constexpr int kDw = kPatchP / 4, kRows = 64 / kDw, kIt = (kPatchW + kRows - 1) / kRows;
-    const int r0 = lane / kDw, cc = lane - r0 * kDw;
+    // 37 rows x 5 qwords, 12 rows (60 lanes) per trip, 4 trips.  Rows are fetched from the patch origin rounded DOWN
+    // to 4 bytes (origin % 4 + 37 <= 40 bytes: still 5 qwords) -- the L1 moves 4-byte-aligned qwords, 5 lanes per row,
+    // in 104 cycles per patch against 144 for unaligned dwords, 10 lanes per row (tools/ubench_tcp.hip) -- and the
+    // shift is undone in registers: the bytes to the right of a lane's qword are the next lane's (DPP), one
+    // v_alignbyte per dword.  The last qword of a row only feeds the unused columns 37..39, so what its right
+    // neighbour holds does not matter.
+    constexpr int kQw = kPatchP / 8, kRows = 64 / kQw, kIt = (kPatchW + kRows - 1) / kRows;
+    static_assert(kPatchP % 8 == 0 && (kIt - 1) * kRows == kPatchW - 1, "the last trip holds exactly one patch row");
+    const int r0 = lane / kQw, cc = lane - r0 * kQw;
     const int pitch = L.pitch;
-    const uint8_t *gp = blur + foff + (size_t)(cy - kPatchR + r0) * pitch + (cx - kPatchR) + 4 * cc;
-    uint8_t *lp = patch + r0 * kPatchP + 4 * cc;
+    const int ox = cx - kPatchR, sh = ox & 3;
+    const uint8_t *gp = blur + foff + (size_t)(cy - kPatchR) * pitch + (ox - sh) + 8 * cc;
+    uint8_t *lp = patch + r0 * kPatchP + 8 * cc;
     const bool act = r0 < kRows;
-    uint32_t pv[kIt];
+    u32x2 pv[kIt];
 #pragma unroll
     for (int it = 0; it < kIt; it++) {
-      // rows past the patch (last trip) re-read the last row: stays inside the image, never stored
-      const int back = it * kRows + r0 < kPatchW ? 0 : it * kRows + r0 - (kPatchW - 1);
-      pv[it] = act ? *(const u32_unaligned *)(gp + (ptrdiff_t)(it * kRows - back) * pitch) : 0u;
+      // the last trip holds one patch row (r0 = 0); its other lanes re-read that row: inside the image, never stored
+      const int r = it < kIt - 1 ? it * kRows + r0 : kPatchW - 1;
+      pv[it] = act ? *(const u64_global_4aligned *)(gp + (ptrdiff_t)r * pitch) : (u32x2){0u, 0u};
     }
 #pragma unroll
-    for (int it = 0; it < kIt; it++)
-      if (act && it * kRows + r0 < kPatchW) *(uint32_t *)(lp + it * kRows * kPatchP) = pv[it];
+    for (int it = 0; it < kIt; it++) {
+      const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pv[it].x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+      u32x2 v;
+      v.x = __builtin_amdgcn_alignbyte(pv[it].y, pv[it].x, (uint32_t)sh);
+      v.y = __builtin_amdgcn_alignbyte(nx, pv[it].y, (uint32_t)sh);
+      if (act && (it < kIt - 1 || r0 == 0)) *(u32x2 *)(lp + it * kRows * kPatchP) = v;
+    }
   }
   // the patch is private to this wavefront: LDS writes complete in order before the reads below
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
