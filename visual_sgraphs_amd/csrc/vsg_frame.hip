@@ -53,11 +53,23 @@ struct WinLaunch {
 // (handful of) entries are put in index order by the thread that owns the cell.
 __global__ __launch_bounds__(1024) void k_frame_grid_build(const KeyPointPOD *__restrict__ kps, int i0, int n,
                                                             float minX, float minY, float invW, float invH,
-                                                            int *__restrict__ cell_start, GridEnt *__restrict__ ent) {
+                                                            int *__restrict__ cell_start, GridEnt *__restrict__ ent,
+                                                            KeyPointPOD *__restrict__ kps_copy,
+                                                            const uint8_t *__restrict__ desc_src,
+                                                            uint8_t *__restrict__ desc_copy,
+                                                            int *__restrict__ zero_cells) {
   __shared__ int s_cnt[kGridCells + 1];
   __shared__ int s_fill[kGridCells];
   __shared__ int s_wtot[16];
   const int tid = threadIdx.x;
+  // making a frame resident straight out of the extractor is ONE launch: the keypoint / descriptor records are copied
+  // into the frame's block and the (absent) right-camera grid is emptied by the threads that build the grid
+  if (kps_copy)
+    for (int i = tid; i < n * 7; i += 1024) ((uint32_t *)kps_copy)[i] = ((const uint32_t *)(kps + i0))[i];
+  if (desc_copy)
+    for (int i = tid; i < n * 8; i += 1024) ((uint32_t *)desc_copy)[i] = ((const uint32_t *)desc_src)[i];
+  if (zero_cells)
+    for (int c = tid; c <= kGridCells; c += 1024) zero_cells[c] = 0;
   for (int c = tid; c <= kGridCells; c += 1024) s_cnt[c] = 0;
   __syncthreads();
   // PosInGrid (Frame.cc:870-880): round() = half away from zero
@@ -558,15 +570,11 @@ int vsg_frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_keyp
   f->n = n, f->nleft = -1, f->has_uright = false;
   f->h_kps.assign(kps_host, kps_host + n);
   if (v.done) F_TRY(hipStreamWaitEvent(c->stream, v.done, 0));
-  if (n) {
-    F_TRY(hipMemcpyAsync(f->d_kps, v.d_kps, (size_t)n * sizeof(KeyPointPOD), hipMemcpyDeviceToDevice, c->stream));
-    F_TRY(hipMemcpyAsync(f->d_desc, v.d_desc, (size_t)n * 32, hipMemcpyDeviceToDevice, c->stream));
-  }
-  // the grid is built from the keypoints where they already are (the extractor's output), beside the two copies
+  // one launch: grid from the keypoints where they already are (the extractor's output) + the two record copies +
+  // an empty right-camera grid
   hipLaunchKernelGGL(k_frame_grid_build, dim3(1), dim3(1024), 0, c->stream, v.d_kps, 0, n, f->minX, f->minY, f->invW,
-                     f->invH, f->d_cell_start[0], f->d_ent[0]);
+                     f->invH, f->d_cell_start[0], f->d_ent[0], f->d_kps, v.d_desc, f->d_desc, f->d_cell_start[1]);
   F_TRY(hipGetLastError());
-  F_TRY(hipMemsetAsync(f->d_cell_start[1], 0, (kGridCells + 1) * 4, c->stream));
   F_TRY(hipStreamSynchronize(c->stream));
   return VSG_OK;
 }

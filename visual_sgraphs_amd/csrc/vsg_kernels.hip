@@ -108,11 +108,15 @@ constexpr int kPyrThreads = VSG_PYR_NT;  // threads per pyramid tile (512: 0.196
 
 __global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                  const Short4 *__restrict__ tile_tab, Src0 s0,
-                                                 const PyrTile *__restrict__ tiles, int ldsA, int ldsAB) {
+                                                 const PyrTile *__restrict__ tiles, int ldsA, int ldsAB,
+                                                 int *__restrict__ cand_count) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
   const BlockXY blk = frame_major_block();
   const PyrTile &T = tiles[blk.x];
   const int frame = blk.y, tid = threadIdx.x;
+  // the per-level FAST candidate counters of this frame start the call at zero (k_fast_cells adds to them after this
+  // kernel): one workgroup per frame clears them here instead of a launch of its own
+  if (cand_count && blk.x == 0 && tid < kMaxLevels) cand_count[frame * kMaxLevels + tid] = 0;
   uint8_t *buf0 = pyr_lds, *buf1 = pyr_lds + ldsA;
   Short4 *s_tab = (Short4 *)(pyr_lds + ldsAB);  // the tile's slices of the resize tables, all levels
   // One round of independent global loads: the tile's (pre-rebased, contiguous) table slice and the level-0 region.
@@ -1381,7 +1385,7 @@ void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sho
   hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, d_fg, d_tab, s0, level);
 }
 void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tile_tab, const Src0 &s0,
-                    const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes) {
+                    const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes, int *cand_count) {
   const int a16 = (ldsA + 15) & ~15, ab16 = a16 + ((ldsB + 15) & ~15);
   const size_t lds = ab16 + tabMax * sizeof(Short4);
   // the raised limit is a per-DEVICE attribute of the function (vsg_ctx.h lds_limit_ensure)
@@ -1389,7 +1393,7 @@ void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sh
   hipGetDevice(&dev);
   lds_limit_ensure(0, dev, (const void *)k_pyramid, lds);
   hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(kPyrThreads), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
-                     d_tile_tab, s0, d_tiles, a16, ab16);
+                     d_tile_tab, s0, d_tiles, a16, ab16, cand_count);
 }
 template <int NT, int TP, int SP>
 static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells,

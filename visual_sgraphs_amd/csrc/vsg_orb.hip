@@ -269,7 +269,7 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
         for (int rep = 0; rep < 2; rep++) {  // first launch warms up, second is timed
           HIP_TRY(hipEventRecord(h->ev[0], h->s_main));
           launch_pyramid(h->s_main, h->d_pyr, h->d_fg, h->d_ptab[ti], s0, h->d_ptiles[ti], (int)PT.tiles.size(), PT.ldsA,
-                         PT.ldsB, PT.tabMax, nf);
+                         PT.ldsB, PT.tabMax, nf, nullptr);
           HIP_TRY(hipEventRecord(h->ev[1], h->s_main));
           HIP_TRY(hipEventSynchronize(h->ev[1]));
           HIP_TRY(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
@@ -329,11 +329,12 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   }
   range_push("ComputePyramid");
   if (ti < 0) {
+    launch_zero(s, cand_count, nf * kMaxLevels);  // the fused kernel clears the candidate counters itself
     for (int l = 1; l < fg.nlevels; l++) launch_resize(s, pyr, h->d_fg, h->d_tab, s0, fg, l, nf);
   } else {
     const PyrTiling &PT = h->G.pyr[ti];
     launch_pyramid(s, pyr, h->d_fg, h->d_ptab[ti], s0, h->d_ptiles[ti], (int)PT.tiles.size(), PT.ldsA, PT.ldsB,
-                   PT.tabMax, nf);
+                   PT.tabMax, nf, cand_count);
   }
   range_pop();
   if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
@@ -387,7 +388,6 @@ static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, i
   if (nsub > nframes) nsub = nframes;
   const bool tm = h->timing && nsub == 1;
   if (tm) harvest_timing(h);
-  launch_zero(s, h->d_counts2, 2 * h->max_batch * kMaxLevels);
   if (nsub == 1) {
     int rc = enqueue_range(h, s0, 0, nframes, lap0, lap1, d_kps, d_desc, d_counts, capacity, s,
                            no_overlap ? s : h->s_blur, h->ev_pyr, h->ev_blur, tm);
