@@ -29,18 +29,41 @@ def parse(path):
     return out
 
 
+def parse_stereo(path):
+    """Stereo rigs: baseline Stereo.b [m] and Camera1.fx [px] (new settings format) or Camera.bf = b * fx and Camera.fx
+    (old format): Frame::mb = mbf / fx and Frame::mbf = b * fx feed ComputeStereoMatches (Frame.cc:957-1127)."""
+    text = path.read_text(errors="replace")
+
+    def num(pat):
+        m = re.search(r"^\s*" + pat + r"\s*:\s*([-0-9.eE+]+)", text, re.M)
+        return float(m.group(1)) if m else None
+
+    fx = num(r"Camera1?\.fx")
+    b, bf = num(r"Stereo\.b"), num(r"Camera\.bf")
+    if fx is None or (b is None and bf is None):
+        return None
+    return {"b": b if b is not None else bf / fx, "fx": fx}
+
+
 def main():
-    seen = {}
+    seen, stereo = {}, {}
     for f in sorted(ROOT.rglob("*.yaml")):
         p = parse(f)
         if p is None:
             continue
         key = tuple(p[k] for k in KEYS)
         seen.setdefault(key, {"params": p, "files": []})["files"].append(str(f.relative_to(ROOT)))
+        st = parse_stereo(f)
+        if st is not None and f.relative_to(ROOT).parts[0].startswith("Stereo"):
+            skey = key + (st["b"], st["fx"])
+            stereo.setdefault(skey, {"params": dict(p, **st), "files": []})["files"].append(str(f.relative_to(ROOT)))
     cases = [seen[k] for k in sorted(seen)]
+    scases = [stereo[k] for k in sorted(stereo)]
     out = Path(__file__).parent / "reference_configs.json"
-    out.write_text(json.dumps({"source": "reference config/**/*.yaml", "cases": cases}, indent=1) + "\n")
-    print(f"{len(cases)} distinct extractor configurations from {sum(len(c['files']) for c in cases)} settings files -> {out}")
+    out.write_text(json.dumps({"source": "reference config/**/*.yaml", "cases": cases, "stereo_cases": scases},
+                              indent=1) + "\n")
+    print(f"{len(cases)} distinct extractor configurations from {sum(len(c['files']) for c in cases)} settings files, "
+          f"{len(scases)} distinct stereo rigs -> {out}")
 
 
 if __name__ == "__main__":

@@ -38,6 +38,35 @@ def test_stereo_matches_two_handles(w, h, nf, disp, mb, mbf):
     assert m.sum() > 300 and abs(np.median(kl["x"][m] - want_u[m]) - disp) < 0.5
 
 
+def _reference_stereo_rigs():
+    """every rectified stereo rig of the reference's settings files (tests/golden/make_reference_configs.py)"""
+    import json
+    from pathlib import Path
+    cases = json.loads((Path(__file__).parent / "golden" / "reference_configs.json").read_text())["stereo_cases"]
+    return [tuple(c["params"][k] for k in ("w", "h", "nFeatures", "nLevels", "iniThFAST", "minThFAST", "b", "fx"))
+            for c in cases]
+
+
+@pytest.mark.parametrize("w,h,nf,nl,ini,mn,b,fx", _reference_stereo_rigs())
+def test_stereo_matches_every_reference_rig(w, h, nf, nl, ini, mn, b, fx):
+    """RealSense D435i (three calibrations) and KITTI 00-12: Frame::mb = b, Frame::mbf = b * fx in float, as
+    Frame.cc computes them; disparity range, sub-pixel refinement and depth bit for bit."""
+    mbf = np.float32(np.float32(b) * np.float32(fx))
+    mb = np.float32(mbf / np.float32(fx))
+    L, R = rectified_pair(w, h, 311 + w, 21)
+    rl, rr = ol.OracleExtractor(nf, 1.2, nl, ini, mn), ol.OracleExtractor(nf, 1.2, nl, ini, mn)
+    _, kl, dl = rl(L)
+    _, kr, dr = rr(R)
+    want_u, want_d = ol.stereo_matches(rl, rr, kl, dl, kr, dr, float(mb), float(mbf))
+    ex = orb.ORBextractor(nf, 1.2, nl, ini, mn, max_batch=2)
+    (_, gkl, gdl), (_, gkr, gdr) = ex.extract_batch(np.stack([L, R]))
+    assert gkl.tobytes() == kl.tobytes() and gkr.tobytes() == kr.tobytes()
+    got_u, got_d = orb.ComputeStereoMatches(ex, 0, ex, 1, gkl, gdl, gkr, gdr, float(mb), float(mbf))
+    assert np.array_equal(got_u.view(np.uint32), want_u.view(np.uint32))
+    assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32))
+    assert (want_u >= 0).sum() > 200
+
+
 def test_stereo_matches_one_handle_two_frame_batch():
     L, R = rectified_pair(752, 480, 5, 23)
     ref_l, ref_r = ol.OracleExtractor(1200, 1.2, 8, 20, 7), ol.OracleExtractor(1200, 1.2, 8, 20, 7)
