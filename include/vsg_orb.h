@@ -320,7 +320,8 @@ int vsg_host_unregister(void *ptr);
  * returns; if they are pinned (vsg_host_register) the device writes the n[i] records of every frame straight into
  * them, otherwise they are filled from the slot's pinned staging inside vsg_orb_wait -- either way only n[i] records
  * per frame cross PCIe, not `capacity`.  `gray` must stay valid until the wait returns if it is pinned; unpinned
- * input is copied before submit returns.  vsg_orb_wait(ticket) blocks until that batch is complete and delivers n[]
+ * input is copied before submit returns (batches of 16 frames and more: by the calling thread and up to three helper
+ * threads the handle keeps asleep between batches; environment VSG_STAGE_THREADS=n, 0 = the calling thread only).  vsg_orb_wait(ticket) blocks until that batch is complete and delivers n[]
  * and mono_index[] (nframes entries each).  Tickets are waited for in submission order. */
 int vsg_orb_slots(const vsg_orb *h);
 int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t frame_stride, int rows, int cols,

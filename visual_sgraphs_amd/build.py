@@ -35,7 +35,7 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", str(LIB)] + [str(CSRC / s) for s in SOURCES] + ["-ldl"]
+    cmd = [_hipcc()] + FLAGS + ["-o", str(LIB)] + [str(CSRC / s) for s in SOURCES] + ["-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=str(CSRC))

@@ -10,6 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -63,10 +67,81 @@ struct Slot {
   bool direct = false;
 };
 
+// Helper threads for the pageable-input path of vsg_orb_submit_batch: the frames of a batch are copied into the slot's
+// pinned staging by the calling thread AND three sleeping helpers (one core copies ~20 GB/s, a 64-frame C2 batch is
+// 20 MB; the copy was the whole cost of that path: 63 k -> 113 k frames/s on the GPU box, flat beyond 3-4 helpers;
+// VSG_STAGE_THREADS=n overrides, 0 = none).  The helpers are created at the first pageable batch of a handle,
+// sleep on a condition variable between batches and are joined by vsg_orb_destroy.
+struct StagePool {
+  struct Job {
+    const uint8_t *src = nullptr;
+    uint8_t *dst = nullptr;
+    size_t frame_stride = 0, fbytes = 0;
+    int stride = 0, ip = 0, rows = 0, cols = 0, nframes = 0;
+  } job;
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::atomic<int> next{0};
+  int generation = 0, pending = 0;
+  bool stop = false;
+
+  static void copy_frame(const Job &j, int f) {
+    uint8_t *dst = j.dst + (size_t)f * j.fbytes;
+    const uint8_t *src = j.src + (size_t)f * j.frame_stride;
+    if (j.stride == j.ip)
+      memcpy(dst, src, j.fbytes);
+    else
+      for (int y = 0; y < j.rows; y++) memcpy(dst + (size_t)y * j.ip, src + (size_t)y * j.stride, (size_t)j.cols);
+  }
+  void drain() {
+    for (int f = next.fetch_add(1); f < job.nframes; f = next.fetch_add(1)) copy_frame(job, f);
+  }
+  void worker() {
+    int seen = 0;
+    std::unique_lock<std::mutex> lk(m);
+    for (;;) {
+      cv_work.wait(lk, [&] { return stop || generation != seen; });
+      if (stop) return;
+      seen = generation;
+      lk.unlock();
+      drain();
+      lk.lock();
+      if (--pending == 0) cv_done.notify_one();
+    }
+  }
+  explicit StagePool(int n) {
+    for (int i = 0; i < n; i++) workers.emplace_back([this] { worker(); });
+  }
+  ~StagePool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_work.notify_all();
+    for (auto &t : workers) t.join();
+  }
+  // copies every frame of the job; returns when all of them are staged
+  void run(const Job &j) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      job = j;
+      next.store(0);
+      pending = (int)workers.size();
+      generation++;
+    }
+    cv_work.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(m);
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+};
+
 struct vsg_orb {
   ExtractorTables T;
   Geometry G;
   int device = 0, max_batch = 1;
+  StagePool *pool = nullptr;  // pageable-input staging helpers (vsg_orb_submit_batch)
   int rows = 0, cols = 0;  // geometry currently built for
   uint16_t taps[7] = {18, 34, 49, 55, 49, 34, 18};
   int gray_coeffs[3] = {4899, 9617, 1868};  // [OCV] 4.2 R2Y, G2Y, B2Y
@@ -538,6 +613,8 @@ void vsg_orb_destroy(vsg_orb *h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->s_main) quiesce(h);
+  delete h->pool;
+  h->pool = nullptr;
   free_image_buffers(h);
   hipFree(h->d_pattern);
   hipFree(h->d_scratch);
@@ -747,20 +824,31 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
                                  hipMemcpyHostToDevice, h->s_h2d));
     }
   } else {
-    // pageable memory: bounce through the slot's pinned staging in chunks, so that the copy engine works on chunk
-    // i while the host copies chunk i + 1
-    const int chunk = 8;
-    for (int f0 = 0; f0 < nframes; f0 += chunk) {
-      const int nf = nframes - f0 < chunk ? nframes - f0 : chunk;
-      for (int f = f0; f < f0 + nf; f++) {
-        uint8_t *dst = S.h_in + f * fbytes;
-        const uint8_t *src = gray + (size_t)f * frame_stride;
-        if (stride == ip)
-          memcpy(dst, src, fbytes);
-        else
-          for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * ip, src + (size_t)y * stride, (size_t)cols);
+    // pageable memory: bounce through the slot's pinned staging.  Small batches: in chunks, so that the copy engine
+    // works on chunk i while this thread copies chunk i + 1.  Large batches: the frames are dealt to this thread and
+    // the handle's helper threads, then ONE DMA (which overlaps the staging of the next batch, another slot).
+    static const int n_helpers = getenv("VSG_STAGE_THREADS") ? atoi(getenv("VSG_STAGE_THREADS")) : 3;
+    if (nframes >= 16 && n_helpers > 0) {
+      if (!h->pool) h->pool = new StagePool(n_helpers < 8 ? n_helpers : 8);
+      StagePool::Job j;
+      j.src = gray, j.dst = S.h_in, j.frame_stride = frame_stride, j.fbytes = fbytes;
+      j.stride = stride, j.ip = ip, j.rows = rows, j.cols = cols, j.nframes = nframes;
+      h->pool->run(j);
+      HIP_TRY(hipMemcpyAsync(S.d_in, S.h_in, fbytes * nframes, hipMemcpyHostToDevice, h->s_h2d));
+    } else {
+      const int chunk = 8;
+      for (int f0 = 0; f0 < nframes; f0 += chunk) {
+        const int nf = nframes - f0 < chunk ? nframes - f0 : chunk;
+        for (int f = f0; f < f0 + nf; f++) {
+          uint8_t *dst = S.h_in + f * fbytes;
+          const uint8_t *src = gray + (size_t)f * frame_stride;
+          if (stride == ip)
+            memcpy(dst, src, fbytes);
+          else
+            for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * ip, src + (size_t)y * stride, (size_t)cols);
+        }
+        HIP_TRY(hipMemcpyAsync(S.d_in + f0 * fbytes, S.h_in + f0 * fbytes, fbytes * nf, hipMemcpyHostToDevice, h->s_h2d));
       }
-      HIP_TRY(hipMemcpyAsync(S.d_in + f0 * fbytes, S.h_in + f0 * fbytes, fbytes * nf, hipMemcpyHostToDevice, h->s_h2d));
     }
   }
   HIP_TRY(hipEventRecord(S.ev_in, h->s_h2d));
