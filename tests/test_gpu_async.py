@@ -56,6 +56,41 @@ def test_submit_wait_three_batches_in_flight(pinned):
             orb.unpin(b), orb.unpin(k), orb.unpin(d)
 
 
+@pytest.mark.parametrize("strided", [False, True])
+def test_large_pageable_batches_are_staged_by_the_helper_threads(strided):
+    """Batches of 16 frames and more from pageable memory take the helper-thread staging path (vsg_orb.hip StagePool);
+    `strided` = frames that are views into a larger buffer (row stride != width, frame stride != rows * stride)."""
+    B = 24
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    packed = [_frames(300 + i, B) for i in range(4)]
+    if strided:
+        big = [np.full((B, H + 5, W + 24), 255, np.uint8) for _ in packed]
+        for b, p in zip(big, packed):
+            b[:, 2:2 + H, 8:8 + W] = p
+        batches = [b[:, 2:2 + H, 8:8 + W] for b in big]
+    else:
+        batches = packed
+    outs = [(np.zeros((B, cap), orb.KP_DTYPE), np.zeros((B, cap, 32), np.uint8)) for _ in batches]
+    tickets = [ex.submit_batch(batches[i], *outs[i]) for i in range(3)]
+    res = [ex.wait(tickets[0])]
+    tickets.append(ex.submit_batch(batches[3], *outs[3]))
+    res += [ex.wait(t) for t in tickets[1:]]
+    want = _oracle(packed[0][:3]) + _oracle(packed[3][-3:])
+    got = [(res[0], outs[0], f) for f in range(3)] + [(res[3], outs[3], f) for f in range(B - 3, B)]
+    for (rm, rk, rd), ((n, mono), (k, d), f) in zip(want, got):
+        assert n[f] == len(rk) and mono[f] == rm
+        assert k[f, :n[f]].tobytes() == rk.tobytes() and np.array_equal(d[f, :n[f]], rd)
+    # every frame of every batch against the blocking single-frame path of a second handle
+    ex1 = orb.ORBextractor(NF, 1.2, 8, 20, 7)
+    for i in (1, 2):
+        n, mono = res[i]
+        for f in range(0, B, 5):
+            m1, k1, d1 = ex1(packed[i][f])
+            assert n[f] == len(k1) and mono[f] == m1 and outs[i][0][f, :n[f]].tobytes() == k1.tobytes()
+            assert np.array_equal(outs[i][1][f, :n[f]], d1)
+
+
 def test_blocking_calls_ride_the_same_pipeline():
     """vsg_orb_extract / _batch = submit + wait; strided (non-packed) input rows and a sub-view of a larger image."""
     ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=2)
