@@ -274,7 +274,8 @@ def case_resident(rng):
 def case_async(rng):
     """vsg_orb_submit_batch / vsg_orb_wait with random batch sizes, strides, pinned / pageable buffers, lapping areas."""
     w, h, nf, sc_, nl, ini, mn = geometry(rng)
-    B = int(rng.integers(1, 6))
+    # one case in eight: batches of 16 frames and more, which pageable input stages with the handle's helper threads
+    B = int(rng.integers(16, 21)) if rng.integers(0, 8) == 0 else int(rng.integers(1, 6))
     ex = orb.ORBextractor(nf, sc_, nl, ini, mn, max_batch=B)
     ref = ol.OracleExtractor(nf, sc_, nl, ini, mn)
     cap = ex.capacity(h, w)
@@ -284,7 +285,7 @@ def case_async(rng):
     tickets, bufs = [], []
     ok = True
     for k in range(nb):
-        b = int(rng.integers(1, B + 1))
+        b = int(rng.integers(max(1, B - 4), B + 1))
         pad = int(rng.integers(0, 9))
         big = np.zeros((b, h, w + pad), np.uint8)
         imgs = np.stack([synth.frame(w, h, int(rng.integers(0, 1 << 20))) for _ in range(b)])
