@@ -88,6 +88,26 @@ def test_every_reference_configuration(w, h, nf, sf, nl, ini, mn):
         assert_same_output(got, want, f"batch {w}x{h}/{nf}/{nl}/{ini}")
 
 
+@pytest.mark.parametrize("w,h,nf,nl", [(1920, 1080, 3000, 8), (2400, 2336, 1500, 3)])
+def test_large_images_take_the_other_candidate_list_forms(w, h, nf, nl):
+    """1920x1080 / 3000 features: level 0 yields more FAST candidates than the octree keeps in registers, so the
+    per-cell segments are compacted into the scratch list first.  2400x2336: 4 355 cells on level 0, more than the
+    octree can prefix in LDS (vsg_common.h kOctMaxCells), so k_fast_cells appends to one list per level instead."""
+    img = synth.frame(w, h, 4321)
+    ref = ol.OracleExtractor(nf, 1.2, nl, 20, 7)
+    want = ref(img)
+    ex = orb.ORBextractor(nf, 1.2, nl, 20, 7)
+    got = ex(img)
+    gx, gy, gr = ex.candidates(0)
+    rx, ry, rr = ref.candidates(0)
+    go, ro = np.lexsort((gx, gy)), np.lexsort((rx, ry))
+    assert len(gx) == len(rx) and np.array_equal(gx[go], rx[ro]) and np.array_equal(gy[go], ry[ro])
+    assert np.array_equal(gr[go], rr[ro])
+    if nl == 8:
+        assert len(rx) > 2048
+    assert_same_output(got, want, f"{w}x{h}")
+
+
 def test_pyramid_with_border_matches_mvImagePyramid():
     img = synth.frame(320, 240, 12)
     ref = ol.OracleExtractor(500, 1.2, 4, 20, 7)

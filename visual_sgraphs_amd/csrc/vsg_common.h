@@ -6,6 +6,7 @@ namespace vsg {
 
 enum {
   kMaxLevels = 16,
+  kOctMaxCells = 4096,   // FAST cells per level whose counts k_octree can prefix in LDS (segmented candidate lists)
   kMaxIniNodes = 16,     // octree: round(width/height) initial nodes (ORBextractor.cc:566)
   kEdgeThreshold = 19,   // ORBextractor.cc:71
   kHalfPatch = 15,       // ORBextractor.cc:70
@@ -56,6 +57,7 @@ struct FrameGeom {
   int cand_frame;        // uint32 per frame in the candidate array
   int sel_frame;         // uint32 per frame in the selected array
   int total_cells;       // FAST cells per frame (all levels)
+  int cand_segmented;    // 1: k_fast_cells writes per-cell segments + counts, 0: one atomically appended list per level
   int total_blur_blocks;
   int out_cap;           // keypoint capacity per frame in the output arrays
   int iniTh, minTh;

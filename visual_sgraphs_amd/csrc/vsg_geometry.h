@@ -73,6 +73,7 @@ struct Short4 {
 
 struct CellDesc {  // one FAST cell: valid region [x0,x1) x [y0,y1) in level coordinates
   int16_t level, x0, y0, x1, y1, pad;
+  int32_t cand_off;  // the cell's own segment of its level's candidate slice (its worst-case survivor count long)
 };
 
 // Fused pyramid: one workgroup computes, for one tile of the TOP level, the regions of every lower level that
@@ -102,6 +103,7 @@ struct PyrTiling {
 struct Geometry {
   FrameGeom fg;
   PyrTiling pyr[kPyrTilings];
+  int maxCellsPerLevel = 0;
   int fastMaxVh = 0, fastMaxVw = 0, fastMaxArea = 0;  // over all FAST cells: rows, columns and pixels of the valid region (LDS sizing)
   std::vector<Short4> resizeTab;  // all levels, x tables then y tables (offsets in LevelGeom)
   std::vector<CellDesc> cells;
@@ -155,6 +157,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   G.resizeTab.clear();
   G.cells.clear();
   G.fastMaxVh = G.fastMaxVw = G.fastMaxArea = 0;
+  G.maxCellsPerLevel = 0;
   G.maxQuota = 0;
   fg.nlevels = T.nlevels;
   fg.rows = rows;
@@ -185,6 +188,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
     L.wCell = (int)std::ceil(width / L.nCols);
     L.hCell = (int)std::ceil(height / L.nRows);
     if ((long long)L.nCols * L.nRows * L.wCell * L.hCell > 0xFFFFFF) return -3;
+    if (L.nCols * L.nRows > G.maxCellsPerLevel) G.maxCellsPerLevel = L.nCols * L.nRows;
     L.cell_base = (int)G.cells.size();
     int cand_cap = 0;
     for (int i = 0; i < L.nRows; i++) {
@@ -200,6 +204,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
         c.x1 = (int16_t)(maxX - 3);
         c.y1 = (int16_t)(maxY - 3);
         c.pad = 0;
+        c.cand_off = 0;
         if (c.x1 < c.x0) c.x1 = c.x0;  // empty (the reference `continue`s or FAST finds nothing)
         if (c.y1 < c.y0) c.y1 = c.y0;
         G.cells.push_back(c);
@@ -207,6 +212,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
         if (c.x1 - c.x0 > G.fastMaxVw) G.fastMaxVw = c.x1 - c.x0;
         if ((c.x1 - c.x0) * (c.y1 - c.y0) > G.fastMaxArea) G.fastMaxArea = (c.x1 - c.x0) * (c.y1 - c.y0);
         // a strict 3x3 local maximum occupies a 2x2 block: worst-case survivors per cell
+        G.cells.back().cand_off = cand_cap;
         cand_cap += ((c.x1 - c.x0 + 1) / 2) * ((c.y1 - c.y0 + 1) / 2);
       }
     }
@@ -350,6 +356,9 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   fg.cand_frame = cand_off;
   fg.sel_frame = sel_off;
   fg.total_cells = (int)G.cells.size();
+  // candidates per cell in fixed segments (no returning atomic in k_fast_cells; the octree gathers them through a
+  // prefix of the cell counts in LDS) as long as a level's cells fit that prefix; beyond: one list per level
+  fg.cand_segmented = G.maxCellsPerLevel <= kOctMaxCells ? 1 : 0;
   fg.total_blur_blocks = blur_blocks;
   // output capacity: what operator() can produce = sum over levels of final list sizes
   fg.out_cap = out_cap;

@@ -394,7 +394,7 @@ template <int NT, int kTileP, int kScoreP>
 __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                     const CellDesc *__restrict__ cells, Src0 s0,
                                                     uint32_t *__restrict__ cand, int *__restrict__ cand_count,
-                                                    int tile_bytes, int score_bytes) {
+                                                    int *__restrict__ cell_count, int tile_bytes, int score_bytes) {
   // LDS is sized by the launch for the largest cell of THIS geometry (rows x fixed pitches, queue = largest
   // valid area), not for the 70 x 70 worst case: more cells resident per CU.
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
@@ -407,8 +407,18 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   const int frame = blk.y;
   const LevelGeom &L = fg->lv[cell.level];
   const int vw = cell.x1 - cell.x0, vh = cell.y1 - cell.y0;
-  if (vw <= 0 || vh <= 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
+  // Segmented candidate lists (the normal case): the cell owns a fixed segment of its level's slice, as long as its
+  // worst-case survivor count, and reports its count; survivors are written the moment non-max suppression finds
+  // them.  No returning global atomic at the end of the cell's dependency chain (a timing-only ablation put that
+  // round trip at 6 % of the kernel), no second pass over the queue.  k_octree gathers through the cell counts.
+  const bool seg = fg->cand_segmented != 0;
+  int *my_count = cell_count + (size_t)frame * fg->total_cells + blk.x;
+  if (vw <= 0 || vh <= 0) {
+    if (seg && tid == 0) *my_count = 0;
+    return;
+  }
+  uint32_t *seg_out = cand + (size_t)frame * fg->cand_frame + L.cand_off + cell.cand_off;
   int pitch;
   const uint8_t *img = level_ptr(fg, s0, pyr, frame, cell.level, pitch);
   // tile column 0 <-> image column ax (4-byte aligned); valid-region column c sits at tile column c + 3 + ox
@@ -530,8 +540,12 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
       mx = max(mx, (int)sp[kScoreP + 1]);
       const bool is_max = s > mx;
       if (is_max) {
-        keep |= 1u << it;
-        atomicAdd(&s_cnt[0], 1);
+        if (seg) {
+          seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
+        } else {
+          keep |= 1u << it;
+          atomicAdd(&s_cnt[0], 1);
+        }
       }
     }
     __syncthreads();
@@ -540,6 +554,10 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     __syncthreads();
   }
   const int nEmit = s_cnt[0];
+  if (seg) {
+    if (tid == 0) *my_count = nEmit;
+    return;
+  }
   if (nEmit == 0) return;
   if (tid == 0) s_cnt[3] = atomicAdd(&cand_count[frame * kMaxLevels + cell.level], nEmit);
   __syncthreads();
@@ -700,9 +718,77 @@ constexpr int kOctThreads = VSG_OCT_NT;  // threads per (frame, level) octree
 // 5 waves per SIMD = 5 octrees per CU (96 VGPRs, 10 dwords spilled off the hot paths): the kernel is latency-bound,
 // so residency is worth more than registers, and 96-register waves leave room for the blur waves that run beside it
 // (4 waves / 127 VGPRs: 0.167 ms per 512 frames and 256 k frames/s; 5: 0.160 ms and 260 k; 6: 255 k; 8: 0.185 ms)
+// Candidates of a level whose cells wrote their survivors into fixed segments.  LDS holds the exclusive prefix of the
+// cell counts and the segment offsets; candidate p lives in the cell found by bisection of the prefix, at segment
+// offset + (p - prefix).
+struct SegSrc {
+  const uint32_t *level_cand;  // the level's slice of the frame's candidate array
+  const int *prefix;           // LDS [ncells + 1]
+  const int *segoff;           // LDS [ncells]
+  int ncells;
+  __device__ int cell_of(int p) const {
+    int lo = 0, hi = ncells;  // invariant: prefix[lo] <= p < prefix[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (prefix[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+  }
+  __device__ uint32_t operator()(int p) const {
+    const int ci = cell_of(p);
+    return level_cand[segoff[ci] + (p - prefix[ci])];
+  }
+};
+// The octree's register-resident point set (octree::RegPts) fed from the segments: a thread takes a CONTIGUOUS run of
+// candidate indices (which thread holds which point is irrelevant to the algorithm), so it bisects once and then
+// walks along the cells; its K loads are independent and in flight together.
+template <int K>
+struct SegRegPts {
+  SegSrc src;
+  uint32_t c[K];
+  int n[K];
+  int cnt;
+  template <class G>
+  __device__ void load(G &g, int npts) {
+    const int per = (npts + g.nthreads - 1) / g.nthreads;  // <= K by the caller's choice of this form
+    const int p0 = min(g.tid * per, npts);
+    cnt = min(per, npts - p0);
+    int ci = cnt > 0 ? src.cell_of(p0) : 0;
+    int next = src.prefix[ci + 1];
+    int off = src.segoff[ci] - src.prefix[ci];  // candidate p of this cell sits at level_cand[off + p]
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      n[k] = 0;
+      c[k] = 0u;
+      if (k < cnt) {
+        const int p = p0 + k;
+        while (p >= next) {  // next non-empty cell
+          ci++;
+          next = src.prefix[ci + 1];
+          off = src.segoff[ci] - src.prefix[ci];
+        }
+        c[k] = src.level_cand[off + p];
+      }
+    }
+  }
+  template <class G, class F>
+  __device__ void for_each(G &, int, F f) {
+#pragma unroll
+    for (int k = 0; k < K; k++)
+      if (k < cnt) f(c[k], n[k]);
+  }
+  template <class G, class F>
+  __device__ void init_each(G &g, int npts, F f) {
+    for_each(g, npts, f);
+  }
+};
+
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_octree(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ cand,
-                                                const int *__restrict__ cand_count, uint16_t *__restrict__ node_of,
-                                                uint32_t *__restrict__ sel, int *__restrict__ sel_count, int cap) {
+                                                const int *__restrict__ cand_count, const CellDesc *__restrict__ cells,
+                                                const int *__restrict__ cell_count, uint32_t *__restrict__ cand2,
+                                                uint16_t *__restrict__ node_of,
+                                                uint32_t *__restrict__ sel, int *__restrict__ sel_count, int cap,
+                                                int prefix_off) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[3 * kSortStack];
@@ -724,14 +810,43 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(5, 
   g.nthreads = blockDim.x;
   g.wtot = wtot;
   g.stk = sort_stack;
-  int npts = cand_count[frame * kMaxLevels + level];
-  if (npts > L.cand_cap) npts = L.cand_cap;
   const size_t coff = (size_t)frame * fg->cand_frame + L.cand_off;
   uint32_t *out = sel + (size_t)frame * fg->sel_frame + L.sel_off;
-  // candidates stay in registers across the passes when they fit (the common case); node_of[] is only touched by
-  // the fallback
-  const int n = npts <= kOctRegPts * kOctThreads ? octree::distribute_reg<kOctRegPts>(g, P, cand + coff, npts, W, out)
+  int n;
+  if (fg->cand_segmented) {
+    // per-cell segments: exclusive prefix of this level's cell counts in LDS (behind the octree workspace)
+    const int ncells = L.nCols * L.nRows;
+    int *prefix = (int *)(oct_lds + prefix_off), *segoff = prefix + ncells + 1;
+    const int *cc = cell_count + (size_t)frame * fg->total_cells + L.cell_base;
+    for (int i = g.tid; i < ncells; i += g.nthreads) {
+      prefix[i] = cc[i];
+      segoff[i] = cells[L.cell_base + i].cand_off;
+    }
+    __syncthreads();
+    const int npts = g.exclusive_scan(prefix, ncells);
+    if (g.tid == 0) prefix[ncells] = npts;
+    __syncthreads();
+    const SegSrc src = {cand + coff, prefix, segoff, ncells};
+    if (npts <= kOctRegPts * kOctThreads) {
+      SegRegPts<kOctRegPts> pts;
+      pts.src = src;
+      n = octree::distribute_pts(g, P, pts, npts, W, out);
+    } else {
+      // too many for the registers: compact once into the scratch list, then the memory-resident form
+      uint32_t *list = cand2 + coff;
+      for (int p = g.tid; p < npts; p += g.nthreads) list[p] = src(p);
+      __threadfence_block();
+      __syncthreads();
+      n = octree::distribute(g, P, list, npts, node_of + coff, W, out);
+    }
+  } else {
+    int npts = cand_count[frame * kMaxLevels + level];
+    if (npts > L.cand_cap) npts = L.cand_cap;
+    // candidates stay in registers across the passes when they fit (the common case); node_of[] is only touched by
+    // the fallback
+    n = npts <= kOctRegPts * kOctThreads ? octree::distribute_reg<kOctRegPts>(g, P, cand + coff, npts, W, out)
                                          : octree::distribute(g, P, cand + coff, npts, node_of + coff, W, out);
+  }
   if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;
 }
 
@@ -1397,36 +1512,40 @@ void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sh
 }
 template <int NT, int TP, int SP>
 static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells,
-                          const Src0 &s0, uint32_t *cand, int *cand_count, const FrameGeom &fg, int maxVh, int maxArea,
-                          int nframes) {
+                          const Src0 &s0, uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg,
+                          int maxVh, int maxArea, int nframes) {
   dim3 grid(fg.total_cells, nframes), block(NT);
   // + one spare row: the necessary test reads (masked) dwords just past the last tile row
   const int tile_bytes = ((maxVh + 6 + 1) * TP + 15) & ~15, score_bytes = ((maxVh + 2) * SP + 15) & ~15;
   const size_t lds = (size_t)tile_bytes + score_bytes + (((size_t)maxArea * 2 + 15) & ~(size_t)15);
   hipLaunchKernelGGL((k_fast_cells<NT, TP, SP>), grid, block, lds, s, pyr, d_fg, d_cells, s0, cand, cand_count,
-                     tile_bytes, score_bytes);
+                     cell_count, tile_bytes, score_bytes);
 }
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
-                 uint32_t *cand, int *cand_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea, int nframes) {
+                 uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea,
+                 int nframes) {
   // tile row = up to 3 alignment bytes + vw + 6 ring bytes, rounded up to dwords; score row = vw + 2
   if (maxVw <= 40)
-    launch_fast_t<VSG_FAST_NT, 52, 44>(s, pyr, d_fg, d_cells, s0, cand, cand_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 52, 44>(s, pyr, d_fg, d_cells, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
   else if (maxVw <= 56)
-    launch_fast_t<VSG_FAST_NT, 68, 60>(s, pyr, d_fg, d_cells, s0, cand, cand_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 68, 60>(s, pyr, d_fg, d_cells, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
   else
-    launch_fast_t<VSG_FAST_NT, 84, 76>(s, pyr, d_fg, d_cells, s0, cand, cand_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 84, 76>(s, pyr, d_fg, d_cells, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
 }
 void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, const int *cand_count,
-                   uint16_t *node_of, uint32_t *sel, int *sel_count, const FrameGeom &fg, int maxQuota, int nframes) {
+                   const CellDesc *d_cells, const int *cell_count, uint32_t *cand2, uint16_t *node_of, uint32_t *sel,
+                   int *sel_count, const FrameGeom &fg, int maxQuota, int maxCellsPerLevel, int nframes) {
   const int cap = octree::node_capacity(maxQuota);
-  const size_t lds = octree::work_bytes(cap);
+  const int prefix_off = (int)((octree::work_bytes(cap) + 15) & ~(size_t)15);
+  const size_t lds = (size_t)prefix_off + (fg.cand_segmented ? (2 * (size_t)maxCellsPerLevel + 1) * 4 : 0);
   // beyond 64 KB of dynamic LDS the launch needs the limit raised (quotas above ~1000 per level, e.g. a single
   // level holding every feature); gfx950 has 160 KB per workgroup
   int dev = 0;
   hipGetDevice(&dev);
   lds_limit_ensure(1, dev, (const void *)k_octree, lds);
   dim3 grid(fg.nlevels, nframes), block(kOctThreads);
-  hipLaunchKernelGGL(k_octree, grid, block, lds, s, d_fg, cand, cand_count, node_of, sel, sel_count, cap);
+  hipLaunchKernelGGL(k_octree, grid, block, lds, s, d_fg, cand, cand_count, d_cells, cell_count, cand2, node_of, sel,
+                     sel_count, cap, prefix_off);
 }
 void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n) {
   hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(256), (size_t)n * 8 + 2 * (n + 2) * 2 + 16, s, d_items, n);

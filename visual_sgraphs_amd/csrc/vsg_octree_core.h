@@ -112,9 +112,15 @@ struct MemPts {
   }
 };
 
-template <int K>
-struct RegPts {
+// where candidate p comes from: a contiguous array, or (device) the per-cell segments k_fast_cells writes
+struct PtrSrc {
   const uint32_t *cand;
+  VSG_OCT_HD uint32_t operator()(int p) const { return cand[p]; }
+};
+
+template <int K, class Src = PtrSrc>
+struct RegPts {
+  Src src;
   uint32_t c[K];
   int n[K];
   template <class G>
@@ -122,7 +128,7 @@ struct RegPts {
     VSG_OCT_UNROLL
     for (int k = 0; k < K; k++) {
       const int p = g.tid + k * g.nthreads;
-      c[k] = p < npts ? cand[p] : 0u;
+      c[k] = p < npts ? src(p) : 0u;
       n[k] = 0;
     }
   }
@@ -507,7 +513,13 @@ VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts,
 template <int K, class G>
 VSG_OCT_HD int distribute_reg(G &g, const Params &P, const uint32_t *cand, int npts, Work &W, uint32_t *sel_out) {
   RegPts<K> pts;
-  pts.cand = cand;
+  pts.src.cand = cand;
+  return distribute_pts(g, P, pts, npts, W, sel_out);
+}
+template <int K, class Src, class G>
+VSG_OCT_HD int distribute_reg_src(G &g, const Params &P, const Src &src, int npts, Work &W, uint32_t *sel_out) {
+  RegPts<K, Src> pts;
+  pts.src = src;
   return distribute_pts(g, P, pts, npts, W, sel_out);
 }
 

@@ -151,6 +151,8 @@ struct vsg_orb {
   FrameGeom *d_fg = nullptr;
   Short4 *d_tab = nullptr;
   CellDesc *d_cells = nullptr;
+  int *d_cell_count = nullptr;    // [max_batch][fg.total_cells] FAST survivors per cell (segmented candidate lists)
+  uint32_t *d_cand2 = nullptr;    // [max_batch][fg.cand_frame] compacted candidates of levels too large for the octree's registers
   int pyr_tiling = 0;                   // the tiling calibration found faster for a full batch of this geometry
   PyrTile *d_ptiles[kPyrTilings] = {};  // Geometry::pyr[i].tiles
   Short4 *d_ptab[kPyrTilings] = {};     // Geometry::pyr[i].tab
@@ -211,6 +213,8 @@ static void free_slot(Slot &S) {
 
 static void free_image_buffers(vsg_orb *h) {
   hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in);
+  hipFree(h->d_cell_count), hipFree(h->d_cand2);
+  h->d_cell_count = nullptr, h->d_cand2 = nullptr;
   for (int i = 0; i < kPyrTilings; i++) {
     hipFree(h->d_ptiles[i]), hipFree(h->d_ptab[i]);
     h->d_ptiles[i] = nullptr, h->d_ptab[i] = nullptr;
@@ -315,6 +319,9 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   HIP_TRY(hipMemset(h->d_pyr, 0, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMemset(h->d_blur, 0, B * fg.pyr_frame_bytes));
   HIP_TRY(hipMalloc(&h->d_cand, B * fg.cand_frame * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&h->d_cand2, B * fg.cand_frame * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(&h->d_cell_count, B * fg.total_cells * sizeof(int)));
+  HIP_TRY(hipMemset(h->d_cell_count, 0, B * fg.total_cells * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_nodeof, B * fg.cand_frame * sizeof(uint16_t)));
   HIP_TRY(hipMalloc(&h->d_sel, B * fg.sel_frame * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&h->d_counts2, 2 * B * kMaxLevels * sizeof(int)));
@@ -383,6 +390,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   uint8_t *pyr = h->d_pyr + F * fg.pyr_frame_bytes, *blur = h->d_blur + F * fg.pyr_frame_bytes;
   uint32_t *cand = h->d_cand + F * fg.cand_frame, *sel = h->d_sel + F * fg.sel_frame;
   uint16_t *nodeof = h->d_nodeof + F * fg.cand_frame;
+  int *cell_count = h->d_cell_count + F * fg.total_cells;
   int *cand_count = h->d_counts2 + F * kMaxLevels;
   int *sel_count = h->d_counts2 + ((size_t)h->max_batch + F) * kMaxLevels;
   int *flags = h->d_flags + F * fg.out_cap, *slots = h->d_slots + F * fg.out_cap;
@@ -420,7 +428,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   static const bool blur_early = getenv("VSG_BLUR_EARLY") != nullptr && getenv("VSG_BLUR_LATE") == nullptr;
   if (!blur_early) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
-    launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
+    launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
   HIP_TRY(hipEventRecord(ev_pyr, s));
@@ -431,12 +439,13 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   HIP_TRY(hipEventRecord(ev_blur, sb));
   if (blur_early) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
-    launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
+    launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
   if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
   Range r_tail("DistributeOctTree + slots + IC_Angle / rBRIEF");
-  launch_octree(s, h->d_fg, cand, cand_count, nodeof, sel, sel_count, fg, h->G.maxQuota, nf);
+  launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel, sel_count,
+                fg, h->G.maxQuota, h->G.maxCellsPerLevel, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
   launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
@@ -1050,8 +1059,30 @@ static int copy_list(vsg_orb *h, const uint32_t *list, size_t frame_elems, int o
 
 int vsg_orb_copy_candidates(vsg_orb *h, int frame, int level, uint32_t *dst, int cap) {
   if (!h || !h->rows || level < 0 || level >= h->T.nlevels) return VSG_ERR_INVALID;
-  const LevelGeom &L = h->G.fg.lv[level];
-  return copy_list(h, h->d_cand, h->G.fg.cand_frame, L.cand_off, L.cand_cap, h->d_counts2, frame, level, dst, cap);
+  const FrameGeom &fg = h->G.fg;
+  const LevelGeom &L = fg.lv[level];
+  if (!fg.cand_segmented)
+    return copy_list(h, h->d_cand, fg.cand_frame, L.cand_off, L.cand_cap, h->d_counts2, frame, level, dst, cap);
+  // per-cell segments: the level's slice and its cell counts come down, the list is assembled here (debug path)
+  if (frame < 0 || frame >= h->max_batch) return VSG_ERR_INVALID;
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = wait_last(h);
+  if (rc != VSG_OK) return rc;
+  const int ncells = L.nCols * L.nRows;
+  std::vector<int> counts((size_t)ncells);
+  std::vector<uint32_t> slice((size_t)L.cand_cap);
+  HIP_TRY(hipMemcpy(counts.data(), h->d_cell_count + (size_t)frame * fg.total_cells + L.cell_base, (size_t)ncells * 4,
+                    hipMemcpyDeviceToHost));
+  if (L.cand_cap > 0)
+    HIP_TRY(hipMemcpy(slice.data(), h->d_cand + (size_t)frame * fg.cand_frame + L.cand_off, (size_t)L.cand_cap * 4,
+                      hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int ci = 0; ci < ncells; ci++) {
+    const CellDesc &c = h->G.cells[(size_t)L.cell_base + ci];
+    for (int k = 0; k < counts[ci]; k++, n++)
+      if (dst && n < cap) dst[n] = slice[(size_t)c.cand_off + k];
+  }
+  return n;
 }
 int vsg_orb_copy_selected(vsg_orb *h, int frame, int level, uint32_t *dst, int cap) {
   if (!h || !h->rows || level < 0 || level >= h->T.nlevels) return VSG_ERR_INVALID;
