@@ -142,6 +142,10 @@ struct vsg_orb {
   Geometry G;
   int device = 0, max_batch = 1;
   StagePool *pool = nullptr;  // pageable-input staging helpers (vsg_orb_submit_batch)
+  // Set by the BLOCKING entry points around their submit: input copy, kernels and export all go to s_main.  The three
+  // streams exist so that consecutive batches overlap; a call that waits for its own batch has nothing to overlap
+  // with, and each cross-stream event wait costs ~15 us of idle GPU (0.175 -> ~0.15 ms per single-frame operator()).
+  bool one_stream = false;
   int rows = 0, cols = 0;  // geometry currently built for
   uint16_t taps[7] = {18, 34, 49, 55, 49, 34, 18};
   int gray_coeffs[3] = {4899, 9617, 1868};  // [OCV] 4.2 R2Y, G2Y, B2Y
@@ -770,8 +774,11 @@ static int submit_tail(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1, vsg
   const Src0 s0 = {S.d_in, (size_t)h->rows * h->in_pitch, h->in_pitch};
   int rc = enqueue_pipeline(h, s0, nframes, lap0, lap1, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, h->s_main);
   if (rc != VSG_OK) return rc;
-  HIP_TRY(hipEventRecord(S.ev_done, h->s_main));
-  HIP_TRY(hipStreamWaitEvent(h->s_d2h, S.ev_done, 0));
+  const hipStream_t s_out = h->one_stream ? h->s_main : h->s_d2h;
+  if (!h->one_stream) {
+    HIP_TRY(hipEventRecord(S.ev_done, h->s_main));
+    HIP_TRY(hipStreamWaitEvent(h->s_d2h, S.ev_done, 0));
+  }
   // export: n records per frame, written by the device into pinned host memory -- the caller's own arrays when they
   // are pinned (no copy left for vsg_orb_wait), the slot's staging otherwise
   void *dk = nullptr, *dd = nullptr;
@@ -780,16 +787,16 @@ static int submit_tail(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1, vsg
   static const bool dma_out = getenv("VSG_D2H_DMA") != nullptr;  // A/B switch: copy-engine D2H of out_cap-sized buffers
   if (dma_out) {
     S.direct = false;
-    HIP_TRY(hipMemcpyAsync(S.h_counts, S.d_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, h->s_d2h));
-    HIP_TRY(hipMemcpyAsync(S.h_kps, S.d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, h->s_d2h));
-    HIP_TRY(hipMemcpyAsync(S.h_desc, S.d_desc, (size_t)nframes * fg.out_cap * 32, hipMemcpyDeviceToHost, h->s_d2h));
+    HIP_TRY(hipMemcpyAsync(S.h_counts, S.d_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, s_out));
+    HIP_TRY(hipMemcpyAsync(S.h_kps, S.d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, s_out));
+    HIP_TRY(hipMemcpyAsync(S.h_desc, S.d_desc, (size_t)nframes * fg.out_cap * 32, hipMemcpyDeviceToHost, s_out));
   } else if (S.direct) {
-    launch_export(h->s_d2h, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, dk, dd, S.h_counts, capacity, nframes);
+    launch_export(s_out, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, dk, dd, S.h_counts, capacity, nframes);
   } else {
-    launch_export(h->s_d2h, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, S.h_kps, S.h_desc, S.h_counts, fg.out_cap, nframes);
+    launch_export(s_out, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, S.h_kps, S.h_desc, S.h_counts, fg.out_cap, nframes);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(S.ev_out, h->s_d2h));
+  HIP_TRY(hipEventRecord(S.ev_out, s_out));
   S.busy = true;
   S.nframes = nframes;
   S.ticket = h->next_ticket++;
@@ -823,14 +830,15 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
   const int ip = h->in_pitch;
   const size_t fbytes = (size_t)rows * ip;
   const bool packed = stride == ip && (nframes == 1 || frame_stride == fbytes);
+  const hipStream_t s_in = h->one_stream ? h->s_main : h->s_h2d;
   if (host_pinned(gray, nullptr)) {
     // pinned caller memory: DMA straight from it (one descriptor for a packed batch, one 2-D copy per frame otherwise)
     if (packed) {
-      HIP_TRY(hipMemcpyAsync(S.d_in, gray, fbytes * nframes, hipMemcpyHostToDevice, h->s_h2d));
+      HIP_TRY(hipMemcpyAsync(S.d_in, gray, fbytes * nframes, hipMemcpyHostToDevice, s_in));
     } else {
       for (int f = 0; f < nframes; f++)
         HIP_TRY(hipMemcpy2DAsync(S.d_in + f * fbytes, ip, gray + (size_t)f * frame_stride, stride, cols, rows,
-                                 hipMemcpyHostToDevice, h->s_h2d));
+                                 hipMemcpyHostToDevice, s_in));
     }
   } else {
     // pageable memory: bounce through the slot's pinned staging.  Small batches: in chunks, so that the copy engine
@@ -843,7 +851,7 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
       j.src = gray, j.dst = S.h_in, j.frame_stride = frame_stride, j.fbytes = fbytes;
       j.stride = stride, j.ip = ip, j.rows = rows, j.cols = cols, j.nframes = nframes;
       h->pool->run(j);
-      HIP_TRY(hipMemcpyAsync(S.d_in, S.h_in, fbytes * nframes, hipMemcpyHostToDevice, h->s_h2d));
+      HIP_TRY(hipMemcpyAsync(S.d_in, S.h_in, fbytes * nframes, hipMemcpyHostToDevice, s_in));
     } else {
       const int chunk = 8;
       for (int f0 = 0; f0 < nframes; f0 += chunk) {
@@ -856,12 +864,14 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
           else
             for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * ip, src + (size_t)y * stride, (size_t)cols);
         }
-        HIP_TRY(hipMemcpyAsync(S.d_in + f0 * fbytes, S.h_in + f0 * fbytes, fbytes * nf, hipMemcpyHostToDevice, h->s_h2d));
+        HIP_TRY(hipMemcpyAsync(S.d_in + f0 * fbytes, S.h_in + f0 * fbytes, fbytes * nf, hipMemcpyHostToDevice, s_in));
       }
     }
   }
-  HIP_TRY(hipEventRecord(S.ev_in, h->s_h2d));
-  HIP_TRY(hipStreamWaitEvent(h->s_main, S.ev_in, 0));
+  if (!h->one_stream) {
+    HIP_TRY(hipEventRecord(S.ev_in, s_in));
+    HIP_TRY(hipStreamWaitEvent(h->s_main, S.ev_in, 0));
+  }
   return submit_tail(h, S, nframes, lap0, lap1, kps, desc, capacity);
 }
 
@@ -900,7 +910,9 @@ int vsg_orb_extract_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t f
   if (!gray || rows <= 0 || cols <= 0) return VSG_ERR_EMPTY_IMAGE;
   Range r("ORBextractor::operator() [blocking batch]");
   const auto t0 = std::chrono::steady_clock::now();
+  h->one_stream = true;
   const int t = vsg_orb_submit_batch(h, gray, nframes, frame_stride, rows, cols, stride, lap0, lap1, kps, desc, capacity);
+  h->one_stream = false;
   if (t < 0) return t;
   const int rc = vsg_orb_wait(h, t, n, mono_index);
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -936,17 +948,17 @@ int vsg_orb_extract_batch_color(vsg_orb *h, const uint8_t *img, int channels, in
   rc = acquire_slot(h, &Sp);
   if (rc != VSG_OK) return rc;
   Slot &S = *Sp;
-  // the scratch buffer is shared by consecutive colour batches: the previous batch's conversion must be done
-  HIP_TRY(hipStreamSynchronize(h->s_h2d));
+  // A blocking call: upload, cvtColor of Tracking::GrabImage* into the slot's gray level-0 staging, the stage chain
+  // and the export all on s_main (see vsg_orb::one_stream).  The scratch buffer is shared by consecutive colour
+  // batches; stream order on s_main is what keeps the previous conversion ahead of this upload.
   for (int f = 0; f < nframes; f++)
     HIP_TRY(hipMemcpy2DAsync(h->d_scratch + f * frame_bytes, row_bytes, img + (size_t)f * frame_stride, stride, row_bytes,
-                             rows, hipMemcpyHostToDevice, h->s_h2d));
-  // cvtColor of Tracking::GrabImage* into the slot's gray level-0 staging, on the upload stream
-  launch_cvt_gray(h->s_h2d, h->d_scratch, frame_bytes, (int)row_bytes, channels, rgb_order, rows, cols, S.d_in,
+                             rows, hipMemcpyHostToDevice, h->s_main));
+  launch_cvt_gray(h->s_main, h->d_scratch, frame_bytes, (int)row_bytes, channels, rgb_order, rows, cols, S.d_in,
                   (size_t)rows * h->in_pitch, h->in_pitch, h->gray_coeffs, h->gray_shift, nframes);
-  HIP_TRY(hipEventRecord(S.ev_in, h->s_h2d));
-  HIP_TRY(hipStreamWaitEvent(h->s_main, S.ev_in, 0));
+  h->one_stream = true;
   const int t = submit_tail(h, S, nframes, lap0, lap1, kps, desc, capacity);
+  h->one_stream = false;
   if (t < 0) return t;
   return vsg_orb_wait(h, t, n, mono_index);
 }
