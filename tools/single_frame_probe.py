@@ -1,3 +1,6 @@
+"""Wall time of one blocking single-frame operator() (host image -> host keypoints) through the ctypes binding; run it
+under `rocprofv3 --kernel-trace --memory-copy-trace` to see the GPU timeline of a call.
+Usage on the GPU box: python3 tools/single_frame_probe.py"""
 import numpy as np, time, sys
 sys.path.insert(0, '.')
 from visual_sgraphs_amd import orb, synth
