@@ -461,6 +461,15 @@ int vsg_frame_search_by_bow_kf_kf(vsg_frame *kf1, const uint8_t *valid1, const i
                                   const int32_t *idx1, int nodes1, vsg_frame *kf2, const uint8_t *valid2,
                                   const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
                                   float nnratio, int check_orientation, int32_t *matches12);
+/* SearchForTriangulation(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:902-1146) with both KeyFrames resident (LocalMapping::
+ * CreateNewMapPoints calls it for the current keyframe against each of its 10-20 best covisible neighbours,
+ * LocalMapping.cc:389: the current keyframe's descriptors go up once, not once per neighbour).  Arguments and result as
+ * vsg_search_for_triangulation; angles come from the frames' host mirrors. */
+int vsg_frame_search_for_triangulation(vsg_frame *kf1, const uint8_t *eligible1, const int32_t *node_id1,
+                                       const int32_t *off1, const int32_t *idx1, int nodes1, vsg_frame *kf2,
+                                       const uint8_t *eligible2, const int32_t *node_id2, const int32_t *off2,
+                                       const int32_t *idx2, int nodes2, const uint32_t *pair_ok, const int32_t *pair_off,
+                                       int check_orientation, int32_t *matches12);
 /* Frame::ComputeBoW (Frame.cc:882-889) on the resident descriptors; outputs as vsg_bow_transform. */
 int vsg_frame_bow_transform(vsg_vocab *voc, vsg_frame *f, int levelsup, int32_t *bow_ids, double *bow_vals,
                             int bow_cap, int *n_bow, int32_t *fv_node, int32_t *fv_off, int32_t *fv_idx, int fv_cap,

@@ -33,9 +33,31 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Per-source objects compiled in parallel (only the sources that changed, or all of them after a header change),
+    then one link.  Objects live in csrc/_obj (git-ignored)."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + ["-o", str(LIB)] + [str(CSRC / s) for s in SOURCES] + ["-ldl", "-lpthread"]
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = CSRC / "_obj"
+    obj_dir.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    cflags = [f for f in FLAGS if f != "-shared"]
+    headers = list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [PKG.parent / "include" / "vsg_orb.h", Path(__file__)]
+    hdr_time = max(h.stat().st_mtime for h in headers)
+    extra = os.environ.get("VSG_EXTRA_FLAGS", "").split()
+
+    def compile_one(src):
+        obj = obj_dir / (src + ".o")
+        if not force and not extra and obj.exists() and obj.stat().st_mtime > max(hdr_time, (CSRC / src).stat().st_mtime):
+            return obj
+        cmd = [hipcc] + cflags + extra + ["-c", "-o", str(obj), str(CSRC / src)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=str(CSRC))
+        return obj
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [str(o) for o in objs] + ["-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=str(CSRC))

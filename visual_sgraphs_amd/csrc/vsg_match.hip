@@ -618,6 +618,60 @@ static int search_by_bow(int device, int mode, int nleftB, const uint8_t *descA,
   return bow_rotation_filter(out, nOut, mode, angleA, angleB, checkOri != 0);
 }
 
+// SearchForTriangulation on descriptors that are host arrays (desc1/desc2, staged) or already resident (dDesc1/dDesc2)
+template <class Angle1, class Angle2>
+static int search_triangulation(int device, const uint8_t *desc1, const uint8_t *dDesc1, Angle1 angle1,
+                                const uint8_t *eligible1, int n1, const int32_t *node_id1, const int32_t *off1,
+                                const int32_t *idx1, int nodes1, const uint8_t *desc2, const uint8_t *dDesc2,
+                                Angle2 angle2, const uint8_t *eligible2, int n2, const int32_t *node_id2,
+                                const int32_t *off2, const int32_t *idx2, int nodes2, const uint32_t *pair_ok,
+                                const int32_t *pair_off, int check_orientation, int32_t *matches12) {
+  int rc = VSG_OK;
+  ThreadCtx *c = vsg::thread_ctx(device, &rc);
+  if (!c) return rc;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  std::vector<NodePair> pairs;
+  join_nodes(node_id1, off1, nodes1, node_id2, off2, nodes2, pairs);
+  if (pairs.empty() || n1 == 0 || n2 == 0) return 0;
+  const int npairs = (int)pairs.size();
+  const int nI1 = off1[nodes1], nI2 = off2[nodes2];
+  // bits of shared node s start at pair_off[s]; the last node ends at pair_off[npairs]
+  const size_t ok_words = pair_ok ? (size_t)(((long long)pair_off[npairs] + 31) / 32 + 1) : 0;
+  Stage st;
+  const size_t oP = st.add(pairs.size() * sizeof(NodePair)), oD1 = st.add(dDesc1 ? 0 : (size_t)n1 * 32),
+               oE1 = st.add((size_t)n1), oI1 = st.add((size_t)nI1 * 4), oD2 = st.add(dDesc2 ? 0 : (size_t)n2 * 32),
+               oE2 = st.add((size_t)n2), oI2 = st.add((size_t)nI2 * 4), oOk = st.add(ok_words * 4),
+               oOff = st.add(pair_ok ? (size_t)(npairs + 1) * 4 : 0);
+  const size_t in_bytes = st.total;
+  const size_t oM = st.add((size_t)n1 * 4);
+  rc = vsg::ctx_reserve(c, st.total, st.total);
+  if (rc != VSG_OK) return rc;
+  uint8_t *h = c->h_pin;
+  memcpy(h + oP, pairs.data(), pairs.size() * sizeof(NodePair));
+  if (!dDesc1) memcpy(h + oD1, desc1, (size_t)n1 * 32);
+  memcpy(h + oE1, eligible1, (size_t)n1);
+  memcpy(h + oI1, idx1, (size_t)nI1 * 4);
+  if (!dDesc2) memcpy(h + oD2, desc2, (size_t)n2 * 32);
+  memcpy(h + oE2, eligible2, (size_t)n2);
+  memcpy(h + oI2, idx2, (size_t)nI2 * 4);
+  if (pair_ok) {
+    memcpy(h + oOk, pair_ok, ok_words * 4);
+    memcpy(h + oOff, pair_off, (size_t)(npairs + 1) * 4);
+  }
+  M_TRY(hipMemcpyAsync(c->d_buf, h, in_bytes, hipMemcpyHostToDevice, c->stream));
+  uint8_t *d = c->d_buf;
+  M_TRY(hipMemsetAsync(d + oM, 0xFF, (size_t)n1 * 4, c->stream));
+  hipLaunchKernelGGL(k_search_triangulation, dim3((npairs + 3) / 4), dim3(256), 0, c->stream, (const NodePair *)(d + oP),
+                     npairs, dDesc1 ? dDesc1 : d + oD1, d + oE1, (const int *)(d + oI1), dDesc2 ? dDesc2 : d + oD2, d + oE2,
+                     (const int *)(d + oI2), pair_ok ? (const uint32_t *)(d + oOk) : (const uint32_t *)nullptr,
+                     pair_ok ? (const int *)(d + oOff) : (const int *)nullptr, (int *)(d + oM));
+  M_TRY(hipGetLastError());
+  M_TRY(hipMemcpyAsync(h + oM, d + oM, (size_t)n1 * 4, hipMemcpyDeviceToHost, c->stream));
+  M_TRY(hipStreamSynchronize(c->stream));
+  memcpy(matches12, h + oM, (size_t)n1 * 4);
+  return bow_rotation_filter(matches12, n1, 1, angle1, angle2, check_orientation != 0);
+}
+
 }  // namespace
 
 extern "C" {
@@ -712,50 +766,24 @@ int vsg_search_for_triangulation(int device, const uint8_t *desc1, const float *
                                  const uint32_t *pair_ok, const int32_t *pair_off, int check_orientation,
                                  int32_t *matches12) {
   if (!matches12 || n1 < 0 || n2 < 0 || (pair_ok && !pair_off)) return VSG_ERR_INVALID;
-  int rc = VSG_OK;
-  ThreadCtx *c = vsg::thread_ctx(device, &rc);
-  if (!c) return rc;
-  for (int i = 0; i < n1; i++) matches12[i] = -1;
-  std::vector<NodePair> pairs;
-  join_nodes(node_id1, off1, nodes1, node_id2, off2, nodes2, pairs);
-  if (pairs.empty() || n1 == 0 || n2 == 0) return 0;
-  const int npairs = (int)pairs.size();
-  const int nI1 = off1[nodes1], nI2 = off2[nodes2];
-  // bits of shared node s start at pair_off[s]; the last node ends at pair_off[npairs]
-  const size_t ok_words = pair_ok ? (size_t)(((long long)pair_off[npairs] + 31) / 32 + 1) : 0;
-  Stage st;
-  const size_t oP = st.add(pairs.size() * sizeof(NodePair)), oD1 = st.add((size_t)n1 * 32), oE1 = st.add((size_t)n1),
-               oI1 = st.add((size_t)nI1 * 4), oD2 = st.add((size_t)n2 * 32), oE2 = st.add((size_t)n2),
-               oI2 = st.add((size_t)nI2 * 4), oOk = st.add(ok_words * 4), oOff = st.add(pair_ok ? (size_t)(npairs + 1) * 4 : 0);
-  const size_t in_bytes = st.total;
-  const size_t oM = st.add((size_t)n1 * 4);
-  rc = vsg::ctx_reserve(c, st.total, st.total);
-  if (rc != VSG_OK) return rc;
-  uint8_t *h = c->h_pin;
-  memcpy(h + oP, pairs.data(), pairs.size() * sizeof(NodePair));
-  memcpy(h + oD1, desc1, (size_t)n1 * 32);
-  memcpy(h + oE1, eligible1, (size_t)n1);
-  memcpy(h + oI1, idx1, (size_t)nI1 * 4);
-  memcpy(h + oD2, desc2, (size_t)n2 * 32);
-  memcpy(h + oE2, eligible2, (size_t)n2);
-  memcpy(h + oI2, idx2, (size_t)nI2 * 4);
-  if (pair_ok) {
-    memcpy(h + oOk, pair_ok, ok_words * 4);
-    memcpy(h + oOff, pair_off, (size_t)(npairs + 1) * 4);
-  }
-  M_TRY(hipMemcpyAsync(c->d_buf, h, in_bytes, hipMemcpyHostToDevice, c->stream));
-  uint8_t *d = c->d_buf;
-  M_TRY(hipMemsetAsync(d + oM, 0xFF, (size_t)n1 * 4, c->stream));
-  hipLaunchKernelGGL(k_search_triangulation, dim3((npairs + 3) / 4), dim3(256), 0, c->stream, (const NodePair *)(d + oP),
-                     npairs, d + oD1, d + oE1, (const int *)(d + oI1), d + oD2, d + oE2, (const int *)(d + oI2),
-                     pair_ok ? (const uint32_t *)(d + oOk) : (const uint32_t *)nullptr,
-                     pair_ok ? (const int *)(d + oOff) : (const int *)nullptr, (int *)(d + oM));
-  M_TRY(hipGetLastError());
-  M_TRY(hipMemcpyAsync(h + oM, d + oM, (size_t)n1 * 4, hipMemcpyDeviceToHost, c->stream));
-  M_TRY(hipStreamSynchronize(c->stream));
-  memcpy(matches12, h + oM, (size_t)n1 * 4);
-  return bow_rotation_filter(matches12, n1, 1, [&](int i) { return angle1[i]; }, [&](int i) { return angle2[i]; },
-                             check_orientation != 0);
+  return search_triangulation(device, desc1, nullptr, [&](int i) { return angle1[i]; }, eligible1, n1, node_id1, off1, idx1,
+                              nodes1, desc2, nullptr, [&](int i) { return angle2[i]; }, eligible2, n2, node_id2, off2, idx2,
+                              nodes2, pair_ok, pair_off, check_orientation, matches12);
+}
+
+// both KeyFrames resident (vsg_frame): only the FeatureVectors, the eligibility flags and the predicate bits go up
+int vsg_frame_search_for_triangulation(vsg_frame *kf1, const uint8_t *eligible1, const int32_t *node_id1,
+                                       const int32_t *off1, const int32_t *idx1, int nodes1, vsg_frame *kf2,
+                                       const uint8_t *eligible2, const int32_t *node_id2, const int32_t *off2,
+                                       const int32_t *idx2, int nodes2, const uint32_t *pair_ok, const int32_t *pair_off,
+                                       int check_orientation, int32_t *matches12) {
+  if (!kf1 || !kf2 || !matches12 || kf1->device != kf2->device || !eligible1 || !eligible2 || (pair_ok && !pair_off))
+    return VSG_ERR_INVALID;
+  const vsg_keypoint *ka = kf1->h_kps.data(), *kb = kf2->h_kps.data();
+  return search_triangulation(kf1->device, nullptr, kf1->d_desc, [&](int i) { return ka[i].angle; }, eligible1, kf1->n,
+                              node_id1, off1, idx1, nodes1, nullptr, kf2->d_desc, [&](int i) { return kb[i].angle; },
+                              eligible2, kf2->n, node_id2, off2, idx2, nodes2, pair_ok, pair_off, check_orientation,
+                              matches12);
 }
 
 int vsg_search_by_bow_kf_f(int device, const uint8_t *kf_desc, const float *kf_angle, const uint8_t *kf_valid,

@@ -54,6 +54,7 @@ EXPORTS = [
     "vsg_frame_search_by_projection_sim3", "vsg_frame_search_by_projection_kf", "vsg_frame_search_by_sim3",
     "vsg_frame_fuse", "vsg_frame_fuse_sim3", "vsg_fuse_decide", "vsg_frame_search_for_initialization",
     "vsg_frame_search_by_bow_kf_f", "vsg_frame_search_by_bow_kf_kf", "vsg_frame_bow_transform",
+    "vsg_frame_search_for_triangulation",
     "vsg_frame_stereo_matches",
     "vsg_shard_last_error", "vsg_shard_record_bytes", "vsg_shard_record_desc_offset", "vsg_shard_frame_owner",
     "vsg_shard_stream_owner", "vsg_shard_unique_id", "vsg_shard_create", "vsg_shard_destroy", "vsg_shard_all_gather",
@@ -216,6 +217,8 @@ def load_library():
                                                _i32p]
     L.vsg_frame_search_by_bow_kf_kf.argtypes = [vp, _u8p, _i32p, _i32p, _i32p, ci, vp, _u8p, _i32p, _i32p, _i32p, ci,
                                                 cf, ci, _i32p]
+    L.vsg_frame_search_for_triangulation.argtypes = [vp, _u8p, _i32p, _i32p, _i32p, ci, vp, _u8p, _i32p, _i32p, _i32p,
+                                                     ci, vp, vp, ci, _i32p]
     L.vsg_frame_bow_transform.argtypes = [vp, vp, ci, _i32p, _f64p, ci, _i32p, _i32p, _i32p, _i32p, ci, _i32p, _i32p,
                                           _i32p, _f64p]
     L.vsg_frame_stereo_matches.argtypes = [vp, ci, vp, ci, vp, vp, cf, cf, _f32p, _f32p]
@@ -970,6 +973,21 @@ class Frame:
             self._h, _p(v1, _u8p), _p(n1, _i32p), _p(o1, _i32p), _p(i1, _i32p), len(fv1[0]), kf2.handle, _p(v2, _u8p),
             _p(n2, _i32p), _p(o2, _i32p), _p(i2, _i32p), len(fv2[0]), float(np.float32(nnratio)),
             int(check_orientation), _p(out, _i32p)), "vsg_frame_search_by_bow_kf_kf")
+        return nm, out[:self.N]
+
+    def SearchForTriangulation(self, eligible1, fv1, kf2, eligible2, fv2, check_orientation, pair_ok=None, pair_off=None):
+        """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:902-1146), self = pKF1, kf2 = pKF2, both resident."""
+        e1, e2 = _u8(eligible1), _u8(eligible2)
+        n1, o1, i1 = (_i32(x) for x in fv1)
+        n2, o2, i2 = (_i32(x) for x in fv2)
+        ok = np.ascontiguousarray(pair_ok, np.uint32) if pair_ok is not None else None
+        po = _i32(pair_off) if pair_ok is not None else None
+        out = np.full(max(self.N, 1), -1, np.int32)
+        nm = _check(self._L.vsg_frame_search_for_triangulation(
+            self._h, _p(e1, _u8p), _p(n1, _i32p), _p(o1, _i32p), _p(i1, _i32p), len(fv1[0]), kf2.handle, _p(e2, _u8p),
+            _p(n2, _i32p), _p(o2, _i32p), _p(i2, _i32p), len(fv2[0]), ok.ctypes.data if ok is not None else None,
+            po.ctypes.data if po is not None else None, int(check_orientation), _p(out, _i32p)),
+            "vsg_frame_search_for_triangulation")
         return nm, out[:self.N]
 
     def ComputeBoW(self, voc, levelsup=4):

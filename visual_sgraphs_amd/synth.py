@@ -77,16 +77,15 @@ def synthetic_vocabulary(k=10, L=3, seed=1, scoring=0, weighting=0, stop_fractio
     positive (idf-like), a few are 0 ("stopped" words).  The real ORBvoc.txt.bin is not in the reference tree."""
     import struct
     n_nodes = (k ** (L + 1) - 1) // (k - 1)
-    r = splitmix64(SEED_BASE ^ 0xB0C ^ (seed << 12), (n_nodes - 1) * 5)
-    desc = r.reshape(n_nodes - 1, 5)[:, :4].copy().view(np.uint8).reshape(n_nodes - 1, 32)
-    wraw = r.reshape(n_nodes - 1, 5)[:, 4]
-    out = bytearray(struct.pack("<iiii", k, L, scoring, weighting))
+    r = splitmix64(SEED_BASE ^ 0xB0C ^ (seed << 12), (n_nodes - 1) * 5).reshape(n_nodes - 1, 5)
     first_leaf = (k ** L - 1) // (k - 1)  # BFS numbering: node i has parent (i - 1) // k
-    for i in range(1, n_nodes):
-        leaf = i >= first_leaf
-        w = 0.0
-        if leaf:
-            u = int(wraw[i - 1] % np.uint64(10000))
-            w = 0.0 if u < stop_fraction * 10000 else 0.5 + u / 1000.0
-        out += struct.pack("<iB", (i - 1) // k, 1 if leaf else 0) + desc[i - 1].tobytes() + struct.pack("<d", w)
-    return bytes(out)
+    # one packed 45-byte record per node, built in bulk (k = 10, L = 6 is 1 111 110 records = 50 MB)
+    rec = np.zeros(n_nodes - 1, dtype=np.dtype([("parent", "<i4"), ("leaf", "u1"), ("desc", "u1", 32), ("w", "<f8")]))
+    ids = np.arange(1, n_nodes, dtype=np.int64)
+    rec["parent"] = (ids - 1) // k
+    leaf = ids >= first_leaf
+    rec["leaf"] = leaf
+    rec["desc"] = np.ascontiguousarray(r[:, :4]).view(np.uint8).reshape(n_nodes - 1, 32)
+    u = (r[:, 4] % np.uint64(10000)).astype(np.int64)
+    rec["w"] = np.where(leaf, np.where(u < stop_fraction * 10000, 0.0, 0.5 + u / 1000.0), 0.0)
+    return struct.pack("<iiii", k, L, scoring, weighting) + rec.tobytes()
