@@ -335,6 +335,11 @@ int vsg_orb_wait(vsg_orb *h, int ticket, int *n, int *mono_index);
  * A small host mirror of the keypoints serves the ordered host-side passes (rotation histogram, level ratio test).
  * Frames are immutable after upload and may be searched concurrently from several threads. */
 typedef struct vsg_frame vsg_frame;
+/* Limits (the packed candidate entries are index : 15 | distance : 9 | octave : 4 bits): capacity <= 32767 features per
+ * frame (vsg_frame_create returns VSG_ERR_INVALID beyond, the host-candidate forms vsg_search_* return
+ * VSG_ERR_UNSUPPORTED for n_t > 32767) and keypoint octaves 0..15 (vsg_frame_upload: VSG_ERR_UNSUPPORTED; the
+ * extractor itself is limited to 16 levels).  The reference's settings use 1000-2000 features and 8 levels.  A frame
+ * that was created but never uploaded is empty: every search on it finds nothing. */
 int vsg_frame_create(int device, int capacity, vsg_frame **out);
 void vsg_frame_destroy(vsg_frame *f);
 /* Frame::Frame(...) after ExtractORB + UndistortKeyPoints: keys = mvKeysUn (Nleft == -1) or mvKeys followed by
@@ -482,7 +487,9 @@ int vsg_frame_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r,
 /* ---- Frame sharding over the GPUs of one node (one process per GPU) -------------------------------
  * The reference has no distributed layer.  Extraction shards by frame (or camera stream) with no collective; the
  * neighbour's features that matching frame t against t-1 needs travel as fixed-capacity per-frame records
- *   { int32 n, int32 monoIndex, pad to 16 | KeyPoint[cap] (padded to 16) | uint8 desc[cap][32] | pad to 64 }
+ *   { int32 n, int32 monoIndex, uint32 flags, pad to 16 | KeyPoint[cap] (padded to 16) | uint8 desc[cap][32] | pad to 64 }
+ * (flags bit 0 = VSG_SHARD_FLAG_TRUNCATED: the frame held more keypoints than the record's capacity; n and monoIndex
+ * are clamped to it.  Slots of a partial batch -- nframes < frames_per_rank -- are sent with n = 0.)
  * in ONE ncclAllGather (RCCL over xGMI) per batch, enqueued on the caller's stream.  RCCL is loaded on first use
  * (dlopen); VSG_ERR_UNSUPPORTED when it is not available.
  *   vsg_shard_unique_id   rank 0 creates the 128-byte ncclUniqueId; the caller hands it to every rank (MPI, a file,
@@ -496,6 +503,7 @@ int vsg_frame_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r,
  *                         n_streams -> rank s (world <= n_streams: s mod world), a stream's frames round-robin over the
  *                         ranks {s, s + n_streams, ...} when there are more ranks than streams (4 cameras on 8 GPUs) */
 typedef struct vsg_shard vsg_shard;
+#define VSG_SHARD_FLAG_TRUNCATED 1u
 const char *vsg_shard_last_error(void);
 size_t vsg_shard_record_bytes(int capacity);
 size_t vsg_shard_record_desc_offset(int capacity);

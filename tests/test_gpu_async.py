@@ -56,6 +56,29 @@ def test_submit_wait_three_batches_in_flight(pinned):
             orb.unpin(b), orb.unpin(k), orb.unpin(d)
 
 
+def test_new_image_size_is_refused_while_tickets_are_pending():
+    """A different image size rebuilds the handle's buffers and frees the pipeline slots; with un-waited tickets that
+    would drop their results silently, so the submit is refused and the pending batch stays intact."""
+    B = 2
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    fr = _frames(31, B)
+    kps, desc = np.zeros((B, cap), orb.KP_DTYPE), np.zeros((B, cap, 32), np.uint8)
+    t = ex.submit_batch(fr, kps, desc)
+    other = np.stack([synth.sequence_frame(256, 192, 32, i) for i in range(B)])
+    cap2 = 600
+    with pytest.raises(orb.VsgError) as e:
+        ex.submit_batch(other, np.zeros((B, cap2), orb.KP_DTYPE), np.zeros((B, cap2, 32), np.uint8))
+    assert e.value.code == -2 and "waited" in str(e.value)
+    n, mono = ex.wait(t)
+    _check(fr, kps, desc, n, mono)
+    outs = ex.extract_batch(other)  # with nothing pending the new size is taken
+    ref = ol.OracleExtractor(NF, 1.2, 8, 20, 7)
+    for img, (m, k, d) in zip(other, outs):
+        rm, rk, rd = ref(img)
+        assert m == rm and k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+
+
 @pytest.mark.parametrize("strided", [False, True])
 def test_large_pageable_batches_are_staged_by_the_helper_threads(strided):
     """Batches of 16 frames and more from pageable memory take the helper-thread staging path (vsg_orb.hip StagePool);

@@ -17,8 +17,12 @@ def frames():
     return (k0, d0), (k1, d1)
 
 
+# (10, 6, levelsup 4) is the reference's scale: ORBvoc.txt.bin is k = 10, L = 6 (1 111 111 nodes, 10^6 words) and
+# Frame::ComputeBoW / KeyFrame::ComputeBoW call transform(..., 4) (Frame.cc:887, KeyFrame.cc:106), which puts the
+# FeatureVector nodes at level 2 = ~100 nodes.  The 50 MB vocabulary image is generated on the fly, never committed.
 @pytest.mark.parametrize("k,L,levelsup,scoring,weighting", [(10, 3, 2, 0, 0), (10, 4, 4, 0, 0), (8, 3, 1, 1, 1),
-                                                            (10, 3, 5, 5, 0), (6, 4, 2, 2, 2), (10, 3, 2, 0, 3)])
+                                                            (10, 3, 5, 5, 0), (6, 4, 2, 2, 2), (10, 3, 2, 0, 3),
+                                                            (10, 6, 4, 0, 0)])
 def test_bow_transform_matches_dbow2_restatement(frames, k, L, levelsup, scoring, weighting):
     (k0, d0), _ = frames
     blob = synth.synthetic_vocabulary(k, L, seed=k * 10 + L, scoring=scoring, weighting=weighting)
@@ -49,6 +53,78 @@ def test_bow_transform_ties_take_first_child():
     want, got = ref.transform(desc, 1), voc.transform(desc, 1)
     assert np.array_equal(got["word"], want["word"]) and np.all(want["word"] == 0)
     assert np.array_equal(got["node"], want["node"])
+
+
+@pytest.fixture(scope="module")
+def reference_scale_vocabulary():
+    blob = synth.synthetic_vocabulary(10, 6, seed=7)
+    return ol.OracleVocabulary(blob), orb.ORBVocabulary(blob)
+
+
+def test_reference_scale_vocabulary_shapes(frames, reference_scale_vocabulary):
+    """k = 10, L = 6, levelsup = 4: the FeatureVector has on the order of 100 level-2 nodes with ~10 features each --
+    the shape SearchByBoW sees in the reference (with L <= 4 and levelsup 4 it collapses to one node)."""
+    ref, voc = reference_scale_vocabulary
+    assert (voc.k, voc.L, voc.nnodes, voc.nwords) == (10, 6, 1111111, 1000000) == (ref.k, ref.L, ref.nnodes, ref.nwords)
+    (k0, d0), _ = frames
+    got, want = voc.transform(d0, 4), ref.transform(d0, 4)
+    assert 60 <= len(want["fv"][0]) <= 100 and np.all(want["fv"][0] >= 11) and np.all(want["fv"][0] <= 110)
+    for a, b in zip(got["fv"], want["fv"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(got["bow_ids"], want["bow_ids"])
+    assert np.array_equal(got["bow_vals"].view(np.uint64), want["bow_vals"].view(np.uint64))
+
+
+def test_c3_chain_at_reference_vocabulary_scale(reference_scale_vocabulary):
+    """Config C3 as BASELINE.json states it, every step on device-resident data: stereo pair -> two extractors
+    (Frame.cc:129-132) -> ComputeStereoMatches (Frame.cc:957) -> ComputeBoW with levelsup 4 (Frame.cc:887) ->
+    SearchByBoW(KF, F) (ORBmatcher.cc:226) and SearchByBoW(KF, KF) / SearchForTriangulation over the ~100 shared
+    nodes, each bit-identical to the same chain on the oracle."""
+    from test_gpu_stereo import rectified_pair
+    ref, voc = reference_scale_vocabulary
+    W, H, NF = 752, 480, 1200
+    exl, exr = orb.ORBextractor(NF, 1.2, 8, 20, 7), orb.ORBextractor(NF, 1.2, 8, 20, 7)
+    rl, rr = ol.OracleExtractor(NF, 1.2, 8, 20, 7), ol.OracleExtractor(NF, 1.2, 8, 20, 7)
+    b = (0.0, 0.0, float(W), float(H))
+    res = []
+    for t in (0, 1):
+        L_, R_ = rectified_pair(W, H, 77 + t, 17)
+        (_, kl, dl), (_, kr, dr) = exl(L_), exr(R_)
+        (_, okl, odl), (_, okr, odr) = rl(L_), rr(R_)
+        assert kl.tobytes() == okl.tobytes() and np.array_equal(dl, odl) and np.array_equal(dr, odr)
+        fl = orb.Frame(exl.capacity(H, W)).from_extractor(exl, 0, kl, b)
+        fr = orb.Frame(exr.capacity(H, W)).from_extractor(exr, 0, kr, b)
+        ur, dep = orb.ComputeStereoMatches_resident(exl, 0, exr, 0, fl, fr, 0.11, 47.9)
+        our, odep = ol.stereo_matches(rl, rr, kl, dl, kr, dr, 0.11, 47.9)
+        assert (our >= 0).sum() > 100 and ur.tobytes() == our.tobytes() and dep.tobytes() == odep.tobytes()
+        bow, obow = fl.ComputeBoW(voc, 4), ref.transform(dl, 4)
+        assert np.array_equal(bow["bow_ids"], obow["bow_ids"])
+        assert np.array_equal(bow["bow_vals"].view(np.uint64), obow["bow_vals"].view(np.uint64))
+        assert all(np.array_equal(x, y) for x, y in zip(bow["fv"], obow["fv"])) and len(obow["fv"][0]) > 50
+        res.append((fl, kl, dl, bow["fv"], our))
+    (f0, k0, d0, fv0, ur0), (f1, k1, d1, fv1, _) = res
+    # the second pair is another scene: descriptors of the first one with a few flipped bits stand in for the tracked
+    # frame so that SearchByBoW has real matches to find across the shared nodes
+    rng = np.random.default_rng(5)
+    d1m = d0.copy()
+    flip = rng.integers(0, 256, (len(d1m), 6))
+    for j in range(flip.shape[1]):
+        d1m[np.arange(len(d1m)), flip[:, j] >> 3] ^= (1 << (flip[:, j] & 7)).astype(np.uint8)
+    f1m = orb.Frame(exl.capacity(H, W)).upload(k0, d1m, b)
+    fv1m, ofv1m = f1m.ComputeBoW(voc, 4)["fv"], ref.transform(d1m, 4)["fv"]
+    assert all(np.array_equal(x, y) for x, y in zip(fv1m, ofv1m))
+    valid = (ur0 >= 0).astype(np.uint8)  # "has a map point": the stereo-matched features
+    got = f0.SearchByBoW_KF_F(valid, fv0, f1m, fv1m, 0.7, True)
+    want = ol.search_by_bow_kf_f(d0, k0["angle"], valid, fv0, d1m, k0["angle"], ofv1m, 0.7, True)
+    assert want[0] > 100 and got[0] == want[0] and np.array_equal(got[1], want[1])
+    v2 = np.ones(len(k0), np.uint8)
+    got = f0.SearchByBoW_KF_KF(valid, fv0, f1m, v2, fv1m, 0.8, True)
+    want = ol.search_by_bow_kf_kf(d0, k0["angle"], valid, fv0, d1m, k0["angle"], v2, ofv1m, 0.8, True)
+    assert want[0] > 100 and got[0] == want[0] and np.array_equal(got[1], want[1])
+    e1 = (ur0 < 0).astype(np.uint8)      # no map point yet
+    got = f0.SearchForTriangulation(e1, fv0, f1m, v2, fv1m, True)
+    want = ol.search_for_triangulation(d0, k0["angle"], e1, fv0, d1m, k0["angle"], v2, ofv1m, None, None, True)
+    assert want[0] > 50 and got[0] == want[0] and np.array_equal(got[1], want[1])
 
 
 def test_c3_chain_extract_bow_search(frames):

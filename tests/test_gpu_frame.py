@@ -235,6 +235,58 @@ def test_bow_chain_on_resident_frames(seed):
     assert ref[0] > 20 and got[0] == ref[0] and np.array_equal(got[1], ref[1])
 
 
+@pytest.mark.parametrize("seed,p_ok,ori", [(1, 0.6, True), (2, None, False), (3, 1.0, True)])
+def test_search_for_triangulation_resident(seed, p_ok, ori):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:902-1146) with both KeyFrames resident == the host-array form
+    == the oracle."""
+    from test_gpu_match import near_duplicates, shared_pair_bits
+    blob = synth.synthetic_vocabulary(k=10, L=3, seed=seed)
+    voc, ovoc = orb.ORBVocabulary(blob), ol.OracleVocabulary(blob)
+    k1, d1 = sc.features(seed, 0)
+    rng = np.random.default_rng(40 + seed)
+    perm = rng.permutation(len(d1))
+    k2, d2 = k1[perm], near_duplicates(d1[perm], rng, 3)
+    f1, f2 = _frame(k1, d1), _frame(k2, d2)
+    fv1, fv2 = f1.ComputeBoW(voc, 2)["fv"], f2.ComputeBoW(voc, 2)["fv"]
+    assert all(np.array_equal(a, b) for a, b in zip(fv1 + fv2, ovoc.transform(d1, 2)["fv"] + ovoc.transform(d2, 2)["fv"]))
+    e1 = (rng.random(len(d1)) > 0.2).astype(np.uint8)
+    e2 = (rng.random(len(d2)) > 0.2).astype(np.uint8)
+    ok, off = shared_pair_bits(fv1, fv2, rng, p_ok) if p_ok is not None else (None, None)
+    got = f1.SearchForTriangulation(e1, fv1, f2, e2, fv2, ori, ok, off)
+    host = orb.ORBmatcher(0.6, ori).SearchForTriangulation(d1, k1["angle"], e1, fv1, d2, k2["angle"], e2, fv2, ok, off)
+    ref = ol.search_for_triangulation(d1, k1["angle"], e1, fv1, d2, k2["angle"], e2, fv2, ok, off, ori)
+    assert ref[0] > 20 and got[0] == ref[0] == host[0] and np.array_equal(got[1], ref[1]) and np.array_equal(host[1], ref[1])
+
+
+def test_created_but_never_uploaded_frame_is_empty():
+    """vsg_frame_create zeroes the device block: searching a frame that holds nothing yet finds nothing (instead of
+    walking whatever cell_start[] the allocation contained)."""
+    s = sc.last_frame_scenario(1)
+    f = orb.Frame(1200)
+    assert f.N == 0
+    cs, en = f.grid()
+    assert not cs.any() and len(en) == 0
+    off, idx = f.GetFeaturesInArea(s["u"][:50], s["v"][:50], np.full(50, 30.0, np.float32))
+    assert not off.any() and len(idx) == 0
+    nm, tm, _ = f.SearchByProjection_Last(s["q_desc"], s["observed"], s["u"], s["v"], s["ur"], s["octave"], s["angle"],
+                                          s["th"], s["direction"], sc.SCALE_FACTORS, True, np.zeros(0, np.uint8))
+    assert nm == 0 and len(tm) == 0
+    k = sc.kf_projection_scenario(2)
+    nm, m = f.SearchByProjection_Sim3(k["q_desc"], k["u"], k["v"], k["radius"], k["level"], 1.0, np.zeros(0, np.int32))
+    assert nm == 0
+    nf, bi, bd = f.Fuse_Sim3(k["q_desc"], k["u"], k["v"], k["radius"], k["level"])
+    assert nf == 0 and np.all(bi == -1)
+
+
+def test_frame_upload_rejects_octaves_the_packed_entries_cannot_hold():
+    k, d = sc.features(1, 0)
+    k = k.copy()
+    k["octave"][3] = 16
+    with pytest.raises(orb.VsgError) as e:
+        orb.Frame(len(k) + 4).upload(k, d, sc.BOUNDS)
+    assert e.value.code == -3
+
+
 def test_stereo_matches_resident():
     exl, exr = orb.ORBextractor(1200, 1.2, 8, 20, 7), orb.ORBextractor(1200, 1.2, 8, 20, 7)
     rl, rr = ol.OracleExtractor(1200, 1.2, 8, 20, 7), ol.OracleExtractor(1200, 1.2, 8, 20, 7)

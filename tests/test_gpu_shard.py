@@ -72,3 +72,51 @@ def test_rccl_all_gather_of_records_world1_and_match_from_gathered_record():
     assert np.array_equal(best[0, :n1].cpu().numpy(), rb) and np.array_equal(second[0, :n1].cpu().numpy(), rs)
     assert np.array_equal(arg[0, :n1].cpu().numpy(), ra)
     comm.close()
+
+
+def _read(ptr, nbytes):
+    raw = np.zeros(nbytes, np.uint8)
+    assert _hip().hipMemcpy(C.c_void_p(raw.ctypes.data), C.c_void_p(ptr), C.c_size_t(nbytes), 2) == 0
+    return raw
+
+
+def test_partial_batch_and_truncated_records():
+    """A partial batch (the last one of a sequence) must not leave the previous batch's records in the slots it does
+    not fill: they are sent with n = 0.  A frame with more keypoints than the record capacity is truncated, its
+    monoIndex clamped, and flagged."""
+    import torch
+    dev = torch.device("cuda", 0)
+    B, W, H, NF = 4, 320, 240, 500
+    fr = np.stack([synth.sequence_frame(W, H, 72, t) for t in range(B)])
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    d_gray = torch.from_numpy(fr).to(dev)
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    small = 100  # record capacity below the ~500 keypoints per frame
+    try:
+        comm, comm_small = sharding.ShardComm(0, 0, 1, cap, B), sharding.ShardComm(0, 0, 1, small, B)
+    except orb.VsgError as e:
+        if e.code == -3:
+            pytest.skip("RCCL not loadable on this box")
+        raise
+    ex.extract_batch_device(d_gray.data_ptr(), B, H * W, H, W, W, d_kps.data_ptr(), d_desc.data_ptr(),
+                            d_counts.data_ptr(), cap, (0, 0), st.cuda_stream)
+    args = (d_counts.data_ptr(), d_kps.data_ptr(), d_desc.data_ptr(), cap)
+    comm.all_gather(*args, B, st.cuda_stream)   # a full batch first ...
+    comm.all_gather(*args, 2, st.cuda_stream)   # ... then a partial one: slots 2, 3 must read as empty
+    comm_small.all_gather(*args, B, st.cuda_stream)
+    st.synchronize()
+    counts = d_counts.cpu().numpy()
+    for f in range(B):
+        hdr = _read(comm.record(0, f)[0], 16).view(np.int32)
+        assert hdr.tolist() == ([int(counts[f, 0]), int(counts[f, 1]), 0, 0] if f < 2 else [0, 0, 0, 0])
+    desc_h = d_desc.cpu().numpy()
+    for f in range(B):
+        cp, _, dp = comm_small.record(0, f)
+        hdr = _read(cp, 16).view(np.int32)
+        assert counts[f, 0] > small and hdr.tolist() == [small, min(int(counts[f, 1]), small), 1, 0]
+        assert np.array_equal(_read(dp, small * 32).reshape(small, 32), desc_h[f, :small])
+    comm.close(), comm_small.close()

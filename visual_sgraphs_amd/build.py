@@ -65,4 +65,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build(force=True, verbose=bool(os.environ.get("VSG_BUILD_VERBOSE"))))

@@ -37,6 +37,8 @@ ThreadCtx *thread_ctx(int device, int *rc) {
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void **)&c->d_counter, 256) != hipSuccess || hipMemset(c->d_counter, 0, 256) != hipSuccess) {
+    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->d_counter) hipFree(c->d_counter);
     delete c;
     if (rc) *rc = VSG_ERR_HIP;
     return nullptr;

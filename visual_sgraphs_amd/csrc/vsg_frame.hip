@@ -334,7 +334,9 @@ FrameDev frame_dev(const vsg_frame *f) {
 
 int WindowCall::begin(int device, int nq_, int mode_, bool with_desc_, size_t arena_base, size_t arena_extra) {
   int rc = VSG_OK;
+  if (range_open) range_pop();  // a retry re-enters begin()
   range_push("ORBmatcher window search");
+  range_open = true;
   if (arena_base == 0) t_prof.t0 = now_us();
   c = thread_ctx(device, &rc);
   if (!c) return rc;
@@ -349,6 +351,10 @@ int WindowCall::begin(int device, int nq_, int mode_, bool with_desc_, size_t ar
   oCnt = st.add(mode == kWinList ? Q * 4 : 0);
   oOut = st.add(mode == kWinList ? (Q * kInline + (size_t)cap) * 4 : Q * 8);
   return ctx_reserve(c, base + st.total + arena_extra, 0);
+}
+
+WindowCall::~WindowCall() {
+  if (range_open) range_pop();  // an error return between begin() and finish()
 }
 
 size_t WindowCall::bytes() const {
@@ -380,7 +386,7 @@ int WindowCall::finish() {
   const double ts = now_us();
   if (nq > 0 && hipStreamSynchronize(c->stream) != hipSuccess) return VSG_ERR_HIP;
   t_prof.sync = now_us() - ts;
-  range_pop();
+  if (range_open) range_pop(), range_open = false;
   if (mode != kWinList) return VSG_OK;
   const int32_t *cn = (const int32_t *)(c->h_pin + base + oCnt);
   long long total = 0;  // entries of the lists that went to the overflow area = what the waves added to the counter
@@ -502,7 +508,10 @@ int vsg_frame_create(int device, int capacity, vsg_frame **out) {
   f->device = device;
   f->capacity = capacity;
   const FrameLayout L(capacity);
-  if (hipMalloc((void **)&f->d_block, L.total) != hipSuccess) {
+  // zeroed: a frame that was created but never uploaded has n = 0 AND all-zero cell_start arrays, so a search on it
+  // walks empty [0, 0) entry ranges instead of whatever the allocation held
+  if (hipMalloc((void **)&f->d_block, L.total) != hipSuccess || hipMemset(f->d_block, 0, L.total) != hipSuccess) {
+    if (f->d_block) hipFree(f->d_block);
     delete f;
     return VSG_ERR_HIP;
   }
@@ -530,6 +539,9 @@ int vsg_frame_upload(vsg_frame *f, const vsg_keypoint *keys, const uint8_t *desc
                      int nleft, float min_x, float min_y, float max_x, float max_y) {
   if (frame_check(f) != VSG_OK || n < 0 || n > f->capacity || (n > 0 && (!keys || !desc)) || nleft < -1 || nleft > n)
     return VSG_ERR_INVALID;
+  // packed candidate entries carry the octave in 4 bits (index : 15 | distance : 9 | octave : 4, vsg_walks.h)
+  for (int i = 0; i < n; i++)
+    if (keys[i].octave < 0 || keys[i].octave > 15) return VSG_ERR_UNSUPPORTED;
   int rc = VSG_OK;
   ThreadCtx *c = thread_ctx(f->device, &rc);
   if (!c) return rc;

@@ -78,6 +78,8 @@ struct WindowCall {
   int gate_mode = kGateNone, best_init = 256;
   float inv_sigma2[16] = {};
   size_t base = 0;  // offset of this call's blocks inside the arena (several calls can share one arena)
+  bool range_open = false;  // a roctx range pushed by begin() and not yet popped (every exit path pops exactly once)
+  ~WindowCall();
 
   int begin(int device, int nq, int mode, bool with_desc, size_t arena_base = 0, size_t arena_extra = 0);
   WinQuery *queries() const { return (WinQuery *)(c->h_pin + base + oQ); }

@@ -296,6 +296,13 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
     return VSG_ERR_UNSUPPORTED;
   }
   HIP_TRY(hipSetDevice(h->device));
+  // a new image size frees every pipeline slot: refuse while tickets of vsg_orb_submit_batch are still un-waited (their
+  // pinned result buffers and counts would silently disappear and vsg_orb_wait could only say "unknown ticket")
+  for (int i = 0; i < kSlots; i++)
+    if (h->slot[i].busy) {
+      set_err("image size changed while submitted batches have not been waited for (vsg_orb_wait them first)");
+      return VSG_ERR_CAPACITY;
+    }
   rc = quiesce(h);
   if (rc != VSG_OK) return rc;
   free_image_buffers(h);

@@ -60,16 +60,28 @@ const Rccl &rccl() {
   return g_rccl;
 }
 
-// records of this rank's batch: {n, monoIndex} + n keypoints + n descriptors per frame into the fixed-capacity layout
-// (rows beyond n are never read by the receiver)
+// records of this rank's batch: {n, monoIndex, flags} + n keypoints + n descriptors per frame into the fixed-capacity
+// layout (rows beyond n are never read by the receiver).  The launch covers ALL `frames` slots of the send block: slots
+// at and beyond `nframes` (a partial batch, e.g. the last one of a sequence) are stamped n = 0 / monoIndex = 0 so that
+// no rank ever receives the previous batch's records as valid neighbours.  A frame with more keypoints than the record
+// holds is truncated to `cap`, its monoIndex is clamped to the same bound and header word 2 carries
+// VSG_SHARD_FLAG_TRUNCATED.
 __global__ __launch_bounds__(256) void k_pack_records(const int *__restrict__ counts, const vsg::KeyPointPOD *__restrict__ kps,
-                                                      const uint8_t *__restrict__ desc, int src_cap, int cap,
+                                                      const uint8_t *__restrict__ desc, int src_cap, int cap, int nframes,
                                                       uint8_t *__restrict__ send, size_t rec) {
   const int f = blockIdx.y;
   uint32_t *r = (uint32_t *)(send + (size_t)f * rec);
-  int n = counts[2 * f];
-  if (n > cap) n = cap;
-  if (blockIdx.x == 0 && threadIdx.x < 2) r[threadIdx.x] = (uint32_t)(threadIdx.x == 0 ? n : counts[2 * f + 1]);
+  if (f >= nframes) {
+    if (blockIdx.x == 0 && threadIdx.x < 4) r[threadIdx.x] = 0u;
+    return;
+  }
+  const int n_src = counts[2 * f];
+  const int n = n_src > cap ? cap : n_src;
+  if (blockIdx.x == 0 && threadIdx.x < 4) {
+    const int mono = counts[2 * f + 1];
+    const uint32_t hdr[4] = {(uint32_t)n, (uint32_t)(mono > n ? n : mono), n_src > cap ? 1u : 0u, 0u};
+    r[threadIdx.x] = hdr[threadIdx.x];
+  }
   const uint32_t *sk = (const uint32_t *)(kps + (size_t)f * src_cap);
   const uint32_t *sd = (const uint32_t *)(desc + (size_t)f * src_cap * 32);
   uint32_t *dk = (uint32_t *)((uint8_t *)r + off_kps()), *dd = (uint32_t *)((uint8_t *)r + off_desc(cap));
@@ -181,8 +193,8 @@ int vsg_shard_all_gather(vsg_shard *s, const int *d_counts, const vsg_keypoint *
   if (!s || !d_counts || !d_kps || !d_desc || nframes < 1 || nframes > s->frames || src_capacity < 1) return VSG_ERR_INVALID;
   S_HIP(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_pack_records, dim3(4, nframes), dim3(256), 0, st, d_counts, (const vsg::KeyPointPOD *)d_kps, d_desc,
-                     src_capacity, s->cap, s->d_send, s->rec);
+  hipLaunchKernelGGL(k_pack_records, dim3(4, s->frames), dim3(256), 0, st, d_counts, (const vsg::KeyPointPOD *)d_kps, d_desc,
+                     src_capacity, s->cap, nframes, s->d_send, s->rec);
   S_HIP(hipGetLastError());
   // every rank always sends its full [frames][rec] block, so that rank r's records sit at a fixed offset
   const ncclResult_t r = rccl().AllGather(s->d_send, s->d_recv, s->rec * (size_t)s->frames, ncclChar, s->comm, st);

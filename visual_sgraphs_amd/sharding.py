@@ -6,7 +6,7 @@ exchange fixed-capacity per-frame records with ONE all-gather per batch (RCCL ov
 library's own communicator, `ShardComm`, or through torch.distributed -- and gloo in the CPU tests).  Record
 layout per frame (the C ABI's, `record_bytes(cap)` bytes; the descriptor block is 16-byte aligned so that a
 gathered record feeds the matcher kernels where it lies):
-    int32 n, int32 monoIndex, 8 B pad | KeyPoint[cap] (28 B each, padded to 16) | uint8 desc[cap][32] | pad to 64
+    int32 n, int32 monoIndex, uint32 flags (bit 0: truncated to cap), 4 B pad | KeyPoint[cap] (28 B each, padded to 16) | uint8 desc[cap][32] | pad to 64
 """
 import ctypes as C
 
@@ -68,6 +68,7 @@ def pack_records(send, counts, kps, desc):
     B, cap = kps.shape[0], kps.shape[1]
     od = desc_offset(cap)
     send[:, :8].copy_(counts.contiguous().view(torch.uint8).view(B, 8))
+    send[:, 8:16].zero_()  # flags: nothing is truncated here (the record capacity is the source capacity)
     send[:, 16:16 + cap * 28].copy_(kps.reshape(B, cap * 28))
     send[:, od:od + cap * 32].copy_(desc.reshape(B, cap * 32))
     return send
@@ -114,10 +115,25 @@ class ShardComm:
         self._L = orb.load_library()
         self._orb = orb
         uid = np.zeros(128, np.uint8)
+        # every rank probes RCCL and its device BEFORE anything collective happens (ncclGetUniqueId is cheap; only rank
+        # 0's id is used), and the ranks agree on the outcome: a one-sided failure would otherwise leave the others
+        # blocked in the broadcast below or inside ncclCommInitRank
+        probe = np.zeros(128, np.uint8)
+        rc = self._L.vsg_shard_unique_id(probe.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if rc == 0 and not (0 <= int(device) < max(self._L.vsg_device_count(), 0)):
+            rc = -4
+        err = self._L.vsg_shard_last_error().decode() if rc != 0 else ""
+        if world > 1 and exchange is None and dist.is_initialized():
+            ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32)
+            if dist.get_backend() == "nccl":
+                ok = ok.cuda(device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and rc == 0:
+                rc, err = -3, "another rank cannot create its communicator (RCCL or device unavailable there)"
+        if rc != 0:
+            raise orb.VsgError(rc, "vsg_shard_unique_id", err)
         if rank == 0:
-            rc = self._L.vsg_shard_unique_id(uid.ctypes.data_as(C.POINTER(C.c_uint8)))
-            if rc != 0:
-                raise orb.VsgError(rc, "vsg_shard_unique_id", self._L.vsg_shard_last_error().decode())
+            uid = probe
         if world > 1:
             if exchange is not None:
                 uid = np.asarray(exchange(uid), np.uint8)
