@@ -147,31 +147,80 @@ def matcher_latency_leg():
         return {"error": str(e)}
 
 
-def device_rate(workload, batch, steps, device):
-    """Device-resident extract-only rate of another BASELINE config (a claim the driver cannot see otherwise)."""
+def config_chain_leg(seconds=2.0, pipelines=4):
+    """BASELINE configs C3 (stereo pair -> ComputeStereoMatches -> ComputeBoW on a k=10, L=6 vocabulary -> SearchByBoW,
+    all on device-resident frames) and C5 (four concurrent 1250-feature camera streams) as BASELINE.json states them,
+    from plain C++ through the C ABI (tools/config_chain.cpp); every output is bit-compared with the same chain on the
+    CPU oracle first, whose rate is reported beside the GPU's."""
+    import subprocess
+    exe = ROOT / "tools" / "_bin" / "config_chain"
+    if not exe.exists():
+        return {"error": "tools/_bin/config_chain not built (make -C tools)"}
+    try:
+        r = subprocess.run([str(exe), str(seconds), str(pipelines)], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": r.stderr.strip()[-300:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
+
+
+def device_rate(workload, batch, steps, device, cpu_seconds=3.0):
+    """Another BASELINE config on the main bench's terms (frames resident in HBM, one batch per step): extract +
+    brute-force best2 match of every frame against its predecessor, the first and last frame and the last match
+    bit-compared with the CPU oracle, the oracle's own rate on one host thread beside it."""
+    import ctypes as C
     import torch
+    import oracle_lib as ol
     from visual_sgraphs_amd import orb, synth
     W, H, nfeat = WORKLOADS[workload]
     dev = torch.device("cuda", device)
     ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, device=device, max_batch=batch)
     cap = ex.capacity(H, W)
-    frames = np.stack([synth.sequence_frame(W, H, 3000, t) for t in range(min(batch, 16))])
-    frames = np.concatenate([frames] * ((batch + len(frames) - 1) // len(frames)))[:batch]
+    nuniq = min(batch, 16)
+    uniq = np.stack([synth.sequence_frame(W, H, 3000, t) for t in range(nuniq)])
+    frames = np.concatenate([uniq] * ((batch + nuniq - 1) // nuniq))[:batch]
     d_gray = torch.from_numpy(frames).to(dev)
-    d_kps = torch.zeros((batch, cap, 28), dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros((batch, cap, 32), dtype=torch.uint8, device=dev)
-    d_counts = torch.zeros((batch, 2), dtype=torch.int32, device=dev)
+    d_kps = torch.zeros((batch + 1, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((batch + 1, cap, 32), dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros((batch + 1, 2), dtype=torch.int32, device=dev)
+    d_best, d_second, d_arg = (torch.zeros((batch, cap), dtype=torch.int32, device=dev) for _ in range(3))
     st = torch.cuda.Stream(device=dev)
-    for i in range(steps + 3):
-        if i == 3:
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-        ex.extract_batch_device(d_gray.data_ptr(), batch, H * W, H, W, W, d_kps.data_ptr(), d_desc.data_ptr(),
-                                d_counts.data_ptr(), cap, (0, 0), st.cuda_stream)
+    L = orb.load_library()
+    vp = C.c_void_p
+    with torch.cuda.stream(st):
+        for i in range(steps + 3):
+            if i == 3:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            d_desc[0].copy_(d_desc[batch])
+            d_counts[0].copy_(d_counts[batch])
+            ex.extract_batch_device(d_gray.data_ptr(), batch, H * W, H, W, W, d_kps[1].data_ptr(), d_desc[1].data_ptr(),
+                                    d_counts[1].data_ptr(), cap, (0, 0), st.cuda_stream)
+            rc = L.vsg_hamming_block_best2_device(device, vp(d_desc[1].data_ptr()), vp(d_desc[0].data_ptr()), cap * 32,
+                                                  vp(d_counts[1].data_ptr()), vp(d_counts[0].data_ptr()), 2, batch, cap,
+                                                  vp(d_best.data_ptr()), vp(d_second.data_ptr()), vp(d_arg.data_ptr()),
+                                                  vp(st.cuda_stream))
+            assert rc == 0, rc
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"workload": f"{workload}: {W}x{H}, nFeatures={nfeat}, extract only", "frames_per_step": batch,
-            "frames_per_s": round(batch * steps / dt, 1), "keypoints_per_frame": round(float(d_counts[:, 0].float().mean()), 1)}
+    counts, kps_h, desc_h = d_counts.cpu().numpy(), d_kps.cpu().numpy(), d_desc.cpu().numpy()
+    ref = ol.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+    ok = True
+    for f in (0, batch - 1):
+        mono, rk, rd = ref(frames[f])
+        n = int(counts[f + 1, 0])
+        ok &= n == len(rk) and int(counts[f + 1, 1]) == mono
+        ok &= kps_h[f + 1, :n].tobytes() == rk.tobytes() and np.array_equal(desc_h[f + 1, :n], rd)
+    n = int(counts[batch, 0])
+    rb, rs, ra = ol.block_best2(desc_h[batch, :n], desc_h[batch - 1, :int(counts[batch - 1, 0])])
+    ok &= np.array_equal(d_best[batch - 1, :n].cpu().numpy(), rb) and np.array_equal(d_arg[batch - 1, :n].cpu().numpy(), ra)
+    ok &= np.array_equal(d_second[batch - 1, :n].cpu().numpy(), rs)
+    v1, n1 = ol.bench_throughput(uniq, nfeat, 1, cpu_seconds, do_match=True)
+    return {"workload": f"{workload}: {W}x{H}, nFeatures={nfeat}, extract + brute-force best2 match vs previous frame, "
+                        f"{batch}-frame batches resident in HBM", "unit": "frames/s", "frames_per_step": batch,
+            "frames_per_s": round(batch * steps / dt, 1), "keypoints_per_frame": round(float(counts[1:, 0].mean()), 1),
+            "parity": bool(ok), "cpu_oracle": {"frames_per_s": round(v1, 2), "threads": 1, "kind": "port", "frames": n1}}
 
 
 def main():
@@ -543,10 +592,16 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["host_api"] = {"error": str(e)}
         out["matcher_latency"] = matcher_latency_leg()
+        # the other BASELINE.json configurations as stated there, each with its parity flag and the CPU oracle's rate
+        other = []
+        chain = config_chain_leg()
+        other.append(chain.get("C3", {"workload": "C3", **chain}))
         try:
-            out["other_configs"] = [device_rate("C4", 128, 10, local_rank)]
+            other.append(device_rate("C4", 128, 10, local_rank))
         except Exception as e:  # noqa: BLE001
-            out["other_configs"] = {"error": str(e)}
+            other.append({"workload": "C4", "error": str(e)})
+        other.append(chain.get("C5", {"workload": "C5", **chain}))
+        out["other_configs"] = other
     print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -76,6 +76,46 @@ static inline int vsg_synth_frame(int w, int h, uint32_t index, int amplitude_di
   return vsg_synth_sequence_frame(w, h, index, 0, amplitude_div, noise, out, stride);
 }
 
+/* A DBoW2 ORB vocabulary image in the reference's binary layout (TemplatedVocabulary.h:1495-1547) -- the C mirror of
+ * synth.synthetic_vocabulary: int k, L, scoring, weighting; then per node (BFS order, node i has parent (i - 1) / k)
+ * int parent, uint8 isLeaf, uint8[32] descriptor, double weight = 45 bytes.  Full k-ary tree; node descriptors and
+ * leaf weights from SplitMix64(0x5EED0000 ^ 0xB0C ^ seed << 12), five outputs per node; leaves whose draw falls below
+ * stop_fraction get weight 0 ("stopped" words).  k = 10, L = 6 (the shape of ORBvoc.txt.bin) is 49 999 966 bytes.
+ * Returns the byte count; with out == NULL (or cap too small) nothing is written. */
+static inline size_t vsg_synth_vocabulary(int k, int L, uint32_t seed, int scoring, int weighting,
+                                          double stop_fraction, uint8_t *out, size_t cap) {
+  if (k < 2 || L < 1) return 0;
+  uint64_t n_nodes = 0, p = 1, first_leaf = 0;
+  for (int l = 0; l <= L; ++l) {
+    if (l == L) first_leaf = n_nodes;
+    n_nodes += p;
+    p *= (uint64_t)k;
+  }
+  const size_t bytes = 16 + (size_t)(n_nodes - 1) * 45;
+  if (!out || cap < bytes) return bytes;
+  const int32_t hdr[4] = {k, L, scoring, weighting};
+  memcpy(out, hdr, 16);
+  const uint64_t s = (VSG_SYNTH_SEED_BASE ^ 0xB0Cull) ^ ((uint64_t)seed << 12);
+  uint8_t *q = out + 16;
+  for (uint64_t i = 1; i < n_nodes; ++i, q += 45) {
+    const int32_t parent = (int32_t)((i - 1) / (uint64_t)k);
+    const int leaf = i >= first_leaf;
+    memcpy(q, &parent, 4);
+    q[4] = (uint8_t)leaf;
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t r = vsg_synth_splitmix64(s, 5 * (i - 1) + 1 + (uint64_t)j);
+      memcpy(q + 5 + 8 * j, &r, 8);
+    }
+    double w = 0.0;
+    if (leaf) {
+      const uint64_t u = vsg_synth_splitmix64(s, 5 * (i - 1) + 5) % 10000;
+      w = (double)u < stop_fraction * 10000 ? 0.0 : 0.5 + (double)u / 1000.0;
+    }
+    memcpy(q + 37, &w, 8);
+  }
+  return bytes;
+}
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,10 @@ float hc_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
 int hc_synth_frame(int w, int h, unsigned seq, int t, int div, int noise, uint8_t *out, size_t stride) {
   return vsg_synth_sequence_frame(w, h, seq, t, div, noise, out, stride);
 }
+size_t hc_synth_vocabulary(int k, int L, unsigned seed, int scoring, int weighting, double stop_fraction, uint8_t *out,
+                           size_t cap) {
+  return vsg_synth_vocabulary(k, L, seed, scoring, weighting, stop_fraction, out, cap);
+}
 void hc_brief_rotation(float angle, float *a, float *b) { brief_rotation(angle, a, b); }
 void hc_brief_offset(int px, int py, float a, float b, int *dx, int *dy) { brief_offset(px, py, a, b, dx, dy); }
 float hc_sinf(float x, int fma) { return fma ? SinCosF<true>::eval(x, false) : SinCosF<false>::eval(x, false); }

@@ -65,8 +65,8 @@ def test_new_image_size_is_refused_while_tickets_are_pending():
     fr = _frames(31, B)
     kps, desc = np.zeros((B, cap), orb.KP_DTYPE), np.zeros((B, cap, 32), np.uint8)
     t = ex.submit_batch(fr, kps, desc)
-    other = np.stack([synth.sequence_frame(256, 192, 32, i) for i in range(B)])
-    cap2 = 600
+    other = np.stack([synth.sequence_frame(400, 300, 32, i) for i in range(B)])
+    cap2 = ex.capacity(H, W) + 100
     with pytest.raises(orb.VsgError) as e:
         ex.submit_batch(other, np.zeros((B, cap2), orb.KP_DTYPE), np.zeros((B, cap2, 32), np.uint8))
     assert e.value.code == -2 and "waited" in str(e.value)

@@ -294,3 +294,16 @@ def test_synth_header_matches_python(hc):
         assert np.array_equal(out[:, :w], want), (w, h, seq, t, div, noise)
         assert not out[:, w:].any()
     assert hc.hc_synth_frame(0, 10, 0, 0, 1, 6, None, 0) == -1
+
+
+def test_synth_header_vocabulary_matches_python(hc):
+    """vsg_synth_vocabulary (C) == synth.synthetic_vocabulary (Python), byte for byte, incl. the reference-scale tree."""
+    hc.hc_synth_vocabulary.restype = C.c_size_t
+    hc.hc_synth_vocabulary.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_size_t]
+    for (k, L, seed, sc_, wt, stop) in [(10, 3, 1, 0, 0, 0.02), (8, 3, 83, 1, 1, 0.02), (6, 4, 64, 2, 2, 0.3),
+                                        (10, 6, 7, 0, 0, 0.02)]:
+        want = synth.synthetic_vocabulary(k, L, seed=seed, scoring=sc_, weighting=wt, stop_fraction=stop)
+        assert hc.hc_synth_vocabulary(k, L, seed, sc_, wt, stop, None, 0) == len(want)
+        out = np.zeros(len(want), np.uint8)
+        assert hc.hc_synth_vocabulary(k, L, seed, sc_, wt, stop, out.ctypes.data, len(out)) == len(want)
+        assert out.tobytes() == want, (k, L, seed)

@@ -1,0 +1,499 @@
+// config_chain.cpp -- the BASELINE.json configurations C3 and C5 AS STATED, through the C ABI from plain C++ (no Python
+// in the timed path), each next to the same chain on the CPU oracle and bit-compared with it first.
+//
+//   C3  EuRoC-style stereo, 752x480, nFeatures 1200 (config/Stereo/EuRoC.yaml): per stereo pair
+//         two ORBextractor::operator() on two host threads            Frame.cc:129-132
+//         -> both eyes' features made resident (device to device)      Frame.cc:133-160 (mvKeys, mDescriptors)
+//         -> Frame::ComputeStereoMatches                               Frame.cc:957-1127
+//         -> Frame::ComputeBoW, transform(..., levelsup 4) on a k = 10, L = 6 vocabulary   Frame.cc:882-889
+//         -> ORBmatcher::SearchByBoW(KeyFrame = previous pair, Frame)  ORBmatcher.cc:226-428 (TrackReferenceKeyFrame)
+//       reported as pairs/s of ONE pipeline (the reference's call pattern) and of several concurrent pipelines.
+//   C5  four concurrent 640x480 / 1250-feature camera streams (rs_d435i_rgbd_inertial.launch:13): one extractor, one
+//       host thread and one resident frame pair per stream; per frame
+//         operator() -> resident frame -> SearchByProjection(Cur, Last) -> SearchByProjection(F, local map points)
+//       (System::TrackRGBD -> Tracking.cc:1583, 2955, 3493), streams pinned to device s mod #devices.
+//
+// Measurement tool: it links the oracle as the checker and as the reported CPU baseline; nothing in libvsg_orb.so does.
+//   usage: config_chain [seconds per timed leg = 2] [pipelines for the C3 throughput leg = 4]
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/vsg_orb.h"
+#include "../include/vsg_synth.h"
+#include "../oracle/orb_oracle.h"
+
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#define CHECK(c)                                                                                              \
+  do {                                                                                                        \
+    if (!(c)) {                                                                                               \
+      fprintf(stderr, "config_chain: check failed: %s (line %d): %s\n", #c, __LINE__, vsg_last_error());      \
+      exit(1);                                                                                                \
+    }                                                                                                         \
+  } while (0)
+
+// a host thread that stays alive between frames and runs one job at a time (the reference spawns two std::threads per
+// stereo Frame, Frame.cc:129-132; a kept worker does the same work without the per-frame thread start)
+struct Worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, done = true, stop = false;
+  Worker() {
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(m);
+      while (true) {
+        cv.wait(lk, [this] { return has_job || stop; });
+        if (stop) return;
+        has_job = false;
+        lk.unlock();
+        job();
+        lk.lock();
+        done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void run(std::function<void()> f) {
+    std::lock_guard<std::mutex> lk(m);
+    job = std::move(f), has_job = true, done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [this] { return done; });
+  }
+  ~Worker() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+      cv.notify_all();
+    }
+    th.join();
+  }
+};
+
+struct FeatureVec {
+  std::vector<int32_t> node, off, idx;
+  int n = 0;
+  void size_for(int cap) { node.resize(cap + 1), off.resize(cap + 2), idx.resize(cap + 1); }
+};
+
+// ------------------------------------------------------------------------------------------------ C3
+static const int W3 = 752, H3 = 480, NF3 = 1200, DISP = 17;
+static const float MB = 0.11f, MBF = 47.9f;
+
+struct StereoInputs {  // T rectified pairs of one sequence: the right eye sees the scene DISP px further left
+  std::vector<std::vector<uint8_t>> left, right;
+  explicit StereoInputs(int T, uint32_t seq) {
+    std::vector<uint8_t> wide((size_t)(W3 + 64) * H3);
+    for (int t = 0; t < T; t++) {
+      CHECK(vsg_synth_sequence_frame(W3 + 64, H3, seq, t, 1, 6, wide.data(), W3 + 64) == 0);
+      left.emplace_back((size_t)W3 * H3), right.emplace_back((size_t)W3 * H3);
+      for (int r = 0; r < H3; r++) {
+        memcpy(&left.back()[(size_t)r * W3], &wide[(size_t)r * (W3 + 64) + 16], W3);
+        memcpy(&right.back()[(size_t)r * W3], &wide[(size_t)r * (W3 + 64) + 16 + DISP], W3);
+      }
+    }
+  }
+};
+
+struct PairResult {  // everything the chain produces for one pair
+  int nL = 0, nR = 0, nstereo = 0, n_bow = 0, nmatch = 0;
+  std::vector<vsg_keypoint> kpL, kpR;
+  std::vector<uint8_t> dsL, dsR, valid;
+  std::vector<float> uR, depth;
+  std::vector<int32_t> bow_id, match;
+  std::vector<double> bow_val;
+  FeatureVec fv;
+  void size_for(int cap) {
+    kpL.resize(cap), kpR.resize(cap), dsL.resize((size_t)cap * 32), dsR.resize((size_t)cap * 32), valid.resize(cap);
+    uR.resize(cap), depth.resize(cap), bow_id.resize(cap + 1), bow_val.resize(cap + 1), match.resize(cap);
+    fv.size_for(cap);
+  }
+};
+
+struct C3Gpu {
+  vsg_orb *exL = nullptr, *exR = nullptr;
+  vsg_frame *FL[2] = {nullptr, nullptr}, *FR = nullptr;
+  vsg_vocab *voc = nullptr;  // shared, not owned
+  int cap = 0, device = 0;
+  PairResult res[2];  // ping-pong: res[t & 1] = current pair, res[(t + 1) & 1] = the previous one (the keyframe)
+  Worker right_eye;
+  double stage_ms[5] = {0, 0, 0, 0, 0};
+  long pairs = 0;
+  void init(int dev, vsg_vocab *v) {
+    device = dev, voc = v;
+    CHECK(vsg_orb_create(NF3, 1.2f, 8, 20, 7, dev, 1, &exL) == VSG_OK);
+    CHECK(vsg_orb_create(NF3, 1.2f, 8, 20, 7, dev, 1, &exR) == VSG_OK);
+    cap = vsg_orb_capacity(exL, H3, W3);
+    CHECK(cap > 0);
+    for (int i = 0; i < 2; i++) {
+      CHECK(vsg_frame_create(dev, cap, &FL[i]) == VSG_OK);
+      res[i].size_for(cap);
+    }
+    CHECK(vsg_frame_create(dev, cap, &FR) == VSG_OK);
+  }
+  // one stereo pair through the chain; `have_prev`: a previous pair exists to search against
+  void pair(const uint8_t *left, const uint8_t *right, int t, bool have_prev) {
+    PairResult &R = res[t & 1], &P = res[(t + 1) & 1];
+    vsg_frame *cur = FL[t & 1], *prev = FL[(t + 1) & 1];
+    double t0 = now_ms();
+    right_eye.run([&] { CHECK(vsg_orb_extract(exR, right, H3, W3, W3, 0, 0, R.kpR.data(), R.dsR.data(), cap, &R.nR) >= 0); });
+    CHECK(vsg_orb_extract(exL, left, H3, W3, W3, 0, 0, R.kpL.data(), R.dsL.data(), cap, &R.nL) >= 0);
+    right_eye.wait();
+    double t1 = now_ms();
+    CHECK(vsg_frame_from_extractor(cur, exL, 0, R.kpL.data(), R.nL, 0.f, 0.f, (float)W3, (float)H3) == VSG_OK);
+    CHECK(vsg_frame_from_extractor(FR, exR, 0, R.kpR.data(), R.nR, 0.f, 0.f, (float)W3, (float)H3) == VSG_OK);
+    double t2 = now_ms();
+    R.nstereo = vsg_frame_stereo_matches(exL, 0, exR, 0, cur, FR, MB, MBF, R.uR.data(), R.depth.data());
+    CHECK(R.nstereo >= 0);
+    double t3 = now_ms();
+    CHECK(vsg_frame_bow_transform(voc, cur, 4, R.bow_id.data(), R.bow_val.data(), cap, &R.n_bow, R.fv.node.data(),
+                                  R.fv.off.data(), R.fv.idx.data(), cap, &R.fv.n, nullptr, nullptr, nullptr) == VSG_OK);
+    double t4 = now_ms();
+    for (int i = 0; i < R.nL; i++) R.valid[i] = R.uR[i] >= 0.f;  // "has a map point": the stereo-initialised features
+    R.nmatch = 0;
+    if (have_prev) {
+      R.nmatch = vsg_frame_search_by_bow_kf_f(prev, P.valid.data(), P.fv.node.data(), P.fv.off.data(), P.fv.idx.data(),
+                                              P.fv.n, cur, R.fv.node.data(), R.fv.off.data(), R.fv.idx.data(), R.fv.n,
+                                              0.7f, 1, R.match.data());
+      CHECK(R.nmatch >= 0);
+    }
+    double t5 = now_ms();
+    stage_ms[0] += t1 - t0, stage_ms[1] += t2 - t1, stage_ms[2] += t3 - t2, stage_ms[3] += t4 - t3, stage_ms[4] += t5 - t4;
+    pairs++;
+  }
+  ~C3Gpu() {
+    for (int i = 0; i < 2; i++) vsg_frame_destroy(FL[i]);
+    vsg_frame_destroy(FR);
+    vsg_orb_destroy(exL), vsg_orb_destroy(exR);
+  }
+};
+
+struct C3Cpu {  // the same chain on the oracle: two host threads for the two eyes, everything else on the caller
+  OrExtractor *exL, *exR;
+  OrVocab *voc;
+  int cap;
+  PairResult res[2];
+  Worker right_eye;
+  long pairs = 0;
+  C3Cpu(OrVocab *v, int cap_) : voc(v), cap(cap_) {
+    exL = or_create(NF3, 1.2f, 8, 20, 7), exR = or_create(NF3, 1.2f, 8, 20, 7);
+    res[0].size_for(cap), res[1].size_for(cap);
+  }
+  void pair(const uint8_t *left, const uint8_t *right, int t, bool have_prev) {
+    PairResult &R = res[t & 1], &P = res[(t + 1) & 1];
+    right_eye.run([&] { or_extract(exR, right, H3, W3, W3, 0, 0, (OrKeyPoint *)R.kpR.data(), R.dsR.data(), cap, &R.nR); });
+    or_extract(exL, left, H3, W3, W3, 0, 0, (OrKeyPoint *)R.kpL.data(), R.dsL.data(), cap, &R.nL);
+    right_eye.wait();
+    or_stereo_matches(exL, exR, (const OrKeyPoint *)R.kpL.data(), R.dsL.data(), R.nL, (const OrKeyPoint *)R.kpR.data(),
+                      R.dsR.data(), R.nR, MB, MBF, R.uR.data(), R.depth.data());
+    R.nstereo = 0;
+    for (int i = 0; i < R.nL; i++) R.valid[i] = R.uR[i] >= 0.f, R.nstereo += R.valid[i];
+    or_vocab_transform(voc, R.dsL.data(), R.nL, 4, R.bow_id.data(), R.bow_val.data(), cap, &R.n_bow, R.fv.node.data(),
+                       R.fv.off.data(), R.fv.idx.data(), cap, &R.fv.n, nullptr, nullptr, nullptr);
+    R.nmatch = 0;
+    if (have_prev) {
+      std::vector<float> aP(P.nL), aR(R.nL);
+      for (int i = 0; i < P.nL; i++) aP[i] = P.kpL[i].angle;
+      for (int i = 0; i < R.nL; i++) aR[i] = R.kpL[i].angle;
+      R.nmatch = or_search_by_bow_kf_f(P.dsL.data(), aP.data(), P.valid.data(), P.nL, P.fv.node.data(), P.fv.off.data(),
+                                       P.fv.idx.data(), P.fv.n, R.dsL.data(), aR.data(), R.nL, R.fv.node.data(),
+                                       R.fv.off.data(), R.fv.idx.data(), R.fv.n, 0.7f, 1, R.match.data());
+    }
+    pairs++;
+  }
+  ~C3Cpu() { or_destroy(exL), or_destroy(exR); }
+};
+
+static bool same_pair(const PairResult &a, const PairResult &b, bool with_match) {
+  if (a.nL != b.nL || a.nR != b.nR || a.n_bow != b.n_bow || a.fv.n != b.fv.n || a.nstereo != b.nstereo) return false;
+  if (memcmp(a.kpL.data(), b.kpL.data(), (size_t)a.nL * 28) || memcmp(a.dsL.data(), b.dsL.data(), (size_t)a.nL * 32)) return false;
+  if (memcmp(a.kpR.data(), b.kpR.data(), (size_t)a.nR * 28) || memcmp(a.dsR.data(), b.dsR.data(), (size_t)a.nR * 32)) return false;
+  if (memcmp(a.uR.data(), b.uR.data(), (size_t)a.nL * 4) || memcmp(a.depth.data(), b.depth.data(), (size_t)a.nL * 4)) return false;
+  if (memcmp(a.bow_id.data(), b.bow_id.data(), (size_t)a.n_bow * 4) || memcmp(a.bow_val.data(), b.bow_val.data(), (size_t)a.n_bow * 8)) return false;
+  if (memcmp(a.fv.node.data(), b.fv.node.data(), (size_t)a.fv.n * 4) || memcmp(a.fv.off.data(), b.fv.off.data(), (size_t)(a.fv.n + 1) * 4)) return false;
+  if (memcmp(a.fv.idx.data(), b.fv.idx.data(), (size_t)a.fv.off[a.fv.n] * 4)) return false;
+  if (with_match && (a.nmatch != b.nmatch || memcmp(a.match.data(), b.match.data(), (size_t)a.nL * 4))) return false;
+  return true;
+}
+
+static std::string run_c3(double seconds, int npipes) {
+  const int T = 8;
+  StereoInputs in(T, 41);
+  std::vector<uint8_t> blob(vsg_synth_vocabulary(10, 6, 7, 0, 0, 0.02, nullptr, 0));
+  CHECK(vsg_synth_vocabulary(10, 6, 7, 0, 0, 0.02, blob.data(), blob.size()) == blob.size());
+  vsg_vocab *voc = nullptr;
+  double t0 = now_ms();
+  CHECK(vsg_vocab_load(0, blob.data(), blob.size(), &voc) == VSG_OK);
+  const double voc_load_ms = now_ms() - t0;
+  OrVocab *ovoc = or_vocab_load(blob.data(), blob.size());
+  CHECK(ovoc != nullptr);
+  int vk, vL, vn, vw;
+  vsg_vocab_info(voc, &vk, &vL, nullptr, nullptr, &vn, &vw);
+  // ---- parity: every pair of the sequence, every output of the chain
+  std::vector<C3Gpu> g(npipes > 1 ? npipes : 1);
+  for (auto &p : g) p.init(0, voc);
+  C3Cpu c(ovoc, g[0].cap);
+  bool parity = true;
+  long matches = 0, stereo = 0, nodes = 0;
+  for (int t = 0; t < T; t++) {
+    g[0].pair(in.left[t].data(), in.right[t].data(), t, t > 0);
+    c.pair(in.left[t].data(), in.right[t].data(), t, t > 0);
+    parity = parity && same_pair(g[0].res[t & 1], c.res[t & 1], t > 0);
+    matches += c.res[t & 1].nmatch, stereo += c.res[t & 1].nstereo, nodes += c.res[t & 1].fv.n;
+  }
+  // ---- one pipeline, the reference's call pattern
+  for (auto &p : g) memset(p.stage_ms, 0, sizeof p.stage_ms), p.pairs = 0;
+  t0 = now_ms();
+  int t = T;
+  while (now_ms() - t0 < seconds * 1e3) g[0].pair(in.left[t % T].data(), in.right[t % T].data(), t, true), t++;
+  const double one_ms = (now_ms() - t0) / g[0].pairs;
+  double st[5];
+  for (int i = 0; i < 5; i++) st[i] = g[0].stage_ms[i] / g[0].pairs;
+  // ---- several pipelines side by side (independent stereo rigs / sequences on one GPU)
+  double multi = 0;
+  if (npipes > 1) {
+    std::atomic<long> total(0);
+    std::vector<std::thread> th;
+    const double tm0 = now_ms();
+    for (int p = 0; p < npipes; p++)
+      th.emplace_back([&, p] {
+        int tt = T;
+        long n = 0;
+        while (now_ms() - tm0 < seconds * 1e3) g[p].pair(in.left[tt % T].data(), in.right[tt % T].data(), tt, true), tt++, n++;
+        total += n;
+      });
+    for (auto &x : th) x.join();
+    multi = total / ((now_ms() - tm0) * 1e-3);
+  }
+  // ---- the oracle's chain
+  c.pairs = 0;
+  t0 = now_ms();
+  t = T;
+  while (now_ms() - t0 < seconds * 1e3) c.pair(in.left[t % T].data(), in.right[t % T].data(), t, true), t++;
+  const double cpu_ms = (now_ms() - t0) / c.pairs;
+  char b[2048];
+  snprintf(b, sizeof b,
+           "{\"workload\": \"C3: stereo 752x480, nFeatures=1200; per pair 2 x operator() on two host threads -> resident "
+           "frames -> ComputeStereoMatches -> ComputeBoW (k=%d, L=%d vocabulary, %d nodes, levelsup 4) -> SearchByBoW(KF = "
+           "previous pair, F)\", \"unit\": \"stereo pairs/s\", \"pairs_per_s\": %.1f, \"ms_per_pair\": %.4f, "
+           "\"stage_ms\": {\"extract_2_eyes\": %.4f, \"make_resident_2\": %.4f, \"stereo_matches\": %.4f, \"compute_bow\": %.4f, "
+           "\"search_by_bow\": %.4f}, \"pipelines\": %d, \"pairs_per_s_all_pipelines\": %.1f, \"parity\": %s, "
+           "\"pairs_checked\": %d, \"per_pair\": {\"stereo_matches\": %.1f, \"feature_vector_nodes\": %.1f, \"bow_matches\": %.1f}, "
+           "\"cpu_oracle\": {\"pairs_per_s\": %.2f, \"ms_per_pair\": %.3f, \"threads\": 2, \"kind\": \"port\"}, "
+           "\"vocabulary_load_ms\": %.1f}",
+           vk, vL, vn, 1e3 / one_ms, one_ms, st[0], st[1], st[2], st[3], st[4], npipes, multi, parity ? "true" : "false", T,
+           (double)stereo / T, (double)nodes / T, (double)matches / (T - 1), 1e3 / cpu_ms, cpu_ms, voc_load_ms);
+  g.clear();
+  vsg_vocab_destroy(voc);
+  or_vocab_destroy(ovoc);
+  return b;
+}
+
+// ------------------------------------------------------------------------------------------------ C5
+static const int W5 = 640, H5 = 480, NF5 = 1250, NSTREAM = 5 - 1;
+
+struct TrackResult {
+  int n = 0, n_last = 0, n_local = 0;
+  std::vector<vsg_keypoint> kp;
+  std::vector<uint8_t> ds, tb;
+  std::vector<int32_t> tm_last, tm_local;
+  void size_for(int cap) { kp.resize(cap), ds.resize((size_t)cap * 32), tb.resize(cap), tm_last.resize(cap), tm_local.resize(cap); }
+};
+
+// the projections of the previous frame's features into the current one: the scene moves by (-3, -2) px per frame
+struct Queries {
+  std::vector<float> u, v, ang, vc;
+  std::vector<int32_t> oct;
+  std::vector<uint8_t> obs;
+  void from(const TrackResult &P) {
+    u.resize(P.n), v.resize(P.n), ang.resize(P.n), vc.assign(P.n, 0.9f), oct.resize(P.n), obs.assign(P.n, 1);
+    for (int i = 0; i < P.n; i++)
+      u[i] = P.kp[i].x - 3.f, v[i] = P.kp[i].y - 2.f, ang[i] = P.kp[i].angle, oct[i] = P.kp[i].octave;
+  }
+};
+
+struct C5Gpu {
+  vsg_orb *ex = nullptr;
+  vsg_frame *F[2] = {nullptr, nullptr};
+  int cap = 0;
+  float sf[8];
+  TrackResult res[2];
+  Queries q;
+  long frames = 0;
+  void init(int dev) {
+    CHECK(vsg_orb_create(NF5, 1.2f, 8, 20, 7, dev, 1, &ex) == VSG_OK);
+    cap = vsg_orb_capacity(ex, H5, W5);
+    CHECK(cap > 0);
+    vsg_orb_get_tables(ex, sf, nullptr, nullptr, nullptr, nullptr, nullptr);
+    for (int i = 0; i < 2; i++) {
+      CHECK(vsg_frame_create(dev, cap, &F[i]) == VSG_OK);
+      res[i].size_for(cap);
+    }
+  }
+  void frame(const uint8_t *img, int t, bool have_prev) {
+    TrackResult &R = res[t & 1], &P = res[(t + 1) & 1];
+    CHECK(vsg_orb_extract(ex, img, H5, W5, W5, 0, 0, R.kp.data(), R.ds.data(), cap, &R.n) >= 0);
+    CHECK(vsg_frame_from_extractor(F[t & 1], ex, 0, R.kp.data(), R.n, 0.f, 0.f, (float)W5, (float)H5) == VSG_OK);
+    R.n_last = R.n_local = 0;
+    if (have_prev) {
+      q.from(P);
+      std::fill(R.tb.begin(), R.tb.begin() + R.n, 0), std::fill(R.tm_last.begin(), R.tm_last.begin() + R.n, -1);
+      R.n_last = vsg_frame_search_by_projection_last(F[t & 1], P.n, P.ds.data(), q.obs.data(), q.u.data(), q.v.data(), nullptr,
+                                                     nullptr, nullptr, q.oct.data(), q.ang.data(), 15.f, 0, sf, 8, 1,
+                                                     R.tb.data(), R.tm_last.data());
+      CHECK(R.n_last >= 0);
+      std::fill(R.tb.begin(), R.tb.begin() + R.n, 0), std::fill(R.tm_local.begin(), R.tm_local.begin() + R.n, -1);
+      R.n_local = vsg_frame_search_by_projection(F[t & 1], P.n, P.ds.data(), q.obs.data(), q.obs.data(), q.u.data(), q.v.data(),
+                                                 q.u.data(), q.oct.data(), q.vc.data(), nullptr, nullptr, nullptr, nullptr,
+                                                 nullptr, 1.f, 0.8f, sf, 8, nullptr, nullptr, R.tb.data(), R.tm_local.data());
+      CHECK(R.n_local >= 0);
+    }
+    frames++;
+  }
+  ~C5Gpu() {
+    vsg_frame_destroy(F[0]), vsg_frame_destroy(F[1]);
+    vsg_orb_destroy(ex);
+  }
+};
+
+struct C5Cpu {
+  OrExtractor *ex;
+  int cap;
+  float sf[8];
+  TrackResult res[2];
+  Queries q;
+  long frames = 0;
+  explicit C5Cpu(int cap_) : cap(cap_) {
+    ex = or_create(NF5, 1.2f, 8, 20, 7);
+    or_get_tables(ex, sf, nullptr, nullptr, nullptr, nullptr, nullptr);
+    res[0].size_for(cap), res[1].size_for(cap);
+  }
+  void frame(const uint8_t *img, int t, bool have_prev) {
+    TrackResult &R = res[t & 1], &P = res[(t + 1) & 1];
+    or_extract(ex, img, H5, W5, W5, 0, 0, (OrKeyPoint *)R.kp.data(), R.ds.data(), cap, &R.n);
+    OrFrame *f = or_frame_create((const OrKeyPoint *)R.kp.data(), R.ds.data(), nullptr, R.n, -1, 0.f, 0.f, (float)W5, (float)H5);
+    R.n_last = R.n_local = 0;
+    if (have_prev) {
+      q.from(P);
+      std::fill(R.tb.begin(), R.tb.begin() + R.n, 0), std::fill(R.tm_last.begin(), R.tm_last.begin() + R.n, -1);
+      R.n_last = or_frame_search_by_projection_last(f, P.n, P.ds.data(), q.obs.data(), q.u.data(), q.v.data(), q.u.data(), nullptr,
+                                                    nullptr, q.oct.data(), q.ang.data(), 15.f, 0, 0, sf, 1, R.tb.data(),
+                                                    R.tm_last.data());
+      std::fill(R.tb.begin(), R.tb.begin() + R.n, 0), std::fill(R.tm_local.begin(), R.tm_local.begin() + R.n, -1);
+      R.n_local = or_frame_search_by_projection(f, P.n, P.ds.data(), q.obs.data(), q.obs.data(), q.u.data(), q.v.data(), q.u.data(),
+                                                q.oct.data(), q.vc.data(), nullptr, nullptr, nullptr, nullptr, nullptr, 1.f, 0.8f,
+                                                sf, nullptr, nullptr, R.tb.data(), R.tm_local.data());
+    }
+    or_frame_destroy(f);
+    frames++;
+  }
+  ~C5Cpu() { or_destroy(ex); }
+};
+
+static bool same_track(const TrackResult &a, const TrackResult &b) {
+  return a.n == b.n && a.n_last == b.n_last && a.n_local == b.n_local && !memcmp(a.kp.data(), b.kp.data(), (size_t)a.n * 28) &&
+         !memcmp(a.ds.data(), b.ds.data(), (size_t)a.n * 32) && !memcmp(a.tm_last.data(), b.tm_last.data(), (size_t)a.n * 4) &&
+         !memcmp(a.tm_local.data(), b.tm_local.data(), (size_t)a.n * 4);
+}
+
+static std::string run_c5(double seconds) {
+  const int T = 6;
+  int ndev = vsg_device_count();
+  CHECK(ndev > 0);
+  std::vector<std::vector<std::vector<uint8_t>>> img(NSTREAM);
+  for (int s = 0; s < NSTREAM; s++)
+    for (int t = 0; t < T; t++) {
+      img[s].emplace_back((size_t)W5 * H5);
+      CHECK(vsg_synth_sequence_frame(W5, H5, 500 + s, t, 1, 6, img[s].back().data(), W5) == 0);
+    }
+  std::vector<C5Gpu> g(NSTREAM);
+  for (int s = 0; s < NSTREAM; s++) g[s].init(s % ndev);  // per-stream GPU pinning
+  // ---- parity, every stream, every frame
+  bool parity = true;
+  long m_last = 0, m_local = 0, kps = 0;
+  {
+    std::vector<std::thread> th;
+    std::vector<int> ok(NSTREAM, 1);
+    std::vector<long> ml(NSTREAM, 0), mo(NSTREAM, 0), kk(NSTREAM, 0);
+    for (int s = 0; s < NSTREAM; s++)
+      th.emplace_back([&, s] {
+        C5Cpu c(g[s].cap);
+        for (int t = 0; t < T; t++) {
+          g[s].frame(img[s][t].data(), t, t > 0);
+          c.frame(img[s][t].data(), t, t > 0);
+          ok[s] &= same_track(g[s].res[t & 1], c.res[t & 1]);
+          ml[s] += c.res[t & 1].n_last, mo[s] += c.res[t & 1].n_local, kk[s] += c.res[t & 1].n;
+        }
+      });
+    for (auto &x : th) x.join();
+    for (int s = 0; s < NSTREAM; s++) parity = parity && ok[s], m_last += ml[s], m_local += mo[s], kps += kk[s];
+  }
+  // ---- the four streams, one host thread each, concurrently
+  auto run_gpu = [&](int nstream) {
+    std::atomic<long> total(0);
+    std::vector<std::thread> th;
+    const double t0 = now_ms();
+    for (int s = 0; s < nstream; s++)
+      th.emplace_back([&, s] {
+        int t = T;
+        long n = 0;
+        while (now_ms() - t0 < seconds * 1e3) g[s].frame(img[s][t % T].data(), t, true), t++, n++;
+        total += n;
+      });
+    for (auto &x : th) x.join();
+    return total / ((now_ms() - t0) * 1e-3);
+  };
+  const double fps4 = run_gpu(NSTREAM), fps1 = run_gpu(1);
+  // ---- the oracle: four host threads, one stream each
+  double cpu_fps;
+  {
+    std::atomic<long> total(0);
+    std::vector<std::thread> th;
+    const double t0 = now_ms();
+    for (int s = 0; s < NSTREAM; s++)
+      th.emplace_back([&, s] {
+        C5Cpu c(g[s].cap);
+        int t = 0;
+        long n = 0;
+        while (now_ms() - t0 < seconds * 1e3) c.frame(img[s][t % T].data(), t, t > 0), t++, n++;
+        total += n;
+      });
+    for (auto &x : th) x.join();
+    cpu_fps = total / ((now_ms() - t0) * 1e-3);
+  }
+  char b[2048];
+  snprintf(b, sizeof b,
+           "{\"workload\": \"C5: %d concurrent 640x480 camera streams, nFeatures=1250, one extractor + one host thread per "
+           "stream, per frame operator() -> resident frame -> SearchByProjection(Cur, Last) -> SearchByProjection(F, local "
+           "map points); stream s on device s mod %d\", \"unit\": \"frames/s\", \"frames_per_s\": %.1f, "
+           "\"frames_per_s_one_stream\": %.1f, \"ms_per_frame_one_stream\": %.4f, \"streams\": %d, \"devices\": %d, "
+           "\"parity\": %s, \"frames_checked\": %d, \"per_frame\": {\"keypoints\": %.1f, \"matches_last_frame\": %.1f, "
+           "\"matches_local_map\": %.1f}, \"cpu_oracle\": {\"frames_per_s\": %.2f, \"threads\": %d, \"kind\": \"port\"}}",
+           NSTREAM, ndev, fps4, fps1, 1e3 / fps1, NSTREAM, ndev, parity ? "true" : "false", NSTREAM * T,
+           (double)kps / (NSTREAM * T), (double)m_last / (NSTREAM * (T - 1)), (double)m_local / (NSTREAM * (T - 1)), cpu_fps,
+           NSTREAM);
+  return b;
+}
+
+int main(int argc, char **argv) {
+  const double seconds = argc > 1 ? atof(argv[1]) : 2.0;
+  const int npipes = argc > 2 ? atoi(argv[2]) : 4;
+  const std::string c3 = run_c3(seconds, npipes);
+  const std::string c5 = run_c5(seconds);
+  printf("{\"C3\": %s, \"C5\": %s}\n", c3.c_str(), c5.c_str());
+  return 0;
+}
