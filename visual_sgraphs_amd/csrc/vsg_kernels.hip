@@ -391,7 +391,7 @@ static_assert(kFastRun == 2 || kFastRun == 4, "the run queue (4 bytes per run) m
 // counts as 0, exactly like the zeroed row buffers of FAST_t).  Emission order is irrelevant (the octree ranks
 // candidates).
 template <int NT, int kTileP, int kScoreP>
-__global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
+__global__ __launch_bounds__(NT) void k_fast_cells_v2(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                     const CellDesc *__restrict__ cells, Src0 s0,
                                                     uint32_t *__restrict__ cand, int *__restrict__ cand_count,
                                                     int *__restrict__ cell_count, int tile_bytes, int score_bytes) {
@@ -568,6 +568,283 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     if (!(keep & (1u << it))) continue;
     const int i = queue[q];
     const int r = i >> 8, c = i & 255;
+    const int s = score[(r + 1) * kScoreP + (c + 1)];
+    const int slot = base + atomicAdd(&s_cnt[2], 1);
+    if (slot < L.cand_cap) out[slot] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Round 3 form of the cell kernel.  Same decomposition (one workgroup per FAST cell, tile in LDS, compaction, exact
+// score on dense wavefronts, cell-confined NMS, per-cell candidate segments) with two arithmetic changes:
+//
+//  * The necessary test runs on 6-BIT pixels, four per 32-bit operation.  With q(x) = x >> 2 per byte,
+//        n < v - t   =>   q(v) - q(n) >= T6 := ceil((t - 2) / 4)        (4 (qv - qn) >= v - n - 3 >= t - 2)
+//    and byte-wise  (q(v) + 128 - T6) - q(n)  stays inside [1, 191] -- no borrow between bytes -- with bit 7 set exactly
+//    when q(v) - q(n) >= T6.  So the dark flags of four pixels against one ring pixel are ONE 32-bit subtract, the
+//    bright flags one add (against 128 - T6 - q(v)), and the pairing (N or S) and (W or E) is plain logic: ~24
+//    instructions per 4 pixels against ~54 for the exact 9-bit form on 16-bit lanes.  The 6-bit test is slightly
+//    weaker than the exact one (it lets differences of t - 3 .. t through); every pixel it passes still gets the exact
+//    score, so the candidate set is a superset of the corners and the result is unchanged.
+//  * The test keeps the POLARITY of every passer (bit 7 / bit 6 of its byte = dark / bright side possible).  A 9-arc
+//    of darker and a 9-arc of brighter ring pixels cannot coexist (9 + 9 > 16), so the exact score of a passer is
+//    the score of its possible side: max over arcs of the min of +-(v - ring), 48 packed min/max instead of 96 (the
+//    sign rides on the v_pk_mad_i16 that forms the differences).  A pixel that passes on both sides is queued twice;
+//    the entry whose side scores below the threshold is dropped, and both cannot score.
+//  * Phase 1 writes one flag word per run of 8 pixels at the run's own index (no ballot, no atomic, no position to
+//    encode); the dense unpack pass turns the words into the pixel queue through a wave scan of their popcounts.
+template <int kTileP>
+__device__ __forceinline__ int fast_score_side(const uint8_t *c, int floor_t, uint32_t dark) {
+  const int P = kTileP;
+  // lane pair (d[k], d[k+8]) of side-signed differences, one v_pk_mad_i16 each: ring * (-1) + v (dark), ring - v (bright)
+  const short sv = dark ? (short)c[0] : (short)-(int)c[0], sn = dark ? (short)-1 : (short)1;
+  const s16x2 vs = {sv, sv}, ns = {sn, sn};
+  auto pair = [&](int o_lo, int o_hi) -> s16x2 {
+    const uint32_t x = (uint32_t)c[o_lo] | ((uint32_t)c[o_hi] << 16);
+    return __builtin_bit_cast(s16x2, x) * ns + vs;
+  };
+  s16x2 D[8];
+  D[0] = pair(3 * P, -3 * P);
+  D[1] = pair(3 * P + 1, -3 * P - 1);
+  D[2] = pair(2 * P + 2, -2 * P - 2);
+  D[3] = pair(P + 3, -P - 3);
+  D[4] = pair(3, -3);
+  D[5] = pair(-P + 3, P - 3);
+  D[6] = pair(-2 * P + 2, 2 * P - 2);
+  D[7] = pair(-3 * P + 1, 3 * P - 1);
+#define DX(k) ((k) < 8 ? D[(k)] : pk_swap(D[(k)-8]))
+  s16x2 mn2[8], mn4[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) mn2[k] = pk_min(D[k], DX(k + 1));
+#define M2N(k) ((k) < 8 ? mn2[(k)] : pk_swap(mn2[(k)-8]))
+#pragma unroll
+  for (int k = 0; k < 8; k++) mn4[k] = pk_min(mn2[k], M2N(k + 2));
+#define M4N(k) ((k) < 8 ? mn4[(k)] : pk_swap(mn4[(k)-8]))
+  s16x2 A = (s16x2){-256, -256};
+#pragma unroll
+  for (int k = 0; k < 8; k++) A = pk_max(A, pk_min(pk_min(mn4[k], M4N(k + 4)), pk_swap(D[k])));  // arcs k..k+8, k+8..k+16
+#undef DX
+#undef M2N
+#undef M4N
+  const int s = max((int)A.x, (int)A.y) - 1;
+  return s >= floor_t ? s : 0;
+}
+
+// flag word of a run of 8 pixels: pixel p < 4 -> byte p, bits 5 (dark) / 4 (bright); pixel p >= 4 -> byte p - 4, bits 7 / 6
+__device__ __forceinline__ uint32_t fast_flag_mask8(uint32_t m8) {
+  uint32_t f = 0;
+#pragma unroll
+  for (int p = 0; p < 8; p++)
+    if (m8 & (1u << p)) f |= (p < 4 ? 0x30u : 0xC0u) << (8 * (p & 3));
+  return f;
+}
+
+template <int NT, int kTileP, int kScoreP>
+__global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
+                                                    const CellDesc *__restrict__ cells, Src0 s0,
+                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count,
+                                                    int *__restrict__ cell_count, int tile_bytes, int score_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
+  uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
+  uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);
+  // flag word + index of every run with a passer; both lists are consumed before the score rows they alias are cleared
+  uint32_t *runF = (uint32_t *)score;
+  __shared__ int s_cnt[5];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base [4]=run entries
+  const BlockXY blk = frame_major_block();
+  const CellDesc cell = cells[blk.x];
+  const int frame = blk.y;
+  const LevelGeom &L = fg->lv[cell.level];
+  const int vw = cell.x1 - cell.x0, vh = cell.y1 - cell.y0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool seg = fg->cand_segmented != 0;
+  int *my_count = cell_count + (size_t)frame * fg->total_cells + blk.x;
+  if (vw <= 0 || vh <= 0) {
+    if (seg && tid == 0) *my_count = 0;
+    return;
+  }
+  uint32_t *seg_out = cand + (size_t)frame * fg->cand_frame + L.cand_off + cell.cand_off;
+  int pitch;
+  const uint8_t *img = level_ptr(fg, s0, pyr, frame, cell.level, pitch);
+  // tile column 0 <-> image column ax (4-byte aligned); valid-region column c sits at tile column c + 3 + ox
+  const int ax = (cell.x0 - 3) & ~3, ox = (cell.x0 - 3) - ax;
+  const int tdw = (ox + vw + 6 + 3) >> 2, th = vh + 6;  // dwords per tile row (<= 21)
+  const float inv_tdw = __builtin_amdgcn_rcpf((float)tdw);
+  {
+    const uint8_t *tsrc = img + (ptrdiff_t)(cell.y0 - 3) * pitch + ax;
+    if (tdw < 4) {  // a sliver of a cell at the right edge of a level (cell-uniform)
+      for (int i = tid; i < tdw * th; i += NT) {
+        const int r = div_small(i, inv_tdw), c = i - r * tdw;
+        *(uint32_t *)&tile[r * kTileP + 4 * c] = *(const uint32_t *)(tsrc + (uint32_t)(r * pitch + 4 * c));
+      }
+    } else {
+      // 16 bytes per lane, the last load of a row pulled back so that it ENDS with the row (see k_fast_cells_v2)
+      typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+      const int nq4 = (tdw + 3) >> 2;
+      const float inv_nq4 = __builtin_amdgcn_rcpf((float)nq4);
+      for (int i = tid; i < nq4 * th; i += NT) {
+        const int r = div_small(i, inv_nq4), c = min(4 * (i - r * nq4), tdw - 4);
+        const u32x4u v = *(const u32x4u *)(tsrc + (uint32_t)(r * pitch + 4 * c));
+        uint32_t *d = (uint32_t *)&tile[r * kTileP + 4 * c];
+        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+      }
+    }
+  }
+  // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1, runs of 2 dwords per row
+  const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0;
+  const int nrun = (ng + 1) >> 1, nruns = nrun * vh;
+  uint16_t *runI = (uint16_t *)(runF + nruns);  // 6 bytes per run <= the score row pitch (static_assert at the launcher)
+  const float inv_nrun = __builtin_amdgcn_rcpf((float)nrun);
+  // first run: its pixel 0 is valid-region column cb0 >= -3; last run: `over` of its 8 columns lie beyond vw
+  const int cb0 = 4 * g0 - 3 - ox, over = 4 * (g0 + (nrun - 1) * 2) - 3 - ox + 8 - vw;
+  const uint32_t first_mask = fast_flag_mask8(cb0 < 0 ? (0xFFu << (-cb0)) & 0xFFu : 0xFFu);
+  const uint32_t last_mask = fast_flag_mask8(over <= 0 ? 0xFFu : over >= 8 ? 0u : (1u << (8 - over)) - 1u);
+  uint32_t keep = 0;
+  int nq = 0, thr = fg->iniTh;
+  for (int pass = 0; pass < 2; pass++) {
+    if (tid < 5) s_cnt[tid] = 0;
+    __syncthreads();  // the tile is staged / the previous pass is done with the score rows
+#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 1  // timing-only ablations: the results are wrong
+    { int keep_alive = tile[7 + tid]; asm volatile("" : : "v"(keep_alive)); }
+    if (seg && tid == 0) *my_count = 0;
+    return;
+#endif
+    // ---- phase 1: 6-bit necessary test, 8 pixels (2 dwords) per thread; runs with a passer are appended (flag word
+    // + run index) to the run list: one ballot and one LDS atomic per wave and iteration
+    {
+      const int t6 = thr <= 2 ? 0 : min(64, (thr + 1) >> 2);  // ceil((t - 2) / 4)
+      const uint32_t K = (uint32_t)(128 - t6) * 0x01010101u, Q = 0x3F3F3F3Fu, H = 0x80808080u;
+      for (int i0 = 0; i0 < nruns; i0 += NT) {
+        const int i = i0 + tid;
+        uint32_t F = 0;
+        if (i < nruns) {
+        const int r = div_small(i, inv_nrun), rr = i - r * nrun;
+        const uint8_t *t = &tile[(r + 3) * kTileP + 4 * (g0 + 2 * rr)];
+        const uint32_t *pc = (const uint32_t *)t, *pu = (const uint32_t *)(t - 3 * kTileP),
+                       *pd = (const uint32_t *)(t + 3 * kTileP);
+        uint32_t qc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) qc[k] = (pc[k - 1] >> 2) & Q;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const uint32_t qu = (pu[k] >> 2) & Q, qd = (pd[k] >> 2) & Q;
+          const uint32_t qw = __builtin_amdgcn_alignbyte(qc[k + 1], qc[k], 1);      // columns -3
+          const uint32_t qe = __builtin_amdgcn_alignbyte(qc[k + 2], qc[k + 1], 3);  // columns +3
+          const uint32_t A = qc[k + 1] + K, B = K - qc[k + 1];
+          const uint32_t dark = ((A - qu) | (A - qd)) & ((A - qw) | (A - qe));
+          const uint32_t bright = ((B + qu) | (B + qd)) & ((B + qw) | (B + qe));
+          const uint32_t f = (dark & H) | ((bright & H) >> 1);
+          F |= k ? f : f >> 2;
+        }
+        if (rr == 0) F &= first_mask;
+        if (rr == nrun - 1) F &= last_mask;
+        }
+        const uint64_t hit = __ballot(F != 0);
+        if (hit) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_cnt[4], __popcll(hit));
+          const int slot = __builtin_amdgcn_readfirstlane(base) + __popcll(hit & ((1ull << lane) - 1));
+          if (F) runF[slot] = F, runI[slot] = (uint16_t)i;
+        }
+      }
+    }
+    __syncthreads();
+#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 2
+    { int keep_alive = s_cnt[4]; asm volatile("" : : "v"(keep_alive)); }
+    if (seg && tid == 0) *my_count = 0;
+    return;
+#endif
+    // ---- run list -> pixel queue (entry = side << 15 | row << 8 | column; rows and columns < 70)
+    const int nr = s_cnt[4];
+    for (int e0 = 0; e0 < nr; e0 += NT) {
+      const int e0t = e0 + tid;
+      uint32_t F = e0t < nr ? runF[e0t] : 0u;
+      const int e = e0t < nr ? runI[e0t] : 0;
+      const int cnt = __popc(F);
+      const int incl = wave_inclusive_scan_i32(cnt);
+      const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+      if (wtotal) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_cnt[1], wtotal);
+        int pos = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+        const int r = div_small(e, inv_nrun), rr = e - r * nrun;
+        const int ent0 = (r << 8) + (4 * (g0 + 2 * rr) - 3 - ox);
+        while (F) {
+          const int b = __builtin_ctz(F);
+          F &= F - 1;
+          // byte b >> 3 = pixel inside its dword; bit 1 of b: second dword of the run; bit 0: dark side (b << 15 puts
+          // it in bit 15, the higher bits fall off the 16-bit entry)
+          queue[pos++] = (uint16_t)(ent0 + (b >> 3) + ((b & 2) << 1) + (b << 15));
+        }
+      }
+    }
+    __syncthreads();
+    nq = s_cnt[1];
+#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 3
+    { int keep_alive = nq + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
+    if (seg && tid == 0) *my_count = 0;
+    return;
+#endif
+    for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    // ---- phase 2: exact score of the queued pixels on their possible side; entries that do not score are dropped
+    for (int q = tid; q < nq; q += NT) {
+      const uint32_t ent = queue[q];
+      const int r = (ent >> 8) & 127, c = ent & 255;
+      const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, ent >> 15);
+      if (s)
+        score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
+      else
+        queue[q] = 0xFFFFu;
+    }
+    __syncthreads();
+#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 4
+    { int keep_alive = score[50 + tid] + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
+    if (seg && tid == 0) *my_count = 0;
+    return;
+#endif
+    // ---- phase 3: non-max suppression inside the cell
+    keep = 0;  // bit per loop iteration: queued pixel survives NMS
+    int it = 0;
+    for (int q = tid; q < nq; q += NT, it++) {
+      const uint32_t ent = queue[q];
+      if (ent == 0xFFFFu) continue;
+      const int r = (ent >> 8) & 127, c = ent & 255;
+      const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
+      const int s = sp[0];
+      int mx = max(max((int)sp[-1], (int)sp[1]), (int)sp[-kScoreP - 1]);
+      mx = max(max(mx, (int)sp[-kScoreP]), (int)sp[-kScoreP + 1]);
+      mx = max(max(mx, (int)sp[kScoreP - 1]), (int)sp[kScoreP]);
+      mx = max(mx, (int)sp[kScoreP + 1]);
+      if (s > mx) {
+        if (seg) {
+          seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
+        } else {
+          keep |= 1u << it;
+          atomicAdd(&s_cnt[0], 1);
+        }
+      }
+    }
+    __syncthreads();
+    if (s_cnt[0] > 0 || pass == 1 || fg->minTh >= thr) break;
+    thr = fg->minTh;  // vKeysCell.empty() -> retry with minThFAST (:848-851)
+    __syncthreads();
+  }
+  const int nEmit = s_cnt[0];
+  if (seg) {
+    if (tid == 0) *my_count = nEmit;
+    return;
+  }
+  if (nEmit == 0) return;
+  if (tid == 0) s_cnt[3] = atomicAdd(&cand_count[frame * kMaxLevels + cell.level], nEmit);
+  __syncthreads();
+  const int base = s_cnt[3];
+  uint32_t *out = cand + (size_t)frame * fg->cand_frame + L.cand_off;
+  int it = 0;
+  for (int q = tid; q < nq; q += NT, it++) {
+    if (!(keep & (1u << it))) continue;
+    const uint32_t ent = queue[q];
+    const int r = (ent >> 8) & 127, c = ent & 255;
     const int s = score[(r + 1) * kScoreP + (c + 1)];
     const int slot = base + atomicAdd(&s_cnt[2], 1);
     if (slot < L.cand_cap) out[slot] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
@@ -1518,8 +1795,13 @@ static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_
   // + one spare row: the necessary test reads (masked) dwords just past the last tile row
   const int tile_bytes = ((maxVh + 6 + 1) * TP + 15) & ~15, score_bytes = ((maxVh + 2) * SP + 15) & ~15;
   const size_t lds = (size_t)tile_bytes + score_bytes + (((size_t)maxArea * 2 + 15) & ~(size_t)15);
-  hipLaunchKernelGGL((k_fast_cells<NT, TP, SP>), grid, block, lds, s, pyr, d_fg, d_cells, s0, cand, cand_count,
-                     cell_count, tile_bytes, score_bytes);
+  static const bool v2 = getenv("VSG_FAST_V2") != nullptr;  // A/B switch: the round-2 kernel (exact 9-bit test, two-sided score)
+  if (v2)
+    hipLaunchKernelGGL((k_fast_cells_v2<NT, TP, SP>), grid, block, lds, s, pyr, d_fg, d_cells, s0, cand, cand_count,
+                       cell_count, tile_bytes, score_bytes);
+  else
+    hipLaunchKernelGGL((k_fast_cells<NT, TP, SP>), grid, block, lds, s, pyr, d_fg, d_cells, s0, cand, cand_count,
+                       cell_count, tile_bytes, score_bytes);
 }
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
                  uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea,
