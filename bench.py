@@ -242,6 +242,10 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo for dry runs")
     ap.add_argument("--torch-gather", action="store_true",
                     help="exchange the records through torch.distributed instead of the library's own RCCL communicator")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "boundary"],
+                    help="N > 1: allgather = every rank's whole batch of records into every GPU (what north_star words); "
+                         "boundary = only what the chunk partition needs, one ncclSend/ncclRecv of the last frame's record "
+                         "to the successor rank")
     ap.add_argument("--one-device", action="store_true",
                     help="dry run of the multi-rank path on a single GPU: every rank uses device 0 (needs gloo)")
     args = ap.parse_args()
@@ -314,9 +318,13 @@ def main():
                 comm.close()
                 comm = None
         if comm is None:
-            comm_kind = f"torch.distributed {args.dist_backend} all_gather_into_tensor"
+            comm_kind = f"torch.distributed {args.dist_backend} " + ("all_gather_into_tensor" if args.exchange == "allgather"
+                                                                     else "batch_isend_irecv")
             send = torch.zeros((B, rec_bytes), dtype=torch.uint8, device=dev)
             recv = torch.zeros((world * B, rec_bytes), dtype=torch.uint8, device=dev)
+            brecv = torch.zeros((1, rec_bytes), dtype=torch.uint8, device=dev)
+        elif args.exchange == "boundary":
+            comm_kind = "C ABI vsg_shard_send_recv_boundary (ncclSend + ncclRecv)"
         # boundary state: this rank's first frame of the previous step, and (rank 0) the last rank's last frame
         d_first_desc = torch.zeros((cap, 32), dtype=torch.uint8, device=dev)
         d_first_cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
@@ -336,7 +344,14 @@ def main():
         assert rc == 0, rc
 
     def gathered_record(r, f):
-        """(counts, desc) device pointers of frame f of rank r in the last completed exchange"""
+        """(counts, desc) device pointers of frame f of rank r in the last completed exchange (boundary mode: the one
+        record that exchange delivers, the predecessor rank's last frame)"""
+        if args.exchange == "boundary":
+            assert r == pred_rank and f == B - 1
+            if comm is not None:
+                c, _, d = comm.boundary_record()
+                return c, d
+            return brecv[0].data_ptr(), brecv[0].data_ptr() + od
         if comm is not None:
             c, _, d = comm.record(r, f)
             return c, d
@@ -390,9 +405,15 @@ def main():
             with torch.cuda.stream(cstream):
                 cstream.wait_event(ev_extracted)  # this step's records exist
                 cstream.wait_event(ev_consumed)   # the previous exchange's records have been read
-                if comm is not None:
+                if comm is not None and args.exchange == "boundary":
+                    comm.send_recv_boundary(d_counts[1].data_ptr(), d_kps[1].data_ptr(), d_desc[1].data_ptr(), cap, B - 1,
+                                            cstream.cuda_stream)
+                elif comm is not None:
                     comm.all_gather(d_counts[1].data_ptr(), d_kps[1].data_ptr(), d_desc[1].data_ptr(), cap, B,
                                     cstream.cuda_stream)
+                elif args.exchange == "boundary":
+                    sharding.pack_records(send[:1], d_counts[B:B + 1], d_kps[B:B + 1], d_desc[B:B + 1])
+                    sharding.send_recv_boundary(brecv, send[:1], (rank + 1) % world, pred_rank)
                 else:
                     sharding.pack_records(send, d_counts[1:], d_kps[1:], d_desc[1:])
                     w = sharding.all_gather_records(recv, send, async_op=args.dist_backend == "nccl")
@@ -404,19 +425,8 @@ def main():
                 tstream.wait_event(ev_gathered)
 
     def L_memcpy(dst, src, nbytes):
-        """device-to-device copy of raw pointers on the compute stream"""
-        rc = hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3, C.c_void_p(stream))
-        assert rc == 0, rc
-
-    hip = None
-    if exchange:
-        for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
-            try:
-                hip = C.CDLL(name)
-                break
-            except OSError:
-                continue
-        assert hip is not None, "HIP runtime not found by name"
+        """device-to-device copy of raw pointers on the compute stream (C ABI: the library's own HIP runtime)"""
+        orb.copy_d2d_async(dst, src, nbytes, stream, local_rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -549,6 +559,14 @@ def main():
 
     cpu = None
     extra = {}
+    if args.cpu_seconds > 0 and world > 1:
+        # N > 1 lines carry the same baseline on a short budget (rank 0's host, one thread; the other ranks are done)
+        sample = [frames[i] for i in range(min(B, 16))]
+        budget = min(3.0, args.cpu_seconds)
+        v1, n1 = cpu_baseline(W, H, nfeat, sample, budget, 1)
+        cpu = {"value": round(v1, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{n1} frames of the same {W}x{H}/{nfeat} workload, extract + brute-force match, "
+                         f"{budget:.0f} s on rank 0's host, CPU oracle (port of the reference algorithm)"}
     if args.cpu_seconds > 0 and world == 1:
         sample = [frames[i] for i in range(min(B, 16))]
         v1, n1 = cpu_baseline(W, H, nfeat, sample, args.cpu_seconds, 1)
@@ -574,10 +592,17 @@ def main():
         "config": {"workload": f"{args.workload}: {W}x{H} gray, nFeatures={nfeat}, 8 levels, scale 1.2, FAST 20/7, "
                                f"extract{'' if args.no_match else ' + brute-force Hamming best2 match vs previous frame'}",
                    "frames_per_step_per_gpu": B, "parallelism": f"frame-sharded x{world}"
-                   + (f", contiguous chunks of one sequence per step; all-gather of keypoint/descriptor records per "
-                      f"step via {comm_kind} on a second stream under the next step's kernels; every rank's first "
-                      "frame is matched against the gathered last frame of the previous rank"
+                   + (f", contiguous chunks of one sequence per step; "
+                      + ("all-gather of every rank's keypoint/descriptor records" if args.exchange == "allgather" else
+                         "neighbour-only exchange of the chunk boundary record (last frame -> successor rank)")
+                      + f" per step via {comm_kind} on a second stream under the next step's kernels; every rank's "
+                      "first frame is matched against the received last frame of the previous rank"
                       if exchange else ""),
+                   **({"exchange": args.exchange,
+                       "exchange_bytes_in_per_gpu_per_step": int((world - 1) * B * rec_bytes if args.exchange == "allgather"
+                                                                 else rec_bytes),
+                       "rccl_ranks_seen": comm.world_seen() if comm is not None else None,
+                       "dist_world_size": dist.get_world_size()} if exchange else {}),
                    "keypoints_per_frame": round(n_kp, 1), "inputs": "resident in HBM"},
         "parity": {"bit_exact_vs_oracle": parity, "checked_frames": [0, B - 1]},
         "roofline": roofline, "cpu_baseline": cpu,

@@ -302,6 +302,9 @@ int vsg_search_for_initialization(int device, const uint8_t *desc1, const float 
  * vsg_thread_arena_growths(device) = number of arena (re)allocations so far on this thread (constant in steady state). */
 int vsg_thread_release(void);
 int vsg_thread_arena_growths(int device);
+/* hipMemcpyAsync(dst, src, bytes, DeviceToDevice, stream) on `device`, for hosts that hold raw device pointers (the
+ * records of vsg_shard_record) and should not bind a second copy of the HIP runtime for one copy. */
+int vsg_copy_d2d_async(int device, void *dst, const void *src, size_t bytes, void *stream);
 /* debug: wall time in microseconds of the calling thread's last vsg_frame_* window search -- {filling the pinned
  * arena, the launch call, the stream synchronisation (kernel + PCIe), the whole entry point} */
 int vsg_debug_call_profile(float us[4]);
@@ -517,6 +520,15 @@ int vsg_shard_all_gather(vsg_shard *s, const int *d_counts, const vsg_keypoint *
                          int src_capacity, int nframes, void *stream);
 int vsg_shard_record(vsg_shard *s, int rank, int frame, const int **d_counts, const vsg_keypoint **d_kps,
                      const uint8_t **d_desc);
+int vsg_shard_world(const vsg_shard *s); /* ranks of the communicator */
+/* Neighbour-only exchange for chunk-partitioned sequences (rank r owns frames [r B, (r + 1) B) of a step): matching
+ * needs ONE remote record per rank and step, the predecessor rank's last frame.  Packs frame `frame` of this rank's
+ * batch and sends it to rank + 1 while receiving the record of rank - 1 (cyclic): one ncclSend / ncclRecv pair on the
+ * caller's stream instead of an all-gather of every record.  vsg_shard_boundary_record: device pointers of the
+ * received record (valid until the next exchange). */
+int vsg_shard_send_recv_boundary(vsg_shard *s, const int *d_counts, const vsg_keypoint *d_kps, const uint8_t *d_desc,
+                                 int src_capacity, int frame, void *stream);
+int vsg_shard_boundary_record(vsg_shard *s, const int **d_counts, const vsg_keypoint **d_kps, const uint8_t **d_desc);
 
 #ifdef __cplusplus
 }

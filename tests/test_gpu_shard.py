@@ -120,3 +120,42 @@ def test_partial_batch_and_truncated_records():
         assert counts[f, 0] > small and hdr.tolist() == [small, min(int(counts[f, 1]), small), 1, 0]
         assert np.array_equal(_read(dp, small * 32).reshape(small, 32), desc_h[f, :small])
     comm.close(), comm_small.close()
+
+
+def test_boundary_send_recv_world1():
+    """vsg_shard_send_recv_boundary with one rank: the record of the chosen frame goes to rank (r + 1) mod 1 = itself
+    through ncclSend / ncclRecv and must arrive bit for bit."""
+    import torch
+    dev = torch.device("cuda", 0)
+    B, W, H, NF = 3, 320, 240, 500
+    fr = np.stack([synth.sequence_frame(W, H, 73, t) for t in range(B)])
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    d_gray = torch.from_numpy(fr).to(dev)
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    try:
+        comm = sharding.ShardComm(0, 0, 1, cap, B)
+    except orb.VsgError as e:
+        if e.code == -3:
+            pytest.skip("RCCL not loadable on this box")
+        raise
+    assert comm.world_seen() == 1
+    ex.extract_batch_device(d_gray.data_ptr(), B, H * W, H, W, W, d_kps.data_ptr(), d_desc.data_ptr(),
+                            d_counts.data_ptr(), cap, (0, 0), st.cuda_stream)
+    comm.send_recv_boundary(d_counts.data_ptr(), d_kps.data_ptr(), d_desc.data_ptr(), cap, B - 1, st.cuda_stream)
+    st.synchronize()
+    cp, kp, dp = comm.boundary_record()
+    rm, rk, rd = ol.OracleExtractor(NF, 1.2, 8, 20, 7)(fr[B - 1])
+    hdr = _read(cp, 16).view(np.int32)
+    assert hdr.tolist() == [len(rk), rm, 0, 0]
+    assert _read(kp, len(rk) * 28).tobytes() == rk.tobytes()
+    assert np.array_equal(_read(dp, len(rk) * 32).reshape(-1, 32), rd)
+    # d2d copy through the C ABI (what bench.py uses for its boundary state)
+    dst = torch.zeros(len(rk) * 32, dtype=torch.uint8, device=dev)
+    orb.copy_d2d_async(dst.data_ptr(), dp, len(rk) * 32, st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(dst.cpu().numpy().reshape(-1, 32), rd)
+    comm.close()

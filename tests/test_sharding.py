@@ -77,6 +77,42 @@ def test_all_gather_records_gloo_world2():
     assert res == [(0, True), (1, True)]
 
 
+def _boundary_worker(rank, world, port, B, cap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    counts, kps, desc = _fake_records(rank, B, cap)
+    rec = sharding.record_bytes(cap)
+    send = torch.zeros((1, rec), dtype=torch.uint8)
+    recv = torch.zeros((1, rec), dtype=torch.uint8)
+    ok = True
+    for step in range(3):  # the record of this rank's LAST frame goes to the successor, the predecessor's arrives
+        sharding.pack_records(send, counts[B - 1:], kps[B - 1:], desc[B - 1:])
+        sharding.send_recv_boundary(recv, send, (rank + 1) % world, (rank - 1) % world)
+        c, k, d = sharding.unpack_records(recv, cap)
+        pc, pk, pd = _fake_records((rank - 1) % world, B, cap)
+        ok &= torch.equal(c[0], pc[B - 1]) and torch.equal(k[0], pk[B - 1]) and torch.equal(d[0], pd[B - 1])
+        ok &= not recv[0, 8:16].any()  # flags / pad words of the header are zero
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_boundary_exchange_gloo_world2():
+    """The neighbour-only exchange (bench.py --exchange boundary): one record to the successor rank per step."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_boundary_worker, args=(r, 2, port, 3, 40, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(timeout=60) for p in procs]
+    assert res == [(0, True), (1, True)]
+
+
 def test_single_process_gather_is_identity():
     counts, kps, desc = _fake_records(0, 2, 10)
     send = torch.zeros((2, sharding.record_bytes(10)), dtype=torch.uint8)

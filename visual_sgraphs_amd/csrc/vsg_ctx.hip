@@ -152,6 +152,17 @@ int vsg_thread_release(void) {
   return VSG_OK;
 }
 
+// device-to-device copy of raw pointers on a caller stream: hosts that hold records as device pointers (the gathered
+// records of vsg_shard_record, bench.py's boundary state) need no second HIP runtime binding for it
+int vsg_copy_d2d_async(int device, void *dst, const void *src, size_t bytes, void *stream) {
+  if (!dst || !src) return VSG_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return VSG_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return VSG_ERR_NO_DEVICE;
+  if (bytes == 0) return VSG_OK;
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? VSG_OK : VSG_ERR_HIP;
+}
+
 int vsg_thread_arena_growths(int device) {
   using namespace vsg;
   if (device < 0 || (size_t)device >= t_ctx.by_device.size() || !t_ctx.by_device[device]) return 0;

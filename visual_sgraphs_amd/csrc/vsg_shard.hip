@@ -5,7 +5,7 @@
 // The reference has no distributed layer; extraction has no cross-frame state, so frames (or camera streams) are dealt
 // to ranks with NO data-path collective.  Only matching frame t against t-1 needs the neighbour's features: ranks
 // exchange fixed-capacity per-frame records
-//     { int32 n, int32 monoIndex, 8 B pad | KeyPoint[cap] (28 B each, padded to 16) | uint8 desc[cap][32] | pad to 64 }
+//     { int32 n, int32 monoIndex, uint32 flags, 4 B pad | KeyPoint[cap] (28 B each, padded to 16) | uint8 desc[cap][32] | pad to 64 }
 // (the descriptor block is 16-byte aligned, so a gathered record feeds the matcher kernels where it lies)
 // with ONE ncclAllGather per batch on the caller's stream (one process per GPU; the 8-GPU node is fully connected, a
 // record batch is tens of MB, so the collective is per-link bandwidth bound and is meant to run under the next
@@ -31,6 +31,10 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
 };
@@ -54,6 +58,10 @@ const Rccl &rccl() {
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(g_rccl.lib, "ncclAllGather");
+    g_rccl.Send = (decltype(g_rccl.Send))dlsym(g_rccl.lib, "ncclSend");
+    g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(g_rccl.lib, "ncclRecv");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.lib, "ncclGroupEnd");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllGather;
   });
@@ -99,6 +107,7 @@ struct vsg_shard {
   size_t rec = 0;
   ncclComm_t comm = nullptr;
   uint8_t *d_send = nullptr, *d_recv = nullptr;  // [frames][rec], [world][frames][rec]
+  uint8_t *d_bsend = nullptr, *d_brecv = nullptr;  // one record each: the boundary exchange (vsg_shard_send_recv_boundary)
 };
 
 #define S_HIP(expr)                                                          \
@@ -170,7 +179,8 @@ int vsg_shard_create(int device, int rank, int world, const uint8_t id[128], int
   }
   const size_t sb = s->rec * (size_t)frames_per_rank;
   if (hipMalloc((void **)&s->d_send, sb) != hipSuccess || hipMalloc((void **)&s->d_recv, sb * (size_t)world) != hipSuccess ||
-      hipMemset(s->d_send, 0, sb) != hipSuccess) {
+      hipMemset(s->d_send, 0, sb) != hipSuccess || hipMalloc((void **)&s->d_bsend, s->rec) != hipSuccess ||
+      hipMalloc((void **)&s->d_brecv, s->rec) != hipSuccess || hipMemset(s->d_brecv, 0, s->rec) != hipSuccess) {
     t_serr = "hipMalloc of the record buffers failed";
     vsg_shard_destroy(s);
     return VSG_ERR_HIP;
@@ -184,7 +194,7 @@ void vsg_shard_destroy(vsg_shard *s) {
   hipSetDevice(s->device);
   hipDeviceSynchronize();
   if (s->comm && rccl().ok) rccl().CommDestroy(s->comm);
-  hipFree(s->d_send), hipFree(s->d_recv);
+  hipFree(s->d_send), hipFree(s->d_recv), hipFree(s->d_bsend), hipFree(s->d_brecv);
   delete s;
 }
 
@@ -204,6 +214,50 @@ int vsg_shard_all_gather(vsg_shard *s, const int *d_counts, const vsg_keypoint *
   }
   return VSG_OK;
 }
+
+// The neighbour-only alternative to the all-gather for CHUNK-partitioned sequences: matching needs exactly one remote
+// record per rank and batch -- the last frame of the predecessor rank -- so every rank sends the record of its frame
+// `frame` to rank + 1 and receives its predecessor's (rank - 1, cyclic) into a one-record buffer: one ncclSend +
+// ncclRecv pair per batch (61 KB at C2) instead of world x frames records into every GPU.
+int vsg_shard_send_recv_boundary(vsg_shard *s, const int *d_counts, const vsg_keypoint *d_kps, const uint8_t *d_desc,
+                                 int src_capacity, int frame, void *stream) {
+  if (!s || !d_counts || !d_kps || !d_desc || frame < 0 || src_capacity < 1) return VSG_ERR_INVALID;
+  const Rccl &R = rccl();
+  if (!R.Send || !R.Recv || !R.GroupStart || !R.GroupEnd) {
+    t_serr = "ncclSend / ncclRecv not available in the loaded RCCL";
+    return VSG_ERR_UNSUPPORTED;
+  }
+  S_HIP(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  // pack ONE record: frame `frame` of the caller's batch into slot 0 of the boundary send buffer
+  hipLaunchKernelGGL(k_pack_records, dim3(4, 1), dim3(256), 0, st, d_counts + 2 * (size_t)frame,
+                     (const vsg::KeyPointPOD *)d_kps + (size_t)frame * src_capacity, d_desc + (size_t)frame * src_capacity * 32,
+                     src_capacity, s->cap, 1, s->d_bsend, s->rec);
+  S_HIP(hipGetLastError());
+  const int next = (s->rank + 1) % s->world, prev = (s->rank + s->world - 1) % s->world;
+  ncclResult_t r = R.GroupStart();
+  if (r == ncclSuccess) r = R.Send(s->d_bsend, s->rec, ncclChar, next, s->comm, st);
+  if (r == ncclSuccess) r = R.Recv(s->d_brecv, s->rec, ncclChar, prev, s->comm, st);
+  const ncclResult_t e = R.GroupEnd();
+  if (r == ncclSuccess) r = e;
+  if (r != ncclSuccess) {
+    t_serr = std::string("ncclSend/ncclRecv: ") + (R.GetErrorString ? R.GetErrorString(r) : "error");
+    return VSG_ERR_HIP;
+  }
+  return VSG_OK;
+}
+
+int vsg_shard_boundary_record(vsg_shard *s, const int **d_counts, const vsg_keypoint **d_kps, const uint8_t **d_desc) {
+  if (!s) return VSG_ERR_INVALID;
+  const uint8_t *r = s->d_brecv;
+  if (d_counts) *d_counts = (const int *)r;
+  if (d_kps) *d_kps = (const vsg_keypoint *)(r + off_kps());
+  if (d_desc) *d_desc = r + off_desc(s->cap);
+  return VSG_OK;
+}
+
+// number of ranks of the communicator (what ncclCommInitRank was given): bench lines report it as rccl_ranks_seen
+int vsg_shard_world(const vsg_shard *s) { return s ? s->world : VSG_ERR_INVALID; }
 
 int vsg_shard_record(vsg_shard *s, int rank, int frame, const int **d_counts, const vsg_keypoint **d_kps,
                      const uint8_t **d_desc) {

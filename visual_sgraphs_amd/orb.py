@@ -58,7 +58,8 @@ EXPORTS = [
     "vsg_frame_stereo_matches",
     "vsg_shard_last_error", "vsg_shard_record_bytes", "vsg_shard_record_desc_offset", "vsg_shard_frame_owner",
     "vsg_shard_stream_owner", "vsg_shard_unique_id", "vsg_shard_create", "vsg_shard_destroy", "vsg_shard_all_gather",
-    "vsg_shard_record",
+    "vsg_shard_record", "vsg_shard_world", "vsg_shard_send_recv_boundary", "vsg_shard_boundary_record",
+    "vsg_copy_d2d_async",
 ]
 
 
@@ -235,6 +236,10 @@ def load_library():
     L.vsg_shard_destroy.restype = None
     L.vsg_shard_all_gather.argtypes = [vp, vp, vp, vp, ci, ci, vp]
     L.vsg_shard_record.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.vsg_shard_world.argtypes = [vp]
+    L.vsg_shard_send_recv_boundary.argtypes = [vp, vp, vp, vp, ci, ci, vp]
+    L.vsg_shard_boundary_record.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.vsg_copy_d2d_async.argtypes = [ci, vp, vp, C.c_size_t, vp]
     _lib = L
     return L
 
@@ -773,6 +778,12 @@ def pin(array):
 
 def unpin(array):
     _check(load_library().vsg_host_unregister(C.c_void_p(array.ctypes.data)), "vsg_host_unregister")
+
+
+def copy_d2d_async(dst, src, nbytes, stream, device=0):
+    """Device-to-device copy of raw pointers (ints) on `stream` through the library's own HIP runtime."""
+    _check(load_library().vsg_copy_d2d_async(int(device), C.c_void_p(dst), C.c_void_p(src), int(nbytes),
+                                            C.c_void_p(stream) if stream else None), "vsg_copy_d2d_async")
 
 
 def thread_arena_growths(device=0):

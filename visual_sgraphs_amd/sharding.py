@@ -105,6 +105,21 @@ def all_gather_records(recv, send, async_op=False):
     return None
 
 
+def send_recv_boundary(recv, send, next_rank, prev_rank):
+    """The neighbour-only exchange through torch.distributed: `send` [1, rec] goes to next_rank, `recv` [1, rec] is filled
+    from prev_rank (one batched isend / irecv pair; device tensors are staged through the host on gloo)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        recv.copy_(send)
+        return
+    via_host = send.is_cuda and dist.get_backend() == "gloo"
+    s = send.cpu() if via_host else send
+    r = torch.empty(recv.shape, dtype=recv.dtype) if via_host else recv
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, s, next_rank), dist.P2POp(dist.irecv, r, prev_rank)]):
+        w.wait()
+    if via_host:
+        recv.copy_(r)
+
+
 class ShardComm:
     """The library's own RCCL communicator (vsg_shard_*, include/vsg_orb.h): pack kernel + ncclAllGather on the
     caller's stream, gathered records addressable as device pointers.  The 128-byte ncclUniqueId is created by rank 0
@@ -167,6 +182,24 @@ class ShardComm:
                                           int(src_capacity), int(nframes), C.c_void_p(stream) if stream else None)
         if rc != 0:
             raise self._orb.VsgError(rc, "vsg_shard_all_gather", self._L.vsg_shard_last_error().decode())
+
+    def world_seen(self):
+        return self._L.vsg_shard_world(self._h)
+
+    def send_recv_boundary(self, d_counts, d_kps, d_desc, src_capacity, frame, stream):
+        """Neighbour-only exchange: this rank's record of `frame` goes to rank + 1, the predecessor's arrives in the
+        boundary slot (`boundary_record`).  Asynchronous on `stream`."""
+        rc = self._L.vsg_shard_send_recv_boundary(self._h, C.c_void_p(d_counts), C.c_void_p(d_kps), C.c_void_p(d_desc),
+                                                  int(src_capacity), int(frame), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise self._orb.VsgError(rc, "vsg_shard_send_recv_boundary", self._L.vsg_shard_last_error().decode())
+
+    def boundary_record(self):
+        c, k, d = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rc = self._L.vsg_shard_boundary_record(self._h, C.byref(c), C.byref(k), C.byref(d))
+        if rc != 0:
+            raise self._orb.VsgError(rc, "vsg_shard_boundary_record", "")
+        return c.value, k.value, d.value
 
     def record(self, rank, frame):
         """(d_counts, d_kps, d_desc) device pointers of one gathered record."""
