@@ -327,6 +327,14 @@ int vsg_host_unregister(void *ptr);
  * threads the handle keeps asleep between batches; environment VSG_STAGE_THREADS=n, 0 = the calling thread only).  vsg_orb_wait(ticket) blocks until that batch is complete and delivers n[]
  * and mono_index[] (nframes entries each).  Tickets are waited for in submission order. */
 int vsg_orb_slots(const vsg_orb *h);
+/* Latency path of the BLOCKING entry points (vsg_orb_extract, vsg_orb_extract_batch with <= 8 frames; the reference
+ * calls operator() once per frame: System::TrackRGBD -> Frame::ExtractORB, System.cc:359, Frame.cc:555-563): the pinned
+ * image is read by a kernel instead of a copy-engine transfer and k_orient_desc writes the records into the pinned
+ * destination itself (no export launch, no DMA).  With VSG_GRAPH=1 in the environment the stream work of a call is additionally recorded as
+ * a hipGraph on the second call with the same source / destination / lapping area and replayed with one
+ * hipGraphLaunch from the third on (measured: no faster than the eager launches on ROCm 7.0, hence opt-in).
+ * Results are identical in every mode.  Returns the number of graph launches so far. */
+long vsg_orb_chain_graph_launches(const vsg_orb *h);
 int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t frame_stride, int rows, int cols,
                          int stride, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc, int capacity);
 int vsg_orb_wait(vsg_orb *h, int ticket, int *n, int *mono_index);

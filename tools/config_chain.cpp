@@ -489,11 +489,104 @@ static std::string run_c5(double seconds) {
   return b;
 }
 
+// ------------------------------------------------------------------------------------------------ frame latency
+// The call pattern the reference has: ONE frame per operator() (System::TrackRGBD -> Tracking::GrabImageRGBD ->
+// Frame::ExtractORB, System.cc:359, Tracking.cc:1583, Frame.cc:344,555-563), then the two tracking searches
+// (Tracking.cc:2955 TrackWithMotionModel, :3493 SearchLocalPoints).  C2 frames (640x480 / 1000), host image in, host
+// records out, wall time per call through the C ABI next to the oracle's on one host thread.
+static std::string run_latency(double seconds) {
+  const int W = 640, H = 480, T = 6;
+  std::vector<std::vector<uint8_t>> img;
+  for (int t = 0; t < T; t++) {
+    img.emplace_back((size_t)W * H);
+    CHECK(vsg_synth_sequence_frame(W, H, 1000, t, 1, 6, img.back().data(), W) == 0);
+  }
+  vsg_orb *ex = nullptr;
+  CHECK(vsg_orb_create(1000, 1.2f, 8, 20, 7, 0, 1, &ex) == VSG_OK);
+  const int cap = vsg_orb_capacity(ex, H, W);
+  OrExtractor *oe = or_create(1000, 1.2f, 8, 20, 7);
+  float sf[8];
+  vsg_orb_get_tables(ex, sf, nullptr, nullptr, nullptr, nullptr, nullptr);
+  vsg_frame *F[2];
+  TrackResult R[2], O[2];
+  for (int i = 0; i < 2; i++) {
+    CHECK(vsg_frame_create(0, cap, &F[i]) == VSG_OK);
+    R[i].size_for(cap), O[i].size_for(cap);
+  }
+  Queries q;
+  bool parity = true;
+  // one frame of each chain; level: 0 = operator() only, 1 = + resident frame, 2 = + the two tracking searches
+  auto gpu = [&](int t, int level) {
+    TrackResult &C = R[t & 1], &P = R[(t + 1) & 1];
+    CHECK(vsg_orb_extract(ex, img[t % T].data(), H, W, W, 0, 0, C.kp.data(), C.ds.data(), cap, &C.n) >= 0);
+    if (level < 1) return;
+    CHECK(vsg_frame_from_extractor(F[t & 1], ex, 0, C.kp.data(), C.n, 0.f, 0.f, (float)W, (float)H) == VSG_OK);
+    if (level < 2 || P.n == 0) return;
+    q.from(P);
+    std::fill(C.tb.begin(), C.tb.begin() + C.n, 0), std::fill(C.tm_last.begin(), C.tm_last.begin() + C.n, -1);
+    C.n_last = vsg_frame_search_by_projection_last(F[t & 1], P.n, P.ds.data(), q.obs.data(), q.u.data(), q.v.data(), nullptr,
+                                                   nullptr, nullptr, q.oct.data(), q.ang.data(), 15.f, 0, sf, 8, 1, C.tb.data(),
+                                                   C.tm_last.data());
+    std::fill(C.tb.begin(), C.tb.begin() + C.n, 0), std::fill(C.tm_local.begin(), C.tm_local.begin() + C.n, -1);
+    C.n_local = vsg_frame_search_by_projection(F[t & 1], P.n, P.ds.data(), q.obs.data(), q.obs.data(), q.u.data(), q.v.data(),
+                                               q.u.data(), q.oct.data(), q.vc.data(), nullptr, nullptr, nullptr, nullptr, nullptr,
+                                               1.f, 0.8f, sf, 8, nullptr, nullptr, C.tb.data(), C.tm_local.data());
+    CHECK(C.n_last >= 0 && C.n_local >= 0);
+  };
+  auto cpu = [&](int t, int level) {
+    TrackResult &C = O[t & 1], &P = O[(t + 1) & 1];
+    or_extract(oe, img[t % T].data(), H, W, W, 0, 0, (OrKeyPoint *)C.kp.data(), C.ds.data(), cap, &C.n);
+    if (level < 1) return;
+    OrFrame *f = or_frame_create((const OrKeyPoint *)C.kp.data(), C.ds.data(), nullptr, C.n, -1, 0.f, 0.f, (float)W, (float)H);
+    if (level >= 2 && P.n > 0) {
+      q.from(P);
+      std::fill(C.tb.begin(), C.tb.begin() + C.n, 0), std::fill(C.tm_last.begin(), C.tm_last.begin() + C.n, -1);
+      C.n_last = or_frame_search_by_projection_last(f, P.n, P.ds.data(), q.obs.data(), q.u.data(), q.v.data(), q.u.data(), nullptr,
+                                                    nullptr, q.oct.data(), q.ang.data(), 15.f, 0, 0, sf, 1, C.tb.data(),
+                                                    C.tm_last.data());
+      std::fill(C.tb.begin(), C.tb.begin() + C.n, 0), std::fill(C.tm_local.begin(), C.tm_local.begin() + C.n, -1);
+      C.n_local = or_frame_search_by_projection(f, P.n, P.ds.data(), q.obs.data(), q.obs.data(), q.u.data(), q.v.data(),
+                                                q.u.data(), q.oct.data(), q.vc.data(), nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                1.f, 0.8f, sf, nullptr, nullptr, C.tb.data(), C.tm_local.data());
+    }
+    or_frame_destroy(f);
+  };
+  for (int t = 0; t < 2 * T; t++) {  // parity over two laps of the sequence (the second one runs on recorded graphs)
+    gpu(t, 2), cpu(t, 2);
+    parity = parity && same_track(R[t & 1], O[t & 1]);
+  }
+  double g_ms[3], c_ms[3];
+  for (int level = 0; level < 3; level++) {
+    int t = 0, n = 0;
+    for (int w = 0; w < 12; w++) gpu(t++, level);
+    double t0 = now_ms();
+    while (now_ms() - t0 < seconds * 400) gpu(t++, level), n++;
+    g_ms[level] = (now_ms() - t0) / n;
+    t = 0, n = 0;
+    t0 = now_ms();
+    while (now_ms() - t0 < seconds * 400) cpu(t++, level), n++;
+    c_ms[level] = (now_ms() - t0) / n;
+  }
+  char b[1024];
+  snprintf(b, sizeof b,
+           "{\"workload\": \"one 640x480 / 1000-feature frame per blocking operator() call through the C ABI, host image in, "
+           "host records out\", \"extract_ms\": %.4f, \"extract_plus_resident_ms\": %.4f, \"track_chain_ms\": %.4f, "
+           "\"cpu_oracle_1_thread\": {\"extract_ms\": %.3f, \"extract_plus_resident_ms\": %.3f, \"track_chain_ms\": %.3f}, "
+           "\"parity\": %s, \"graph_launches\": %ld, \"track_chain\": \"operator() -> resident frame -> "
+           "SearchByProjection(Cur, Last) -> SearchByProjection(F, local map points)\"}",
+           g_ms[0], g_ms[1], g_ms[2], c_ms[0], c_ms[1], c_ms[2], parity ? "true" : "false", vsg_orb_chain_graph_launches(ex));
+  for (int i = 0; i < 2; i++) vsg_frame_destroy(F[i]);
+  vsg_orb_destroy(ex);
+  or_destroy(oe);
+  return b;
+}
+
 int main(int argc, char **argv) {
   const double seconds = argc > 1 ? atof(argv[1]) : 2.0;
   const int npipes = argc > 2 ? atoi(argv[2]) : 4;
   const std::string c3 = run_c3(seconds, npipes);
   const std::string c5 = run_c5(seconds);
-  printf("{\"C3\": %s, \"C5\": %s}\n", c3.c_str(), c5.c_str());
+  const std::string lat = run_latency(seconds);
+  printf("{\"C3\": %s, \"C5\": %s, \"frame_latency\": %s}\n", c3.c_str(), c5.c_str(), lat.c_str());
   return 0;
 }

@@ -6,12 +6,22 @@
 #include "vsg_geometry.h"
 
 namespace vsg {
+// second destination of k_orient_desc's records: pinned host memory the device writes directly on the latency path of
+// the blocking entry points (only the n records of a frame cross PCIe, and no export launch follows); all null: none
+struct OutMirror {
+  KeyPointPOD *kps = nullptr;
+  uint8_t *desc = nullptr;
+  int *counts = nullptr;
+  int capacity = 0;
+};
 void launch_stereo(hipStream_t s, const PyrView &pl, const PyrView &pr, float mb, float mbf, const float *scale,
                    const float *invScale, int nlevels, const KeyPointPOD *kpsL, const uint8_t *descL, int nL,
                    const KeyPointPOD *kpsR, const uint8_t *descR, int nR, float *uRight, float *depth, int *sadBest);
 void launch_cvt_gray(hipStream_t s, const uint8_t *src, size_t sframe, int spitch, int channels, int rgb_order, int rows,
                      int cols, uint8_t *dst, size_t dframe, int dpitch, const int coeffs[3], int shift, int nframes);
 void launch_zero(hipStream_t s, int *p, int n);
+void launch_ingest(hipStream_t s, const uint8_t *src, size_t sframe, int spitch, uint8_t *dst, size_t dframe, int dpitch,
+                   int rows, int cols, int nframes);
 void launch_export(hipStream_t s, const KeyPointPOD *kps, const uint8_t *desc, const int *counts, int src_cap,
                    void *h_kps, void *h_desc, int *h_counts, int dst_cap, int nframes);
 void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
@@ -31,6 +41,7 @@ void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, con
                   int *slots, FrameHeader *hdr, int lap0, int lap1, int nframes);
 void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                         const uint32_t *sel, const int *slots, const FrameHeader *hdr, const int8_t *pattern,
-                        KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes);
+                        KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes,
+                        const OutMirror &mir);
 void launch_border_copy(hipStream_t s, const uint8_t *img, int w, int h, int pitch, uint8_t *dst, int dpitch, int b);
 }  // namespace vsg

@@ -1301,13 +1301,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 // ------------------------------------------------------------------------------------------------
 // Output slots: keypoints are visited level by level in octree order; those inside the lapping area
 // fill the arrays from the back, the others from the front (ORBextractor.cc:1119,1152-1163).
-__global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ sel,
+__device__ __forceinline__ void slots_of_frame(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ sel,
                                                const int *__restrict__ sel_count, int *__restrict__ flags,
-                                               int *__restrict__ slots, FrameHeader *__restrict__ hdr, int lap0,
-                                               int lap1) {
-  __shared__ int wtot[2 * kMaxWaves];
-  __shared__ int lstart[kMaxLevels + 1];
-  const int frame = blockIdx.x, tid = threadIdx.x;
+                                               int *__restrict__ slots, FrameHeader *__restrict__ hdr, int lap0, int lap1,
+                                               int frame, int *wtot, int *lstart) {
+  const int tid = threadIdx.x;
   if (tid == 0) {
     int s = 0;
     for (int l = 0; l < fg->nlevels; l++) {
@@ -1346,6 +1344,15 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
     hdr[frame].mono = n - T;
     for (int l = 0; l <= kMaxLevels; l++) hdr[frame].level_start[l] = lstart[l];
   }
+}
+
+__global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ sel,
+                                               const int *__restrict__ sel_count, int *__restrict__ flags,
+                                               int *__restrict__ slots, FrameHeader *__restrict__ hdr, int lap0,
+                                               int lap1) {
+  __shared__ int wtot[2 * kMaxWaves];
+  __shared__ int lstart[kMaxLevels + 1];
+  slots_of_frame(fg, sel, sel_count, flags, slots, hdr, lap0, lap1, blockIdx.x, wtot, lstart);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1405,12 +1412,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // into LDS, one barrier).  2: 0.396 -> 0.386 ms per 512 frames; 4: no gain (fewer, longer workgroups)
 constexpr int kOdKpPerWave = VSG_OD_G;
 
+template <bool kMirror>
 __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                      const FrameGeom *__restrict__ fg, Src0 s0,
                                                      const uint32_t *__restrict__ sel,
                                                      const int *__restrict__ slots, const FrameHeader *__restrict__ hdr,
                                                      const int8_t *__restrict__ pattern, KeyPointPOD *__restrict__ kps,
-                                                     uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity) {
+                                                     uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity,
+                                                     OutMirror mir) {
   __shared__ f32x4 patf[256];            // test k: (x0, y0, x1, y1) of bit_pattern_31_ as floats
   __shared__ int s_hdr[kMaxLevels + 3];  // n, mono, level_start[0..kMaxLevels]
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchW * kPatchP];
@@ -1428,6 +1437,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
   if (blk.x == 0 && tid == 0) {
     counts[frame * 2 + 0] = n;
     counts[frame * 2 + 1] = s_hdr[1];
+    if (kMirror) mir.counts[frame * 2 + 0] = n, mir.counts[frame * 2 + 1] = s_hdr[1];
   }
   const int lane = tid & 63;
   // everything derived from the keypoint index is wave-uniform: keep it in SGPRs so the per-level geometry comes
@@ -1544,7 +1554,10 @@ __global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__
       kp.octave = l;
       kp.class_id = -1;
       kps[(size_t)frame * capacity + slot] = kp;
+      if (kMirror && slot < mir.capacity) mir.kps[(size_t)frame * mir.capacity + slot] = kp;
     }
+    if (kMirror && slot < mir.capacity && lane < 4)
+      *(uint64_t *)(mir.desc + ((size_t)frame * mir.capacity + slot) * 32 + lane * 8) = word;
   }
   // the next keypoint overwrites the patch: this wave's LDS reads above are issued (and, in order, completed) first
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1758,6 +1771,33 @@ void launch_export(hipStream_t s, const KeyPointPOD *kps, const uint8_t *desc, c
                      (uint32_t *)h_desc, h_counts, dst_cap);
 }
 
+// Level-0 ingest of the blocking entry points: the device itself reads the caller's (or the slot's) PINNED host image
+// over PCIe and writes the level-0 staging -- no copy-engine start-up on the latency path of a single-frame operator()
+// (a 307 KB hipMemcpyAsync costs ~15 us end to end, this kernel ~6).  Thread = 16 bytes of a row; rows that are not a
+// multiple of 16 bytes end with narrower moves.
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t *__restrict__ src, size_t sframe, int spitch,
+                                                uint8_t *__restrict__ dst, size_t dframe, int dpitch, int rows, int cols) {
+  const int chunks = (cols + 15) >> 4;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= chunks * rows) return;
+  const int y = i / chunks, c = i - y * chunks, x = c << 4;
+  const uint8_t *s = src + (size_t)blockIdx.y * sframe + (size_t)y * spitch + x;
+  uint8_t *d = dst + (size_t)blockIdx.y * dframe + (size_t)y * dpitch + x;
+  if (x + 16 <= cols) {
+    typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+    typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+    *(u32x4a4 *)d = *(const u32x4a1 *)s;
+  } else {
+    for (int k = 0; x + k < cols; k++) d[k] = s[k];
+  }
+}
+void launch_ingest(hipStream_t s, const uint8_t *src, size_t sframe, int spitch, uint8_t *dst, size_t dframe, int dpitch,
+                   int rows, int cols, int nframes) {
+  const int n = ((cols + 15) >> 4) * rows;
+  hipLaunchKernelGGL(k_ingest, dim3((n + 255) / 256, nframes), dim3(256), 0, s, src, sframe, spitch, dst, dframe, dpitch,
+                     rows, cols);
+}
+
 // per-call reset of the candidate / selection counters (a kernel rather than hipMemsetAsync so that it is
 // ordered like every other stage on the stream and the stage-timing events bracket real work)
 __global__ void k_zero(int *p, int n) {
@@ -1843,10 +1883,15 @@ void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, con
 }
 void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                         const uint32_t *sel, const int *slots, const FrameHeader *hdr, const int8_t *pattern,
-                        KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes) {
+                        KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes,
+                        const OutMirror &mir) {
   dim3 grid((fg.out_cap + 4 * kOdKpPerWave - 1) / (4 * kOdKpPerWave), nframes), block(256);
-  hipLaunchKernelGGL(k_orient_desc, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
-                     counts, capacity);
+  if (mir.kps)
+    hipLaunchKernelGGL(k_orient_desc<true>, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
+                       counts, capacity, mir);
+  else
+    hipLaunchKernelGGL(k_orient_desc<false>, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
+                       counts, capacity, mir);
 }
 void launch_border_copy(hipStream_t s, const uint8_t *img, int w, int h, int pitch, uint8_t *dst, int dpitch, int b) {
   dim3 grid((w + 2 * b + 255) / 256, h + 2 * b), block(256);

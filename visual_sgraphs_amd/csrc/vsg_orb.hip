@@ -54,6 +54,7 @@ enum { kStages = 7, kEv = 12, kMaxSub = 8, kSlots = 3 };
 // pinned host memory, plus the events that chain  H2D -> kernels -> export  across the three streams.
 struct Slot {
   uint8_t *d_in = nullptr, *h_in = nullptr;  // [B][rows][in_pitch]
+  uint8_t *h_in_dev = nullptr;               // device alias of h_in (the ingest kernel reads it over PCIe)
   KeyPointPOD *d_kps = nullptr, *h_kps = nullptr;
   uint8_t *d_desc = nullptr, *h_desc = nullptr;
   int *d_counts = nullptr, *h_counts = nullptr;
@@ -137,6 +138,29 @@ struct StagePool {
   }
 };
 
+// Latency mode of the blocking entry points: the stream work of one call -- ingest, the stage chain with its blur fork /
+// join, the export -- captured once as a hipGraph and replayed with ONE hipGraphLaunch per operator() (the reference's
+// call pattern is one frame per call: System::TrackRGBD -> Frame::ExtractORB, Frame.cc:555-563).  A graph is tied to
+// everything its nodes hold by value: the slot, the frame count, the lapping area, the source (the slot's pinned
+// staging or a pinned caller image) and the destination (the slot's pinned records or pinned caller arrays).
+struct ChainKey {
+  int slot = -1, nframes = 0, lap0 = 0, lap1 = 0, stride = 0, capacity = 0;
+  size_t frame_stride = 0;
+  const void *src = nullptr, *dk = nullptr, *dd = nullptr;
+  bool operator==(const ChainKey &o) const {
+    return slot == o.slot && nframes == o.nframes && lap0 == o.lap0 && lap1 == o.lap1 && stride == o.stride &&
+           capacity == o.capacity && frame_stride == o.frame_stride && src == o.src && dk == o.dk && dd == o.dd;
+  }
+};
+struct ChainGraph {
+  ChainKey key;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int seen = 0;  // eager runs with this key so far: the graph is captured on the second call
+  long stamp = 0;
+};
+enum { kChainGraphs = 8 };
+
 struct vsg_orb {
   ExtractorTables T;
   Geometry G;
@@ -146,6 +170,10 @@ struct vsg_orb {
   // streams exist so that consecutive batches overlap; a call that waits for its own batch has nothing to overlap
   // with, and each cross-stream event wait costs ~15 us of idle GPU (0.175 -> ~0.15 ms per single-frame operator()).
   bool one_stream = false;
+  bool capturing = false;  // the calls below are being recorded into a ChainGraph (no timing events, no host waits)
+  OutMirror mirror;        // set around an enqueue by the latency path: k_orient_desc also writes pinned host records
+  ChainGraph chain[kChainGraphs];
+  long chain_clock = 0, chain_launches = 0;
   int rows = 0, cols = 0;  // geometry currently built for
   uint16_t taps[7] = {18, 34, 49, 55, 49, 34, 18};
   int gray_coeffs[3] = {4899, 9617, 1868};  // [OCV] 4.2 R2Y, G2Y, B2Y
@@ -207,7 +235,7 @@ constexpr int kPyrLdsLimit = 150000;
 static void free_slot(Slot &S) {
   hipFree(S.d_in), hipFree(S.d_kps), hipFree(S.d_desc), hipFree(S.d_counts);
   hipHostFree(S.h_in), hipHostFree(S.h_kps), hipHostFree(S.h_desc), hipHostFree(S.h_counts);
-  S.d_in = S.h_in = nullptr;
+  S.d_in = S.h_in = S.h_in_dev = nullptr;
   S.d_kps = S.h_kps = nullptr;
   S.d_desc = S.h_desc = nullptr;
   S.d_counts = S.h_counts = nullptr;
@@ -215,7 +243,16 @@ static void free_slot(Slot &S) {
   S.ticket = -1;
 }
 
+static void free_chain_graphs(vsg_orb *h) {
+  for (ChainGraph &g : h->chain) {
+    if (g.exec) hipGraphExecDestroy(g.exec);
+    if (g.graph) hipGraphDestroy(g.graph);
+    g = ChainGraph();
+  }
+}
+
 static void free_image_buffers(vsg_orb *h) {
+  free_chain_graphs(h);  // their nodes point into the buffers below
   hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in);
   hipFree(h->d_cell_count), hipFree(h->d_cand2);
   h->d_cell_count = nullptr, h->d_cand2 = nullptr;
@@ -257,7 +294,8 @@ static int ensure_slot(vsg_orb *h, int i) {
   // outputs live in mapped pinned memory: the export kernel stores the records there straight from the device
   const unsigned flags = hipHostMallocMapped | hipHostMallocPortable;
   HIP_TRY(hipMalloc(&S.d_in, in_bytes));
-  HIP_TRY(hipHostMalloc(&S.h_in, in_bytes, hipHostMallocPortable));
+  HIP_TRY(hipHostMalloc(&S.h_in, in_bytes, hipHostMallocPortable | hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer((void **)&S.h_in_dev, S.h_in, 0));
   HIP_TRY(hipMalloc(&S.d_kps, B * fg.out_cap * sizeof(KeyPointPOD)));
   HIP_TRY(hipMalloc(&S.d_desc, B * fg.out_cap * 32));
   HIP_TRY(hipMalloc(&S.d_counts, B * 2 * sizeof(int)));
@@ -443,27 +481,42 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
   HIP_TRY(hipEventRecord(ev_pyr, s));
+  // Host enqueue order: the latency-critical launch (the octree) goes out BEFORE the three calls that fork the blur onto
+  // its stream -- on the single-frame path the GPU catches up with the enqueueing thread around FAST, and every call
+  // ahead of the octree launch showed up as idle GPU time in front of it (tools/latency_timeline.py).  Serialised runs
+  // (sb == s, per-stage timing) keep stream order = stage order: blur, then octree.
+  const bool octree_first = !blur_early && sb != s;
+  if (octree_first) {
+    if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
+    launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel,
+                  sel_count, fg, h->G.maxQuota, h->G.maxCellsPerLevel, nf);
+    if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
+  }
   HIP_TRY(hipStreamWaitEvent(sb, ev_pyr, 0));
   if (tm) HIP_TRY(hipEventRecord(h->ev[6], sb));
   launch_blur(sb, pyr, blur, h->d_fg, s0, fg, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[7], sb));
   HIP_TRY(hipEventRecord(ev_blur, sb));
+  Range r_tail("DistributeOctTree + slots + IC_Angle / rBRIEF");
   if (blur_early) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
     launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
-  if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
-  Range r_tail("DistributeOctTree + slots + IC_Angle / rBRIEF");
-  launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel, sel_count,
-                fg, h->G.maxQuota, h->G.maxCellsPerLevel, nf);
-  if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
+  if (!octree_first) {
+    if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
+    launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel,
+                  sel_count, fg, h->G.maxQuota, h->G.maxCellsPerLevel, nf);
+    if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
+  }
   launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
   HIP_TRY(hipStreamWaitEvent(s, ev_blur, 0));
   if (tm) HIP_TRY(hipEventRecord(h->ev[9], s));
+  OutMirror mir = h->mirror;
+  if (mir.kps) mir.kps += F * mir.capacity, mir.desc += F * mir.capacity * 32, mir.counts += F * 2;
   launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, slots, hdr, h->d_pattern, d_kps + F * capacity,
-                     d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf);
+                     d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf, mir);
   if (tm) HIP_TRY(hipEventRecord(h->ev[5], s));
   return VSG_OK;
 }
@@ -481,7 +534,7 @@ static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, i
   // sub-batches cost 2-4 % at 128-256 frames and nothing is gained at 512 (MI355X, C2-C4), so the cut stays a knob.
   int nsub = no_overlap ? 1 : h->nsub > 0 ? h->nsub : 1;
   if (nsub > nframes) nsub = nframes;
-  const bool tm = h->timing && nsub == 1;
+  const bool tm = h->timing && nsub == 1 && !h->capturing;
   if (tm) harvest_timing(h);
   if (nsub == 1) {
     int rc = enqueue_range(h, s0, 0, nframes, lap0, lap1, d_kps, d_desc, d_counts, capacity, s,
@@ -773,41 +826,144 @@ int vsg_orb_extract_batch_device_color(vsg_orb *h, const uint8_t *d_img, int cha
 
 int vsg_orb_slots(const vsg_orb *h) { return h ? kSlots : VSG_ERR_INVALID; }
 
-// kernels of the chain + export for slot S, behind its ev_in; `color`: the slot's d_in holds interleaved colour frames
-// in d_scratch instead (host colour entry)
-static int submit_tail(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc,
-                       int capacity) {
+long vsg_orb_chain_graph_launches(const vsg_orb *h) { return h ? h->chain_launches : VSG_ERR_INVALID; }
+
+// where the export of slot S goes: the caller's own arrays when both are pinned (the device writes them directly, nothing
+// is left for vsg_orb_wait to copy), the slot's pinned staging otherwise
+struct ExportDst {
+  bool direct = false;
+  void *dk = nullptr, *dd = nullptr;
+};
+static ExportDst export_dst(vsg_keypoint *kps, uint8_t *desc, int capacity) {
+  ExportDst e;
+  e.direct = kps && desc && capacity > 0 && host_pinned(kps, &e.dk) && host_pinned(desc, &e.dd) && e.dk && e.dd;
+  return e;
+}
+
+// the stage chain + the export of slot S on the handle's streams (what a ChainGraph records)
+static int tail_stream_work(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1, const ExportDst &E, int capacity,
+                            bool mirror_out = false) {
   const FrameGeom &fg = h->G.fg;
   const Src0 s0 = {S.d_in, (size_t)h->rows * h->in_pitch, h->in_pitch};
+  static const bool dma_out_ = getenv("VSG_D2H_DMA") != nullptr, export_kernel = getenv("VSG_EXPORT_KERNEL") != nullptr;
+  mirror_out = mirror_out && !dma_out_ && !export_kernel;  // VSG_EXPORT_KERNEL=1: A/B switch, the separate export launch
+  if (mirror_out) {
+    // latency path: k_orient_desc writes the records into the pinned destination as it produces them
+    h->mirror.kps = (KeyPointPOD *)(E.direct ? E.dk : (void *)S.h_kps), h->mirror.desc = (uint8_t *)(E.direct ? E.dd : (void *)S.h_desc);
+    h->mirror.counts = S.h_counts, h->mirror.capacity = E.direct ? capacity : fg.out_cap;
+  }
   int rc = enqueue_pipeline(h, s0, nframes, lap0, lap1, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, h->s_main);
+  h->mirror = OutMirror();
   if (rc != VSG_OK) return rc;
+  if (mirror_out) return VSG_OK;
   const hipStream_t s_out = h->one_stream ? h->s_main : h->s_d2h;
   if (!h->one_stream) {
     HIP_TRY(hipEventRecord(S.ev_done, h->s_main));
     HIP_TRY(hipStreamWaitEvent(h->s_d2h, S.ev_done, 0));
   }
-  // export: n records per frame, written by the device into pinned host memory -- the caller's own arrays when they
-  // are pinned (no copy left for vsg_orb_wait), the slot's staging otherwise
-  void *dk = nullptr, *dd = nullptr;
-  S.direct = kps && desc && capacity > 0 && host_pinned(kps, &dk) && host_pinned(desc, &dd) && dk && dd;
-  S.out_kps = kps, S.out_desc = desc, S.out_cap = capacity;
+  // export: n records per frame, written by the device into pinned host memory
   static const bool dma_out = getenv("VSG_D2H_DMA") != nullptr;  // A/B switch: copy-engine D2H of out_cap-sized buffers
   if (dma_out) {
-    S.direct = false;
     HIP_TRY(hipMemcpyAsync(S.h_counts, S.d_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, s_out));
     HIP_TRY(hipMemcpyAsync(S.h_kps, S.d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, s_out));
     HIP_TRY(hipMemcpyAsync(S.h_desc, S.d_desc, (size_t)nframes * fg.out_cap * 32, hipMemcpyDeviceToHost, s_out));
-  } else if (S.direct) {
-    launch_export(s_out, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, dk, dd, S.h_counts, capacity, nframes);
+  } else if (E.direct) {
+    launch_export(s_out, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, E.dk, E.dd, S.h_counts, capacity, nframes);
   } else {
     launch_export(s_out, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, S.h_kps, S.h_desc, S.h_counts, fg.out_cap, nframes);
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(S.ev_out, s_out));
+  return VSG_OK;
+}
+
+// bookkeeping of a submitted batch; records the completion event behind whatever was enqueued / launched
+static int finish_submit(vsg_orb *h, Slot &S, int nframes, vsg_keypoint *kps, uint8_t *desc, int capacity, bool direct) {
+  static const bool dma_out = getenv("VSG_D2H_DMA") != nullptr;
+  S.direct = direct && !dma_out;
+  S.out_kps = kps, S.out_desc = desc, S.out_cap = capacity;
+  HIP_TRY(hipEventRecord(S.ev_out, h->one_stream ? h->s_main : h->s_d2h));
   S.busy = true;
   S.nframes = nframes;
   S.ticket = h->next_ticket++;
   return S.ticket;
+}
+
+// kernels of the chain + export for slot S, behind its ev_in
+static int submit_tail(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc,
+                       int capacity) {
+  const ExportDst E = export_dst(kps, desc, capacity);
+  int rc = tail_stream_work(h, S, nframes, lap0, lap1, E, capacity);
+  if (rc != VSG_OK) return rc;
+  return finish_submit(h, S, nframes, kps, desc, capacity, E.direct);
+}
+
+// ---- latency mode (see ChainGraph): ingest kernel + chain + export of a blocking call, replayed as one graph launch
+static int chain_stream_work(vsg_orb *h, Slot &S, const uint8_t *src_dev, size_t sframe, int sstride, int nframes, int lap0,
+                             int lap1, const ExportDst &E, int capacity) {
+  launch_ingest(h->s_main, src_dev, sframe, sstride, S.d_in, (size_t)h->rows * h->in_pitch, h->in_pitch, h->rows, h->cols,
+                nframes);
+  HIP_TRY(hipGetLastError());
+  return tail_stream_work(h, S, nframes, lap0, lap1, E, capacity, true);
+}
+
+static int run_chain(vsg_orb *h, Slot &S, int slot_index, const uint8_t *src_dev, size_t sframe, int sstride, int nframes,
+                     int lap0, int lap1, const ExportDst &E, int capacity) {
+  // Opt-in (VSG_GRAPH=1): measured on MI355X / ROCm 7.0 the graph launch of this 8-node chain is no faster than eight
+  // eager launches from the calling thread (single-frame operator() 0.139 ms with the graph, 0.131 ms without:
+  // profiles/r03_*_frame_latency*); the GPU-side dependency chain is what a call waits for, not the host enqueue.
+  static const bool use_graph = getenv("VSG_GRAPH") != nullptr;
+  const bool eligible = use_graph && !h->timing && !h->serialize && h->nsub <= 1 && nframes <= 4;
+  if (!eligible) return chain_stream_work(h, S, src_dev, sframe, sstride, nframes, lap0, lap1, E, capacity);
+  ChainKey key;
+  key.slot = slot_index, key.nframes = nframes, key.lap0 = lap0, key.lap1 = lap1, key.stride = sstride;
+  key.capacity = E.direct ? capacity : 0, key.frame_stride = sframe, key.src = src_dev;
+  key.dk = E.direct ? E.dk : nullptr, key.dd = E.direct ? E.dd : nullptr;
+  ChainGraph *g = nullptr, *lru = &h->chain[0];
+  for (ChainGraph &c : h->chain) {
+    if (c.seen && c.key == key) g = &c;
+    if (c.stamp < lru->stamp) lru = &c;
+  }
+  if (!g) {  // first call with this key: run eagerly (this also raises the LDS limits, times the tilings, ...)
+    if (lru->exec) hipGraphExecDestroy(lru->exec);
+    if (lru->graph) hipGraphDestroy(lru->graph);
+    *lru = ChainGraph();
+    lru->key = key, lru->seen = 1, lru->stamp = ++h->chain_clock;
+    return chain_stream_work(h, S, src_dev, sframe, sstride, nframes, lap0, lap1, E, capacity);
+  }
+  g->stamp = ++h->chain_clock;
+  if (!g->exec) {  // second call: record the same calls instead of running them
+    HIP_TRY(hipStreamBeginCapture(h->s_main, hipStreamCaptureModeThreadLocal));
+    h->capturing = true;
+    const int rc = chain_stream_work(h, S, src_dev, sframe, sstride, nframes, lap0, lap1, E, capacity);
+    h->capturing = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(h->s_main, &graph);
+    if (rc != VSG_OK || e != hipSuccess || !graph) {
+      if (graph) hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      g->seen = 0;  // do not try again with this key
+      g->key.slot = -2;
+      return chain_stream_work(h, S, src_dev, sframe, sstride, nframes, lap0, lap1, E, capacity);
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      g->seen = 0, g->key.slot = -2;
+      return chain_stream_work(h, S, src_dev, sframe, sstride, nframes, lap0, lap1, E, capacity);
+    }
+    g->graph = graph, g->exec = exec;
+  }
+  HIP_TRY(hipGraphLaunch(g->exec, h->s_main));
+  h->chain_launches++;
+  // what enqueue_pipeline notes on the host when it runs (it only ran while being recorded)
+  const FrameGeom &fg = h->G.fg;
+  h->last_src0 = {S.d_in, (size_t)h->rows * h->in_pitch, h->in_pitch};
+  h->last_frames = nframes;
+  h->last_kps = S.d_kps, h->last_desc = S.d_desc, h->last_counts = S.d_counts, h->last_cap = fg.out_cap;
+  HIP_TRY(hipEventRecord(h->ev_last, h->s_main));
+  h->have_last = true;
+  return VSG_OK;
 }
 
 static int acquire_slot(vsg_orb *h, Slot **out) {
@@ -838,6 +994,33 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
   const size_t fbytes = (size_t)rows * ip;
   const bool packed = stride == ip && (nframes == 1 || frame_stride == fbytes);
   const hipStream_t s_in = h->one_stream ? h->s_main : h->s_h2d;
+  static const bool ingest_dma = getenv("VSG_INGEST_DMA") != nullptr;  // A/B switch: copy engine on the blocking path too
+  if (h->one_stream && nframes <= 8 && !ingest_dma) {
+    // Blocking call, small batch (the reference's one frame per operator()): the latency path.  Pageable images are
+    // staged into the slot's pinned buffer by this thread; the device then reads the pinned image itself (ingest
+    // kernel) and the whole call's stream work is one graph launch.
+    void *alias = nullptr;
+    const uint8_t *src_dev;
+    size_t sframe;
+    int sstride;
+    if (host_pinned(gray, &alias) && alias) {
+      src_dev = (const uint8_t *)alias, sframe = frame_stride, sstride = stride;
+    } else {
+      for (int f = 0; f < nframes; f++) {
+        uint8_t *dst = S.h_in + f * fbytes;
+        const uint8_t *src = gray + (size_t)f * frame_stride;
+        if (stride == ip)
+          memcpy(dst, src, fbytes);
+        else
+          for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * ip, src + (size_t)y * stride, (size_t)cols);
+      }
+      src_dev = S.h_in_dev, sframe = fbytes, sstride = ip;
+    }
+    const ExportDst E = export_dst(kps, desc, capacity);
+    rc = run_chain(h, S, (int)(Sp - h->slot), src_dev, sframe, sstride, nframes, lap0, lap1, E, capacity);
+    if (rc != VSG_OK) return rc;
+    return finish_submit(h, S, nframes, kps, desc, capacity, E.direct);
+  }
   if (host_pinned(gray, nullptr)) {
     // pinned caller memory: DMA straight from it (one descriptor for a packed batch, one 2-D copy per frame otherwise)
     if (packed) {

@@ -59,7 +59,7 @@ EXPORTS = [
     "vsg_shard_last_error", "vsg_shard_record_bytes", "vsg_shard_record_desc_offset", "vsg_shard_frame_owner",
     "vsg_shard_stream_owner", "vsg_shard_unique_id", "vsg_shard_create", "vsg_shard_destroy", "vsg_shard_all_gather",
     "vsg_shard_record", "vsg_shard_world", "vsg_shard_send_recv_boundary", "vsg_shard_boundary_record",
-    "vsg_copy_d2d_async",
+    "vsg_copy_d2d_async", "vsg_orb_chain_graph_launches",
 ]
 
 
@@ -189,6 +189,8 @@ def load_library():
     L.vsg_host_register.argtypes = [vp, C.c_size_t]
     L.vsg_host_unregister.argtypes = [vp]
     L.vsg_orb_slots.argtypes = [vp]
+    L.vsg_orb_chain_graph_launches.argtypes = [vp]
+    L.vsg_orb_chain_graph_launches.restype = C.c_long
     L.vsg_orb_submit_batch.argtypes = [vp, vp, ci, C.c_size_t, ci, ci, ci, ci, ci, vp, vp, ci]
     L.vsg_orb_wait.argtypes = [vp, ci, _i32p, _i32p]
     L.vsg_orb_copy_pyramid.argtypes = [vp, ci, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -382,6 +384,10 @@ class ORBextractor:
     # ---- asynchronous host pipeline (vsg_orb_submit_batch / vsg_orb_wait)
     def slots(self):
         return self._L.vsg_orb_slots(self._h)
+
+    def chain_graph_launches(self):
+        """Blocking calls served by one hipGraphLaunch so far (latency mode, include/vsg_orb.h)."""
+        return self._L.vsg_orb_chain_graph_launches(self._h)
 
     def submit_batch(self, images, kps_out, desc_out, vLappingArea=(0, 0)):
         """images [B,H,W] uint8 (pinned via `pin()` => DMA straight from it), kps_out [B,cap] KP_DTYPE, desc_out
