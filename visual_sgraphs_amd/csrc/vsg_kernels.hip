@@ -1060,16 +1060,31 @@ struct SegRegPts {
   }
 };
 
-__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_octree(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ cand,
-                                                const int *__restrict__ cand_count, const CellDesc *__restrict__ cells,
-                                                const int *__restrict__ cell_count, uint32_t *__restrict__ cand2,
-                                                uint16_t *__restrict__ node_of,
-                                                uint32_t *__restrict__ sel, int *__restrict__ sel_count, int cap,
-                                                int prefix_off) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
-  __shared__ int wtot[2 * kMaxWaves];
-  __shared__ int sort_stack[3 * kSortStack];
-  const int level = blockIdx.x, frame = blockIdx.y;
+struct OctArgs {
+  const FrameGeom *fg;
+  const uint32_t *cand;
+  const int *cand_count;
+  const CellDesc *cells;
+  const int *cell_count;
+  uint32_t *cand2;
+  uint16_t *node_of;
+  uint32_t *sel;
+  int *sel_count;
+  int cap, prefix_off;
+};
+
+__device__ __forceinline__ void octree_block(const OctArgs &a, int level, int frame, uint8_t *oct_lds, int *wtot,
+                                             int *sort_stack) {
+  const FrameGeom *__restrict__ fg = a.fg;
+  const uint32_t *__restrict__ cand = a.cand;
+  const int *__restrict__ cand_count = a.cand_count;
+  const CellDesc *__restrict__ cells = a.cells;
+  const int *__restrict__ cell_count = a.cell_count;
+  uint32_t *__restrict__ cand2 = a.cand2;
+  uint16_t *__restrict__ node_of = a.node_of;
+  uint32_t *__restrict__ sel = a.sel;
+  int *__restrict__ sel_count = a.sel_count;
+  const int cap = a.cap, prefix_off = a.prefix_off;
   const LevelGeom &L = fg->lv[level];
   octree::Params P;
   P.N = L.quota;
@@ -1127,6 +1142,13 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(5, 
   if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;
 }
 
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_octree(OctArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
+  __shared__ int wtot[2 * kMaxWaves];
+  __shared__ int sort_stack[3 * kSortStack];
+  octree_block(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
+}
+
 // Test hook (vsg_debug_device_sort): the octree's std::sort replay -- wave-parallel partition phase + stable rank --
 // on arbitrary items, so that tests can compare it with the real std::sort directly.
 __global__ __launch_bounds__(256) void k_debug_sort(uint64_t *items, int n) {
@@ -1182,9 +1204,8 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
-__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
-                                              const FrameGeom *__restrict__ fg, Src0 s0) {
-  const BlockXY blk = frame_major_block();
+__device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                           const FrameGeom *__restrict__ fg, const Src0 &s0, BlockXY blk) {
   int level = 0;
   while (level + 1 < fg->nlevels && blk.x >= fg->lv[level + 1].blur_block_base) level++;
   const LevelGeom &L = fg->lv[level];
@@ -1296,6 +1317,28 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                              const FrameGeom *__restrict__ fg, Src0 s0) {
+  blur_block(pyr, blur, fg, s0, frame_major_block());
+}
+
+// Latency path of the blocking single-frame calls: the blur workgroups ride in the octree's launch (blocks
+// [nlevels, nlevels + blur blocks) of a frame), hidden under the octree's 30-odd microseconds, instead of on a second
+// stream whose fork / join events cost the chain as much GPU idle time as the blur itself takes (measured: 5-7 us at
+// each of the two cross-stream waits against 12 us of blur).  Both need only the pyramid.  Throughput batches keep the
+// two kernels apart: there the blur is issue-bound work that wants its own occupancy.
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_octree_blur(
+    OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
+  __shared__ int wtot[2 * kMaxWaves];
+  __shared__ int sort_stack[3 * kSortStack];
+  static_assert(kOctThreads == 256, "the blur body is written for 256-thread workgroups");
+  if ((int)blockIdx.x < nlevels)
+    octree_block(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
+  else
+    blur_block(pyr, blur, a.fg, s0, BlockXY{(int)blockIdx.x - nlevels, (int)blockIdx.y});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1856,7 +1899,8 @@ void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const
 }
 void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, const int *cand_count,
                    const CellDesc *d_cells, const int *cell_count, uint32_t *cand2, uint16_t *node_of, uint32_t *sel,
-                   int *sel_count, const FrameGeom &fg, int maxQuota, int maxCellsPerLevel, int nframes) {
+                   int *sel_count, const FrameGeom &fg, int maxQuota, int maxCellsPerLevel, int nframes,
+                   const uint8_t *blur_pyr, uint8_t *blur_out, const Src0 *blur_s0) {
   const int cap = octree::node_capacity(maxQuota);
   const int prefix_off = (int)((octree::work_bytes(cap) + 15) & ~(size_t)15);
   const size_t lds = (size_t)prefix_off + (fg.cand_segmented ? (2 * (size_t)maxCellsPerLevel + 1) * 4 : 0);
@@ -1864,10 +1908,16 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   // level holding every feature); gfx950 has 160 KB per workgroup
   int dev = 0;
   hipGetDevice(&dev);
+  const OctArgs a = {d_fg, cand, cand_count, d_cells, cell_count, cand2, node_of, sel, sel_count, cap, prefix_off};
+  if (blur_out) {  // the blur of the same frames as extra workgroups of this launch (latency path)
+    lds_limit_ensure(2, dev, (const void *)k_octree_blur, lds);
+    hipLaunchKernelGGL(k_octree_blur, dim3(fg.nlevels + fg.total_blur_blocks, nframes), dim3(kOctThreads), lds, s, a, blur_pyr,
+                       blur_out, *blur_s0, fg.nlevels);
+    return;
+  }
   lds_limit_ensure(1, dev, (const void *)k_octree, lds);
   dim3 grid(fg.nlevels, nframes), block(kOctThreads);
-  hipLaunchKernelGGL(k_octree, grid, block, lds, s, d_fg, cand, cand_count, d_cells, cell_count, cand2, node_of, sel,
-                     sel_count, cap, prefix_off);
+  hipLaunchKernelGGL(k_octree, grid, block, lds, s, a);
 }
 void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n) {
   hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(256), (size_t)n * 8 + 2 * (n + 2) * 2 + 16, s, d_items, n);

@@ -480,11 +480,20 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
     launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
+  // Latency path (blocking call, a handful of frames): the blur's workgroups ride in the octree's launch -- one stream,
+  // no fork / join events (each cross-stream wait cost the chain 5-7 us of idle GPU, as much as the blur saves by
+  // running beside the octree).  VSG_BLUR_STREAM=1: A/B switch, the two-stream form everywhere.
+  static const bool blur_stream = getenv("VSG_BLUR_STREAM") != nullptr;
+  const bool fused_blur = h->one_stream && nf <= 8 && !tm && !blur_early && !blur_stream && sb != s;
+  if (fused_blur) {
+    Range r_tail("DistributeOctTree (+ blur workgroups) + slots + IC_Angle / rBRIEF");
+    launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel,
+                  sel_count, fg, h->G.maxQuota, h->G.maxCellsPerLevel, nf, pyr, blur, &s0);
+    launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
+  } else {
   HIP_TRY(hipEventRecord(ev_pyr, s));
   // Host enqueue order: the latency-critical launch (the octree) goes out BEFORE the three calls that fork the blur onto
-  // its stream -- on the single-frame path the GPU catches up with the enqueueing thread around FAST, and every call
-  // ahead of the octree launch showed up as idle GPU time in front of it (tools/latency_timeline.py).  Serialised runs
-  // (sb == s, per-stage timing) keep stream order = stage order: blur, then octree.
+  // its stream.  Serialised runs (sb == s, per-stage timing) keep stream order = stage order: blur, then octree.
   const bool octree_first = !blur_early && sb != s;
   if (octree_first) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
@@ -513,6 +522,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
   HIP_TRY(hipStreamWaitEvent(s, ev_blur, 0));
   if (tm) HIP_TRY(hipEventRecord(h->ev[9], s));
+  }
   OutMirror mir = h->mirror;
   if (mir.kps) mir.kps += F * mir.capacity, mir.desc += F * mir.capacity * 32, mir.counts += F * 2;
   launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, slots, hdr, h->d_pattern, d_kps + F * capacity,
