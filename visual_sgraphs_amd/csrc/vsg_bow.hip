@@ -9,9 +9,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <map>
+#include <utility>
 #include <vector>
 
 #include "../../include/vsg_orb.h"
@@ -19,42 +20,78 @@
 #include "vsg_frame_int.h"
 
 namespace {
-__global__ void k_bow_descend(const int *child_off, const int *child_list, const uint8_t *node_desc,
-                              const double *node_weight, const int *node_word, const uint8_t *desc, int n, int nid_level,
-                              int *word_of, int *node_of, double *weight_of) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// Device image of the vocabulary: one 48-byte record per node IN CHILD-LIST ORDER (the children of a node are
+// contiguous, in the order transform() scans them): 32-byte descriptor | link = position of the node's first child |
+// its child count << 24 | node id | word id (leaves).  The root's children start at position 0.
+struct alignas(16) NodeRec {
+  uint32_t d[8];
+  uint32_t link;  // first child position | number of children << 24  (0 children: a leaf = a word)
+  int32_t node_id, word;
+  uint32_t pad;
+};
+static_assert(sizeof(NodeRec) == 48, "NodeRec layout");
+
+// min over the G lanes of a group (G = 16 or 32, groups aligned to G lanes), every lane gets it: DPP row operations, the
+// 32-lane form finishes with one xor-16 exchange
+template <int G>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror
+  if (G == 32) v = min(v, (uint32_t)__shfl_xor((int)v, 16));
+  return v;
+}
+
+// One group of G lanes per descriptor, one lane per child: a level of the descent is ONE round of loads (the k child
+// records, contiguous), k Hamming distances in parallel, a group minimum of (distance << 8 | child) -- the first
+// minimum, like the strict '<' scan of transform() (TemplatedVocabulary.h:1250-1259) -- and one broadcast of the
+// winner's link.  The thread-per-descriptor form chained three dependent loads per level (child range, child ids,
+// descriptors): 18 memory hops for the reference's L = 6 vocabulary against 6 here.
+template <int G>
+__global__ __launch_bounds__(256) void k_bow_descend(const NodeRec *__restrict__ rec, const double *__restrict__ weight,
+                                                     uint32_t root_link, const uint8_t *__restrict__ desc, int n,
+                                                     int nid_level, int *__restrict__ word_of, int *__restrict__ node_of,
+                                                     double *__restrict__ weight_of) {
+  const int i = (blockIdx.x * 256 + threadIdx.x) / G, j = threadIdx.x & (G - 1);
+  if (i >= n) return;  // whole groups leave together
   const uint4 *f = (const uint4 *)(desc + (size_t)i * 32);
   const uint4 a0 = f[0], a1 = f[1];
-  int final_id = 0, nid = 0, level = 0;
-  while (child_off[final_id + 1] > child_off[final_id]) {  // !isLeaf()
+  uint32_t link = root_link;
+  int level = 0, nid = 0;
+  while (link >> 24) {  // !isLeaf()
     ++level;
-    const int c0 = child_off[final_id], c1 = child_off[final_id + 1];
-    int best = 0x7FFFFFFF;
-    for (int c = c0; c < c1; c++) {
-      const int id = child_list[c];
-      const uint4 *d = (const uint4 *)(node_desc + (size_t)id * 32);
-      const uint4 b0 = d[0], b1 = d[1];
+    const uint32_t first = link & 0xFFFFFFu, cnt = link >> 24;
+    uint32_t key = 0xFFFFFFFFu, mylink = 0;
+    int myid = 0, myword = 0;
+    if ((uint32_t)j < cnt) {
+      const uint4 *r = (const uint4 *)(rec + first + j);
+      const uint4 b0 = r[0], b1 = r[1], m = r[2];
       const int dist = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
                        __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
-      if (dist < best) {  // first child initialises, later ones need a strictly smaller distance (:1250-1259)
-        best = dist;
-        final_id = id;
+      key = ((uint32_t)dist << 8) | (uint32_t)j;
+      mylink = m.x, myid = (int)m.y, myword = (int)m.z;
+    }
+    const uint32_t best = group_min_u32<G>(key);
+    const int jw = (int)(best & 0xFFu);
+    link = (uint32_t)__shfl((int)mylink, jw, G);
+    if (j == jw) {  // the winner's lane holds everything the outputs need
+      if (level == nid_level) nid = myid, node_of[i] = myid;
+      if (!(link >> 24)) {
+        word_of[i] = myword;
+        weight_of[i] = weight[first + jw];
+        if (nid_level > level || nid_level <= 0) node_of[i] = 0;  // levelsup beyond the tree height: nid stays 0
       }
     }
-    if (level == nid_level) nid = final_id;
   }
-  word_of[i] = node_word[final_id];
-  node_of[i] = nid;
-  weight_of[i] = node_weight[final_id];
 }
 }  // namespace
 
 struct vsg_vocab {
-  int device = 0, k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0;
-  int *d_child_off = nullptr, *d_child_list = nullptr, *d_word = nullptr;
-  uint8_t *d_desc = nullptr;
-  double *d_weight = nullptr;
+  int device = 0, k = 0, L = 0, scoring = 0, weighting = 0, nnodes = 0, nwords = 0, max_children = 0;
+  uint32_t root_link = 0;
+  NodeRec *d_rec = nullptr;    // [nnodes - 1] child-list order
+  double *d_weight = nullptr;  // same order
 };
 
 #define B_TRY(expr)                               \
@@ -67,7 +104,7 @@ extern "C" {
 void vsg_vocab_destroy(vsg_vocab *v) {
   if (!v) return;
   hipSetDevice(v->device);
-  hipFree(v->d_child_off), hipFree(v->d_child_list), hipFree(v->d_word), hipFree(v->d_desc), hipFree(v->d_weight);
+  hipFree(v->d_rec), hipFree(v->d_weight);
   delete v;
 }
 
@@ -88,10 +125,14 @@ int vsg_vocab_load(int device, const uint8_t *blob, size_t size, vsg_vocab **out
   if (!rd(&k, 4) || !rd(&L, 4) || !rd(&n1, 4) || !rd(&n2, 4)) return VSG_ERR_INVALID;
   if (k < 2 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) return VSG_ERR_INVALID;
   const long expected = (long)((std::pow((double)k, (double)L + 1) - 1) / (k - 1));
-  std::vector<int> parent(1, 0), word(1, 0);
+  // pass 1: the nodes as the file lists them (parents before children, TemplatedVocabulary.h:1519-1545)
+  std::vector<int> parent(1, 0), word(1, 0), nchild(1, 0);
   std::vector<uint8_t> desc(32, 0);
   std::vector<double> weight(1, 0.0);
-  std::vector<std::vector<int>> children(1);
+  if (expected > 0 && expected < (1 << 26)) {
+    parent.reserve(expected), word.reserve(expected), nchild.reserve(expected), weight.reserve(expected);
+    desc.reserve((size_t)expected * 32);
+  }
   int nwords = 0;
   while (pos < size && (long)parent.size() < expected) {
     const int nid = (int)parent.size();
@@ -104,29 +145,37 @@ int vsg_vocab_load(int device, const uint8_t *blob, size_t size, vsg_vocab **out
     desc.insert(desc.end(), d, d + 32);
     weight.push_back(w);
     word.push_back(leaf > 0 ? nwords++ : 0);
-    children.push_back({});
-    children[pid].push_back(nid);
+    nchild.push_back(0);
+    nchild[pid]++;
   }
   const int nn = (int)parent.size();
-  std::vector<int> off(nn + 1, 0), list;
+  // pass 2: child-list positions (children of a node contiguous, in file order = the order transform() scans them)
+  std::vector<int> first(nn + 1, 0), fill(nn, 0), posn(nn, -1);
+  int max_children = 0;
   for (int i = 0; i < nn; i++) {
-    off[i] = (int)list.size();
-    list.insert(list.end(), children[i].begin(), children[i].end());
+    first[i + 1] = first[i] + nchild[i];
+    if (nchild[i] > max_children) max_children = nchild[i];
   }
-  off[nn] = (int)list.size();
+  if (nn >= (1 << 24) || max_children > 32) return VSG_ERR_UNSUPPORTED;  // link = position : 24 | children : 8; <= 32 lanes
+  for (int i = 1; i < nn; i++) posn[i] = first[parent[i]] + fill[parent[i]]++;
+  std::vector<NodeRec> rec((size_t)(nn > 1 ? nn - 1 : 1));
+  std::vector<double> wpos((size_t)(nn > 1 ? nn - 1 : 1), 0.0);
+  for (int i = 1; i < nn; i++) {
+    NodeRec &r = rec[posn[i]];
+    memcpy(r.d, &desc[(size_t)i * 32], 32);
+    r.link = (uint32_t)first[i] | ((uint32_t)nchild[i] << 24);
+    r.node_id = i, r.word = word[i], r.pad = 0;
+    wpos[posn[i]] = weight[i];
+  }
   B_TRY(hipSetDevice(device));
   vsg_vocab *v = new vsg_vocab();
   v->device = device, v->k = k, v->L = L, v->scoring = n1, v->weighting = n2, v->nnodes = nn, v->nwords = nwords;
-  hipError_t e = hipMalloc(&v->d_child_off, 4 * (size_t)(nn + 1));
-  if (e == hipSuccess) e = hipMalloc(&v->d_child_list, 4 * (list.size() + 1));
-  if (e == hipSuccess) e = hipMalloc(&v->d_word, 4 * (size_t)nn);
-  if (e == hipSuccess) e = hipMalloc(&v->d_desc, 32 * (size_t)nn);
-  if (e == hipSuccess) e = hipMalloc(&v->d_weight, 8 * (size_t)nn);
-  if (e == hipSuccess) e = hipMemcpy(v->d_child_off, off.data(), 4 * (size_t)(nn + 1), hipMemcpyHostToDevice);
-  if (e == hipSuccess && !list.empty()) e = hipMemcpy(v->d_child_list, list.data(), 4 * list.size(), hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(v->d_word, word.data(), 4 * (size_t)nn, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(v->d_desc, desc.data(), 32 * (size_t)nn, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(v->d_weight, weight.data(), 8 * (size_t)nn, hipMemcpyHostToDevice);
+  v->max_children = max_children;
+  v->root_link = (uint32_t)first[0] | ((uint32_t)nchild[0] << 24);
+  hipError_t e = hipMalloc(&v->d_rec, rec.size() * sizeof(NodeRec));
+  if (e == hipSuccess) e = hipMalloc(&v->d_weight, wpos.size() * 8);
+  if (e == hipSuccess) e = hipMemcpy(v->d_rec, rec.data(), rec.size() * sizeof(NodeRec), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(v->d_weight, wpos.data(), wpos.size() * 8, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     vsg_vocab_destroy(v);
     return VSG_ERR_HIP;
@@ -166,9 +215,14 @@ static int bow_descend(vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_des
     B_TRY(hipMemcpyAsync(c->d_buf, c->h_pin, in_bytes, hipMemcpyHostToDevice, c->stream));
     d_desc = c->d_buf + oD;
   }
-  hipLaunchKernelGGL(k_bow_descend, dim3((n + 63) / 64), dim3(64), 0, c->stream, voc->d_child_off, voc->d_child_list,
-                     voc->d_desc, voc->d_weight, voc->d_word, d_desc, n, voc->L - levelsup, (int *)(c->d_pin + oWord),
-                     (int *)(c->d_pin + oNode), (double *)(c->d_pin + oW));
+  if (voc->max_children <= 16)
+    hipLaunchKernelGGL(k_bow_descend<16>, dim3((n * 16 + 255) / 256), dim3(256), 0, c->stream, voc->d_rec, voc->d_weight,
+                       voc->root_link, d_desc, n, voc->L - levelsup, (int *)(c->d_pin + oWord), (int *)(c->d_pin + oNode),
+                       (double *)(c->d_pin + oW));
+  else
+    hipLaunchKernelGGL(k_bow_descend<32>, dim3((n * 32 + 255) / 256), dim3(256), 0, c->stream, voc->d_rec, voc->d_weight,
+                       voc->root_link, d_desc, n, voc->L - levelsup, (int *)(c->d_pin + oWord), (int *)(c->d_pin + oNode),
+                       (double *)(c->d_pin + oW));
   B_TRY(hipGetLastError());
   B_TRY(hipStreamSynchronize(c->stream));
   *word = (const int *)(c->h_pin + oWord);
@@ -189,23 +243,34 @@ static int bow_transform(vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_d
   const double *w = nullptr;
   int rc = bow_descend(voc, desc, d_desc, n, levelsup, &word, &node, &w);
   if (rc != VSG_OK) return rc;
-  // ---- BowVector / FeatureVector assembly in feature order (:1158-1206)
-  std::map<unsigned, double> v;
-  std::map<unsigned, std::vector<unsigned>> fv;
-  const bool tf = voc->weighting == 0 || voc->weighting == 1;  // TF_IDF, TF
+  // ---- BowVector / FeatureVector assembly (:1158-1206).  The reference inserts feature by feature into two std::maps;
+  // the same content falls out of two sorts of (id << 32 | feature) keys: ascending ids, features of an id in feature
+  // order.  Every feature of a word carries the word's weight, so addWeight's running sum in feature order is the
+  // weight added to itself (count - 1) times, left to right -- bit-identical doubles.
+  static thread_local std::vector<uint64_t> kw, kn;
+  kw.clear(), kn.clear();
   for (int i = 0; i < n; i++) {
     if (word_of) word_of[i] = word[i];
     if (node_of) node_of[i] = node[i];
     if (weight_of) weight_of[i] = w[i];
     if (!(w[i] > 0)) continue;  // stopped word
-    const unsigned id = (unsigned)word[i];
-    auto it = v.lower_bound(id);
-    if (it != v.end() && it->first == id) {
-      if (tf) it->second += w[i];  // addWeight; addIfNotExist leaves it
-    } else {
-      v.insert(it, std::make_pair(id, w[i]));
-    }
-    fv[(unsigned)node[i]].push_back((unsigned)i);
+    kw.push_back(((uint64_t)(uint32_t)word[i] << 32) | (uint32_t)i);
+    kn.push_back(((uint64_t)(uint32_t)node[i] << 32) | (uint32_t)i);
+  }
+  std::sort(kw.begin(), kw.end());
+  std::sort(kn.begin(), kn.end());
+  const bool tf = voc->weighting == 0 || voc->weighting == 1;  // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
+  static thread_local std::vector<std::pair<unsigned, double>> v;
+  v.clear();
+  for (size_t a = 0; a < kw.size();) {
+    size_t b = a + 1;
+    while (b < kw.size() && (kw[b] >> 32) == (kw[a] >> 32)) b++;
+    const double wi = w[(uint32_t)kw[a]];
+    double val = wi;
+    if (tf)
+      for (size_t r = a + 1; r < b; r++) val += wi;
+    v.emplace_back((unsigned)(kw[a] >> 32), val);
+    a = b;
   }
   const bool must = voc->scoring != 5;  // DotProductScoring: no normalisation (ScoringObject.h:73-89)
   if (tf && !v.empty() && !must) {
@@ -229,16 +294,19 @@ static int bow_transform(vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_d
     if (bi < bow_cap && bow_ids && bow_vals) bow_ids[bi] = (int)kv.first, bow_vals[bi] = kv.second;
     bi++;
   }
-  *n_fv = (int)fv.size();
   int j = 0, o = 0;
-  for (auto &kv : fv) {
+  for (size_t a = 0; a < kn.size();) {
+    size_t b = a + 1;
+    while (b < kn.size() && (kn[b] >> 32) == (kn[a] >> 32)) b++;
     if (j < fv_cap && fv_node && fv_idx) {
-      fv_node[j] = (int)kv.first;
-      for (unsigned f : kv.second) fv_idx[o++] = (int)f;
+      fv_node[j] = (int)(kn[a] >> 32);
+      for (size_t r = a; r < b; r++) fv_idx[o++] = (int)(uint32_t)kn[r];
       fv_off[j + 1] = o;
     }
     j++;
+    a = b;
   }
+  *n_fv = j;
   return (*n_bow > bow_cap || *n_fv > fv_cap) ? VSG_ERR_CAPACITY : VSG_OK;
 }
 
