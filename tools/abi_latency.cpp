@@ -199,6 +199,117 @@ int main(int argc, char **argv) {
     CHECK(a == b && a > 50 && m12 == m12o);
     emit("SearchForInitialization", time_ms([&]() { g(); }, N), time_ms([&]() { o(); }, N / 4));
   }
+  // ---- the per-keyframe routines on resident frames at the reference's vocabulary scale (k = 10, L = 6, levelsup 4):
+  // Frame::ComputeBoW (Frame.cc:882-889), SearchByBoW(KF, F) (ORBmatcher.cc:226-428; TrackReferenceKeyFrame,
+  // Tracking.cc:2838), SearchForTriangulation (ORBmatcher.cc:902-1146; LocalMapping.cc:389)
+  {
+    std::vector<uint8_t> blob(vsg_synth_vocabulary(10, 6, 7, 0, 0, 0.02, nullptr, 0));
+    CHECK(vsg_synth_vocabulary(10, 6, 7, 0, 0, 0.02, blob.data(), blob.size()) == blob.size());
+    vsg_vocab *voc = nullptr;
+    CHECK(vsg_vocab_load(0, blob.data(), blob.size(), &voc) == VSG_OK);
+    OrVocab *ovoc = or_vocab_load(blob.data(), blob.size());
+    CHECK(ovoc != nullptr);
+    struct FV {
+      std::vector<int32_t> node, off, idx, bid;
+      std::vector<double> bval;
+      int n = 0, nb = 0;
+      explicit FV(int cap) : node(cap + 1), off(cap + 2), idx(cap + 1), bid(cap + 1), bval(cap + 1) {}
+    };
+    FV g0(cap), g1(cap), o0(cap), o1(cap);
+    auto bow_g = [&](int t, FV &f) {
+      return vsg_frame_bow_transform(voc, F[t], 4, f.bid.data(), f.bval.data(), cap, &f.nb, f.node.data(), f.off.data(),
+                                     f.idx.data(), cap, &f.n, nullptr, nullptr, nullptr);
+    };
+    auto bow_o = [&](int t, FV &f) {
+      return or_vocab_transform(ovoc, ds[t].data(), n[t], 4, f.bid.data(), f.bval.data(), cap, &f.nb, f.node.data(),
+                                f.off.data(), f.idx.data(), cap, &f.n, nullptr, nullptr, nullptr);
+    };
+    CHECK(bow_g(0, g0) == VSG_OK && bow_g(1, g1) == VSG_OK && bow_o(0, o0) == 0 && bow_o(1, o1) == 0);
+    CHECK(g0.n == o0.n && g0.nb == o0.nb && g0.n > 50 && g0.node == o0.node && g0.off == o0.off && g0.idx == o0.idx &&
+          g0.bid == o0.bid && !memcmp(g0.bval.data(), o0.bval.data(), (size_t)g0.nb * 8) && g1.node == o1.node && g1.idx == o1.idx);
+    char extra[128];
+    snprintf(extra, sizeof extra, ", \"feature_vector_nodes\": %d, \"words\": %d, \"vocabulary_nodes\": 1111111", g0.n, g0.nb);
+    emit("ComputeBoW_resident_k10_L6", time_ms([&]() { bow_g(0, g0); }, N), time_ms([&]() { bow_o(0, o0); }, N / 4), extra);
+    std::vector<uint8_t> valid(nq, 1);
+    std::vector<float> a0(nq), a1(nt);
+    for (int i = 0; i < nq; i++) a0[i] = kp[0][i].angle;
+    for (int i = 0; i < nt; i++) a1[i] = kp[1][i].angle;
+    std::vector<int32_t> mf(nt), mfo(nt);
+    auto sg = [&]() {
+      return vsg_frame_search_by_bow_kf_f(F[0], valid.data(), g0.node.data(), g0.off.data(), g0.idx.data(), g0.n, F[1],
+                                          g1.node.data(), g1.off.data(), g1.idx.data(), g1.n, 0.7f, 1, mf.data());
+    };
+    auto so = [&]() {
+      return or_search_by_bow_kf_f(ds[0].data(), a0.data(), valid.data(), nq, o0.node.data(), o0.off.data(), o0.idx.data(), o0.n,
+                                   ds[1].data(), a1.data(), nt, o1.node.data(), o1.off.data(), o1.idx.data(), o1.n, 0.7f, 1,
+                                   mfo.data());
+    };
+    {
+      const int a = sg(), b = so();
+      CHECK(a == b && a > 50 && mf == mfo);
+      snprintf(extra, sizeof extra, ", \"matches\": %d", a);
+      emit("SearchByBoW_resident_k10_L6", time_ms([&]() { sg(); }, N), time_ms([&]() { so(); }, N / 4), extra);
+    }
+    std::vector<int32_t> m12(nq), m12o(nq);
+    std::vector<uint8_t> e2(nt, 1);
+    auto tg = [&]() {
+      return vsg_frame_search_for_triangulation(F[0], valid.data(), g0.node.data(), g0.off.data(), g0.idx.data(), g0.n, F[1],
+                                                e2.data(), g1.node.data(), g1.off.data(), g1.idx.data(), g1.n, nullptr, nullptr,
+                                                1, m12.data());
+    };
+    auto to = [&]() {
+      return or_search_for_triangulation(ds[0].data(), a0.data(), valid.data(), nq, o0.node.data(), o0.off.data(), o0.idx.data(),
+                                         o0.n, ds[1].data(), a1.data(), e2.data(), nt, o1.node.data(), o1.off.data(),
+                                         o1.idx.data(), o1.n, nullptr, nullptr, 1, m12o.data());
+    };
+    {
+      const int a = tg(), b = to();
+      CHECK(a == b && a > 50 && m12 == m12o);
+      snprintf(extra, sizeof extra, ", \"matches\": %d", a);
+      emit("SearchForTriangulation_resident_k10_L6", time_ms([&]() { tg(); }, N), time_ms([&]() { to(); }, N / 4), extra);
+    }
+    vsg_vocab_destroy(voc);
+    or_vocab_destroy(ovoc);
+  }
+  // ---- Frame::ComputeStereoMatches (Frame.cc:957-1127) on two resident eyes: a rectified pair cut out of one wider
+  // synthetic frame, the right eye 17 px further along the scene
+  {
+    std::vector<uint8_t> wide((size_t)(W + 64) * H), imL((size_t)W * H), imR((size_t)W * H);
+    CHECK(vsg_synth_sequence_frame(W + 64, H, 41, 0, 1, 6, wide.data(), W + 64) == 0);
+    for (int r = 0; r < H; r++) {
+      memcpy(&imL[(size_t)r * W], &wide[(size_t)r * (W + 64) + 16], W);
+      memcpy(&imR[(size_t)r * W], &wide[(size_t)r * (W + 64) + 16 + 17], W);
+    }
+    vsg_orb *exr = nullptr;
+    CHECK(vsg_orb_create(1000, 1.2f, 8, 20, 7, 0, 1, &exr) == VSG_OK);
+    OrExtractor *ol = or_create(1000, 1.2f, 8, 20, 7), *orr = or_create(1000, 1.2f, 8, 20, 7);
+    std::vector<vsg_keypoint> kl(cap), kr(cap);
+    std::vector<uint8_t> dl(cap * 32), dr(cap * 32);
+    int nl = 0, nr = 0, onl = 0, onr = 0;
+    CHECK(vsg_orb_extract(ex, imL.data(), H, W, W, 0, 0, kl.data(), dl.data(), cap, &nl) >= 0);
+    CHECK(vsg_orb_extract(exr, imR.data(), H, W, W, 0, 0, kr.data(), dr.data(), cap, &nr) >= 0);
+    std::vector<OrKeyPoint> okl(cap), okr(cap);
+    std::vector<uint8_t> odl(cap * 32), odr(cap * 32);
+    or_extract(ol, imL.data(), H, W, W, 0, 0, okl.data(), odl.data(), cap, &onl);
+    or_extract(orr, imR.data(), H, W, W, 0, 0, okr.data(), odr.data(), cap, &onr);
+    CHECK(nl == onl && nr == onr);
+    vsg_frame *FL = nullptr, *FR = nullptr;
+    CHECK(vsg_frame_create(0, cap, &FL) == VSG_OK && vsg_frame_create(0, cap, &FR) == VSG_OK);
+    CHECK(vsg_frame_from_extractor(FL, ex, 0, kl.data(), nl, 0.f, 0.f, (float)W, (float)H) == VSG_OK);
+    CHECK(vsg_frame_from_extractor(FR, exr, 0, kr.data(), nr, 0.f, 0.f, (float)W, (float)H) == VSG_OK);
+    std::vector<float> ur(cap), dp(cap), our(cap), odp(cap);
+    auto g = [&]() { return vsg_frame_stereo_matches(ex, 0, exr, 0, FL, FR, 0.05f, 40.f, ur.data(), dp.data()); };
+    auto o = [&]() { or_stereo_matches(ol, orr, okl.data(), odl.data(), onl, okr.data(), odr.data(), onr, 0.05f, 40.f, our.data(), odp.data()); };
+    const int a = g();
+    o();
+    CHECK(a > 100 && !memcmp(ur.data(), our.data(), (size_t)nl * 4) && !memcmp(dp.data(), odp.data(), (size_t)nl * 4));
+    char extra[64];
+    snprintf(extra, sizeof extra, ", \"stereo_matches\": %d", a);
+    emit("ComputeStereoMatches_resident", time_ms([&]() { g(); }, N), time_ms([&]() { o(); }, N / 4), extra);
+    vsg_frame_destroy(FL), vsg_frame_destroy(FR);
+    vsg_orb_destroy(exr);
+    or_destroy(ol), or_destroy(orr);
+  }
   // ---- making a frame resident
   {
     const double up = time_ms([&]() { vsg_frame_upload(F[0], kp[0].data(), ds[0].data(), nullptr, n[0], -1, 0.f, 0.f, (float)W, (float)H); }, N);

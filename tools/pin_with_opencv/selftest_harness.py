@@ -27,7 +27,50 @@ def put(f, name, a):
     f.write(struct.pack(f"<{a.ndim}I", *a.shape) + a.tobytes())
 
 
+def selftest_dbow2():
+    """The same for the DBoW2 target: an oracle-generated dump in pin_dbow2's format through pack_npz.py and
+    tests/test_pin_dbow2.py."""
+    target = ROOT / "tests" / "golden" / "dbow2_v1.npz"
+    assert not target.exists(), "a real pin exists: not touching it"
+    with tempfile.TemporaryDirectory() as td:
+        dump = Path(td) / "dbow2.bin"
+        with open(dump, "wb") as f:
+            put(f, "opencv_version", np.frombuffer(b"ORACLE-FAKE", np.uint8))
+            for name, k, L, seed, sc, wt, lu, nd in [("k10_L3_l2", 10, 3, 31, 1, 1, 2, 400), ("k6_L4_bin", 6, 4, 64, 5, 3, 5, 400)]:
+                blob = synth.synthetic_vocabulary(k, L, seed=seed, scoring=sc, weighting=wt)
+                d = synth.random_descriptors(nd, 100 + seed)
+                nn = (len(blob) - 16) // 45
+                raw = np.frombuffer(blob, np.uint8)
+                for i in range(0, nd, 7):
+                    o = 16 + ((37 * i) % nn) * 45 + 5
+                    d[i] = raw[o:o + 32]
+                v = ol.OracleVocabulary(blob)
+                r = v.transform(d, lu)
+                put(f, name + "/params", np.array([k, L, seed, sc, wt, lu, nd, v.nwords], np.int32))
+                put(f, name + "/desc", d)
+                put(f, name + "/bow_ids", r["bow_ids"].astype(np.int32))
+                put(f, name + "/bow_vals", r["bow_vals"].astype(np.float64))
+                put(f, name + "/fv_node", r["fv"][0].astype(np.int32))
+                put(f, name + "/fv_off", r["fv"][1].astype(np.int32))
+                put(f, name + "/fv_idx", r["fv"][2].astype(np.int32))
+                put(f, name + "/word", r["word"].astype(np.int32))
+            a, b = synth.random_descriptors(512, 901), synth.random_descriptors(512, 902)
+            a[0], b[0], b[1] = 0, 255, a[1]
+            put(f, "forb/a", a)
+            put(f, "forb/b", b)
+            put(f, "forb/distance", np.unpackbits(a ^ b, axis=1).sum(1).astype(np.int32))
+            put(f, "layout/facts", np.array([28, 0, 8, 12, 16, 20, 24, 1, 32, 1, 8, -1], np.int32))
+        try:
+            subprocess.check_call([sys.executable, str(Path(__file__).parent / "pack_npz.py"), str(dump), str(target)])
+            return subprocess.call([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_pin_dbow2.py"), "-q",
+                                    "-m", "not gpu"])
+        finally:
+            target.unlink(missing_ok=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "dbow2":
+        sys.exit(selftest_dbow2())
     target = ROOT / "tests" / "golden" / "opencv42_v1.npz"
     assert not target.exists(), "a real pin exists: not touching it"
     with tempfile.TemporaryDirectory() as td:
