@@ -511,26 +511,53 @@ def main():
         dom_bytes = stages.get(dom, 0) * B  # algorithmic bytes one launch (batch of B frames) moves
         ach = dom_bytes / (timed[dom] * 1e-3) / 1e9 if timed[dom] > 0 else 0.0
         traffic, valu = None, None
-        stage_traffic = {}
-        try:  # PMC-derived HBM bytes / VALU instructions per launch of every kernel, collected offline (profiles/)
-            doc = {}
-            for name in ("traffic_r02.json", "traffic_r01.json"):
+        stage_traffic, issue, traffic_note = {}, {}, None
+        try:  # PMC-derived HBM bytes / SQ counters per launch of every kernel, collected offline (profiles/)
+            sys.path.insert(0, str(ROOT / "tools"))
+            from source_hash import source_hash
+            doc, traffic_source = {}, None
+            for name in ("traffic_r03.json",):
                 if (ROOT / "profiles" / name).exists():
                     doc = json.load(open(ROOT / "profiles" / name))
                     traffic_source = f"profiles/{name}"
                     break
+            if doc and doc.get("source_hash") != source_hash():
+                # counters of other sources say nothing about this build: refuse them instead of quoting them
+                traffic_note = (f"{traffic_source} was measured on sources {doc.get('source_hash')}, this build is "
+                                f"{source_hash()}: PMC figures withheld (re-run tools/profile_round.sh)")
+                doc = {}
+            isa = {}
+            if (ROOT / "profiles" / "r03_isa_mix.json").exists():
+                isa = json.load(open(ROOT / "profiles" / "r03_isa_mix.json"))
+                if isa.get("source_hash") != source_hash():
+                    isa = {}
             per_stage = doc.get(f"{args.workload}/{B}", {})
             tr = per_stage.get(dom)
             if tr:
                 traffic = tr["fetch_bytes"] + tr["write_bytes"]
-                if tr.get("valu_insts") and timed[dom] > 0:
-                    # what actually bounds the kernel: VALU issue.  1024 SIMDs, measured issue cost 2.3 cycles per
-                    # wave64 instruction for plain add/logic/fp32 and 4.2 for everything else (tools/ubench.hip)
-                    simd_cycles = 1024 * timed[dom] * 1e-3 * 2.4e9
-                    valu = {"insts_per_launch": tr["valu_insts"],
-                            "busy_frac_range": [round(min(1.0, tr["valu_insts"] * 2.3 / simd_cycles), 3),
-                                                round(min(1.0, tr["valu_insts"] * 4.2 / simd_cycles), 3)],
-                            "source": "SQ_INSTS_VALU (profiles/), issue cycles from profiles/r01_c_ubench_valu_rates.txt"}
+            # Issue roofline per stage.  MI355X: 1024 SIMDs; a wave64 VALU instruction holds its SIMD's vector issue
+            # for 2.3 cycles (plain 32-bit add / logic / fp32) or 4.2 (everything else these kernels use; measured:
+            # profiles/r01_c_ubench_valu_rates.txt).  frac_at_4_cycles prices every instruction at the classic 4
+            # cycles; frac_priced uses the kernel's STATIC full-rate / half-rate mix (profiles/r03_isa_mix.json).
+            # wait_any = share of resident wave-cycles parked at s_waitcnt / barriers (SQ_WAIT_ANY / SQ_WAVE_CYCLES),
+            # issue_stall = SQ_WAIT_INST_ANY share (the instruction buffer has work, the pipe is not free).
+            for k, v in per_stage.items():
+                if stage_ms.get(k, 0) > 0 and v.get("valu_insts"):
+                    simd_cycles = 1024 * stage_ms[k] * 1e-3 * 2.4e9
+                    e = {"valu_insts_per_launch": v["valu_insts"],
+                         "frac_at_4_cycles": round(v["valu_insts"] * 4.0 / simd_cycles, 3)}
+                    if k in isa:
+                        e["frac_priced"] = round(v["valu_insts"] * isa[k]["priced_cycles_per_inst"] / simd_cycles, 3)
+                        e["static_mix_cycles_per_inst"] = isa[k]["priced_cycles_per_inst"]
+                    if v.get("wave_cycles"):
+                        e["wait_any_frac"] = round(v.get("wait_any", 0) / v["wave_cycles"], 3)
+                        e["issue_stall_frac"] = round(v.get("wait_inst_any", 0) / v["wave_cycles"], 3)
+                        # SQ_WAVE_CYCLES counts quad-cycles summed over waves: resident waves per SIMD on average
+                        e["waves_per_simd"] = round(v["wave_cycles"] * 4.0 / simd_cycles, 2)
+                    issue[k] = e
+            if issue:
+                issue["_source"] = (f"{traffic_source} (rocprofv3 --pmc SQ_* passes of tools/profile_round.sh, source hash "
+                                    f"{doc.get('source_hash')}); durations = stage_ms of this run")
             # PMC traffic over algorithmic bytes per stage: well above 1 = wasted re-reads (the first thing to fix)
             for k, v in per_stage.items():
                 if k in stages and stages[k] > 0 and "fetch_bytes" in v:
@@ -539,11 +566,21 @@ def main():
                                         "ratio": round((v["fetch_bytes"] + v.get("write_bytes", 0)) / (stages[k] * B), 2)}
             if stage_traffic:
                 stage_traffic["_source"] = traffic_source + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, ImportError):
             pass
+        # what the counters say limits the dominant kernel (the HBM roof below is the contract's pricing, not a claim
+        # that the kernel is bandwidth-bound)
+        limited_by = None
+        if issue.get(dom):
+            d_ = issue[dom]
+            limited_by = ("VALU issue: %.0f %% of the vector issue slots at 4 cycles per instruction" % (100 * d_["frac_at_4_cycles"])
+                          + (", %.0f %% priced by the static instruction mix" % (100 * d_["frac_priced"]) if "frac_priced" in d_ else "")
+                          + ("; waves parked %.0f %% of their cycles" % (100 * d_["wait_any_frac"]) if "wait_any_frac" in d_ else ""))
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    **({"valu_issue": valu} if valu else {}),
+                    **({"limited_by": limited_by} if limited_by else {}),
+                    **({"issue": issue} if issue else {}),
+                    **({"traffic_note": traffic_note} if traffic_note else {}),
                     **({"stage_traffic_vs_algorithmic": stage_traffic} if stage_traffic else {}),
                     "launch_ms": round(timed[dom], 4), "bytes_per_launch": int(dom_bytes),
                     "timing": "HIP events per kernel, serialized pass of the same steps (stage_ms); the timed "

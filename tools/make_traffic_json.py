@@ -12,6 +12,7 @@ from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 from pmc_summary import load  # noqa: E402
+from source_hash import source_hash  # noqa: E402
 
 STAGE = {"k_pyramid": "pyramid", "k_fast_cells": "fast", "k_blur": "blur", "k_octree": "octree", "k_slots": "slots",
          "k_orient_desc": "orient_desc", "best2": "match"}
@@ -39,6 +40,16 @@ def main():
             e["write_bytes"] = int(d["WRITE_SIZE"] * 1024)
         if "SQ_INSTS_VALU" in d:
             e["valu_insts"] = int(d["SQ_INSTS_VALU"])
+        # SQ occupancy / wait counters (quad-cycles summed over waves; MI355X_MICROARCH.md "SQ": WAIT_ANY + WAIT_INST_ANY +
+        # ACTIVE_INST_ANY ~ WAVE_CYCLES) and instruction counts, when their passes were run
+        for c, key in (("SQ_INSTS_SALU", "salu_insts"), ("SQ_INSTS_LDS", "lds_insts"), ("SQ_WAVES", "waves"),
+                       ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_BUSY_CYCLES", "busy_cycles"), ("SQ_WAIT_ANY", "wait_any"),
+                       ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_ACTIVE_INST_ANY", "active_inst_any"),
+                       ("SQ_ACTIVE_INST_VALU", "active_inst_valu"), ("SQ_ACTIVE_INST_LDS", "active_inst_lds"),
+                       ("SQ_INSTS_VMEM_RD", "vmem_rd_insts"), ("TCP_TOTAL_CACHE_ACCESSES_sum", "l1_accesses"),
+                       ("TCP_TCC_READ_REQ_sum", "l1_to_l2_read_req"), ("TCP_PENDING_STALL_CYCLES_sum", "l1_pending_stall_cycles")):
+            if c in d:
+                e[key] = int(d[c])
         res[stage] = e
     doc = json.loads(out.read_text()) if out.exists() else {
         "_comment": "HBM-side traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), raw "
@@ -47,6 +58,7 @@ def main():
                     "loads used here, so fetch_bytes is a lower bound; Infinity-Cache hits are counted. valu_insts = "
                     "SQ_INSTS_VALU per launch."}
     doc[tag] = res
+    doc["source_hash"] = source_hash()  # tools/source_hash.py: the sources these counters were measured on
     out.write_text(json.dumps(doc, indent=1))
     print(json.dumps(res))
 

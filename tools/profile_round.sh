@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round profile: un-profiled bench line, rocprofv3 kernel stats of the SAME command (serialized so kernel
-# durations are interference-free), PMC passes (FETCH_SIZE / WRITE_SIZE / SQ instruction counts, one counter set per
-# run, --kernel-trace only) for HBM traffic, and the kernel stats of the C-ABI matcher probe.
-# Usage (on the GPU box): bash tools/profile_round.sh <tag>
+# Round profile: un-profiled bench line, rocprofv3 kernel stats of the SAME command (serialized so kernel durations are
+# interference-free), PMC passes -- FETCH_SIZE / WRITE_SIZE for HBM traffic, SQ instruction counts, SQ wave / wait /
+# active cycles, L1 (TCP) activity; one counter set per run, --pmc only -- for EVERY kernel of the step, the kernel
+# stats of the C-ABI matcher probe, the BASELINE config chains and the single-frame timeline.
+# Usage (on the GPU box): bash tools/profile_round.sh <tag>     -> gpurun_out/<tag>/ (copy what is to be kept to profiles/)
 set -u
 TAG=${1:-rXX}
 OUT=gpurun_out/$TAG
@@ -11,16 +12,27 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 B="python3 bench.py --cpu-seconds 0 --no-stage-timing --no-extras"
 VSG_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/bench_rocprof.json 2> $OUT/rocprof.err
-VSG_NO_OVERLAP=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 3 --warmup 1 > /dev/null 2>&1
-VSG_NO_OVERLAP=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B --steps 3 --warmup 1 > /dev/null 2>&1
-VSG_NO_OVERLAP=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/pmc_sq -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+P="--steps 3 --warmup 1"
+pass() {  # name, counters...
+  local name=$1; shift
+  VSG_NO_OVERLAP=1 timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- $B $P > /dev/null 2>>$OUT/rocprof.err
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES
+pass wait SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
+pass active SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD
+pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
 cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.txt 2>&1
-python3 tools/pmc_summary.py $OUT/pmc_sq > $OUT/pmc_sq.txt 2>&1
-python3 tools/make_traffic_json.py C2/512 $OUT/traffic.json $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq > /dev/null 2>&1
+python3 tools/pmc_summary.py $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > $OUT/pmc_sq.txt 2>&1
+python3 tools/make_traffic_json.py C2/512 $OUT/traffic.json $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_abi -- tools/_bin/abi_latency 300 > $OUT/abi_latency.json 2>> $OUT/rocprof.err
 cp $OUT/stats_abi/*/*kernel_stats.csv $OUT/abi_kernel_stats.csv 2>/dev/null
-rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/stats_abi/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
-cat $OUT/bench.json | cut -c1-1500
+tools/_bin/config_chain 2 4 > $OUT/config_chain.json 2>> $OUT/rocprof.err
+rocprofv3 --kernel-trace --output-format csv -d $OUT/lt -- tools/_bin/extract_latency 300 > $OUT/extract_latency.json 2>> $OUT/rocprof.err
+python3 tools/latency_timeline.py $OUT/lt > $OUT/frame_timeline.txt 2>&1
+for e in "" VSG_GRAPH=1 VSG_BLUR_STREAM=1 VSG_EXPORT_KERNEL=1 VSG_INGEST_DMA=1; do echo "== ${e:-default}"; env $e tools/_bin/extract_latency 1000; done > $OUT/frame_latency_ab.txt 2>&1
+rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/stats_abi/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp $OUT/lt
+cat $OUT/bench.json | cut -c1-1200
 cat $OUT/pmc_traffic.txt $OUT/pmc_sq.txt
-cat $OUT/traffic.json | head -50
