@@ -574,6 +574,57 @@ class ResidentMatcher {
     check(rc, "vsg_frame_search_by_bow_kf_f");
     return rc;
   }
+  int SearchByBoW(ResidentFrame &pKF1, const uint8_t *valid1, const FeatureVectorCSR &fv1, ResidentFrame &pKF2,
+                  const uint8_t *valid2, const FeatureVectorCSR &fv2, std::vector<int32_t> &vMatches12) const {
+    vMatches12.assign(pKF1.N(), -1);
+    int rc = vsg_frame_search_by_bow_kf_kf(pKF1.handle(), valid1, fv1.node.data(), fv1.off.data(), fv1.idx.data(),
+                                           fv1.nodes(), pKF2.handle(), valid2, fv2.node.data(), fv2.off.data(),
+                                           fv2.idx.data(), fv2.nodes(), mfNNratio, mbCheckOrientation, vMatches12.data());
+    check(rc, "vsg_frame_search_by_bow_kf_kf");
+    return rc;
+  }
+
+  // SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, vMatchedPairs, bOnlyStereo, bCoarse)  (ORBmatcher.cc:902-1146)
+  // with both KeyFrames resident (LocalMapping::CreateNewMapPoints, LocalMapping.cc:389: the current keyframe against
+  // each covisible neighbour).  eligible / pairOk as in ORBmatcher::SearchForTriangulation above: the predicate of
+  // :1031-1071 is evaluated here for every pair of every shared node and goes up as a bitmask; nullptr_t = all pass.
+  template <class Pred>
+  int SearchForTriangulation(ResidentFrame &pKF1, const uint8_t *eligible1, const FeatureVectorCSR &fv1,
+                             ResidentFrame &pKF2, const uint8_t *eligible2, const FeatureVectorCSR &fv2, Pred pairOk,
+                             std::vector<std::pair<size_t, size_t>> &vMatchedPairs) const {
+    std::vector<uint32_t> bits(1, 0u);
+    std::vector<int32_t> off(1, 0);
+    size_t a = 0, b = 0;
+    while (a < fv1.node.size() && b < fv2.node.size()) {  // the reference's merge-join, shared nodes in id order
+      if (fv1.node[a] == fv2.node[b]) {
+        const int n2 = fv2.off[b + 1] - fv2.off[b];
+        for (int i1 = fv1.off[a]; i1 < fv1.off[a + 1]; i1++)
+          for (int i2 = fv2.off[b]; i2 < fv2.off[b + 1]; i2++) {
+            const long long bit = (long long)off.back() + (long long)(i1 - fv1.off[a]) * n2 + (i2 - fv2.off[b]);
+            if ((size_t)(bit >> 5) >= bits.size()) bits.resize((size_t)(bit >> 5) + 64, 0u);
+            if (eligible1[fv1.idx[i1]] && eligible2[fv2.idx[i2]] && pairOk(fv1.idx[i1], fv2.idx[i2]))
+              bits[bit >> 5] |= 1u << (bit & 31);
+          }
+        off.push_back(off.back() + (fv1.off[a + 1] - fv1.off[a]) * n2);
+        a++, b++;
+      } else if (fv1.node[a] < fv2.node[b]) {
+        a++;
+      } else {
+        b++;
+      }
+    }
+    bits.resize((size_t)(off.back() >> 5) + 2, 0u);
+    std::vector<int32_t> m12(pKF1.N() > 0 ? pKF1.N() : 1, -1);
+    int rc = vsg_frame_search_for_triangulation(pKF1.handle(), eligible1, fv1.node.data(), fv1.off.data(), fv1.idx.data(),
+                                                fv1.nodes(), pKF2.handle(), eligible2, fv2.node.data(), fv2.off.data(),
+                                                fv2.idx.data(), fv2.nodes(), bits.data(), off.data(), mbCheckOrientation,
+                                                m12.data());
+    check(rc, "vsg_frame_search_for_triangulation");
+    vMatchedPairs.clear();
+    for (int i = 0; i < pKF1.N(); i++)
+      if (m12[i] >= 0) vMatchedPairs.emplace_back((size_t)i, (size_t)m12[i]);  // :1131-1141: pairs in idx1 order
+    return rc;
+  }
 
  protected:
   float mfNNratio;

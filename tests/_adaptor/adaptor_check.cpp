@@ -106,6 +106,14 @@ int main(int argc, char **argv) {
     std::vector<float> px, py;
     for (auto &k : kps[0]) px.push_back(k.x), py.push_back(k.y);
     const int nrinit = rm.SearchForInitialization(R0, R1, px, py, 100, rInit);
+    // the same triangulation search on the two resident frames: identical pairs expected
+    std::vector<std::pair<size_t, size_t>> rtri;
+    const int nrtri = rm.SearchForTriangulation(R0, elig0.data(), fv0, R1, elig1.data(), fv[1],
+                                                [](int i1, int i2) { return (i1 * 7 + i2 * 3) % 5 != 0; }, rtri);
+    if (nrtri != ntri || rtri != tri) {
+      printf("resident SearchForTriangulation differs from the host-array form (%d vs %d)\n", nrtri, ntri);
+      return 4;
+    }
 
     std::ofstream f(argv[2], std::ios::binary);
     std::vector<int32_t> head{mono[0], mono[1], nwin, nbow, ninit, d01, ntri, nlast, nsim3, nfuse, nrinit};

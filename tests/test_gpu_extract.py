@@ -339,6 +339,41 @@ def test_fuzz_random_geometries(case):
     assert_same_output(got, want, f"fuzz {case}")
 
 
+def _contrast_ladder(w, h, seed):
+    """Corners at every contrast from 1 to 255 gray levels (bright-on-dark and dark-on-bright squares on a noise-free
+    background, plus a noisy band): thresholds right at a corner's contrast exercise the 6-bit necessary test's margin
+    (it must never drop a pixel the exact 9-bit comparison passes) and both polarities of the one-sided score."""
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 128, np.uint8)
+    for i in range(256):
+        x, y = 20 + (i % 24) * ((w - 60) // 24), 20 + (i // 24) * ((h - 60) // 11)
+        base = int(rng.integers(0, 256 - i)) if i else 100
+        img[y - 6:y + 14, x - 6:x + 14] = base                      # pedestal
+        img[y:y + 7, x:x + 7] = base + i if (i & 1) else base       # brighter square ...
+        if not (i & 1):
+            img[y - 6:y + 14, x - 6:x + 14] = base + i              # ... or a darker one on a brighter pedestal
+            img[y:y + 7, x:x + 7] = base
+    band = img[h - 40:h - 10].astype(np.int32) + rng.integers(-9, 10, (30, w))
+    img[h - 40:h - 10] = np.clip(band, 0, 255).astype(np.uint8)
+    return img
+
+
+@pytest.mark.parametrize("ini,mn", [(1, 1), (2, 1), (3, 2), (4, 3), (5, 5), (6, 2), (7, 7), (9, 8), (10, 3), (11, 10),
+                                    (19, 18), (20, 7), (21, 20), (22, 21), (23, 5), (62, 61), (63, 62), (64, 63), (65, 64),
+                                    (127, 126), (128, 127), (200, 199), (250, 249), (253, 252), (254, 253), (255, 254),
+                                    (20, 25), (7, 20)])
+def test_fast_thresholds_around_every_contrast_step(ini, mn):
+    img = _contrast_ladder(640, 480, ini * 257 + mn)
+    want = ol.OracleExtractor(1500, 1.2, 4, ini, mn)
+    ex = orb.ORBextractor(1500, 1.2, 4, ini, mn)
+    got = ex(img)
+    assert_same_output(got, want(img), f"thresholds {ini}/{mn}")
+    for l in range(4):  # the candidate multiset of every level, before the octree picks
+        gx, gy, gr = ex.candidates(l)
+        ox, oy, orr = want.candidates(l)
+        assert sorted(zip(gx.tolist(), gy.tolist(), gr.tolist())) == sorted(zip(ox.tolist(), oy.tolist(), orr.tolist())), (ini, mn, l)
+
+
 def test_single_level_with_large_quota_needs_more_than_64kb_of_lds():
     """nlevels = 1 puts the whole feature budget on one level: quota 2400 -> a 150 KB octree workspace (the
     launch raises the dynamic-LDS limit); beyond kMaxQuota the handle refuses the geometry."""

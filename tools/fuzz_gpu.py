@@ -268,6 +268,10 @@ def case_resident(rng):
         r = (sum(len(x) for x in want), np.concatenate([[0], np.cumsum([len(x) for x in want])]).astype(np.int32),
              np.concatenate(want).astype(np.int32) if want else np.zeros(0, np.int32))
     ok = g[0] == r[0] and all(np.array_equal(x, y) for x, y in zip(g[1:], r[1:]))
+    if not ok and which == 5:  # keep the failing window case for a look at it off the box
+        np.savez_compressed(ROOT / "gpurun_out" / "fuzz_fail_windows.npz", keys=keys, desc=desc, bounds=np.array(bounds),
+                            ur=ur if ur is not None else np.zeros(0, np.float32), nleft=nleft, u=u[:nq], v=v[:nq], r=rr_,
+                            lo=lo, hi=hi, right=right, got_off=g[1], got_idx=g[2], want_off=r[1], want_idx=r[2])
     return ok, tag
 
 

@@ -36,7 +36,9 @@ ThreadCtx *thread_ctx(int device, int *rc) {
   ThreadCtx *c = new ThreadCtx();
   c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipMalloc((void **)&c->d_counter, 256) != hipSuccess || hipMemset(c->d_counter, 0, 256) != hipSuccess) {
+      hipMalloc((void **)&c->d_counter, 256) != hipSuccess ||
+      // on the thread's own (non-blocking) stream: the NULL stream's hipMemset is not ordered against it
+      hipMemsetAsync(c->d_counter, 0, 256, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->d_counter) hipFree(c->d_counter);
     delete c;

@@ -509,8 +509,17 @@ int vsg_frame_create(int device, int capacity, vsg_frame **out) {
   f->capacity = capacity;
   const FrameLayout L(capacity);
   // zeroed: a frame that was created but never uploaded has n = 0 AND all-zero cell_start arrays, so a search on it
-  // walks empty [0, 0) entry ranges instead of whatever the allocation held
-  if (hipMalloc((void **)&f->d_block, L.total) != hipSuccess || hipMemset(f->d_block, 0, L.total) != hipSuccess) {
+  // walks empty [0, 0) entry ranges instead of whatever the allocation held.  The fill runs on the calling thread's own
+  // stream and is WAITED for: uploads and searches use non-blocking streams, which the NULL stream's hipMemset is not
+  // ordered against (it could land after an upload and wipe it).
+  int rc = VSG_OK;
+  ThreadCtx *c = thread_ctx(device, &rc);
+  if (!c) {
+    delete f;
+    return rc;
+  }
+  if (hipMalloc((void **)&f->d_block, L.total) != hipSuccess ||
+      hipMemsetAsync(f->d_block, 0, L.total, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
     if (f->d_block) hipFree(f->d_block);
     delete f;
     return VSG_ERR_HIP;

@@ -590,8 +590,8 @@ __global__ __launch_bounds__(NT) void k_fast_cells_v2(const uint8_t *__restrict_
 //  * The test keeps the POLARITY of every passer (bit 7 / bit 6 of its byte = dark / bright side possible).  A 9-arc
 //    of darker and a 9-arc of brighter ring pixels cannot coexist (9 + 9 > 16), so the exact score of a passer is
 //    the score of its possible side: max over arcs of the min of +-(v - ring), 48 packed min/max instead of 96 (the
-//    sign rides on the v_pk_mad_i16 that forms the differences).  A pixel that passes on both sides is queued twice;
-//    the entry whose side scores below the threshold is dropped, and both cannot score.
+//    sign rides on the v_pk_mad_i16 that forms the differences).  A pixel that passes on both sides (noise at low
+//    thresholds) keeps ONE queue entry carrying both flags and is scored on one side after the other; both cannot score.
 //  * Phase 1 writes one flag word per run of 8 pixels at the run's own index (no ballot, no atomic, no position to
 //    encode); the dense unpack pass turns the words into the pixel queue through a wave scan of their popcounts.
 template <int kTileP>
@@ -644,10 +644,11 @@ template <int NT, int kTileP, int kScoreP>
 __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                     const CellDesc *__restrict__ cells, Src0 s0,
                                                     uint32_t *__restrict__ cand, int *__restrict__ cand_count,
-                                                    int *__restrict__ cell_count, int tile_bytes, int score_bytes) {
+                                                    int *__restrict__ cell_count, int tile_bytes, int score_bytes,
+                                                    int queue_cap) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
-  uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);
+  uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);  // queue_cap entries = the largest cell's pixels
   // flag word + index of every run with a passer; both lists are consumed before the score rows they alias are cleared
   uint32_t *runF = (uint32_t *)score;
   __shared__ int s_cnt[5];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base [4]=run entries
@@ -754,31 +755,58 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     if (seg && tid == 0) *my_count = 0;
     return;
 #endif
-    // ---- run list -> pixel queue (entry = side << 15 | row << 8 | column; rows and columns < 70)
+    // ---- run list -> pixel queue.  Entry = dark side << 15 | retry << 14 | row << 7 | column (rows, columns < 70).
+    // A pixel that passed the necessary test on both sides (noise at low thresholds) normally gets one entry per side
+    // -- a spare lane in phase 2, at most one of the two can score.  That can exceed the queue (one slot per pixel of
+    // the largest cell) when most of a cell passes on both sides; such a cell is unpacked again with ONE entry per pixel: both-sided pixels flagged dark + retry, scored dark first and, in a second pass of
+    // their own, bright.
     const int nr = s_cnt[4];
-    for (int e0 = 0; e0 < nr; e0 += NT) {
-      const int e0t = e0 + tid;
-      uint32_t F = e0t < nr ? runF[e0t] : 0u;
-      const int e = e0t < nr ? runI[e0t] : 0;
-      const int cnt = __popc(F);
-      const int incl = wave_inclusive_scan_i32(cnt);
-      const int wtotal = __builtin_amdgcn_readlane(incl, 63);
-      if (wtotal) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&s_cnt[1], wtotal);
-        int pos = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
-        const int r = div_small(e, inv_nrun), rr = e - r * nrun;
-        const int ent0 = (r << 8) + (4 * (g0 + 2 * rr) - 3 - ox);
-        while (F) {
-          const int b = __builtin_ctz(F);
-          F &= F - 1;
-          // byte b >> 3 = pixel inside its dword; bit 1 of b: second dword of the run; bit 0: dark side (b << 15 puts
-          // it in bit 15, the higher bits fall off the 16-bit entry)
-          queue[pos++] = (uint16_t)(ent0 + (b >> 3) + ((b & 2) << 1) + (b << 15));
+    auto unpack = [&](const bool single) {
+      for (int e0 = 0; e0 < nr; e0 += NT) {
+        const int e0t = e0 + tid;
+        const uint32_t F = e0t < nr ? runF[e0t] : 0u;
+        const int e = e0t < nr ? runI[e0t] : 0;
+        uint32_t P = single ? (F | (F >> 1)) & 0x50505050u : F;  // one bit per pixel (at its bright flag) / per flag
+        const int cnt = __popc(P);
+        const int incl = wave_inclusive_scan_i32(cnt);
+        const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+        if (wtotal) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&s_cnt[1], wtotal);
+          const int wbase = __builtin_amdgcn_readfirstlane(base);
+          // a wave whose entries would run past the queue writes none of them (wave-uniform test, nothing per entry):
+          // the total then exceeds the capacity and the cell is unpacked again below
+          if (wbase + wtotal <= queue_cap) {
+            int pos = wbase + incl - cnt;
+            const int r = div_small(e, inv_nrun), rr = e - r * nrun;
+            const int ent0 = (r << 7) + (4 * (g0 + 2 * rr) - 3 - ox);
+            while (P) {
+              const int b = __builtin_ctz(P);
+              P &= P - 1;
+              // byte b >> 3 = pixel inside its dword; bit 1 of b: second dword of the run; bit 0 of b: dark flag
+              uint32_t ent = ent0 + (b >> 3) + ((b & 2) << 1);
+              if (single) {
+                const uint32_t fb = (F >> b) & 3u;  // bit 1 dark, bit 0 bright
+                ent += ((fb & 2u) << 14) + (((fb + 1u) & 4u) << 12);
+              } else {
+                ent += (uint32_t)b << 15;  // bit 0 of b lands in bit 15, the rest falls off the 16-bit entry
+              }
+              queue[pos++] = (uint16_t)ent;
+            }
+          }
         }
       }
-    }
+    };
+    unpack(false);
     __syncthreads();
+    const bool single = s_cnt[1] > queue_cap;  // cell-uniform; only cells where most pixels pass on both sides
+    if (single) {
+      __syncthreads();
+      if (tid == 0) s_cnt[1] = 0;
+      __syncthreads();
+      unpack(true);
+      __syncthreads();
+    }
     nq = s_cnt[1];
 #if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 3
     { int keep_alive = nq + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
@@ -787,17 +815,31 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
 #endif
     for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    // ---- phase 2: exact score of the queued pixels on their possible side; entries that do not score are dropped
+    // ---- phase 2: exact score of the queued pixels on their flagged side; entries that do not score are dropped
+    // (retry-flagged ones -- single-entry cells only -- become bright-side entries for the second pass below)
     for (int q = tid; q < nq; q += NT) {
       const uint32_t ent = queue[q];
-      const int r = (ent >> 8) & 127, c = ent & 255;
+      const int r = (ent >> 7) & 127, c = ent & 127;
       const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, ent >> 15);
       if (s)
         score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
       else
-        queue[q] = 0xFFFFu;
+        queue[q] = (uint16_t)((ent & 0x4000u) ? ent & 0x7FFFu : 0xFFFFu);  // retry flags exist in single-entry cells only
     }
     __syncthreads();
+    if (single) {
+      for (int q = tid; q < nq; q += NT) {
+        const uint32_t ent = queue[q];
+        if ((ent >> 14) != 1u) continue;  // bright side, retry flag: the dark side did not score
+        const int r = (ent >> 7) & 127, c = ent & 127;
+        const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, 0u);
+        if (s)
+          score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
+        else
+          queue[q] = 0xFFFFu;
+      }
+      __syncthreads();
+    }
 #if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 4
     { int keep_alive = score[50 + tid] + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
     if (seg && tid == 0) *my_count = 0;
@@ -809,7 +851,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     for (int q = tid; q < nq; q += NT, it++) {
       const uint32_t ent = queue[q];
       if (ent == 0xFFFFu) continue;
-      const int r = (ent >> 8) & 127, c = ent & 255;
+      const int r = (ent >> 7) & 127, c = ent & 127;
       const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
       const int s = sp[0];
       int mx = max(max((int)sp[-1], (int)sp[1]), (int)sp[-kScoreP - 1]);
@@ -844,7 +886,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   for (int q = tid; q < nq; q += NT, it++) {
     if (!(keep & (1u << it))) continue;
     const uint32_t ent = queue[q];
-    const int r = (ent >> 8) & 127, c = ent & 255;
+    const int r = (ent >> 7) & 127, c = ent & 127;
     const int s = score[(r + 1) * kScoreP + (c + 1)];
     const int slot = base + atomicAdd(&s_cnt[2], 1);
     if (slot < L.cand_cap) out[slot] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
@@ -1884,7 +1926,7 @@ static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_
                        cell_count, tile_bytes, score_bytes);
   else
     hipLaunchKernelGGL((k_fast_cells<NT, TP, SP>), grid, block, lds, s, pyr, d_fg, d_cells, s0, cand, cand_count,
-                       cell_count, tile_bytes, score_bytes);
+                       cell_count, tile_bytes, score_bytes, maxArea);
 }
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
                  uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea,

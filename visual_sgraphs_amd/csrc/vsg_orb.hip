@@ -371,6 +371,8 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   HIP_TRY(hipMalloc(&h->d_cand2, B * fg.cand_frame * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&h->d_cell_count, B * fg.total_cells * sizeof(int)));
   HIP_TRY(hipMemset(h->d_cell_count, 0, B * fg.total_cells * sizeof(int)));
+  // the fills above ran on the NULL stream; the handle's streams are non-blocking, i.e. NOT ordered against it
+  HIP_TRY(hipStreamSynchronize(nullptr));
   HIP_TRY(hipMalloc(&h->d_nodeof, B * fg.cand_frame * sizeof(uint16_t)));
   HIP_TRY(hipMalloc(&h->d_sel, B * fg.sel_frame * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&h->d_counts2, 2 * B * kMaxLevels * sizeof(int)));

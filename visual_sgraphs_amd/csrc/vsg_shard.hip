@@ -185,6 +185,7 @@ int vsg_shard_create(int device, int rank, int world, const uint8_t id[128], int
     vsg_shard_destroy(s);
     return VSG_ERR_HIP;
   }
+  (void)hipStreamSynchronize(nullptr);  // the fills ran on the NULL stream; callers' streams may be non-blocking
   *out = s;
   return VSG_OK;
 }
