@@ -35,6 +35,7 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
                    const CellDesc *d_cells, const int *cell_count, uint32_t *cand2, uint16_t *node_of, uint32_t *sel,
                    int *sel_count, const FrameGeom &fg, int maxQuota, int maxCellsPerLevel, int nframes,
                    const uint8_t *blur_pyr = nullptr, uint8_t *blur_out = nullptr, const Src0 *blur_s0 = nullptr);
+size_t octree_lds_bytes(const FrameGeom &fg, int maxQuota, int maxCellsPerLevel);
 void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                  const FrameGeom &fg, int nframes);

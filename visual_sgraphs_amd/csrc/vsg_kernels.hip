@@ -1371,16 +1371,21 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 // stream whose fork / join events cost the chain as much GPU idle time as the blur itself takes (measured: 5-7 us at
 // each of the two cross-stream waits against 12 us of blur).  Both need only the pyramid.  Throughput batches keep the
 // two kernels apart: there the blur is issue-bound work that wants its own occupancy.
-__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_octree_blur(
+#ifndef VSG_OB_WAVES
+#define VSG_OB_WAVES 5
+#endif
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG_OB_WAVES, VSG_OB_WAVES))) void k_octree_blur(
     OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[3 * kSortStack];
   static_assert(kOctThreads == 256, "the blur body is written for 256-thread workgroups");
-  if ((int)blockIdx.x < nlevels)
-    octree_block(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
+  // frame-major over the combined grid: the workgroups that share an XCD (and its L2) work on whole frames
+  const BlockXY blk = frame_major_block();
+  if (blk.x < nlevels)
+    octree_block(a, blk.x, blk.y, oct_lds, wtot, sort_stack);
   else
-    blur_block(pyr, blur, a.fg, s0, BlockXY{(int)blockIdx.x - nlevels, (int)blockIdx.y});
+    blur_block(pyr, blur, a.fg, s0, BlockXY{blk.x - nlevels, blk.y});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1939,6 +1944,13 @@ void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const
   else
     launch_fast_t<VSG_FAST_NT, 84, 76>(s, pyr, d_fg, d_cells, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
 }
+// dynamic LDS of one octree workgroup (also what every blur workgroup of the fused launch is charged)
+size_t octree_lds_bytes(const FrameGeom &fg, int maxQuota, int maxCellsPerLevel) {
+  const int cap = octree::node_capacity(maxQuota);
+  const size_t prefix_off = (octree::work_bytes(cap) + 15) & ~(size_t)15;
+  return prefix_off + (fg.cand_segmented ? (2 * (size_t)maxCellsPerLevel + 1) * 4 : 0);
+}
+
 void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, const int *cand_count,
                    const CellDesc *d_cells, const int *cell_count, uint32_t *cand2, uint16_t *node_of, uint32_t *sel,
                    int *sel_count, const FrameGeom &fg, int maxQuota, int maxCellsPerLevel, int nframes,

@@ -482,11 +482,19 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
     launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
-  // Latency path (blocking call, a handful of frames): the blur's workgroups ride in the octree's launch -- one stream,
-  // no fork / join events (each cross-stream wait cost the chain 5-7 us of idle GPU, as much as the blur saves by
-  // running beside the octree).  VSG_BLUR_STREAM=1: A/B switch, the two-stream form everywhere.
+  // The blur's workgroups ride in the octree's launch (k_octree_blur): both need only the pyramid, the octree is a
+  // latency-bound handful of workgroups per frame and the blur issue-bound filler, and inside ONE kernel (one register
+  // allocation) the two kinds of waves co-reside on a SIMD -- as two kernels on two streams the octree's 96-register
+  // waves left no room for an 80-register blur wave, so the two shared the CUs in time.  Measured: + 1.6-2.7 % on the
+  // 512-frame step (295.0 -> 299.8 k frames/s, 302.9 k on a second box), and on the one-frame latency path no fork /
+  // join events (each cross-stream wait cost the chain 5-7 us of idle GPU): 0.127 -> 0.108 ms.  VSG_BLUR_STREAM=1: A/B
+  // switch back to the blur on its own stream; timed / serialised runs keep the two kernels apart.
+  // Throughput batches only take the fused launch while five of its workgroups (the 5 waves per SIMD it is compiled
+  // for) still fit a CU's 160 KB of LDS: every blur workgroup is charged the octree's workspace, and at 1280x720 /
+  // 2000 features (33 KB) the fifth no longer fits -- 93.1 -> 90.1 k frames/s there, so that geometry keeps two streams.
   static const bool blur_stream = getenv("VSG_BLUR_STREAM") != nullptr;
-  const bool fused_blur = h->one_stream && nf <= 8 && !tm && !blur_early && !blur_stream && sb != s;
+  const bool lds_fits = 5 * octree_lds_bytes(fg, h->G.maxQuota, h->G.maxCellsPerLevel) <= 160 * 1024;
+  const bool fused_blur = !tm && !blur_early && !blur_stream && sb != s && (lds_fits || (h->one_stream && nf <= 8));
   if (fused_blur) {
     Range r_tail("DistributeOctTree (+ blur workgroups) + slots + IC_Angle / rBRIEF");
     launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel,
