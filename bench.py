@@ -664,6 +664,16 @@ def main():
             other.append({"workload": "C4", "error": str(e)})
         other.append(chain.get("C5", {"workload": "C5", **chain}))
         out["other_configs"] = other
+        # the call pattern the reference has: ONE frame per blocking operator() (System.cc:359, Tracking.cc:1583,
+        # Frame.cc:344,555-563), from plain C++ through the C ABI, with the CPU oracle's chain beside each figure
+        fl = dict(chain.get("frame_latency") or {"error": chain.get("error", "config_chain gave no frame_latency")})
+        c3 = chain.get("C3") or {}
+        if "stage_ms" in c3:
+            st = c3["stage_ms"]
+            fl["stereo_pair_ms"] = round(st["extract_2_eyes"] + st["make_resident_2"] + st["stereo_matches"], 4)
+            fl["stereo_pair"] = ("752x480 / 1200: two handles on two host threads (Frame.cc:129-132) -> both eyes resident "
+                                 "-> ComputeStereoMatches (Frame.cc:957)")
+        out["frame_latency"] = fl
     print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()
