@@ -63,6 +63,15 @@ __global__ void __launch_bounds__(256) k(uint32_t *out, int iters, uint32_t b, u
   if (WHICH == 35) { BODY(I8("v_ashrrev_i32", F_AB)) }
   if (WHICH == 36) { BODY(I8("v_max_u32", F_AB)) }
   if (WHICH == 37) { BODY(I8("v_subrev_u32", F_AB)) }
+#define F_ABC_BITOP(n) "%" #n ", %8, %9 bitop3:0xa8"
+  if (WHICH == 38) { BODY(I8("v_bitop3_b32", F_ABC_BITOP)) }
+  if (WHICH == 39) { BODY(I8("v_bfi_b32", F_ABC)) }
+  if (WHICH == 40) { BODY(I8("v_ffbl_b32", F_A)) }
+  if (WHICH == 41) { BODY(I8("v_pk_mad_i16", F_ABC)) }
+  if (WHICH == 42) { BODY(I8("v_lshl_or_b32", F_ABC)) }
+  if (WHICH == 43) { BODY(I8("v_cvt_i32_f32", F_A)) }
+  if (WHICH == 44) { BODY(I8("v_mbcnt_lo_u32_b32", F_AB)) }
+  if (WHICH == 45) { BODY(I8("v_or3_b32", F_ABC)) }
   out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
 }
 
@@ -189,7 +198,9 @@ int main() {
                          "v_sad_u8", "v_bcnt_u32_b32", "v_max3_i32", "v_med3_i32", "v_pk_add_u16",
                          "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshlrev_b32", "v_lshrrev_b32", "v_min_u32",
                          "v_max_i32", "v_sub_u32", "v_add_f32", "v_fma_f32", "v_and_or_b32", "v_add3_u32",
-                         "v_min_i16", "v_add_u16", "v_mov_b32", "v_ashrrev_i32", "v_max_u32", "v_subrev_u32"};
+                         "v_min_i16", "v_add_u16", "v_mov_b32", "v_ashrrev_i32", "v_max_u32", "v_subrev_u32",
+                         "v_bitop3_b32", "v_bfi_b32", "v_ffbl_b32", "v_pk_mad_i16", "v_lshl_or_b32", "v_cvt_i32_f32",
+                         "v_mbcnt_lo_u32_b32", "v_or3_b32"};
   auto report = [&](const char *name, double ms, double instr_per_wave) {
     const double waves = (double)blocks * 4;
     const double per_simd = waves * instr_per_wave / (p.multiProcessorCount * 4);
@@ -199,7 +210,8 @@ int main() {
 #define RUN(W) report(names[W], time_ms([&] { hipLaunchKernelGGL(k<W>, dim3(blocks), dim3(256), 0, 0, out, iters, 3u, 5u); }), iters * 64.0);
   RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14)
   RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26) RUN(27) RUN(28)
-  RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34) RUN(35) RUN(36) RUN(37)
+  RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34) RUN(35) RUN(36) RUN(37) RUN(38) RUN(39) RUN(40) RUN(41) RUN(42)
+  RUN(43) RUN(44) RUN(45)
   report("v_mad_u64_u32", time_ms([&] { hipLaunchKernelGGL(k_mad64, dim3(blocks), dim3(256), 0, 0, (uint64_t *)out, iters, 3u, 5u); }), iters * 64.0);
   report("v_max_i32_sdwa", time_ms([&] { hipLaunchKernelGGL(k_sdwa, dim3(blocks), dim3(256), 0, 0, out, iters, 3u, 5u); }), iters * 64.0);
   report("v_cmp+v_cndmask", time_ms([&] { hipLaunchKernelGGL(k_cmpsel, dim3(blocks), dim3(256), 0, 0, out, iters, 3u, 5u); }), iters * 64.0);

@@ -631,6 +631,22 @@ __device__ __forceinline__ int fast_score_side(const uint8_t *c, int floor_t, ui
   return s >= floor_t ? s : 0;
 }
 
+// any 3-input boolean function in one v_bitop3_b32: the truth table is the function applied to 0xF0, 0xCC, 0xAA
+#define VSG_BITOP3(a, b, c, expr) \
+  __builtin_amdgcn_bitop3_b32((a), (b), (c), (uint32_t)([](uint32_t A, uint32_t B, uint32_t C) constexpr { return (expr); }(0xF0u, 0xCCu, 0xAAu)) & 0xFFu)
+// One ds_add_rtn_u32 by the calling lane.  atomicAdd() on LDS goes through the compiler's atomic optimizer, which
+// wraps the single-lane add in 8 more vector instructions (mbcnt over exec, a multiply, a second readfirstlane).
+__device__ __forceinline__ int lds_add_rtn(int *p, int v) {
+  const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)p;
+  int old;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(a), "v"(v) : "memory");
+  return old;
+}
+// number of set bits of a wave mask below the calling lane
+__device__ __forceinline__ int mbcnt64(uint64_t m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // flag word of a run of 8 pixels: pixel p < 4 -> byte p, bits 5 (dark) / 4 (bright); pixel p >= 4 -> byte p - 4, bits 7 / 6
 __device__ __forceinline__ uint32_t fast_flag_mask8(uint32_t m8) {
   uint32_t f = 0;
@@ -640,8 +656,13 @@ __device__ __forceinline__ uint32_t fast_flag_mask8(uint32_t m8) {
   return f;
 }
 
+// More than 80 SGPRs (VCC and the reserved ones included) cost a wave slot per SIMD on gfx950: with 75-77 numbered SGPRs
+// this kernel ran at 0.470 ms per 512 C2 frames, capped (a few scalars live in VGPR lanes instead) at 0.440.
+#ifndef VSG_FAST_SGPRS
+#define VSG_FAST_SGPRS 72
+#endif
 template <int NT, int kTileP, int kScoreP>
-__global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS))) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                     const CellDesc *__restrict__ cells, Src0 s0,
                                                     uint32_t *__restrict__ cand, int *__restrict__ cand_count,
                                                     int *__restrict__ cell_count, int tile_bytes, int score_bytes,
@@ -649,6 +670,9 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
   uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);  // queue_cap entries = the largest cell's pixels
+  // the tile once more as 6-bit pixels (x >> 2 per byte), read by the necessary test only: it lives where the pixel
+  // queue is built afterwards (the launcher sizes that region for both)
+  uint8_t *qtile = (uint8_t *)queue;
   // flag word + index of every run with a passer; both lists are consumed before the score rows they alias are cleared
   uint32_t *runF = (uint32_t *)score;
   __shared__ int s_cnt[5];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base [4]=run entries
@@ -671,12 +695,19 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   const int ax = (cell.x0 - 3) & ~3, ox = (cell.x0 - 3) - ax;
   const int tdw = (ox + vw + 6 + 3) >> 2, th = vh + 6;  // dwords per tile row (<= 21)
   const float inv_tdw = __builtin_amdgcn_rcpf((float)tdw);
+#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 5  // timing only: the workgroup ends once it knows its cell (launch + descriptor chain)
+  { int keep_alive = tdw + th + pitch + (int)(size_t)img; asm volatile("" : : "s"(keep_alive)); }
+  if (seg && tid == 0) *my_count = 0;
+  return;
+#endif
   {
     const uint8_t *tsrc = img + (ptrdiff_t)(cell.y0 - 3) * pitch + ax;
     if (tdw < 4) {  // a sliver of a cell at the right edge of a level (cell-uniform)
       for (int i = tid; i < tdw * th; i += NT) {
         const int r = div_small(i, inv_tdw), c = i - r * tdw;
-        *(uint32_t *)&tile[r * kTileP + 4 * c] = *(const uint32_t *)(tsrc + (uint32_t)(r * pitch + 4 * c));
+        const uint32_t v = *(const uint32_t *)(tsrc + (uint32_t)(r * pitch + 4 * c));
+        *(uint32_t *)&tile[r * kTileP + 4 * c] = v;
+        *(uint32_t *)&qtile[r * kTileP + 4 * c] = (v >> 2) & 0x3F3F3F3Fu;
       }
     } else {
       // 16 bytes per lane, the last load of a row pulled back so that it ENDS with the row (see k_fast_cells_v2)
@@ -685,9 +716,17 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
       const float inv_nq4 = __builtin_amdgcn_rcpf((float)nq4);
       for (int i = tid; i < nq4 * th; i += NT) {
         const int r = div_small(i, inv_nq4), c = min(4 * (i - r * nq4), tdw - 4);
+#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 6  // timing only: the staging pass without its global loads
+        const uint32_t fake = (uint32_t)(size_t)tsrc + (uint32_t)(r * pitch + 4 * c);
+        const u32x4u v = {fake, fake + 1u, fake + 2u, fake + 3u};
+#else
         const u32x4u v = *(const u32x4u *)(tsrc + (uint32_t)(r * pitch + 4 * c));
+#endif
         uint32_t *d = (uint32_t *)&tile[r * kTileP + 4 * c];
         d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+        uint32_t *dq = (uint32_t *)&qtile[r * kTileP + 4 * c];
+        dq[0] = (v.x >> 2) & 0x3F3F3F3Fu, dq[1] = (v.y >> 2) & 0x3F3F3F3Fu;
+        dq[2] = (v.z >> 2) & 0x3F3F3F3Fu, dq[3] = (v.w >> 2) & 0x3F3F3F3Fu;
       }
     }
   }
@@ -705,7 +744,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
   for (int pass = 0; pass < 2; pass++) {
     if (tid < 5) s_cnt[tid] = 0;
     __syncthreads();  // the tile is staged / the previous pass is done with the score rows
-#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 1  // timing-only ablations: the results are wrong
+#if defined(VSG_FAST_ABL) && (VSG_FAST_ABL == 1 || VSG_FAST_ABL == 6)  // timing-only ablations: the results are wrong
     { int keep_alive = tile[7 + tid]; asm volatile("" : : "v"(keep_alive)); }
     if (seg && tid == 0) *my_count = 0;
     return;
@@ -714,37 +753,39 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     // + run index) to the run list: one ballot and one LDS atomic per wave and iteration
     {
       const int t6 = thr <= 2 ? 0 : min(64, (thr + 1) >> 2);  // ceil((t - 2) / 4)
-      const uint32_t K = (uint32_t)(128 - t6) * 0x01010101u, Q = 0x3F3F3F3Fu, H = 0x80808080u;
+      const uint32_t K = (uint32_t)(128 - t6) * 0x01010101u, H = 0x80808080u;
       for (int i0 = 0; i0 < nruns; i0 += NT) {
         const int i = i0 + tid;
         uint32_t F = 0;
         if (i < nruns) {
-        const int r = div_small(i, inv_nrun), rr = i - r * nrun;
-        const uint8_t *t = &tile[(r + 3) * kTileP + 4 * (g0 + 2 * rr)];
-        const uint32_t *pc = (const uint32_t *)t, *pu = (const uint32_t *)(t - 3 * kTileP),
-                       *pd = (const uint32_t *)(t + 3 * kTileP);
-        uint32_t qc[4];
+          const int r = div_small(i, inv_nrun), rr = i - r * nrun;
+          const uint32_t *pc = (const uint32_t *)&qtile[(r + 3) * kTileP + 4 * (g0 + 2 * rr)];
+          const uint32_t *pu = pc - 3 * (kTileP / 4), *pd = pc + 3 * (kTileP / 4);
+          uint32_t qc[4] = {pc[-1], pc[0], pc[1], pc[2]};
+          // Bytes of the 6-bit tile that were never staged (beyond a row's last staged dword) may hold anything, and
+          // a byte above 63 carries into the bytes ABOVE it.  Those are pixels further right, invalid like the
+          // byte itself -- except in the dword left of tile column 0, whose bytes sit BELOW a valid pixel's neighbour
+          if (g0 == 0 && rr == 0) qc[0] = 0;
+          uint32_t f[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) qc[k] = (pc[k - 1] >> 2) & Q;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-          const uint32_t qu = (pu[k] >> 2) & Q, qd = (pd[k] >> 2) & Q;
-          const uint32_t qw = __builtin_amdgcn_alignbyte(qc[k + 1], qc[k], 1);      // columns -3
-          const uint32_t qe = __builtin_amdgcn_alignbyte(qc[k + 2], qc[k + 1], 3);  // columns +3
-          const uint32_t A = qc[k + 1] + K, B = K - qc[k + 1];
-          const uint32_t dark = ((A - qu) | (A - qd)) & ((A - qw) | (A - qe));
-          const uint32_t bright = ((B + qu) | (B + qd)) & ((B + qw) | (B + qe));
-          const uint32_t f = (dark & H) | ((bright & H) >> 1);
-          F |= k ? f : f >> 2;
-        }
-        if (rr == 0) F &= first_mask;
-        if (rr == nrun - 1) F &= last_mask;
+          for (int k = 0; k < 2; k++) {
+            const uint32_t qu = pu[k], qd = pd[k];
+            const uint32_t qw = __builtin_amdgcn_alignbyte(qc[k + 1], qc[k], 1);      // columns -3
+            const uint32_t qe = __builtin_amdgcn_alignbyte(qc[k + 2], qc[k + 1], 3);  // columns +3
+            const uint32_t A = qc[k + 1] + K, B = K - qc[k + 1];
+            const uint32_t dark = VSG_BITOP3(A - qu, A - qd, (A - qw) | (A - qe), (A | B) & C);
+            const uint32_t bright = VSG_BITOP3(B + qu, B + qd, (B + qw) | (B + qe), (A | B) & C);
+            f[k] = VSG_BITOP3(dark, bright >> 1, H, (A & C) | (B & ~C));  // bit 7 dark, bit 6 bright, the rest: anything
+          }
+          F = VSG_BITOP3(f[1], f[0] >> 2, 0xC0C0C0C0u, (A & C) | (B & ~C));
+          // the run masks hold flag bits only (0xF0 per byte), so they also clear what the merges above left below them
+          F &= (rr == 0 ? first_mask : 0xF0F0F0F0u) & (rr == nrun - 1 ? last_mask : 0xF0F0F0F0u);
         }
         const uint64_t hit = __ballot(F != 0);
         if (hit) {
           int base = 0;
-          if (lane == 0) base = atomicAdd(&s_cnt[4], __popcll(hit));
-          const int slot = __builtin_amdgcn_readfirstlane(base) + __popcll(hit & ((1ull << lane) - 1));
+          if (lane == 0) base = lds_add_rtn(&s_cnt[4], __popcll(hit));
+          const int slot = __builtin_amdgcn_readfirstlane(base) + mbcnt64(hit);
           if (F) runF[slot] = F, runI[slot] = (uint16_t)i;
         }
       }
@@ -755,43 +796,41 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     if (seg && tid == 0) *my_count = 0;
     return;
 #endif
-    // ---- run list -> pixel queue.  Entry = dark side << 15 | retry << 14 | row << 7 | column (rows, columns < 70).
-    // A pixel that passed the necessary test on both sides (noise at low thresholds) normally gets one entry per side
-    // -- a spare lane in phase 2, at most one of the two can score.  That can exceed the queue (one slot per pixel of
-    // the largest cell) when most of a cell passes on both sides; such a cell is unpacked again with ONE entry per pixel: both-sided pixels flagged dark + retry, scored dark first and, in a second pass of
-    // their own, bright.
+    // ---- run list -> pixel queue.  Entry = retry << 15 | run index << 5 | bit position of the flag in the run's word
+    // (bit 0 of the position: dark side); phase 2 turns an entry into row << 7 | column (rows, columns < 70) once per
+    // lane instead of once per entry of the unpack loop.  A pixel that passed the necessary test on both sides (noise
+    // at low thresholds) normally gets one entry per side -- a spare lane in phase 2, at most one of the two can score.
+    // That can exceed the queue (one slot per pixel of the largest cell) when most of a cell passes on both sides;
+    // such a cell is unpacked again with ONE entry per pixel: both-sided pixels flagged dark + retry, scored dark
+    // first and, in a second pass of their own, bright.
     const int nr = s_cnt[4];
     auto unpack = [&](const bool single) {
       for (int e0 = 0; e0 < nr; e0 += NT) {
         const int e0t = e0 + tid;
         const uint32_t F = e0t < nr ? runF[e0t] : 0u;
-        const int e = e0t < nr ? runI[e0t] : 0;
+        const uint32_t e = e0t < nr ? runI[e0t] : 0u;
         uint32_t P = single ? (F | (F >> 1)) & 0x50505050u : F;  // one bit per pixel (at its bright flag) / per flag
         const int cnt = __popc(P);
         const int incl = wave_inclusive_scan_i32(cnt);
         const int wtotal = __builtin_amdgcn_readlane(incl, 63);
         if (wtotal) {
           int base = 0;
-          if (lane == 0) base = atomicAdd(&s_cnt[1], wtotal);
+          if (lane == 0) base = lds_add_rtn(&s_cnt[1], wtotal);
           const int wbase = __builtin_amdgcn_readfirstlane(base);
           // a wave whose entries would run past the queue writes none of them (wave-uniform test, nothing per entry):
           // the total then exceeds the capacity and the cell is unpacked again below
           if (wbase + wtotal <= queue_cap) {
-            int pos = wbase + incl - cnt;
-            const int r = div_small(e, inv_nrun), rr = e - r * nrun;
-            const int ent0 = (r << 7) + (4 * (g0 + 2 * rr) - 3 - ox);
+            uint16_t *qp = queue + (wbase + incl - cnt);
+            const uint32_t ent0 = e << 5;
             while (P) {
-              const int b = __builtin_ctz(P);
+              const uint32_t b = (uint32_t)__builtin_ctz(P);
               P &= P - 1;
-              // byte b >> 3 = pixel inside its dword; bit 1 of b: second dword of the run; bit 0 of b: dark flag
-              uint32_t ent = ent0 + (b >> 3) + ((b & 2) << 1);
+              uint32_t ent = ent0 + b;  // bit 0 of b is the dark flag's bit of the pair
               if (single) {
-                const uint32_t fb = (F >> b) & 3u;  // bit 1 dark, bit 0 bright
-                ent += ((fb & 2u) << 14) + (((fb + 1u) & 4u) << 12);
-              } else {
-                ent += (uint32_t)b << 15;  // bit 0 of b lands in bit 15, the rest falls off the 16-bit entry
+                const uint32_t fb = (F >> b) & 3u;  // b = the bright flag's (even) position: bit 1 dark, bit 0 bright
+                ent += (fb >> 1) + (((fb + 1u) & 4u) << 13);
               }
-              queue[pos++] = (uint16_t)ent;
+              *qp++ = (uint16_t)ent;
             }
           }
         }
@@ -819,12 +858,15 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     // (retry-flagged ones -- single-entry cells only -- become bright-side entries for the second pass below)
     for (int q = tid; q < nq; q += NT) {
       const uint32_t ent = queue[q];
-      const int r = (ent >> 7) & 127, c = ent & 127;
-      const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, ent >> 15);
-      if (s)
-        score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
-      else
-        queue[q] = (uint16_t)((ent & 0x4000u) ? ent & 0x7FFFu : 0xFFFFu);  // retry flags exist in single-entry cells only
+      const int e = (ent >> 5) & 1023, b = ent & 31;
+      const int r = div_small(e, inv_nrun), rr = e - r * nrun;
+      // byte b >> 3 = pixel inside its dword; bit 1 of b: second dword of the run
+      const int c = 4 * (g0 + 2 * rr) - 3 - ox + (b >> 3) + ((b & 2) << 1);
+      const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, ent & 1u);
+      const uint32_t rc = (uint32_t)((r << 7) | c);
+      if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
+      // phase 3 reads row << 7 | column; 0xFFFF = dropped; bit 14 = bright-side retry (single-entry cells only)
+      queue[q] = (uint16_t)(s ? rc : (ent & 0x8000u) ? (rc | 0x4000u) : 0xFFFFu);
     }
     __syncthreads();
     if (single) {
@@ -871,7 +913,11 @@ __global__ __launch_bounds__(NT) void k_fast_cells(const uint8_t *__restrict__ p
     if (s_cnt[0] > 0 || pass == 1 || fg->minTh >= thr) break;
     thr = fg->minTh;  // vKeysCell.empty() -> retry with minThFAST (:848-851)
     __syncthreads();
+    // the queue was built over the 6-bit tile: derive it again (whole rows: unstaged bytes come out as 6-bit values too)
+    for (int i = tid; i < ((th + 1) * kTileP) / 4; i += NT)
+      ((uint32_t *)qtile)[i] = (((const uint32_t *)tile)[i] >> 2) & 0x3F3F3F3Fu;
   }
+
   const int nEmit = s_cnt[0];
   if (seg) {
     if (tid == 0) *my_count = nEmit;
@@ -1502,8 +1548,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // into LDS, one barrier).  2: 0.396 -> 0.386 ms per 512 frames; 4: no gain (fewer, longer workgroups)
 constexpr int kOdKpPerWave = VSG_OD_G;
 
+#ifndef VSG_OD_SGPRS
+#define VSG_OD_SGPRS 72
+#endif
 template <bool kMirror>
-__global__ __launch_bounds__(256) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS))) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                      const FrameGeom *__restrict__ fg, Src0 s0,
                                                      const uint32_t *__restrict__ sel,
                                                      const int *__restrict__ slots, const FrameHeader *__restrict__ hdr,
@@ -1924,7 +1973,9 @@ static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_
   dim3 grid(fg.total_cells, nframes), block(NT);
   // + one spare row: the necessary test reads (masked) dwords just past the last tile row
   const int tile_bytes = ((maxVh + 6 + 1) * TP + 15) & ~15, score_bytes = ((maxVh + 2) * SP + 15) & ~15;
-  const size_t lds = (size_t)tile_bytes + score_bytes + (((size_t)maxArea * 2 + 15) & ~(size_t)15);
+  // the pixel queue's region also holds the 6-bit copy of the tile during the necessary test
+  const size_t queue_bytes = std::max<size_t>(((size_t)maxArea * 2 + 15) & ~(size_t)15, (size_t)tile_bytes);
+  const size_t lds = (size_t)tile_bytes + score_bytes + queue_bytes;
   static const bool v2 = getenv("VSG_FAST_V2") != nullptr;  // A/B switch: the round-2 kernel (exact 9-bit test, two-sided score)
   if (v2)
     hipLaunchKernelGGL((k_fast_cells_v2<NT, TP, SP>), grid, block, lds, s, pyr, d_fg, d_cells, s0, cand, cand_count,
