@@ -66,6 +66,20 @@ struct FrameGeom {
   LevelGeom lv[kMaxLevels];
 };
 
+// Everything k_fast_cells needs to know about one cell, derived on the host once per geometry and read with ONE 32-byte
+// scalar load (cell descriptor -> level geometry -> derived constants was a chain of dependent scalar loads and ~40
+// scalar instructions in front of every cell).
+//   w0 = ax | ty << 16        tile origin in the level image: ax = (x0 - 3) & ~3, ty = y0 - 3
+//   w1 = byte offset of the level inside a frame's pyramid block (level 0: unused, the frame is read in place)
+//   w2 = pitch | level << 20  row pitch of the level in bytes (level 0: 0 = take the caller's pitch)
+//   w3 = vw | vh << 7 | ox << 14 | tdw << 16 | nq4 << 21 | g0 << 24 | nrun << 25     (all 0: empty cell)
+//   w4, w5 = flag masks of the first / last run of a row (k_fast_cells: fast_flag_mask8)
+//   w6 = the cell's segment in the frame's candidate array (level slice + cell offset, uint32 units)
+//   w7 = x0 | y0 << 16        valid region origin in level coordinates
+struct FastCellRec {
+  uint32_t w[8];
+};
+
 // Level 0 is read in place from the caller's (or the staging) buffer: no ingest copy.
 struct Src0 {
   const uint8_t *base;   // frame 0, 4-byte aligned

@@ -107,6 +107,7 @@ struct Geometry {
   int fastMaxVh = 0, fastMaxVw = 0, fastMaxArea = 0;  // over all FAST cells: rows, columns and pixels of the valid region (LDS sizing)
   std::vector<Short4> resizeTab;  // all levels, x tables then y tables (offsets in LevelGeom)
   std::vector<CellDesc> cells;
+  std::vector<FastCellRec> fastRecs;  // one per cell, same order
   int maxQuota = 0;
 };
 
@@ -353,6 +354,38 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
       }
   }
   fg.pyr_frame_bytes = (img_off + 255) & ~255;
+  // FastCellRec per cell (layout: vsg_common.h); the run / mask arithmetic is the kernel's, done here once
+  G.fastRecs.assign(G.cells.size(), FastCellRec());
+  for (size_t i = 0; i < G.cells.size(); i++) {
+    const CellDesc &c = G.cells[i];
+    const LevelGeom &L = fg.lv[c.level];
+    FastCellRec &R = G.fastRecs[i];
+    memset(&R, 0, sizeof(R));
+    const int vw = c.x1 - c.x0, vh = c.y1 - c.y0;
+    R.w[1] = (uint32_t)L.img_off;
+    R.w[2] = (uint32_t)(c.level == 0 ? 0 : L.pitch) | ((uint32_t)c.level << 20);
+    R.w[6] = (uint32_t)(L.cand_off + c.cand_off);
+    R.w[7] = (uint32_t)(uint16_t)c.x0 | ((uint32_t)(uint16_t)c.y0 << 16);
+    if (vw <= 0 || vh <= 0) continue;
+    if (L.pitch >= (1 << 20) || vw > 127 || vh > 127 || c.x0 < 3 || c.y0 < 3) return -3;
+    const int ax = (c.x0 - 3) & ~3, ox = (c.x0 - 3) - ax;
+    const int tdw = (ox + vw + 6 + 3) >> 2, nq4 = (tdw + 3) >> 2;
+    const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0, nrun = (ng + 1) >> 1;
+    if (tdw > 31 || nq4 > 7 || nrun > 15 || g0 > 1) return -3;
+    // first run of a row: its pixel 0 is valid-region column cb0 >= -3; last run: `over` of its 8 columns lie beyond vw
+    const int cb0 = 4 * g0 - 3 - ox, over = 4 * (g0 + (nrun - 1) * 2) - 3 - ox + 8 - vw;
+    auto mask8 = [](uint32_t m8) {  // pixel p < 4 -> byte p, bits 5 (dark) / 4 (bright); p >= 4 -> byte p - 4, bits 7 / 6
+      uint32_t f = 0;
+      for (int p = 0; p < 8; p++)
+        if (m8 & (1u << p)) f |= (p < 4 ? 0x30u : 0xC0u) << (8 * (p & 3));
+      return f;
+    };
+    R.w[0] = (uint32_t)ax | ((uint32_t)(c.y0 - 3) << 16);
+    R.w[3] = (uint32_t)vw | ((uint32_t)vh << 7) | ((uint32_t)ox << 14) | ((uint32_t)tdw << 16) | ((uint32_t)nq4 << 21) |
+             ((uint32_t)g0 << 24) | ((uint32_t)nrun << 25);
+    R.w[4] = mask8(cb0 < 0 ? (0xFFu << (-cb0)) & 0xFFu : 0xFFu);
+    R.w[5] = mask8(over <= 0 ? 0xFFu : over >= 8 ? 0u : (1u << (8 - over)) - 1u);
+  }
   fg.cand_frame = cand_off;
   fg.sel_frame = sel_off;
   fg.total_cells = (int)G.cells.size();

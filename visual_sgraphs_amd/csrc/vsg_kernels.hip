@@ -657,16 +657,55 @@ __device__ __forceinline__ uint32_t fast_flag_mask8(uint32_t m8) {
 }
 
 // More than 80 SGPRs (VCC and the reserved ones included) cost a wave slot per SIMD on gfx950: with 75-77 numbered SGPRs
-// this kernel ran at 0.470 ms per 512 C2 frames, capped (a few scalars live in VGPR lanes instead) at 0.440.
+// the one-cell form of this kernel ran at 0.470 ms per 512 C2 frames, capped (a few scalars live in VGPR lanes) at 0.440.
 #ifndef VSG_FAST_SGPRS
-#define VSG_FAST_SGPRS 72
+#define VSG_FAST_SGPRS 80
 #endif
-template <int NT, int kTileP, int kScoreP>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS))) void k_fast_cells(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
-                                                    const CellDesc *__restrict__ cells, Src0 s0,
-                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count,
-                                                    int *__restrict__ cell_count, int tile_bytes, int score_bytes,
-                                                    int queue_cap) {
+// One cell's record (FastCellRec, vsg_common.h) as ONE 32-byte scalar load, and what the staging code derives from it.
+struct FastCell {
+  uint32_t w3, first_mask, last_mask, cand_off, xy;
+  const uint8_t *tsrc;  // image address of tile row 0, column 0
+  int pitch, level;
+  __device__ __forceinline__ int vw() const { return (int)(w3 & 127u); }
+  __device__ __forceinline__ int vh() const { return (int)((w3 >> 7) & 127u); }
+  __device__ __forceinline__ int ox() const { return (int)((w3 >> 14) & 3u); }
+  __device__ __forceinline__ int tdw() const { return (int)((w3 >> 16) & 31u); }
+  __device__ __forceinline__ int nq4() const { return (int)((w3 >> 21) & 7u); }
+  __device__ __forceinline__ int g0() const { return (int)((w3 >> 24) & 1u); }
+  __device__ __forceinline__ int nrun() const { return (int)(w3 >> 25); }
+  __device__ __forceinline__ int th() const { return vh() + 6; }
+  __device__ __forceinline__ bool live() const { return w3 != 0; }
+};
+__device__ __forceinline__ FastCell load_fast_cell(const FastCellRec *__restrict__ recs, int idx, const Src0 &s0,
+                                                   const uint8_t *pyr, int pyr_frame_bytes, int frame) {
+  typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+  const u32x8 r = *reinterpret_cast<const u32x8 *>(recs + idx);
+  FastCell c;
+  c.w3 = r[3], c.first_mask = r[4], c.last_mask = r[5], c.cand_off = r[6], c.xy = r[7];
+  c.level = (int)(r[2] >> 20);
+  const uint8_t *img;
+  if (c.level == 0) {
+    c.pitch = s0.pitch;
+    img = s0.base + (size_t)frame * s0.frame_stride;
+  } else {
+    c.pitch = (int)(r[2] & 0xFFFFFu);
+    img = pyr + (size_t)frame * pyr_frame_bytes + r[1];
+  }
+  c.tsrc = img + (size_t)((r[0] >> 16) * (uint32_t)c.pitch + (r[0] & 0xFFFFu));
+  return c;
+}
+
+// A workgroup works through `cells_per_wg` consecutive cells of one frame.  The tile of the NEXT cell is fetched into
+// registers (kPre 16-byte chunks per thread) while the current cell is tested, scored and suppressed, and written to LDS
+// when the current cell is done: the kernel is bound by the workgroup slots of a CU (16: LDS and wave slots) times the
+// life of a workgroup, and ~3 us of a one-cell workgroup's 6 us were launch + descriptor chain + the tile's trip from
+// L2 (profiles/r03_c_fast_ablation.txt: 0.065 / 0.074 / 0.108 / 0.221 ms for workgroups that end at once / after the
+// descriptors / after a staging pass without loads / after the real staging pass, of 0.441 ms).
+template <int NT, int kTileP, int kScoreP, int kPre>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS), amdgpu_waves_per_eu(8, 8))) void k_fast_cells(
+    const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg, const FastCellRec *__restrict__ recs, Src0 s0,
+    uint32_t *__restrict__ cand, int *__restrict__ cand_count, int *__restrict__ cell_count, int tile_bytes,
+    int score_bytes, int queue_cap, int cells_per_wg) {
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
   uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);  // queue_cap entries = the largest cell's pixels
@@ -677,265 +716,294 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS))
   uint32_t *runF = (uint32_t *)score;
   __shared__ int s_cnt[5];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base [4]=run entries
   const BlockXY blk = frame_major_block();
-  const CellDesc cell = cells[blk.x];
   const int frame = blk.y;
-  const LevelGeom &L = fg->lv[cell.level];
-  const int vw = cell.x1 - cell.x0, vh = cell.y1 - cell.y0;
   const int tid = threadIdx.x, lane = tid & 63;
   const bool seg = fg->cand_segmented != 0;
-  int *my_count = cell_count + (size_t)frame * fg->total_cells + blk.x;
-  if (vw <= 0 || vh <= 0) {
-    if (seg && tid == 0) *my_count = 0;
-    return;
-  }
-  uint32_t *seg_out = cand + (size_t)frame * fg->cand_frame + L.cand_off + cell.cand_off;
-  int pitch;
-  const uint8_t *img = level_ptr(fg, s0, pyr, frame, cell.level, pitch);
-  // tile column 0 <-> image column ax (4-byte aligned); valid-region column c sits at tile column c + 3 + ox
-  const int ax = (cell.x0 - 3) & ~3, ox = (cell.x0 - 3) - ax;
-  const int tdw = (ox + vw + 6 + 3) >> 2, th = vh + 6;  // dwords per tile row (<= 21)
-  const float inv_tdw = __builtin_amdgcn_rcpf((float)tdw);
-#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 5  // timing only: the workgroup ends once it knows its cell (launch + descriptor chain)
-  { int keep_alive = tdw + th + pitch + (int)(size_t)img; asm volatile("" : : "s"(keep_alive)); }
-  if (seg && tid == 0) *my_count = 0;
-  return;
-#endif
-  {
-    const uint8_t *tsrc = img + (ptrdiff_t)(cell.y0 - 3) * pitch + ax;
-    if (tdw < 4) {  // a sliver of a cell at the right edge of a level (cell-uniform)
-      for (int i = tid; i < tdw * th; i += NT) {
-        const int r = div_small(i, inv_tdw), c = i - r * tdw;
-        const uint32_t v = *(const uint32_t *)(tsrc + (uint32_t)(r * pitch + 4 * c));
-        *(uint32_t *)&tile[r * kTileP + 4 * c] = v;
-        *(uint32_t *)&qtile[r * kTileP + 4 * c] = (v >> 2) & 0x3F3F3F3Fu;
-      }
-    } else {
-      // 16 bytes per lane, the last load of a row pulled back so that it ENDS with the row (see k_fast_cells_v2)
-      typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
-      const int nq4 = (tdw + 3) >> 2;
-      const float inv_nq4 = __builtin_amdgcn_rcpf((float)nq4);
-      for (int i = tid; i < nq4 * th; i += NT) {
-        const int r = div_small(i, inv_nq4), c = min(4 * (i - r * nq4), tdw - 4);
-#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 6  // timing only: the staging pass without its global loads
-        const uint32_t fake = (uint32_t)(size_t)tsrc + (uint32_t)(r * pitch + 4 * c);
-        const u32x4u v = {fake, fake + 1u, fake + 2u, fake + 3u};
-#else
-        const u32x4u v = *(const u32x4u *)(tsrc + (uint32_t)(r * pitch + 4 * c));
-#endif
-        uint32_t *d = (uint32_t *)&tile[r * kTileP + 4 * c];
-        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
-        uint32_t *dq = (uint32_t *)&qtile[r * kTileP + 4 * c];
-        dq[0] = (v.x >> 2) & 0x3F3F3F3Fu, dq[1] = (v.y >> 2) & 0x3F3F3F3Fu;
-        dq[2] = (v.z >> 2) & 0x3F3F3F3Fu, dq[3] = (v.w >> 2) & 0x3F3F3F3Fu;
-      }
-    }
-  }
-  // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1, runs of 2 dwords per row
-  const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0;
-  const int nrun = (ng + 1) >> 1, nruns = nrun * vh;
-  uint16_t *runI = (uint16_t *)(runF + nruns);  // 6 bytes per run <= the score row pitch (static_assert at the launcher)
-  const float inv_nrun = __builtin_amdgcn_rcpf((float)nrun);
-  // first run: its pixel 0 is valid-region column cb0 >= -3; last run: `over` of its 8 columns lie beyond vw
-  const int cb0 = 4 * g0 - 3 - ox, over = 4 * (g0 + (nrun - 1) * 2) - 3 - ox + 8 - vw;
-  const uint32_t first_mask = fast_flag_mask8(cb0 < 0 ? (0xFFu << (-cb0)) & 0xFFu : 0xFFu);
-  const uint32_t last_mask = fast_flag_mask8(over <= 0 ? 0xFFu : over >= 8 ? 0u : (1u << (8 - over)) - 1u);
-  uint32_t keep = 0;
-  int nq = 0, thr = fg->iniTh;
-  for (int pass = 0; pass < 2; pass++) {
-    if (tid < 5) s_cnt[tid] = 0;
-    __syncthreads();  // the tile is staged / the previous pass is done with the score rows
-#if defined(VSG_FAST_ABL) && (VSG_FAST_ABL == 1 || VSG_FAST_ABL == 6)  // timing-only ablations: the results are wrong
-    { int keep_alive = tile[7 + tid]; asm volatile("" : : "v"(keep_alive)); }
-    if (seg && tid == 0) *my_count = 0;
-    return;
-#endif
-    // ---- phase 1: 6-bit necessary test, 8 pixels (2 dwords) per thread; runs with a passer are appended (flag word
-    // + run index) to the run list: one ballot and one LDS atomic per wave and iteration
-    {
-      const int t6 = thr <= 2 ? 0 : min(64, (thr + 1) >> 2);  // ceil((t - 2) / 4)
-      const uint32_t K = (uint32_t)(128 - t6) * 0x01010101u, H = 0x80808080u;
-      for (int i0 = 0; i0 < nruns; i0 += NT) {
-        const int i = i0 + tid;
-        uint32_t F = 0;
-        if (i < nruns) {
-          const int r = div_small(i, inv_nrun), rr = i - r * nrun;
-          const uint32_t *pc = (const uint32_t *)&qtile[(r + 3) * kTileP + 4 * (g0 + 2 * rr)];
-          const uint32_t *pu = pc - 3 * (kTileP / 4), *pd = pc + 3 * (kTileP / 4);
-          uint32_t qc[4] = {pc[-1], pc[0], pc[1], pc[2]};
-          // Bytes of the 6-bit tile that were never staged (beyond a row's last staged dword) may hold anything, and
-          // a byte above 63 carries into the bytes ABOVE it.  Those are pixels further right, invalid like the
-          // byte itself -- except in the dword left of tile column 0, whose bytes sit BELOW a valid pixel's neighbour
-          if (g0 == 0 && rr == 0) qc[0] = 0;
-          uint32_t f[2];
+  const int total_cells = fg->total_cells, pyr_frame_bytes = fg->pyr_frame_bytes, cand_frame = fg->cand_frame;
+  const int iniTh = fg->iniTh, minTh = fg->minTh;
+  const int c_begin = blk.x * cells_per_wg, c_end = min(c_begin + cells_per_wg, total_cells);
+  typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  u32x4u pre[kPre];
+  auto put = [&](int off, const u32x4u &v) {
+    uint32_t *d = (uint32_t *)&tile[off];
+    d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+    uint32_t *dq = (uint32_t *)&qtile[off];
+    dq[0] = (v.x >> 2) & 0x3F3F3F3Fu, dq[1] = (v.y >> 2) & 0x3F3F3F3Fu;
+    dq[2] = (v.z >> 2) & 0x3F3F3F3Fu, dq[3] = (v.w >> 2) & 0x3F3F3F3Fu;
+  };
+  // 16 bytes per lane and chunk, the last chunk of a row pulled back so that it ENDS with the row (see k_fast_cells_v2).
+  // Every lane loads (the ones past the last chunk load it again): the kPre loads of a thread stay one block of
+  // back-to-back instructions -- behind per-load branches the compiler put a vmcnt(0) in front of each.
+  // Not for slivers (rows shorter than a chunk) or tiles beyond kPre chunks per thread: staged when their turn comes.
+  auto fetch = [&](const FastCell &N) -> bool {
+    const int n = N.nq4() * N.th();
+    if (!N.live() || N.tdw() < 4 || n > kPre * NT) return false;
+    const float inv_nq4 = __builtin_amdgcn_rcpf((float)N.nq4());
 #pragma unroll
-          for (int k = 0; k < 2; k++) {
-            const uint32_t qu = pu[k], qd = pd[k];
-            const uint32_t qw = __builtin_amdgcn_alignbyte(qc[k + 1], qc[k], 1);      // columns -3
-            const uint32_t qe = __builtin_amdgcn_alignbyte(qc[k + 2], qc[k + 1], 3);  // columns +3
-            const uint32_t A = qc[k + 1] + K, B = K - qc[k + 1];
-            const uint32_t dark = VSG_BITOP3(A - qu, A - qd, (A - qw) | (A - qe), (A | B) & C);
-            const uint32_t bright = VSG_BITOP3(B + qu, B + qd, (B + qw) | (B + qe), (A | B) & C);
-            f[k] = VSG_BITOP3(dark, bright >> 1, H, (A & C) | (B & ~C));  // bit 7 dark, bit 6 bright, the rest: anything
-          }
-          F = VSG_BITOP3(f[1], f[0] >> 2, 0xC0C0C0C0u, (A & C) | (B & ~C));
-          // the run masks hold flag bits only (0xF0 per byte), so they also clear what the merges above left below them
-          F &= (rr == 0 ? first_mask : 0xF0F0F0F0u) & (rr == nrun - 1 ? last_mask : 0xF0F0F0F0u);
-        }
-        const uint64_t hit = __ballot(F != 0);
-        if (hit) {
-          int base = 0;
-          if (lane == 0) base = lds_add_rtn(&s_cnt[4], __popcll(hit));
-          const int slot = __builtin_amdgcn_readfirstlane(base) + mbcnt64(hit);
-          if (F) runF[slot] = F, runI[slot] = (uint16_t)i;
-        }
-      }
+    for (int k = 0; k < kPre; k++) {
+      const int i = min(tid + k * NT, n - 1);
+      const int r = div_small(i, inv_nq4), c = min(4 * (i - r * N.nq4()), N.tdw() - 4);
+      pre[k] = *(const u32x4u *)(N.tsrc + (uint32_t)(r * N.pitch + 4 * c));
     }
-    __syncthreads();
-#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 2
-    { int keep_alive = s_cnt[4]; asm volatile("" : : "v"(keep_alive)); }
-    if (seg && tid == 0) *my_count = 0;
-    return;
-#endif
-    // ---- run list -> pixel queue.  Entry = retry << 15 | run index << 5 | bit position of the flag in the run's word
-    // (bit 0 of the position: dark side); phase 2 turns an entry into row << 7 | column (rows, columns < 70) once per
-    // lane instead of once per entry of the unpack loop.  A pixel that passed the necessary test on both sides (noise
-    // at low thresholds) normally gets one entry per side -- a spare lane in phase 2, at most one of the two can score.
-    // That can exceed the queue (one slot per pixel of the largest cell) when most of a cell passes on both sides;
-    // such a cell is unpacked again with ONE entry per pixel: both-sided pixels flagged dark + retry, scored dark
-    // first and, in a second pass of their own, bright.
-    const int nr = s_cnt[4];
-    auto unpack = [&](const bool single) {
-      for (int e0 = 0; e0 < nr; e0 += NT) {
-        const int e0t = e0 + tid;
-        const uint32_t F = e0t < nr ? runF[e0t] : 0u;
-        const uint32_t e = e0t < nr ? runI[e0t] : 0u;
-        uint32_t P = single ? (F | (F >> 1)) & 0x50505050u : F;  // one bit per pixel (at its bright flag) / per flag
-        const int cnt = __popc(P);
-        const int incl = wave_inclusive_scan_i32(cnt);
-        const int wtotal = __builtin_amdgcn_readlane(incl, 63);
-        if (wtotal) {
-          int base = 0;
-          if (lane == 0) base = lds_add_rtn(&s_cnt[1], wtotal);
-          const int wbase = __builtin_amdgcn_readfirstlane(base);
-          // a wave whose entries would run past the queue writes none of them (wave-uniform test, nothing per entry):
-          // the total then exceeds the capacity and the cell is unpacked again below
-          if (wbase + wtotal <= queue_cap) {
-            uint16_t *qp = queue + (wbase + incl - cnt);
-            const uint32_t ent0 = e << 5;
-            while (P) {
-              const uint32_t b = (uint32_t)__builtin_ctz(P);
-              P &= P - 1;
-              uint32_t ent = ent0 + b;  // bit 0 of b is the dark flag's bit of the pair
-              if (single) {
-                const uint32_t fb = (F >> b) & 3u;  // b = the bright flag's (even) position: bit 1 dark, bit 0 bright
-                ent += (fb >> 1) + (((fb + 1u) & 4u) << 13);
-              }
-              *qp++ = (uint16_t)ent;
+    return true;
+  };
+  FastCell C = load_fast_cell(recs, c_begin, s0, pyr, pyr_frame_bytes, frame);
+  bool have_pre = fetch(C);  // the first cell of the workgroup waits for its tile
+  for (int ci = c_begin; ci < c_end; ci++) {
+    // the record of the next cell: its scalar load runs beside the LDS writes below
+    const FastCell N = load_fast_cell(recs, min(ci + 1, c_end - 1), s0, pyr, pyr_frame_bytes, frame);
+    const bool live = C.live();
+    if (live) {
+      if (C.tdw() < 4) {  // a sliver of a cell at the right edge of a level (cell-uniform)
+        const float inv_tdw = __builtin_amdgcn_rcpf((float)C.tdw());
+        for (int i = tid; i < C.tdw() * C.th(); i += NT) {
+          const int r = div_small(i, inv_tdw), c = i - r * C.tdw();
+          const uint32_t v = *(const uint32_t *)(C.tsrc + (uint32_t)(r * C.pitch + 4 * c));
+          *(uint32_t *)&tile[r * kTileP + 4 * c] = v;
+          *(uint32_t *)&qtile[r * kTileP + 4 * c] = (v >> 2) & 0x3F3F3F3Fu;
+        }
+      } else {
+        const int n = C.nq4() * C.th();
+        const float inv_nq4 = __builtin_amdgcn_rcpf((float)C.nq4());
+        if (have_pre) {
+#pragma unroll
+          for (int k = 0; k < kPre; k++) {
+            const int i = tid + k * NT;
+            if (i < n) {
+              const int r = div_small(i, inv_nq4), c = min(4 * (i - r * C.nq4()), C.tdw() - 4);
+              put(r * kTileP + 4 * c, pre[k]);
             }
           }
-        }
-      }
-    };
-    unpack(false);
-    __syncthreads();
-    const bool single = s_cnt[1] > queue_cap;  // cell-uniform; only cells where most pixels pass on both sides
-    if (single) {
-      __syncthreads();
-      if (tid == 0) s_cnt[1] = 0;
-      __syncthreads();
-      unpack(true);
-      __syncthreads();
-    }
-    nq = s_cnt[1];
-#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 3
-    { int keep_alive = nq + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
-    if (seg && tid == 0) *my_count = 0;
-    return;
-#endif
-    for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    // ---- phase 2: exact score of the queued pixels on their flagged side; entries that do not score are dropped
-    // (retry-flagged ones -- single-entry cells only -- become bright-side entries for the second pass below)
-    for (int q = tid; q < nq; q += NT) {
-      const uint32_t ent = queue[q];
-      const int e = (ent >> 5) & 1023, b = ent & 31;
-      const int r = div_small(e, inv_nrun), rr = e - r * nrun;
-      // byte b >> 3 = pixel inside its dword; bit 1 of b: second dword of the run
-      const int c = 4 * (g0 + 2 * rr) - 3 - ox + (b >> 3) + ((b & 2) << 1);
-      const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, ent & 1u);
-      const uint32_t rc = (uint32_t)((r << 7) | c);
-      if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
-      // phase 3 reads row << 7 | column; 0xFFFF = dropped; bit 14 = bright-side retry (single-entry cells only)
-      queue[q] = (uint16_t)(s ? rc : (ent & 0x8000u) ? (rc | 0x4000u) : 0xFFFFu);
-    }
-    __syncthreads();
-    if (single) {
-      for (int q = tid; q < nq; q += NT) {
-        const uint32_t ent = queue[q];
-        if ((ent >> 14) != 1u) continue;  // bright side, retry flag: the dark side did not score
-        const int r = (ent >> 7) & 127, c = ent & 127;
-        const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, 0u);
-        if (s)
-          score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
-        else
-          queue[q] = 0xFFFFu;
-      }
-      __syncthreads();
-    }
-#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 4
-    { int keep_alive = score[50 + tid] + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
-    if (seg && tid == 0) *my_count = 0;
-    return;
-#endif
-    // ---- phase 3: non-max suppression inside the cell
-    keep = 0;  // bit per loop iteration: queued pixel survives NMS
-    int it = 0;
-    for (int q = tid; q < nq; q += NT, it++) {
-      const uint32_t ent = queue[q];
-      if (ent == 0xFFFFu) continue;
-      const int r = (ent >> 7) & 127, c = ent & 127;
-      const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
-      const int s = sp[0];
-      int mx = max(max((int)sp[-1], (int)sp[1]), (int)sp[-kScoreP - 1]);
-      mx = max(max(mx, (int)sp[-kScoreP]), (int)sp[-kScoreP + 1]);
-      mx = max(max(mx, (int)sp[kScoreP - 1]), (int)sp[kScoreP]);
-      mx = max(mx, (int)sp[kScoreP + 1]);
-      if (s > mx) {
-        if (seg) {
-          seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
         } else {
-          keep |= 1u << it;
-          atomicAdd(&s_cnt[0], 1);
+          for (int i = tid; i < n; i += NT) {
+            const int r = div_small(i, inv_nq4), c = min(4 * (i - r * C.nq4()), C.tdw() - 4);
+            put(r * kTileP + 4 * c, *(const u32x4u *)(C.tsrc + (uint32_t)(r * C.pitch + 4 * c)));
+          }
         }
       }
     }
-    __syncthreads();
-    if (s_cnt[0] > 0 || pass == 1 || fg->minTh >= thr) break;
-    thr = fg->minTh;  // vKeysCell.empty() -> retry with minThFAST (:848-851)
-    __syncthreads();
-    // the queue was built over the 6-bit tile: derive it again (whole rows: unstaged bytes come out as 6-bit values too)
-    for (int i = tid; i < ((th + 1) * kTileP) / 4; i += NT)
-      ((uint32_t *)qtile)[i] = (((const uint32_t *)tile)[i] >> 2) & 0x3F3F3F3Fu;
-  }
+    // the next cell's tile is on its way while this one is worked on
+    have_pre = ci + 1 < c_end && fetch(N);
+    int *my_count = cell_count + (size_t)frame * total_cells + ci;
+    if (!live) {  // empty cell
+      if (seg && tid == 0) *my_count = 0;
+      C = N;
+      continue;
+    }
+    {
+      uint32_t *seg_out = cand + (size_t)frame * cand_frame + C.cand_off;
+      const int vw = C.vw(), vh = C.vh(), ox = C.ox(), th = C.th();
+      const int cell_x0 = (int)(C.xy & 0xFFFFu), cell_y0 = (int)(C.xy >> 16), cell_level = C.level;
+        // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1, runs of 2 dwords per row
+        const int g0 = C.g0(), nrun = C.nrun(), nruns = nrun * vh;
+        uint16_t *runI = (uint16_t *)(runF + nruns);  // 6 bytes per run <= the score row pitch (static_assert at the launcher)
+        const float inv_nrun = __builtin_amdgcn_rcpf((float)nrun);
+        const uint32_t first_mask = C.first_mask, last_mask = C.last_mask;
+        uint32_t keep = 0;
+        int nq = 0, thr = iniTh;
+        for (int pass = 0; pass < 2; pass++) {
+          if (tid < 5) s_cnt[tid] = 0;
+          __syncthreads();  // the tile is staged / the previous pass is done with the score rows
+#if defined(VSG_FAST_ABL) && (VSG_FAST_ABL == 1 || VSG_FAST_ABL == 6)  // timing-only ablations: the results are wrong
+          { int keep_alive = tile[7 + tid]; asm volatile("" : : "v"(keep_alive)); }
+          if (seg && tid == 0) *my_count = 0;
+          goto cell_done;
+#endif
+          // ---- phase 1: 6-bit necessary test, 8 pixels (2 dwords) per thread; runs with a passer are appended (flag word
+          // + run index) to the run list: one ballot and one LDS atomic per wave and iteration
+          {
+            const int t6 = thr <= 2 ? 0 : min(64, (thr + 1) >> 2);  // ceil((t - 2) / 4)
+            const uint32_t K = (uint32_t)(128 - t6) * 0x01010101u, H = 0x80808080u;
+            for (int i0 = 0; i0 < nruns; i0 += NT) {
+              const int i = i0 + tid;
+              uint32_t F = 0;
+              if (i < nruns) {
+                const int r = div_small(i, inv_nrun), rr = i - r * nrun;
+                const uint32_t *pc = (const uint32_t *)&qtile[(r + 3) * kTileP + 4 * (g0 + 2 * rr)];
+                const uint32_t *pu = pc - 3 * (kTileP / 4), *pd = pc + 3 * (kTileP / 4);
+                uint32_t qc[4] = {pc[-1], pc[0], pc[1], pc[2]};
+                // Bytes of the 6-bit tile that were never staged (beyond a row's last staged dword) may hold anything, and
+                // a byte above 63 carries into the bytes ABOVE it.  Those are pixels further right, invalid like the
+                // byte itself -- except in the dword left of tile column 0, whose bytes sit BELOW a valid pixel's neighbour
+                if (g0 == 0 && rr == 0) qc[0] = 0;
+                uint32_t f[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                  const uint32_t qu = pu[k], qd = pd[k];
+                  const uint32_t qw = __builtin_amdgcn_alignbyte(qc[k + 1], qc[k], 1);      // columns -3
+                  const uint32_t qe = __builtin_amdgcn_alignbyte(qc[k + 2], qc[k + 1], 3);  // columns +3
+                  const uint32_t A = qc[k + 1] + K, B = K - qc[k + 1];
+                  const uint32_t dark = VSG_BITOP3(A - qu, A - qd, (A - qw) | (A - qe), (A | B) & C);
+                  const uint32_t bright = VSG_BITOP3(B + qu, B + qd, (B + qw) | (B + qe), (A | B) & C);
+                  f[k] = VSG_BITOP3(dark, bright >> 1, H, (A & C) | (B & ~C));  // bit 7 dark, bit 6 bright, the rest: anything
+                }
+                F = VSG_BITOP3(f[1], f[0] >> 2, 0xC0C0C0C0u, (A & C) | (B & ~C));
+                // the run masks hold flag bits only (0xF0 per byte), so they also clear what the merges above left below them
+                F &= (rr == 0 ? first_mask : 0xF0F0F0F0u) & (rr == nrun - 1 ? last_mask : 0xF0F0F0F0u);
+              }
+              const uint64_t hit = __ballot(F != 0);
+              if (hit) {
+                int base = 0;
+                if (lane == 0) base = lds_add_rtn(&s_cnt[4], __popcll(hit));
+                const int slot = __builtin_amdgcn_readfirstlane(base) + mbcnt64(hit);
+                if (F) runF[slot] = F, runI[slot] = (uint16_t)i;
+              }
+            }
+          }
+          __syncthreads();
+#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 2
+          { int keep_alive = s_cnt[4]; asm volatile("" : : "v"(keep_alive)); }
+          if (seg && tid == 0) *my_count = 0;
+          goto cell_done;
+#endif
+          // ---- run list -> pixel queue.  Entry = retry << 15 | run index << 5 | bit position of the flag in the run's word
+          // (bit 0 of the position: dark side); phase 2 turns an entry into row << 7 | column (rows, columns < 70) once per
+          // lane instead of once per entry of the unpack loop.  A pixel that passed the necessary test on both sides (noise
+          // at low thresholds) normally gets one entry per side -- a spare lane in phase 2, at most one of the two can score.
+          // That can exceed the queue (one slot per pixel of the largest cell) when most of a cell passes on both sides;
+          // such a cell is unpacked again with ONE entry per pixel: both-sided pixels flagged dark + retry, scored dark
+          // first and, in a second pass of their own, bright.
+          const int nr = s_cnt[4];
+          auto unpack = [&](const bool single) {
+            for (int e0 = 0; e0 < nr; e0 += NT) {
+              const int e0t = e0 + tid;
+              const uint32_t F = e0t < nr ? runF[e0t] : 0u;
+              const uint32_t e = e0t < nr ? runI[e0t] : 0u;
+              uint32_t P = single ? (F | (F >> 1)) & 0x50505050u : F;  // one bit per pixel (at its bright flag) / per flag
+              const int cnt = __popc(P);
+              const int incl = wave_inclusive_scan_i32(cnt);
+              const int wtotal = __builtin_amdgcn_readlane(incl, 63);
+              if (wtotal) {
+                int base = 0;
+                if (lane == 0) base = lds_add_rtn(&s_cnt[1], wtotal);
+                const int wbase = __builtin_amdgcn_readfirstlane(base);
+                // a wave whose entries would run past the queue writes none of them (wave-uniform test, nothing per entry):
+                // the total then exceeds the capacity and the cell is unpacked again below
+                if (wbase + wtotal <= queue_cap) {
+                  uint16_t *qp = queue + (wbase + incl - cnt);
+                  const uint32_t ent0 = e << 5;
+                  while (P) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(P);
+                    P &= P - 1;
+                    uint32_t ent = ent0 + b;  // bit 0 of b is the dark flag's bit of the pair
+                    if (single) {
+                      const uint32_t fb = (F >> b) & 3u;  // b = the bright flag's (even) position: bit 1 dark, bit 0 bright
+                      ent += (fb >> 1) + (((fb + 1u) & 4u) << 13);
+                    }
+                    *qp++ = (uint16_t)ent;
+                  }
+                }
+              }
+            }
+          };
+          unpack(false);
+          __syncthreads();
+          const bool single = s_cnt[1] > queue_cap;  // cell-uniform; only cells where most pixels pass on both sides
+          if (single) {
+            __syncthreads();
+            if (tid == 0) s_cnt[1] = 0;
+            __syncthreads();
+            unpack(true);
+            __syncthreads();
+          }
+          nq = s_cnt[1];
+#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 3
+          { int keep_alive = nq + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
+          if (seg && tid == 0) *my_count = 0;
+          goto cell_done;
+#endif
+          for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
+          __syncthreads();
+          // ---- phase 2: exact score of the queued pixels on their flagged side; entries that do not score are dropped
+          // (retry-flagged ones -- single-entry cells only -- become bright-side entries for the second pass below)
+          for (int q = tid; q < nq; q += NT) {
+            const uint32_t ent = queue[q];
+            const int e = (ent >> 5) & 1023, b = ent & 31;
+            const int r = div_small(e, inv_nrun), rr = e - r * nrun;
+            // byte b >> 3 = pixel inside its dword; bit 1 of b: second dword of the run
+            const int c = 4 * (g0 + 2 * rr) - 3 - ox + (b >> 3) + ((b & 2) << 1);
+            const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, ent & 1u);
+            const uint32_t rc = (uint32_t)((r << 7) | c);
+            if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
+            // phase 3 reads row << 7 | column; 0xFFFF = dropped; bit 14 = bright-side retry (single-entry cells only)
+            queue[q] = (uint16_t)(s ? rc : (ent & 0x8000u) ? (rc | 0x4000u) : 0xFFFFu);
+          }
+          __syncthreads();
+          if (single) {
+            for (int q = tid; q < nq; q += NT) {
+              const uint32_t ent = queue[q];
+              if ((ent >> 14) != 1u) continue;  // bright side, retry flag: the dark side did not score
+              const int r = (ent >> 7) & 127, c = ent & 127;
+              const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, 0u);
+              if (s)
+                score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
+              else
+                queue[q] = 0xFFFFu;
+            }
+            __syncthreads();
+          }
+#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 4
+          { int keep_alive = score[50 + tid] + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
+          if (seg && tid == 0) *my_count = 0;
+          goto cell_done;
+#endif
+          // ---- phase 3: non-max suppression inside the cell
+          keep = 0;  // bit per loop iteration: queued pixel survives NMS
+          int it = 0;
+          for (int q = tid; q < nq; q += NT, it++) {
+            const uint32_t ent = queue[q];
+            if (ent == 0xFFFFu) continue;
+            const int r = (ent >> 7) & 127, c = ent & 127;
+            const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
+            const int s = sp[0];
+            int mx = max(max((int)sp[-1], (int)sp[1]), (int)sp[-kScoreP - 1]);
+            mx = max(max(mx, (int)sp[-kScoreP]), (int)sp[-kScoreP + 1]);
+            mx = max(max(mx, (int)sp[kScoreP - 1]), (int)sp[kScoreP]);
+            mx = max(mx, (int)sp[kScoreP + 1]);
+            if (s > mx) {
+              if (seg) {
+                seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell_x0 + c - kFastBorder, cell_y0 + r - kFastBorder, s);
+              } else {
+                keep |= 1u << it;
+                atomicAdd(&s_cnt[0], 1);
+              }
+            }
+          }
+          __syncthreads();
+          if (s_cnt[0] > 0 || pass == 1 || minTh >= thr) break;
+          thr = minTh;  // vKeysCell.empty() -> retry with minThFAST (:848-851)
+          __syncthreads();
+          // the queue was built over the 6-bit tile: derive it again (whole rows: unstaged bytes come out as 6-bit values too)
+          for (int i = tid; i < ((th + 1) * kTileP) / 4; i += NT)
+            ((uint32_t *)qtile)[i] = (((const uint32_t *)tile)[i] >> 2) & 0x3F3F3F3Fu;
+        }
 
-  const int nEmit = s_cnt[0];
-  if (seg) {
-    if (tid == 0) *my_count = nEmit;
-    return;
-  }
-  if (nEmit == 0) return;
-  if (tid == 0) s_cnt[3] = atomicAdd(&cand_count[frame * kMaxLevels + cell.level], nEmit);
-  __syncthreads();
-  const int base = s_cnt[3];
-  uint32_t *out = cand + (size_t)frame * fg->cand_frame + L.cand_off;
-  int it = 0;
-  for (int q = tid; q < nq; q += NT, it++) {
-    if (!(keep & (1u << it))) continue;
-    const uint32_t ent = queue[q];
-    const int r = (ent >> 7) & 127, c = ent & 127;
-    const int s = score[(r + 1) * kScoreP + (c + 1)];
-    const int slot = base + atomicAdd(&s_cnt[2], 1);
-    if (slot < L.cand_cap) out[slot] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
+
+      const int nEmit = s_cnt[0];
+      if (seg) {
+        if (tid == 0) *my_count = nEmit;
+      } else if (nEmit) {
+        const LevelGeom &L = fg->lv[cell_level];
+        if (tid == 0) s_cnt[3] = atomicAdd(&cand_count[frame * kMaxLevels + cell_level], nEmit);
+        __syncthreads();
+        const int base = s_cnt[3];
+        uint32_t *out = cand + (size_t)frame * cand_frame + L.cand_off;
+        int it = 0;
+        for (int q = tid; q < nq; q += NT, it++) {
+          if (!(keep & (1u << it))) continue;
+          const uint32_t ent = queue[q];
+          const int r = (ent >> 7) & 127, c = ent & 127;
+          const int s = score[(r + 1) * kScoreP + (c + 1)];
+          const int slot = base + atomicAdd(&s_cnt[2], 1);
+          if (slot < L.cand_cap) out[slot] = pack_cand(cell_x0 + c - kFastBorder, cell_y0 + r - kFastBorder, s);
+        }
+      }
+    }
+#if defined(VSG_FAST_ABL)
+  cell_done:
+#endif
+    __syncthreads();  // the cell is done with the tile, the score rows and the queue: the next one may be written
+    C = N;
   }
 }
 
@@ -1966,11 +2034,26 @@ void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sh
   hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(kPyrThreads), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
                      d_tile_tab, s0, d_tiles, a16, ab16, cand_count);
 }
-template <int NT, int TP, int SP>
+template <int NT, int TP, int SP, int PRE>
 static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells,
-                          const Src0 &s0, uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg,
+                          const FastCellRec *d_recs, const Src0 &s0, uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg,
                           int maxVh, int maxArea, int nframes) {
-  dim3 grid(fg.total_cells, nframes), block(NT);
+  // Cells per workgroup: the first cell of a workgroup waits for its tile, the others find theirs fetched -- 2, 3 and 4
+  // measure the same (0.425 ms per 512 C2 frames against 0.446 with 1; 6: 0.432, 8: 0.440, the tail of a launch grows).
+  // Launches that would not fill the workgroup slots a few times over (16 per CU) keep one cell per workgroup: a
+  // single frame is 577 workgroups on 256 CUs.  VSG_FAST_K overrides.
+  static const int kenv = getenv("VSG_FAST_K") ? atoi(getenv("VSG_FAST_K")) : 0;
+  int dev = 0, cus = 256;
+  static int s_cus = 0;
+  if (!s_cus) {
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    s_cus = cus;
+  }
+  const long long cells_total = (long long)fg.total_cells * nframes;
+  const int kauto = cells_total >= 3LL * 4 * 16 * s_cus ? 3 : 1;
+  const int cells_per_wg = std::max(1, std::min(kenv > 0 ? kenv : kauto, fg.total_cells));
+  dim3 grid((fg.total_cells + cells_per_wg - 1) / cells_per_wg, nframes), block(NT);
   // + one spare row: the necessary test reads (masked) dwords just past the last tile row
   const int tile_bytes = ((maxVh + 6 + 1) * TP + 15) & ~15, score_bytes = ((maxVh + 2) * SP + 15) & ~15;
   // the pixel queue's region also holds the 6-bit copy of the tile during the necessary test
@@ -1978,22 +2061,23 @@ static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_
   const size_t lds = (size_t)tile_bytes + score_bytes + queue_bytes;
   static const bool v2 = getenv("VSG_FAST_V2") != nullptr;  // A/B switch: the round-2 kernel (exact 9-bit test, two-sided score)
   if (v2)
-    hipLaunchKernelGGL((k_fast_cells_v2<NT, TP, SP>), grid, block, lds, s, pyr, d_fg, d_cells, s0, cand, cand_count,
-                       cell_count, tile_bytes, score_bytes);
+    hipLaunchKernelGGL((k_fast_cells_v2<NT, TP, SP>), dim3(fg.total_cells, nframes), block, lds, s, pyr, d_fg, d_cells, s0,
+                       cand, cand_count, cell_count, tile_bytes, score_bytes);
   else
-    hipLaunchKernelGGL((k_fast_cells<NT, TP, SP>), grid, block, lds, s, pyr, d_fg, d_cells, s0, cand, cand_count,
-                       cell_count, tile_bytes, score_bytes, maxArea);
+    hipLaunchKernelGGL((k_fast_cells<NT, TP, SP, PRE>), grid, block, lds, s, pyr, d_fg, d_recs, s0, cand, cand_count,
+                       cell_count, tile_bytes, score_bytes, maxArea, cells_per_wg);
 }
-void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells, const Src0 &s0,
+void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells,
+                 const FastCellRec *d_recs, const Src0 &s0,
                  uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea,
                  int nframes) {
   // tile row = up to 3 alignment bytes + vw + 6 ring bytes, rounded up to dwords; score row = vw + 2
   if (maxVw <= 40)
-    launch_fast_t<VSG_FAST_NT, 52, 44>(s, pyr, d_fg, d_cells, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 52, 44, 2>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
   else if (maxVw <= 56)
-    launch_fast_t<VSG_FAST_NT, 68, 60>(s, pyr, d_fg, d_cells, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 68, 60, 3>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
   else
-    launch_fast_t<VSG_FAST_NT, 84, 76>(s, pyr, d_fg, d_cells, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 84, 76, 4>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
 }
 // dynamic LDS of one octree workgroup (also what every blur workgroup of the fused launch is charged)
 size_t octree_lds_bytes(const FrameGeom &fg, int maxQuota, int maxCellsPerLevel) {

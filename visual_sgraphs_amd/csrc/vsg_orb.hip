@@ -183,6 +183,7 @@ struct vsg_orb {
   FrameGeom *d_fg = nullptr;
   Short4 *d_tab = nullptr;
   CellDesc *d_cells = nullptr;
+  FastCellRec *d_fast = nullptr;  // one record per cell for k_fast_cells (vsg_common.h)
   int *d_cell_count = nullptr;    // [max_batch][fg.total_cells] FAST survivors per cell (segmented candidate lists)
   uint32_t *d_cand2 = nullptr;    // [max_batch][fg.cand_frame] compacted candidates of levels too large for the octree's registers
   int pyr_tiling = 0;                   // the tiling calibration found faster for a full batch of this geometry
@@ -253,7 +254,7 @@ static void free_chain_graphs(vsg_orb *h) {
 
 static void free_image_buffers(vsg_orb *h) {
   free_chain_graphs(h);  // their nodes point into the buffers below
-  hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_in);
+  hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_fast), hipFree(h->d_in);
   hipFree(h->d_cell_count), hipFree(h->d_cand2);
   h->d_cell_count = nullptr, h->d_cand2 = nullptr;
   for (int i = 0; i < kPyrTilings; i++) {
@@ -263,7 +264,7 @@ static void free_image_buffers(vsg_orb *h) {
   hipFree(h->d_pyr), hipFree(h->d_blur), hipFree(h->d_cand), hipFree(h->d_sel), hipFree(h->d_nodeof);
   hipFree(h->d_counts2), hipFree(h->d_flags), hipFree(h->d_slots), hipFree(h->d_hdr);
   for (int i = 0; i < kSlots; i++) free_slot(h->slot[i]);
-  h->d_fg = nullptr, h->d_tab = nullptr, h->d_cells = nullptr, h->d_in = nullptr;
+  h->d_fg = nullptr, h->d_tab = nullptr, h->d_cells = nullptr, h->d_fast = nullptr, h->d_in = nullptr;
   h->last_src0 = {nullptr, 0, 0};
   h->have_last = false;
   h->d_pyr = h->d_blur = nullptr;
@@ -354,6 +355,8 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   if (!h->G.resizeTab.empty())
     HIP_TRY(hipMemcpy(h->d_tab, h->G.resizeTab.data(), sizeof(Short4) * h->G.resizeTab.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->d_cells, h->G.cells.data(), sizeof(CellDesc) * h->G.cells.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&h->d_fast, sizeof(FastCellRec) * h->G.fastRecs.size()));
+  HIP_TRY(hipMemcpy(h->d_fast, h->G.fastRecs.data(), sizeof(FastCellRec) * h->G.fastRecs.size(), hipMemcpyHostToDevice));
   for (int i = 0; i < kPyrTilings; i++) {
     const PyrTiling &PT = h->G.pyr[i];
     HIP_TRY(hipMalloc(&h->d_ptiles[i], sizeof(PyrTile) * (PT.tiles.size() + 1)));
@@ -479,7 +482,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   static const bool blur_early = getenv("VSG_BLUR_EARLY") != nullptr && getenv("VSG_BLUR_LATE") == nullptr;
   if (!blur_early) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
-    launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
+    launch_fast(s, pyr, h->d_fg, h->d_cells, h->d_fast, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
   // The blur's workgroups ride in the octree's launch (k_octree_blur): both need only the pyramid, the octree is a
@@ -519,7 +522,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   Range r_tail("DistributeOctTree + slots + IC_Angle / rBRIEF");
   if (blur_early) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
-    launch_fast(s, pyr, h->d_fg, h->d_cells, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
+    launch_fast(s, pyr, h->d_fg, h->d_cells, h->d_fast, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
     if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
   if (!octree_first) {
