@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for v in "$@"; do
   if [ "$v" = cur ]; then unset VSG_LIB; else export VSG_LIB="$PWD/tools/_bin/libvsg_$v.so"; fi  # never overwrite the in-tree library
   rm -rf gpurun_out/pmc_$v
-  B="python3 bench.py --batch 64 --cpu-seconds 0 --no-stage-timing --steps 2 --warmup 1 --no-extras"
+  B="python3 bench.py --batch ${PMC_BATCH:-64} --cpu-seconds 0 --no-stage-timing --steps 2 --warmup 1 --no-extras"
   VSG_NO_OVERLAP=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d gpurun_out/pmc_$v/a -- $B > /dev/null 2>>gpurun_out/pmc_ab.err
   VSG_NO_OVERLAP=1 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc_$v/b -- $B > /dev/null 2>&1
   VSG_NO_OVERLAP=1 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc_$v/c -- $B > /dev/null 2>&1

@@ -576,30 +576,36 @@ __global__ __launch_bounds__(NT) void k_fast_cells_v2(const uint8_t *__restrict_
 
 
 // ------------------------------------------------------------------------------------------------
-// Round 3 form of the cell kernel.  Same decomposition (one workgroup per FAST cell, tile in LDS, compaction, exact
-// score on dense wavefronts, cell-confined NMS, per-cell candidate segments) with two arithmetic changes:
+// Round 3 form of the cell kernel.  Same decomposition per cell as k_fast_cells_v2 (tile in LDS, compaction, exact score
+// on dense wavefronts, cell-confined NMS, per-cell candidate segments); what changed:
 //
 //  * The necessary test runs on 6-BIT pixels, four per 32-bit operation.  With q(x) = x >> 2 per byte,
 //        n < v - t   =>   q(v) - q(n) >= T6 := ceil((t - 2) / 4)        (4 (qv - qn) >= v - n - 3 >= t - 2)
 //    and byte-wise  (q(v) + 128 - T6) - q(n)  stays inside [1, 191] -- no borrow between bytes -- with bit 7 set exactly
 //    when q(v) - q(n) >= T6.  So the dark flags of four pixels against one ring pixel are ONE 32-bit subtract, the
-//    bright flags one add (against 128 - T6 - q(v)), and the pairing (N or S) and (W or E) is plain logic: ~24
-//    instructions per 4 pixels against ~54 for the exact 9-bit form on 16-bit lanes.  The 6-bit test is slightly
-//    weaker than the exact one (it lets differences of t - 3 .. t through); every pixel it passes still gets the exact
-//    score, so the candidate set is a superset of the corners and the result is unchanged.
+//    bright flags one add (against 128 - T6 - q(v)), and the pairing (N or S) and (W or E) is two v_bitop3 per side.
+//    The 6-bit pixels are a second copy of the tile, written by the staging pass (every tile dword is read ~3 times by
+//    the test, once by the staging).  The 6-bit test is slightly weaker than the exact one (it lets differences of
+//    t - 3 .. t through); every pixel it passes still gets the exact score, so the result is unchanged.
 //  * The test keeps the POLARITY of every passer (bit 7 / bit 6 of its byte = dark / bright side possible).  A 9-arc
 //    of darker and a 9-arc of brighter ring pixels cannot coexist (9 + 9 > 16), so the exact score of a passer is
 //    the score of its possible side: max over arcs of the min of +-(v - ring), 48 packed min/max instead of 96 (the
 //    sign rides on the v_pk_mad_i16 that forms the differences).  A pixel that passes on both sides (noise at low
-//    thresholds) keeps ONE queue entry carrying both flags and is scored on one side after the other; both cannot score.
-//  * Phase 1 writes one flag word per run of 8 pixels at the run's own index (no ballot, no atomic, no position to
-//    encode); the dense unpack pass turns the words into the pixel queue through a wave scan of their popcounts.
+//    thresholds) takes one queue entry per side; when that would overflow the queue the cell is unpacked again with one
+//    entry per pixel and a bright-side retry pass.
+//  * Runs of 8 pixels with a passer are appended (flag word + run index) by one ballot + one LDS add per wave; a dense
+//    pass unpacks them into the pixel queue through a wave scan of their popcounts; queue entries name the run and the
+//    flag's bit, and the lane that scores an entry turns it into (row, column).
+//  * Workgroups of several consecutive cells with the next cell's tile in flight, one 32-byte record per cell
+//    (k_fast_cells below), and the register caps that keep 8 waves per SIMD resident.
 template <int kTileP>
 __device__ __forceinline__ int fast_score_side(const uint8_t *c, int floor_t, uint32_t dark) {
   const int P = kTileP;
   // lane pair (d[k], d[k+8]) of side-signed differences, one v_pk_mad_i16 each: ring * (-1) + v (dark), ring - v (bright)
   const short sv = dark ? (short)c[0] : (short)-(int)c[0], sn = dark ? (short)-1 : (short)1;
   const s16x2 vs = {sv, sv}, ns = {sn, sn};
+  // (ds_read_u8_d16 / _d16_hi into the two halves of one register would save the packing, but with SRAM ECC on -- as on
+  // this part -- a D16 load clears the other half instead of keeping it)
   auto pair = [&](int o_lo, int o_hi) -> s16x2 {
     const uint32_t x = (uint32_t)c[o_lo] | ((uint32_t)c[o_hi] << 16);
     return __builtin_bit_cast(s16x2, x) * ns + vs;
@@ -724,6 +730,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
   const int c_begin = blk.x * cells_per_wg, c_end = min(c_begin + cells_per_wg, total_cells);
   typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
   u32x4u pre[kPre];
+  int pre_off[kPre];  // where the chunk goes in the tile
   auto put = [&](int off, const u32x4u &v) {
     uint32_t *d = (uint32_t *)&tile[off];
     d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
@@ -744,6 +751,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
       const int i = min(tid + k * NT, n - 1);
       const int r = div_small(i, inv_nq4), c = min(4 * (i - r * N.nq4()), N.tdw() - 4);
       pre[k] = *(const u32x4u *)(N.tsrc + (uint32_t)(r * N.pitch + 4 * c));
+      pre_off[k] = r * kTileP + 4 * c;
     }
     return true;
   };
@@ -767,13 +775,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
         const float inv_nq4 = __builtin_amdgcn_rcpf((float)C.nq4());
         if (have_pre) {
 #pragma unroll
-          for (int k = 0; k < kPre; k++) {
-            const int i = tid + k * NT;
-            if (i < n) {
-              const int r = div_small(i, inv_nq4), c = min(4 * (i - r * C.nq4()), C.tdw() - 4);
-              put(r * kTileP + 4 * c, pre[k]);
-            }
-          }
+          for (int k = 0; k < kPre; k++)
+            if (tid + k * NT < n) put(pre_off[k], pre[k]);
         } else {
           for (int i = tid; i < n; i += NT) {
             const int r = div_small(i, inv_nq4), c = min(4 * (i - r * C.nq4()), C.tdw() - 4);
