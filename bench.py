@@ -438,7 +438,10 @@ def main():
         step()
     barrier()
     if not args.no_stage_timing:
-        ex.enable_timing(True)
+        # events around the dominant kernel's launch only (on the stream it is launched on): the chain keeps the shape
+        # of an untimed call -- with events around every stage the blur leaves the octree's launch and the step is
+        # a few % slower (the per-stage figures come from the serialized pass below)
+        ex.enable_timing(2)
     t0 = time.perf_counter()
     for _ in range(K):
         step()
@@ -508,6 +511,10 @@ def main():
     timed = {k: stage_ms[k] for k in ("pyramid", "fast", "blur", "orient_desc", "match") if stage_ms.get(k, 0) > 0}
     if timed:
         dom = max(timed, key=timed.get)
+        # the dominant kernel's launches were bracketed by HIP events inside the timed region itself (on its own stream,
+        # nothing beside it): that figure prices the roofline; the serialized pass supplies the other stages
+        if dom == "fast" and stage_ms_timed.get("fast", 0) > 0:
+            timed[dom] = stage_ms_timed["fast"]
         dom_bytes = stages.get(dom, 0) * B  # algorithmic bytes one launch (batch of B frames) moves
         ach = dom_bytes / (timed[dom] * 1e-3) / 1e9 if timed[dom] > 0 else 0.0
         traffic, valu = None, None
@@ -583,13 +590,14 @@ def main():
                     **({"traffic_note": traffic_note} if traffic_note else {}),
                     **({"stage_traffic_vs_algorithmic": stage_traffic} if stage_traffic else {}),
                     "launch_ms": round(timed[dom], 4), "bytes_per_launch": int(dom_bytes),
-                    "timing": "HIP events per kernel, serialized pass of the same steps (stage_ms); the timed "
-                              "region the blur runs beside the octree on a second stream",
+                    "timing": "launch_ms: HIP events around the dominant kernel's launches inside the timed region, on the "
+                              "stream it is launched on; stage_ms: HIP events per kernel in a serialized pass of the same "
+                              "steps (in the timed region the blur's workgroups ride in the octree's launch)",
                     "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                     # every stage against the same HBM roof: algorithmic bytes per launch / its duration
                     "stage_algorithmic_GBs": {k: round(stages[k] * B / (v * 1e-3) / 1e9, 1)
                                               for k, v in stage_ms.items() if k in stages and v > 0},
-                    **({"stage_ms_timed_region": {k: round(v, 4) for k, v in stage_ms_timed.items()}}
+                    **({"stage_ms_timed_region": {k: round(v, 4) for k, v in stage_ms_timed.items() if v > 0}}
                        if any(v > 0 for v in stage_ms_timed.values()) else {}),
                     "pipeline_achieved_GBs": round(bytes_per_frame * fps / world / 1e9, 2),
                     "bytes_per_frame": int(bytes_per_frame)}

@@ -127,7 +127,10 @@ int vsg_orb_copy_candidates(vsg_orb *h, int frame, int level, uint32_t *dst, int
 int vsg_orb_copy_selected(vsg_orb *h, int frame, int level, uint32_t *dst, int cap);
 
 /* Average device time per stage of the last N timed calls (HIP events on the handle's streams).
- * names: "pyramid","fast","octree","blur","slots","orient_desc","total".  Returns number of stages. */
+ * names: "pyramid","fast","octree","blur","slots","orient_desc","total".  Returns number of stages.
+ * vsg_orb_enable_timing: 0 = off; 1 = events around every stage (the blur then runs as its own launch on its own stream
+ * instead of riding in the octree's launch, so the chain is a few % slower than an untimed call); 2 = events around the
+ * FAST launch only, everything else exactly as in an untimed call (only "fast" is filled in). */
 /* Tracing: VSG_ROCTX=1 in the environment wraps the stage chain and the entry points in roctx ranges for
  * rocprofv3 --marker-trace.  vsg_orb_time_stats is the REGISTER_TIMES analogue (Settings.h:23): mean / std in ms of
  * the host wall time of the blocking operator() calls so far ("ORB Extraction" in Tracking::PrintTimeStats,

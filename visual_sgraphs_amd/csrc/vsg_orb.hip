@@ -224,6 +224,7 @@ struct vsg_orb {
   long host_calls = 0;
   // timing
   bool timing = false;
+  bool timing_fast = false;  // events around the FAST launch only: the stage chain keeps the shape of an untimed call
   hipEvent_t ev[kEv] = {};
   double acc_ms[kStages] = {};
   int acc_n = 0;
@@ -423,8 +424,14 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
 static void harvest_timing(vsg_orb *h) {
   if (!h->ev_pending) return;
   h->ev_pending = false;
-  if (hipEventSynchronize(h->ev[5]) != hipSuccess || hipEventSynchronize(h->ev[7]) != hipSuccess) return;
   float ms;
+  if (h->timing_fast) {
+    if (hipEventSynchronize(h->ev[2]) != hipSuccess) return;
+    if (hipEventElapsedTime(&ms, h->ev[8], h->ev[2]) == hipSuccess) h->acc_ms[1] += ms;
+    h->acc_n++;
+    return;
+  }
+  if (hipEventSynchronize(h->ev[5]) != hipSuccess || hipEventSynchronize(h->ev[7]) != hipSuccess) return;
   // main chain: 0 start, 1 pyramid end, 8 fast begin, 2 fast end, 10 octree begin, 3 octree end, 4 slots end,
   // 9 orient begin, 5 orient end; blur (own stream unless serialised, then between FAST and the octree): 6 begin, 7 end
   const int pairs[kStages][2] = {{0, 1}, {8, 2}, {10, 3}, {6, 7}, {3, 4}, {9, 5}, {0, 5}};
@@ -437,7 +444,7 @@ static void harvest_timing(vsg_orb *h) {
 // Every buffer is frame-strided, so a sub-batch is just offset base pointers.
 static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, int lap1, KeyPointPOD *d_kps,
                          uint8_t *d_desc, int *d_counts, int capacity, hipStream_t s, hipStream_t sb,
-                         hipEvent_t ev_pyr, hipEvent_t ev_blur, bool tm) {
+                         hipEvent_t ev_pyr, hipEvent_t ev_blur, bool tm, bool tmf = false) {
   const FrameGeom &fg = h->G.fg;
   const size_t F = (size_t)f0;
   const Src0 s0 = {src.base + F * src.frame_stride, src.frame_stride, src.pitch};
@@ -481,9 +488,9 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   // 254 k frames/s against 250 k with the blur released right after the pyramid (VSG_BLUR_EARLY=1).
   static const bool blur_early = getenv("VSG_BLUR_EARLY") != nullptr && getenv("VSG_BLUR_LATE") == nullptr;
   if (!blur_early) {
-    if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
+    if (tm || tmf) HIP_TRY(hipEventRecord(h->ev[8], s));
     launch_fast(s, pyr, h->d_fg, h->d_cells, h->d_fast, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
-    if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
+    if (tm || tmf) HIP_TRY(hipEventRecord(h->ev[2], s));
   }
   // The blur's workgroups ride in the octree's launch (k_octree_blur): both need only the pyramid, the octree is a
   // latency-bound handful of workgroups per frame and the blur issue-bound filler, and inside ONE kernel (one register
@@ -558,12 +565,13 @@ static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, i
   int nsub = no_overlap ? 1 : h->nsub > 0 ? h->nsub : 1;
   if (nsub > nframes) nsub = nframes;
   const bool tm = h->timing && nsub == 1 && !h->capturing;
-  if (tm) harvest_timing(h);
+  const bool tmf = !tm && h->timing_fast && nsub == 1 && !h->capturing;
+  if (tm || tmf) harvest_timing(h);
   if (nsub == 1) {
     int rc = enqueue_range(h, s0, 0, nframes, lap0, lap1, d_kps, d_desc, d_counts, capacity, s,
-                           no_overlap ? s : h->s_blur, h->ev_pyr, h->ev_blur, tm);
+                           no_overlap ? s : h->s_blur, h->ev_pyr, h->ev_blur, tm, tmf);
     if (rc != VSG_OK) return rc;
-    if (tm) h->ev_pending = true;
+    if (tm || tmf) h->ev_pending = true;
   } else {
     HIP_TRY(hipEventRecord(h->ev_fork, s));
     const int per = (nframes + nsub - 1) / nsub;
@@ -1444,7 +1452,8 @@ int vsg_orb_set_serialize(vsg_orb *h, int serialize) {
 
 int vsg_orb_enable_timing(vsg_orb *h, int enable) {
   if (!h) return VSG_ERR_INVALID;
-  h->timing = enable != 0;
+  h->timing = enable == 1;
+  h->timing_fast = enable == 2;
   h->ev_pending = false;
   memset(h->acc_ms, 0, sizeof(h->acc_ms));
   h->acc_n = 0;
