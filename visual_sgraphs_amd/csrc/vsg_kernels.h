@@ -41,9 +41,9 @@ void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                  const FrameGeom &fg, int nframes);
 void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, const int *sel_count, int *flags,
-                  int *slots, FrameHeader *hdr, int lap0, int lap1, int nframes);
+                  int4 *slots, FrameHeader *hdr, int lap0, int lap1, int nframes);
 void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
-                        const uint32_t *sel, const int *slots, const FrameHeader *hdr, const int8_t *pattern,
+                        const uint32_t *sel, const int4 *slots, const FrameHeader *hdr, const int8_t *pattern,
                         KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes,
                         const OutMirror &mir);
 void launch_border_copy(hipStream_t s, const uint8_t *img, int w, int h, int pitch, uint8_t *dst, int dpitch, int b);

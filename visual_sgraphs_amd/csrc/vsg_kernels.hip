@@ -1510,7 +1510,7 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG
 // fill the arrays from the back, the others from the front (ORBextractor.cc:1119,1152-1163).
 __device__ __forceinline__ void slots_of_frame(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ sel,
                                                const int *__restrict__ sel_count, int *__restrict__ flags,
-                                               int *__restrict__ slots, FrameHeader *__restrict__ hdr, int lap0, int lap1,
+                                               int4 *__restrict__ slots, FrameHeader *__restrict__ hdr, int lap0, int lap1,
                                                int frame, int *wtot, int *lstart) {
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -1524,7 +1524,7 @@ __device__ __forceinline__ void slots_of_frame(const FrameGeom *__restrict__ fg,
   __syncthreads();
   const int n = lstart[fg->nlevels];
   int *fl = flags + (size_t)frame * fg->out_cap;
-  int *sl = slots + (size_t)frame * fg->out_cap;
+  int4 *sl = slots + (size_t)frame * fg->out_cap;
   const float flap0 = (float)lap0, flap1 = (float)lap1;
   for (int i = tid; i < n; i += 256) {
     int l = 0;
@@ -1544,7 +1544,12 @@ __device__ __forceinline__ void slots_of_frame(const FrameGeom *__restrict__ fg,
   for (int i = tid; i < n; i += 256) {
     const int before = fl[i];
     const int after = (i + 1 < n) ? fl[i + 1] : T;
-    sl[i] = (after - before) ? (n - 1 - before) : (i - before);  // stereoIndex-- / monoIndex++
+    // everything k_orient_desc needs to start on keypoint i in ONE load whose address it knows at launch: the selected
+    // candidate, its output slot (stereoIndex-- / monoIndex++) and its level
+    int l = 0;
+    while (i >= lstart[l + 1]) l++;
+    const uint32_t c = sel[(size_t)frame * fg->sel_frame + fg->lv[l].sel_off + (i - lstart[l])];
+    sl[i] = make_int4((int)c, (after - before) ? (n - 1 - before) : (i - before), l, 0);
   }
   if (tid == 0) {
     hdr[frame].n = n;
@@ -1555,7 +1560,7 @@ __device__ __forceinline__ void slots_of_frame(const FrameGeom *__restrict__ fg,
 
 __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg, const uint32_t *__restrict__ sel,
                                                const int *__restrict__ sel_count, int *__restrict__ flags,
-                                               int *__restrict__ slots, FrameHeader *__restrict__ hdr, int lap0,
+                                               int4 *__restrict__ slots, FrameHeader *__restrict__ hdr, int lap0,
                                                int lap1) {
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int lstart[kMaxLevels + 1];
@@ -1626,7 +1631,7 @@ template <bool kMirror>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS))) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                      const FrameGeom *__restrict__ fg, Src0 s0,
                                                      const uint32_t *__restrict__ sel,
-                                                     const int *__restrict__ slots, const FrameHeader *__restrict__ hdr,
+                                                     const int4 *__restrict__ slots, const FrameHeader *__restrict__ hdr,
                                                      const int8_t *__restrict__ pattern, KeyPointPOD *__restrict__ kps,
                                                      uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity,
                                                      OutMirror mir) {
@@ -1636,6 +1641,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   __shared__ u32x4 s_ic[2 * 64];  // c_disc, one 16-byte entry per (it, lane)
   const BlockXY blk = frame_major_block();
   const int frame = blk.y, tid = threadIdx.x;
+  // The wave's keypoints (k_slots' records: candidate, slot, level), fetched at an address known at launch, beside the
+  // table loads below: header -> level search -> selected list -> keypoint used to be a chain of dependent round trips
+  // in front of every keypoint's patch loads.  Records at or past the frame's count are stale but inside the array.
+  int4 rec[kOdKpPerWave];
+  {
+    const int cap1 = fg->out_cap - 1;
+#pragma unroll
+    for (int j = 0; j < kOdKpPerWave; j++) {
+      const int g = __builtin_amdgcn_readfirstlane((blk.x * kOdKpPerWave + j) * 4 + (tid >> 6));
+      rec[j] = slots[(size_t)frame * fg->out_cap + min(g, cap1)];
+    }
+  }
   if (tid < 128) s_ic[tid] = ((const u32x4 *)c_disc.w)[tid];
   {
     const uint32_t pw = ((const uint32_t *)pattern)[tid];
@@ -1652,20 +1669,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   const int lane = tid & 63;
   // everything derived from the keypoint index is wave-uniform: keep it in SGPRs so the per-level geometry comes
   // through the scalar cache in one round trip instead of a chain of dependent vector loads
-  const int *level_start = &s_hdr[2];
   uint8_t *patch = &s_patch[(tid >> 6) * (kPatchW * kPatchP)];
-#pragma unroll 1
+#pragma unroll
   for (int j = 0; j < kOdKpPerWave; j++) {
   // the workgroup's keypoints: wave w takes blk.x * 4 * G + 4 * j + w  (adjacent keypoints run side by side)
   const int g = __builtin_amdgcn_readfirstlane((blk.x * kOdKpPerWave + j) * 4 + (tid >> 6));
   if (g >= n) break;
-  int l = 0;
-  while (g >= level_start[l + 1]) l++;
-  l = __builtin_amdgcn_readfirstlane(l);
+  const int l = __builtin_amdgcn_readfirstlane(rec[j].z);
   const LevelGeom &L = fg->lv[l];
-  const int gi = __builtin_amdgcn_readfirstlane(g - level_start[l]);
-  const uint32_t c = __builtin_amdgcn_readfirstlane(sel[(size_t)frame * fg->sel_frame + L.sel_off + gi]);
-  const int slot = slots[(size_t)frame * fg->out_cap + g];  // issued early, consumed at the very end
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane(rec[j].x);
+  const int slot = __builtin_amdgcn_readfirstlane(rec[j].y);
   const int cx = VSG_CAND_X(c) + kFastBorder, cy = VSG_CAND_Y(c) + kFastBorder;
   const size_t foff = (size_t)frame * fg->pyr_frame_bytes + L.img_off;
   int upitch;
@@ -2120,11 +2133,11 @@ void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGe
   hipLaunchKernelGGL(k_blur, grid, block, 0, s, pyr, blur, d_fg, s0);
 }
 void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, const int *sel_count, int *flags,
-                  int *slots, FrameHeader *hdr, int lap0, int lap1, int nframes) {
+                  int4 *slots, FrameHeader *hdr, int lap0, int lap1, int nframes) {
   hipLaunchKernelGGL(k_slots, dim3(nframes), dim3(256), 0, s, d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1);
 }
 void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
-                        const uint32_t *sel, const int *slots, const FrameHeader *hdr, const int8_t *pattern,
+                        const uint32_t *sel, const int4 *slots, const FrameHeader *hdr, const int8_t *pattern,
                         KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes,
                         const OutMirror &mir) {
   dim3 grid((fg.out_cap + 4 * kOdKpPerWave - 1) / (4 * kOdKpPerWave), nframes), block(256);

@@ -210,7 +210,8 @@ struct vsg_orb {
   uint32_t *d_cand = nullptr, *d_sel = nullptr;
   uint16_t *d_nodeof = nullptr;
   int *d_counts2 = nullptr;  // [2][B][kMaxLevels]: cand_count then sel_count
-  int *d_flags = nullptr, *d_slots = nullptr;
+  int *d_flags = nullptr;
+  int4 *d_slots = nullptr;  // per output index: {selected candidate, output slot, level, 0} (k_slots -> k_orient_desc)
   FrameHeader *d_hdr = nullptr;
   hipStream_t s_main = nullptr, s_blur = nullptr;
   hipEvent_t ev_pyr = nullptr, ev_blur = nullptr, ev_fork = nullptr;
@@ -271,7 +272,8 @@ static void free_image_buffers(vsg_orb *h) {
   h->d_pyr = h->d_blur = nullptr;
   h->d_cand = h->d_sel = nullptr;
   h->d_nodeof = nullptr;
-  h->d_counts2 = h->d_flags = h->d_slots = nullptr;
+  h->d_counts2 = h->d_flags = nullptr;
+  h->d_slots = nullptr;
   h->d_hdr = nullptr;
   h->rows = h->cols = 0;
 }
@@ -381,7 +383,7 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   HIP_TRY(hipMalloc(&h->d_sel, B * fg.sel_frame * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&h->d_counts2, 2 * B * kMaxLevels * sizeof(int)));
   HIP_TRY(hipMalloc(&h->d_flags, B * fg.out_cap * sizeof(int)));
-  HIP_TRY(hipMalloc(&h->d_slots, B * fg.out_cap * sizeof(int)));
+  HIP_TRY(hipMalloc(&h->d_slots, B * fg.out_cap * sizeof(int4)));
   HIP_TRY(hipMalloc(&h->d_hdr, B * sizeof(FrameHeader)));
   h->in_pitch = (cols + 3) & ~3;
   HIP_TRY(hipMalloc(&h->d_in, B * (size_t)rows * h->in_pitch + 64));
@@ -454,7 +456,8 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   int *cell_count = h->d_cell_count + F * fg.total_cells;
   int *cand_count = h->d_counts2 + F * kMaxLevels;
   int *sel_count = h->d_counts2 + ((size_t)h->max_batch + F) * kMaxLevels;
-  int *flags = h->d_flags + F * fg.out_cap, *slots = h->d_slots + F * fg.out_cap;
+  int *flags = h->d_flags + F * fg.out_cap;
+  int4 *slots = h->d_slots + F * fg.out_cap;
   FrameHeader *hdr = h->d_hdr + F;
   Range r_all("vsg_orb: enqueue stage chain");
   if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
