@@ -18,7 +18,8 @@ from source_hash import source_hash  # noqa: E402
 
 FULL = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32", "v_ashrrev_i32",
         "v_mov_b32", "v_add_f32", "v_mul_f32", "v_fma_f32", "v_min_i16", "v_add_u16", "v_sub_u16", "v_not_b32",
-        "v_sub_f32", "v_subrev_f32", "v_fmac_f32", "v_mac_f32", "v_add_co_u32", "v_sub_co_u32", "v_cndmask_b32"}
+        "v_sub_f32", "v_subrev_f32", "v_fmac_f32", "v_mac_f32", "v_add_co_u32", "v_sub_co_u32", "v_cndmask_b32",
+        "v_bitop3_b32"}  # v_bitop3_b32: 2.3 cycles measured (tools/ubench.hip)
 KERNELS = {"k_pyramid": "pyramid", "k_fast_cells": "fast", "k_blur": "blur", "k_octree": "octree", "k_orient_desc": "orient_desc",
            "k_block_best2_mfma": "match"}
 

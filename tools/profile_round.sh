@@ -9,7 +9,6 @@ TAG=${1:-rXX}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 B="python3 bench.py --cpu-seconds 0 --no-stage-timing --no-extras"
 VSG_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/bench_rocprof.json 2> $OUT/rocprof.err
 P="--steps 3 --warmup 1"
@@ -27,6 +26,11 @@ cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > $OUT/pmc_sq.txt 2>&1
 python3 tools/make_traffic_json.py C2/512 $OUT/traffic.json $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > /dev/null 2>&1
+# the un-profiled bench line LAST among the bench runs, with this build's own counters in place (bench.py only quotes a
+# traffic file whose source hash is the hash of the sources it runs on): the copies under profiles/ on this box are scratch
+cp $OUT/traffic.json profiles/traffic_r03.json
+python3 tools/isa_mix.py > $OUT/isa_mix.json 2>> $OUT/rocprof.err && cp $OUT/isa_mix.json profiles/r03_isa_mix.json
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_abi -- tools/_bin/abi_latency 300 > $OUT/abi_latency.json 2>> $OUT/rocprof.err
 cp $OUT/stats_abi/*/*kernel_stats.csv $OUT/abi_kernel_stats.csv 2>/dev/null
 tools/_bin/config_chain 2 4 > $OUT/config_chain.json 2>> $OUT/rocprof.err
