@@ -51,6 +51,12 @@ void hc_cell(int i, int *out) {
   const CellDesc &c = g_geom.cells[i];
   out[0] = c.level, out[1] = c.x0, out[2] = c.y0, out[3] = c.x1, out[4] = c.y1;
 }
+// the FAST record of cell i (FastCellRec, vsg_common.h: 8 words) plus {img_off, cand_off of its level}
+void hc_fast_rec(int i, unsigned *out) {
+  memcpy(out, g_geom.fastRecs[i].w, 32);
+  const LevelGeom &L = g_geom.fg.lv[g_geom.cells[i].level];
+  out[8] = (unsigned)L.img_off, out[9] = (unsigned)L.cand_off, out[10] = (unsigned)g_geom.cells[i].cand_off;
+}
 // resize tables of level l (from l-1): xs[4*w], ys[4*h]
 void hc_resize_tables(int l, short *xs, short *ys) {
   const LevelGeom &L = g_geom.fg.lv[l];

@@ -103,6 +103,57 @@ def test_geometry_matches_oracle_for_every_reference_config(hc, w, h, nf, sf, nl
         assert info["quota"] == t["features_per_level"][l]
 
 
+@pytest.mark.parametrize("w,h,nf,nl", GEOM_CASES + [(2400, 2336, 1500, 3), (100, 100, 300, 2)])
+def test_fast_cell_records_restate_the_cells(hc, w, h, nf, nl):
+    """FastCellRec (one 32-byte scalar load per cell in k_fast_cells) against an independent restatement of the per-cell
+    arithmetic the kernel used to do itself: tile origin, dwords and 16-byte chunks per tile row, run layout of the
+    necessary test (8 pixels per run, runs start at a dword boundary) and the flag masks of a row's first / last run."""
+    assert hc.hc_build(nf, 1.2, nl, 20, 7, h, w) == 0
+    n = hc.hc_total_cells()
+    assert n > 0
+
+    def mask8(m8):  # pixel p < 4 -> byte p, bits 5 (dark) / 4 (bright); p >= 4 -> byte p - 4, bits 7 / 6
+        f = 0
+        for p in range(8):
+            if m8 >> p & 1:
+                f |= (0x30 if p < 4 else 0xC0) << (8 * (p & 3))
+        return f
+
+    cell, rec = np.zeros(5, np.int32), np.zeros(11, np.uint32)
+    for i in range(n):
+        hc.hc_cell(i, cell.ctypes.data_as(_i32p))
+        hc.hc_fast_rec(i, rec.ctypes.data_as(C.POINTER(C.c_uint)))
+        level, x0, y0, x1, y1 = (int(v) for v in cell)
+        r = [int(v) for v in rec]
+        info = level_info(hc, level)
+        assert r[2] >> 20 == level and r[2] & 0xFFFFF == (0 if level == 0 else info["pitch"])
+        assert r[1] == r[8] and r[6] == r[9] + r[10]
+        assert r[7] == (x0 & 0xFFFF) | (y0 & 0xFFFF) << 16
+        vw, vh = x1 - x0, y1 - y0
+        if vw <= 0 or vh <= 0:
+            assert r[3] == 0
+            continue
+        ax = (x0 - 3) & ~3
+        ox = x0 - 3 - ax
+        assert r[0] == ax | (y0 - 3) << 16
+        tdw = -(-(ox + vw + 6) // 4)           # dwords that cover tile columns [0, ox + vw + 6)
+        first = (3 + ox) // 4                  # dword of the first centre pixel (tile column 3 + ox)
+        last = (3 + ox + vw - 1) // 4          # dword of the last one
+        nrun = (last - first + 2) // 2         # runs of 2 dwords from `first`
+        w3 = r[3]
+        assert (w3 & 127, w3 >> 7 & 127, w3 >> 14 & 3, w3 >> 16 & 31, w3 >> 21 & 7, w3 >> 24 & 1, w3 >> 25) == \
+            (vw, vh, ox, tdw, -(-tdw // 4), first, nrun), (i, level)
+        # pixel p of run k is tile column 4 * (first + 2 k) + p = valid-region column 4 * (first + 2 k) + p - 3 - ox
+        col0 = 4 * first - 3 - ox
+        m_first = sum(1 << p for p in range(8) if 0 <= col0 + p < vw)
+        colL = 4 * (first + 2 * (nrun - 1)) - 3 - ox
+        m_last = sum(1 << p for p in range(8) if colL + p < vw)
+        if nrun == 1:
+            assert mask8(m_first) & mask8(m_last) == r[4] & r[5]
+        else:
+            assert (mask8(m_first), mask8(m_last)) == (r[4], r[5]), (i, level, hex(r[4]), hex(r[5]))
+
+
 def test_geometry_known_answers_c2(hc):
     assert hc.hc_build(1000, 1.2, 8, 20, 7, 480, 640) == 0
     cells = [(17, 12, 36, 38), (14, 10, 36, 37), (11, 8, 38, 38), (9, 7, 38, 36), (7, 5, 40, 40), (6, 4, 38, 41),
