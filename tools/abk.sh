@@ -1,8 +1,9 @@
 #!/bin/bash
-# usage: abk.sh K1 K2 ... ; runs bench with VSG_FAST_K
+# In-run A/B of cells per FAST workgroup (VSG_FAST_K; 0 = the launcher's own choice): tools/abk.sh "<bench args>" K1 K2 ...
+args="$1"; shift
 for k in "$@"; do
   for rep in 1 2; do
-    VSG_FAST_K=$k python bench.py --cpu-seconds 0 --no-extras 2>>gpurun_out/ab.err | python -c "
+    VSG_FAST_K=$k python bench.py --cpu-seconds 0 --no-extras $args 2>>gpurun_out/ab.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 s=d['roofline']['stage_ms']
