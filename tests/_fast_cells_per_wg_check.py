@@ -29,7 +29,10 @@ def frames(w, h):
 def main():
     checked = 0
     for (w, h, nf, nl, ini, mn) in ((640, 480, 1000, 8, 20, 7), (640, 480, 1500, 4, 2, 1), (752, 480, 1200, 8, 9, 8),
-                                    (416, 300, 700, 5, 20, 7)):
+                                    (416, 300, 700, 5, 20, 7),
+                                    # 40 x 69-pixel cells: their tiles (75 rows of 4 chunks) exceed the two prefetch chunks
+                                    # per thread of the narrow tile class, so these cells are staged when their turn comes
+                                    (151, 101, 200, 2, 20, 7)):
         imgs = frames(w, h)
         ex = orb.ORBextractor(nf, 1.2, nl, ini, mn, max_batch=len(imgs))
         ref = ol.OracleExtractor(nf, 1.2, nl, ini, mn)
