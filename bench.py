@@ -540,8 +540,16 @@ def main():
                     isa = {}
             per_stage = doc.get(f"{args.workload}/{B}", {})
             tr = per_stage.get(dom)
+            # gfx950 correction of the guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-B requests of wide
+            # (16 B per lane) streaming reads at 64 B, i.e. reports half their bytes -> doubled for the kernels whose
+            # global reads are 16 B per lane (FAST's tile chunks, the pyramid's level-0 region); the others read 4-8 B
+            # per lane, for which the counter is uncalibrated: raw value, a lower bound.  WRITE_SIZE is exact.
+            wide = {"fast": 2, "pyramid": 2}
             if tr:
-                traffic = tr["fetch_bytes"] + tr["write_bytes"]
+                traffic = wide.get(dom, 1) * tr["fetch_bytes"] + tr["write_bytes"]
+                if not traffic_note:
+                    traffic_note = (f"FETCH_SIZE x {wide.get(dom, 1)} (gfx950: 16-B-per-lane reads are tallied at half their "
+                                    f"bytes) + WRITE_SIZE, per launch; raw counters in {traffic_source}")
             # Issue roofline per stage.  MI355X: 1024 SIMDs; a wave64 VALU instruction holds its SIMD's vector issue
             # for 2.3 cycles (plain 32-bit add / logic / fp32) or 4.2 (everything else these kernels use; measured:
             # profiles/r01_c_ubench_valu_rates.txt).  frac_at_4_cycles prices every instruction at the classic 4
@@ -568,9 +576,10 @@ def main():
             # PMC traffic over algorithmic bytes per stage: well above 1 = wasted re-reads (the first thing to fix)
             for k, v in per_stage.items():
                 if k in stages and stages[k] > 0 and "fetch_bytes" in v:
-                    stage_traffic[k] = {"pmc_bytes": v["fetch_bytes"] + v.get("write_bytes", 0),
+                    pmc_b = wide.get(k, 1) * v["fetch_bytes"] + v.get("write_bytes", 0)
+                    stage_traffic[k] = {"pmc_bytes": pmc_b, "fetch_correction": wide.get(k, 1),
                                         "algorithmic_bytes": int(stages[k] * B),
-                                        "ratio": round((v["fetch_bytes"] + v.get("write_bytes", 0)) / (stages[k] * B), 2)}
+                                        "ratio": round(pmc_b / (stages[k] * B), 2)}
             if stage_traffic:
                 stage_traffic["_source"] = traffic_source + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except (OSError, ValueError, KeyError, ImportError):

@@ -3,9 +3,9 @@
 the form bench.py attaches to its `roofline` object: bytes / instructions PER LAUNCH of every stage kernel.
     python tools/make_traffic_json.py <tag e.g. C2/512> <out.json> <pmc_dir> [<pmc_dir> ...]
 Units as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE / WRITE_SIZE are reported in KB -> x 1024; on
-gfx950 FETCH_SIZE counts 64 B per 128-B request of wide (16 B / lane) streaming reads, i.e. half the bytes -- the
-kernels here read 4-12 B per lane, for which the counter is uncalibrated, so the raw value is kept and labelled a
-lower bound rather than doubled."""
+gfx950 FETCH_SIZE counts 64 B per 128-B request of wide (16 B / lane) streaming reads, i.e. half the bytes.  The RAW
+values are stored here; bench.py doubles FETCH_SIZE for the kernels whose global reads are 16 B per lane (FAST,
+pyramid) and keeps the raw value -- a lower bound -- for the 4-8 B per lane readers (blur, orient+desc, octree)."""
 import json
 import sys
 from pathlib import Path
