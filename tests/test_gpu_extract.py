@@ -415,3 +415,22 @@ def test_device_entry_with_aligned_and_unaligned_layouts(offset, pad):
         n = int(counts[f, 0])
         assert (n, int(counts[f, 1])) == (len(rk), mono)
         assert kps[f, :n].tobytes() == rk.tobytes() and np.array_equal(desc[f, :n], rd)
+
+
+def test_stage_timing_modes_do_not_change_results():
+    """vsg_orb_enable_timing: 1 = events around every stage (the blur runs as its own launch), 2 = events around the
+    FAST launch only (the stage chain of an untimed call); results are the same, and mode 2 fills in "fast" alone."""
+    imgs = np.stack([synth.sequence_frame(640, 480, 3, t) for t in range(4)])
+    ex = orb.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=4)
+    want = [ol.OracleExtractor(1000, 1.2, 8, 20, 7)(im) for im in imgs]
+    for mode in (0, 1, 2, 0):
+        ex.enable_timing(mode)
+        for _ in range(3):  # a timed call's events are harvested by the next one
+            outs = ex.extract_batch(imgs)
+        for t in range(4):
+            assert_same_output(outs[t], want[t], f"timing mode {mode} frame {t}")
+        ms = ex.timing_ms()
+        if mode == 1:
+            assert all(ms[k] > 0 for k in ("pyramid", "fast", "octree", "blur", "orient_desc", "total")), ms
+        elif mode == 2:
+            assert ms["fast"] > 0 and all(v == 0 for k, v in ms.items() if k != "fast"), ms
