@@ -1363,6 +1363,16 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
+// rows whose loads a blur thread keeps in flight ahead of the row it works on: 7 inside the octree's launch (the fused
+// kernel is compiled for the octree's 96 VGPRs: 311-313 k frames/s with 7-12 rows ahead against 306-308 k for the
+// fetch-7 / work-7 form, 14 spills), 14 in the blur's own launch (0.285 against 0.294 ms per 512 C2 frames; 7: 0.298)
+#ifndef VSG_BLUR_AHEAD
+#define VSG_BLUR_AHEAD 7
+#endif
+#ifndef VSG_BLUR_AHEAD_ALONE
+#define VSG_BLUR_AHEAD_ALONE 14
+#endif
+template <int kBlurAhead>
 __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                            const FrameGeom *__restrict__ fg, const Src0 &s0, BlockXY blk) {
   int level = 0;
@@ -1415,64 +1425,66 @@ __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint
   uint32_t pw[7][4], hprev[4] = {0, 0, 0, 0};
   const u16x2 K01 = {(unsigned short)k[0], (unsigned short)k[1]}, K23 = {(unsigned short)k[2], (unsigned short)k[3]},
               K45 = {(unsigned short)k[4], (unsigned short)k[5]};
+  // The 36 + 6 source rows of the strip as a software pipeline: the three dwords of row r + kBlurAhead are requested
+  // before row r is worked on, so a wave always has kBlurAhead rows' loads in flight under its arithmetic (the first form
+  // fetched 7 rows, waited for them, worked through them and only then fetched the next 7: every 7th row paid a full
+  // trip to L2 / HBM with nothing of its own to do meanwhile).  Fully unrolled: the arrays are registers, the ring
+  // indices constants.
+  constexpr int kRowsIn = kBlurStrip + 6;
+  uint32_t d0[kRowsIn], d1[kRowsIn], d2[kRowsIn];
+  auto fetch_row = [&](int rr) {
+    // REFLECT_101 of the row without a loop: rows start at >= -3 and overshoot the bottom by < h (levels are
+    // >= 64 rows, a strip is 36 + 6), so one fold per side is exact; rows past the fold are never stored
+    int ysrc = y0 - 3 + rr;
+    ysrc = ysrc < 0 ? -ysrc : ysrc;
+    ysrc = ysrc >= h ? 2 * h - 2 - ysrc : ysrc;
+    const uint8_t *row = img + (uint32_t)(ysrc * spitch + base);  // uniform base + 32-bit lane offset
+    d0[rr] = *(const u32_unaligned *)(row);
+    d1[rr] = *(const u32_unaligned *)(row + 4);
+    d2[rr] = *(const u32_unaligned *)(row + 8);
+  };
 #pragma unroll
-  for (int turn = 0; turn < (kBlurStrip + 6) / 7; turn++) {
-    // issue the loads of the next 7 rows together, then consume them
-    uint32_t d0[7], d1[7], d2[7];
+  for (int rr = 0; rr < kBlurAhead; rr++) fetch_row(rr);
 #pragma unroll
-    for (int s = 0; s < 7; s++) {
-      // REFLECT_101 of the row without a loop: rows start at >= -3 and overshoot the bottom by < h (levels are
-      // >= 64 rows, a strip is 36 + 6), so one fold per side is exact; rows past the fold are never stored
-      int ysrc = y0 - 3 + turn * 7 + s;
-      ysrc = ysrc < 0 ? -ysrc : ysrc;
-      ysrc = ysrc >= h ? 2 * h - 2 - ysrc : ysrc;
-      const uint8_t *row = img + (uint32_t)(ysrc * spitch + base);  // uniform base + 32-bit lane offset
-      d0[s] = *(const u32_unaligned *)(row);
-      d1[s] = *(const u32_unaligned *)(row + 4);
-      d2[s] = *(const u32_unaligned *)(row + 8);
-    }
+  for (int rr = 0; rr < kRowsIn; rr++) {  // source row y0 - 3 + rr
+    if (rr + kBlurAhead < kRowsIn) fetch_row(rr + kBlurAhead);
+    const int s = rr % 7;
+    uint32_t e0 = d0[rr], e1 = d1[rr], e2 = d2[rr];
     if (!interior) {
-#pragma unroll
-      for (int s = 0; s < 7; s++) {
-        const uint32_t a0 = d0[s], a1 = d1[s], a2 = d2[s];
-        d0[s] = __builtin_amdgcn_perm(a1, a0, selLo[0]) | __builtin_amdgcn_perm(0u, a2, selHi[0]);
-        d1[s] = __builtin_amdgcn_perm(a1, a0, selLo[1]) | __builtin_amdgcn_perm(0u, a2, selHi[1]);
-        d2[s] = __builtin_amdgcn_perm(a1, a0, selLo[2]) | __builtin_amdgcn_perm(0u, a2, selHi[2]);
-      }
+      const uint32_t a0 = e0, a1 = e1, a2 = e2;
+      e0 = __builtin_amdgcn_perm(a1, a0, selLo[0]) | __builtin_amdgcn_perm(0u, a2, selHi[0]);
+      e1 = __builtin_amdgcn_perm(a1, a0, selLo[1]) | __builtin_amdgcn_perm(0u, a2, selHi[1]);
+      e2 = __builtin_amdgcn_perm(a1, a0, selLo[2]) | __builtin_amdgcn_perm(0u, a2, selHi[2]);
     }
+    // pixel j: taps over bytes j+1 .. j+7 of {e0,e1,e2}
+    uint32_t H[4];
+    H[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e1, e0, 1), T0,
+                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e2, e1, 1), T1, 0u, false), false);
+    H[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e1, e0, 2), T0,
+                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e2, e1, 2), T1, 0u, false), false);
+    H[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e1, e0, 3), T0,
+                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e2, e1, 3), T1, 0u, false), false);
+    H[3] = __builtin_amdgcn_udot4(e1, T0, __builtin_amdgcn_udot4(e2, T1, 0u, false), false);
 #pragma unroll
-    for (int s = 0; s < 7; s++) {
-      const int rr = turn * 7 + s;  // 0 .. kBlurStrip+5 : source row y0 - 3 + rr
-      // pixel j: taps over bytes j+1 .. j+7 of {d0,d1,d2}
-      uint32_t H[4];
-      H[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 1), T0,
-                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 1), T1, 0u, false), false);
-      H[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 2), T0,
-                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 2), T1, 0u, false), false);
-      H[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1[s], d0[s], 3), T0,
-                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2[s], d1[s], 3), T1, 0u, false), false);
-      H[3] = __builtin_amdgcn_udot4(d1[s], T0, __builtin_amdgcn_udot4(d2[s], T1, 0u, false), false);
+    for (int j = 0; j < 4; j++) {
+      pw[s][j] = hprev[j] | (H[j] << 16);
+      hprev[j] = H[j];
+    }
+    if (rr >= 6) {
+      const int yo = y0 + rr - 6;
+      if (yo < h) {
+        uint32_t cl[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        pw[s][j] = hprev[j] | (H[j] << 16);
-        hprev[j] = H[j];
-      }
-      if (rr >= 6) {
-        const int yo = y0 + rr - 6;
-        if (yo < h) {
-          uint32_t cl[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            uint32_t acc = __umul24(k[6], H[j]) + 32768u;
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 2) % 7][j]), K01, acc, false);  // rows r-6, r-5
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 4) % 7][j]), K23, acc, false);  // rows r-4, r-3
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 6) % 7][j]), K45, acc, false);  // rows r-2, r-1
-            cl[j] = min(acc, 0x00FFFFFFu);  // saturate_cast<uchar>(acc >> 16): byte 2 of the clamped sum
-          }
-          const uint32_t out = __builtin_amdgcn_perm(cl[1], cl[0], 0x0C0C0602u) |
-                               (__builtin_amdgcn_perm(cl[3], cl[2], 0x0C0C0602u) << 16);
-          *(uint32_t *)(dst + (uint32_t)(yo * L.pitch + x0)) = out;
+        for (int j = 0; j < 4; j++) {
+          uint32_t acc = __umul24(k[6], H[j]) + 32768u;
+          acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 2) % 7][j]), K01, acc, false);  // rows r-6, r-5
+          acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 4) % 7][j]), K23, acc, false);  // rows r-4, r-3
+          acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 6) % 7][j]), K45, acc, false);  // rows r-2, r-1
+          cl[j] = min(acc, 0x00FFFFFFu);  // saturate_cast<uchar>(acc >> 16): byte 2 of the clamped sum
         }
+        const uint32_t out = __builtin_amdgcn_perm(cl[1], cl[0], 0x0C0C0602u) |
+                             (__builtin_amdgcn_perm(cl[3], cl[2], 0x0C0C0602u) << 16);
+        *(uint32_t *)(dst + (uint32_t)(yo * L.pitch + x0)) = out;
       }
     }
   }
@@ -1480,7 +1492,7 @@ __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                               const FrameGeom *__restrict__ fg, Src0 s0) {
-  blur_block(pyr, blur, fg, s0, frame_major_block());
+  blur_block<VSG_BLUR_AHEAD_ALONE>(pyr, blur, fg, s0, frame_major_block());
 }
 
 // Latency path of the blocking single-frame calls: the blur workgroups ride in the octree's launch (blocks
@@ -1502,7 +1514,7 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG
   if (blk.x < nlevels)
     octree_block(a, blk.x, blk.y, oct_lds, wtot, sort_stack);
   else
-    blur_block(pyr, blur, a.fg, s0, BlockXY{blk.x - nlevels, blk.y});
+    blur_block<VSG_BLUR_AHEAD>(pyr, blur, a.fg, s0, BlockXY{blk.x - nlevels, blk.y});
 }
 
 // ------------------------------------------------------------------------------------------------
