@@ -120,9 +120,16 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ p
   uint8_t *buf0 = pyr_lds, *buf1 = pyr_lds + ldsA;
   Short4 *s_tab = (Short4 *)(pyr_lds + ldsAB);  // the tile's slices of the resize tables, all levels
   // One round of independent global loads: the tile's (pre-rebased, contiguous) table slice and the level-0 region.
+  // Written as "request everything, then store": as a plain loop the compiler waited for every load before the next one
+  // was issued (load, vmcnt(0), ds_write, branch) -- 4-5 dependent trips to L2 / HBM for the region and 3 more for the
+  // table at the head of every workgroup.  Every lane loads (clamped index) so that the requests stay one block.
   {
+    constexpr int kTabAhead = 4, kRegAhead = 6;  // per thread: table entries (8 B) / region chunks (16 B) requested at once
     const Short4 *tt = tile_tab + T.tab_off;
-    for (int i = tid; i < T.tab_n; i += kPyrThreads) s_tab[i] = tt[i];
+    const int tab_n = T.tab_n;
+    Short4 tv[kTabAhead];
+#pragma unroll
+    for (int k = 0; k < kTabAhead; k++) tv[k] = tt[min(tid + k * kPyrThreads, tab_n - 1)];
     const int x0a = T.need[0][0] & ~3, y0 = T.need[0][1];
     const int w4 = ((T.need[0][2] - x0a) + 3) >> 2, hh = T.need[0][3] - y0, pitch = 4 * w4;
     const uint8_t *src = s0.base + (size_t)frame * s0.frame_stride + (size_t)y0 * s0.pitch + x0a;
@@ -141,15 +148,34 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ p
     } else {
       // 16 bytes per lane; the last load of a row is pulled back so that it ends with the row (see k_fast_cells)
       typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
-      const int nq4 = (w4 + 3) >> 2;
+      const int nq4 = (w4 + 3) >> 2, n = nq4 * hh;
       const float inv = __builtin_amdgcn_rcpf((float)nq4);
-      for (int i = tid; i < nq4 * hh; i += kPyrThreads) {
+      u32x4u rv[kRegAhead];
+      int ro[kRegAhead];
+#pragma unroll
+      for (int k = 0; k < kRegAhead; k++) {
+        const int i = min(tid + k * kPyrThreads, n - 1);
+        const int r = div_small(i, inv), c = min(4 * (i - r * nq4), w4 - 4);
+        rv[k] = *(const u32x4u *)(src + (uint32_t)(r * s0.pitch + 4 * c));
+        ro[k] = r * pitch + 4 * c;
+      }
+#pragma unroll
+      for (int k = 0; k < kRegAhead; k++)
+        if (tid + k * kPyrThreads < n) {
+          uint32_t *d = (uint32_t *)(buf0 + ro[k]);
+          d[0] = rv[k].x, d[1] = rv[k].y, d[2] = rv[k].z, d[3] = rv[k].w;
+        }
+      for (int i = tid + kRegAhead * kPyrThreads; i < n; i += kPyrThreads) {  // regions beyond 24 KB
         const int r = div_small(i, inv), c = min(4 * (i - r * nq4), w4 - 4);
         const u32x4u v = *(const u32x4u *)(src + (uint32_t)(r * s0.pitch + 4 * c));
         uint32_t *d = (uint32_t *)(buf0 + r * pitch + 4 * c);
         d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
       }
     }
+#pragma unroll
+    for (int k = 0; k < kTabAhead; k++)
+      if (tid + k * kPyrThreads < tab_n) s_tab[tid + k * kPyrThreads] = tv[k];
+    for (int i = tid + kTabAhead * kPyrThreads; i < tab_n; i += kPyrThreads) s_tab[i] = tt[i];
   }
   __syncthreads();
   uint8_t *frame_base = pyr + (size_t)frame * fg->pyr_frame_bytes;
