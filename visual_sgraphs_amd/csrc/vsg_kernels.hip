@@ -1530,13 +1530,21 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 #define VSG_OB_WAVES 5
 #endif
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG_OB_WAVES, VSG_OB_WAVES))) void k_octree_blur(
-    OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels) {
+    OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels, int nframes, int lead) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[3 * kSortStack];
   static_assert(kOctThreads == 256, "the blur body is written for 256-thread workgroups");
   // frame-major over the combined grid: the workgroups that share an XCD (and its L2) work on whole frames
-  const BlockXY blk = frame_major_block();
+  BlockXY blk = frame_major_block();
+  if (lead > 0) {
+    // The octree workgroups run `lead` rows of the grid AHEAD of the blur workgroups (grid rows = frames + lead): an
+    // octree workgroup lives several times as long as a blur workgroup, and dealt out frame by frame the last frames'
+    // octrees were a tail of the launch with most workgroup slots empty (3.5 of 5 waves per SIMD resident on average).
+    // Row r: octree of frame r (if there is one), blur of frame r - lead (if there is one).
+    if (blk.x >= nlevels) blk.y -= lead;
+    if (blk.y < 0 || blk.y >= nframes) return;
+  }
   if (blk.x < nlevels)
     octree_block(a, blk.x, blk.y, oct_lds, wtot, sort_stack);
   else
@@ -2154,8 +2162,11 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   const OctArgs a = {d_fg, cand, cand_count, d_cells, cell_count, cand2, node_of, sel, sel_count, cap, prefix_off};
   if (blur_out) {  // the blur of the same frames as extra workgroups of this launch (latency path)
     lds_limit_ensure(2, dev, (const void *)k_octree_blur, lds);
-    hipLaunchKernelGGL(k_octree_blur, dim3(fg.nlevels + fg.total_blur_blocks, nframes), dim3(kOctThreads), lds, s, a, blur_pyr,
-                       blur_out, *blur_s0, fg.nlevels);
+    // octree workgroups `lead` frames ahead of the blur's (see the kernel); only for launches long enough to have a tail
+    static const int lead_env = getenv("VSG_OB_LEAD") ? atoi(getenv("VSG_OB_LEAD")) : 64;
+    const int lead = nframes >= 4 * lead_env && lead_env > 0 ? (lead_env + 7) & ~7 : 0;  // multiple of 8: whole XCD rounds
+    hipLaunchKernelGGL(k_octree_blur, dim3(fg.nlevels + fg.total_blur_blocks, nframes + lead), dim3(kOctThreads), lds, s, a,
+                       blur_pyr, blur_out, *blur_s0, fg.nlevels, nframes, lead);
     return;
   }
   lds_limit_ensure(1, dev, (const void *)k_octree, lds);
