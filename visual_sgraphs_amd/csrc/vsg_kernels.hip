@@ -625,7 +625,7 @@ __global__ __launch_bounds__(NT) void k_fast_cells_v2(const uint8_t *__restrict_
 //  * Workgroups of several consecutive cells with the next cell's tile in flight, one 32-byte record per cell
 //    (k_fast_cells below), and the register caps that keep 8 waves per SIMD resident.
 template <int kTileP>
-__device__ __forceinline__ int fast_score_side(const uint8_t *c, int floor_t, uint32_t dark) {
+__device__ __forceinline__ int fast_score_side_raw(const uint8_t *c, uint32_t dark) {
   const int P = kTileP;
   // lane pair (d[k], d[k+8]) of side-signed differences, one v_pk_mad_i16 each: ring * (-1) + v (dark), ring - v (bright)
   const short sv = dark ? (short)c[0] : (short)-(int)c[0], sn = dark ? (short)-1 : (short)1;
@@ -660,7 +660,11 @@ __device__ __forceinline__ int fast_score_side(const uint8_t *c, int floor_t, ui
   s16x2 A = (s16x2){-256, -256};
 #pragma unroll
   for (int k = 0; k < 8; k++) A = pk_max(A, pk_min(H[k], pk_swap(G[k])));
-  const int s = max((int)A.x, (int)A.y) - 1;
+  return max((int)A.x, (int)A.y) - 1;
+}
+template <int kTileP>
+__device__ __forceinline__ int fast_score_side(const uint8_t *c, int floor_t, uint32_t dark) {
+  const int s = fast_score_side_raw<kTileP>(c, dark);
   return s >= floor_t ? s : 0;
 }
 
@@ -946,17 +950,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
           __syncthreads();
           // ---- phase 2: exact score of the queued pixels on their flagged side; entries that do not score are dropped
           // (retry-flagged ones -- single-entry cells only -- become bright-side entries for the second pass below)
+          const int thr1 = max(thr, 1);
           for (int q = tid; q < nq; q += NT) {
             const uint32_t ent = queue[q];
             const int e = (ent >> 5) & 1023, b = ent & 31;
             const int r = div_small(e, inv_nrun), rr = e - r * nrun;
             // byte b >> 3 = pixel inside its dword; bit 1 of b: second dword of the run
             const int c = 4 * (g0 + 2 * rr) - 3 - ox + (b >> 3) + ((b & 2) << 1);
-            const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, ent & 1u);
+            const int s = fast_score_side_raw<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], ent & 1u);
             const uint32_t rc = (uint32_t)((r << 7) | c);
-            if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
             // phase 3 reads row << 7 | column; 0xFFFF = dropped; bit 14 = bright-side retry (single-entry cells only)
-            queue[q] = (uint16_t)(s ? rc : (ent & 0x8000u) ? (rc | 0x4000u) : 0xFFFFu);
+            if (s >= thr1) {  // thr1 = max(thr, 1): a corner at the threshold, and never a zero score
+              score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
+              queue[q] = (uint16_t)rc;
+            } else {
+              queue[q] = (uint16_t)((ent & 0x8000u) ? (rc | 0x4000u) : 0xFFFFu);
+            }
           }
           __syncthreads();
           if (single) {
