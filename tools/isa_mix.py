@@ -42,7 +42,7 @@ def main():
                                  and "octree_blur" not in m.group(1)), None)
                     if name == "orient_desc" and "ILb1E" in m.group(1):
                         name = None  # the mirroring variant of the latency path
-                    if name == "fast" and "Li128ELi52ELi44E" not in m.group(1):
+                    if name == "fast" and "Li128ELi52ELi52E" not in m.group(1):
                         name = None  # the tile-pitch class of 640x480
                     counts = {"full": 0, "half": 0, "dpp_sdwa": 0} if name else None
                     continue

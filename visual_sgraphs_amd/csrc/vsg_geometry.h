@@ -386,6 +386,12 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
     R.w[4] = mask8(cb0 < 0 ? (0xFFu << (-cb0)) & 0xFFu : 0xFFu);
     R.w[5] = mask8(over <= 0 ? 0xFFu : over >= 8 ? 0u : (1u << (8 - over)) - 1u);
   }
+  {
+    // k_fast_cells: a queue entry holds a run's dword index in the tile in 11 bits, a surviving pixel's byte offset in
+    // 13 (vsg_kernels.hip); the tile pitch classes are launch_fast's.  The reference's 35 px cell grid gives <= 69 x 69.
+    const int tp = G.fastMaxVw <= 40 ? 52 : G.fastMaxVw <= 56 ? 68 : 84;
+    if (G.fastMaxVw + 9 > tp || (G.fastMaxVh + 7) * tp > 8192) return -3;
+  }
   fg.cand_frame = cand_off;
   fg.sel_frame = sel_off;
   fg.total_cells = (int)G.cells.size();

@@ -624,27 +624,29 @@ __global__ __launch_bounds__(NT) void k_fast_cells_v2(const uint8_t *__restrict_
 //    flag's bit, and the lane that scores an entry turns it into (row, column).
 //  * Workgroups of several consecutive cells with the next cell's tile in flight, one 32-byte record per cell
 //    (k_fast_cells below), and the register caps that keep 8 waves per SIMD resident.
+// c0 = the centre pixel's address - (3 P + 1): every ring byte then sits at a non-negative offset from ONE register
+// (LDS instructions take unsigned immediates; from the centre the compiler rebased and added per negative offset)
 template <int kTileP>
-__device__ __forceinline__ int fast_score_side_raw(const uint8_t *c, uint32_t dark) {
+__device__ __forceinline__ int fast_score_side_raw(const uint8_t *c0, uint32_t dark) {
   const int P = kTileP;
-  // lane pair (d[k], d[k+8]) of side-signed differences, one v_pk_mad_i16 each: ring * (-1) + v (dark), ring - v (bright)
-  const short sv = dark ? (short)c[0] : (short)-(int)c[0], sn = dark ? (short)-1 : (short)1;
-  const s16x2 vs = {sv, sv}, ns = {sn, sn};
+  const uint8_t *c = c0 + (3 * P + 1);
   // (ds_read_u8_d16 / _d16_hi into the two halves of one register would save the packing, but with SRAM ECC on -- as on
   // this part -- a D16 load clears the other half instead of keeping it)
-  auto pair = [&](int o_lo, int o_hi) -> s16x2 {
-    const uint32_t x = (uint32_t)c[o_lo] | ((uint32_t)c[o_hi] << 16);
-    return __builtin_bit_cast(s16x2, x) * ns + vs;
-  };
+  // the centre and the 16 ring bytes are requested back to back and waited for once (the empty asm needs all of them):
+  // left alone the scheduler interleaves read / wait / use pairs, one LDS round trip after the other
+  const int olo[8] = {3 * P, 3 * P + 1, 2 * P + 2, P + 3, 3, -P + 3, -2 * P + 2, -3 * P + 1};
+  uint32_t lo[8], hi[8], ctr = c[0];
+#pragma unroll
+  for (int k = 0; k < 8; k++) lo[k] = c[olo[k]], hi[k] = c[-olo[k]];
+  asm volatile("" : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+                    "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]),
+                    "+v"(ctr));
+  // lane pair (d[k], d[k+8]) of side-signed differences, one v_pk_mad_i16 each: ring * (-1) + v (dark), ring - v (bright)
+  const short sv = dark ? (short)ctr : (short)-(int)ctr, sn = dark ? (short)-1 : (short)1;
+  const s16x2 vs = {sv, sv}, ns = {sn, sn};
   s16x2 D[8];
-  D[0] = pair(3 * P, -3 * P);
-  D[1] = pair(3 * P + 1, -3 * P - 1);
-  D[2] = pair(2 * P + 2, -2 * P - 2);
-  D[3] = pair(P + 3, -P - 3);
-  D[4] = pair(3, -3);
-  D[5] = pair(-P + 3, P - 3);
-  D[6] = pair(-2 * P + 2, 2 * P - 2);
-  D[7] = pair(-3 * P + 1, 3 * P - 1);
+#pragma unroll
+  for (int k = 0; k < 8; k++) D[k] = __builtin_bit_cast(s16x2, lo[k] | (hi[k] << 16)) * ns + vs;
   // Minimum over every 9-arc with prefix / suffix minima of the two half rings (the packed lanes): with G[i] = min of
   // D[0..i] and H[i] = min of D[i..7] (low half: ring 0..7, high half: ring 8..15), the arc that starts at ring position
   // i is H_lo[i] with G_hi[i] and the one that starts at i + 8 is H_hi[i] with G_lo[i] -- pk_min(H[i], swap(G[i])) holds
@@ -663,8 +665,8 @@ __device__ __forceinline__ int fast_score_side_raw(const uint8_t *c, uint32_t da
   return max((int)A.x, (int)A.y) - 1;
 }
 template <int kTileP>
-__device__ __forceinline__ int fast_score_side(const uint8_t *c, int floor_t, uint32_t dark) {
-  const int s = fast_score_side_raw<kTileP>(c, dark);
+__device__ __forceinline__ int fast_score_side(const uint8_t *c0, int floor_t, uint32_t dark) {
+  const int s = fast_score_side_raw<kTileP>(c0, dark);
   return s >= floor_t ? s : 0;
 }
 
@@ -743,6 +745,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
     const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg, const FastCellRec *__restrict__ recs, Src0 s0,
     uint32_t *__restrict__ cand, int *__restrict__ cand_count, int *__restrict__ cell_count, int tile_bytes,
     int score_bytes, int queue_cap, int cells_per_wg) {
+  static_assert(kScoreP == kTileP, "a pixel's score offset is its tile offset minus a constant");
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
   uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);  // queue_cap entries = the largest cell's pixels
@@ -851,9 +854,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             for (int i0 = 0; i0 < nruns; i0 += NT) {
               const int i = i0 + tid;
               uint32_t F = 0;
+              int runB = 0;
               if (i < nruns) {
                 const int r = div_small(i, inv_nrun), rr = i - r * nrun;
-                const uint32_t *pc = (const uint32_t *)&qtile[(r + 3) * kTileP + 4 * (g0 + 2 * rr)];
+                runB = (r + 3) * kTileP + 4 * (g0 + 2 * rr);  // the run's first byte in the tile
+                const uint32_t *pc = (const uint32_t *)&qtile[runB];
                 const uint32_t *pu = pc - 3 * (kTileP / 4), *pd = pc + 3 * (kTileP / 4);
                 uint32_t qc[4] = {pc[-1], pc[0], pc[1], pc[2]};
                 // Bytes of the 6-bit tile that were never staged (beyond a row's last staged dword) may hold anything, and
@@ -880,7 +885,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
                 int base = 0;
                 if (lane == 0) base = lds_add_rtn(&s_cnt[4], __popcll(hit));
                 const int slot = __builtin_amdgcn_readfirstlane(base) + mbcnt64(hit);
-                if (F) runF[slot] = F, runI[slot] = (uint16_t)i;
+                if (F) runF[slot] = F, runI[slot] = (uint16_t)runB;
               }
             }
           }
@@ -890,9 +895,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
           if (seg && tid == 0) *my_count = 0;
           goto cell_done;
 #endif
-          // ---- run list -> pixel queue.  Entry = retry << 15 | run index << 5 | bit position of the flag in the run's word
-          // (bit 0 of the position: dark side); phase 2 turns an entry into row << 7 | column (rows, columns < 70) once per
-          // lane instead of once per entry of the unpack loop.  A pixel that passed the necessary test on both sides (noise
+          // ---- run list -> pixel queue.  Entry = the run's dword index in the tile << 5 | bit position of the flag in the
+          // run's word (bit 0 of the position: dark side; bit 2, set in every flag position, cleared = retry); phase 2 turns
+          // an entry into the pixel's byte offset in the tile -- two shifts and two masks, no division by the run count, no
+          // multiply by the row pitch -- once per lane instead of once per entry of the unpack loop.  A pixel that passed the necessary test on both sides (noise
           // at low thresholds) normally gets one entry per side -- a spare lane in phase 2, at most one of the two can score.
           // That can exceed the queue (one slot per pixel of the largest cell) when most of a cell passes on both sides;
           // such a cell is unpacked again with ONE entry per pixel: both-sided pixels flagged dark + retry, scored dark
@@ -915,14 +921,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
                 // the total then exceeds the capacity and the cell is unpacked again below
                 if (wbase + wtotal <= queue_cap) {
                   uint16_t *qp = queue + (wbase + incl - cnt);
-                  const uint32_t ent0 = e << 5;
+                  const uint32_t ent0 = e << 3;  // e = the run's byte offset in the tile, a multiple of 4: dword index << 5
                   while (P) {
                     const uint32_t b = (uint32_t)__builtin_ctz(P);
                     P &= P - 1;
                     uint32_t ent = ent0 + b;  // bit 0 of b is the dark flag's bit of the pair
                     if (single) {
                       const uint32_t fb = (F >> b) & 3u;  // b = the bright flag's (even) position: bit 1 dark, bit 0 bright
-                      ent += (fb >> 1) + (((fb + 1u) & 4u) << 13);
+                      ent += (fb >> 1) - ((fb + 1u) & 4u);  // both sides: dark first, bit 2 cleared = retry bright
                     }
                     *qp++ = (uint16_t)ent;
                   }
@@ -951,20 +957,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
           // ---- phase 2: exact score of the queued pixels on their flagged side; entries that do not score are dropped
           // (retry-flagged ones -- single-entry cells only -- become bright-side entries for the second pass below)
           const int thr1 = max(thr, 1);
+          // score rows have the tile's pitch, so pixel (r, c) of the cell -- tile byte (r + 3) * P + c + 3 + ox -- has its
+          // score at (r + 1) * P + c + 1 = tile offset - soff0: one subtraction apart
+          // fast_score_side_raw's bias, hidden from the compiler: it would fold "- bias + (bias + ring offset)" back into
+          // signed offsets from the centre and spend an add on every negative one
+          int kBias = 3 * kTileP + 1;
+          asm volatile("" : "+s"(kBias));
+          const uint8_t *tile_b = tile - kBias;
+          const int soff0 = 2 * kTileP + 2 + ox;
           for (int q = tid; q < nq; q += NT) {
             const uint32_t ent = queue[q];
-            const int e = (ent >> 5) & 1023, b = ent & 31;
-            const int r = div_small(e, inv_nrun), rr = e - r * nrun;
-            // byte b >> 3 = pixel inside its dword; bit 1 of b: second dword of the run
-            const int c = 4 * (g0 + 2 * rr) - 3 - ox + (b >> 3) + ((b & 2) << 1);
-            const int s = fast_score_side_raw<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], ent & 1u);
-            const uint32_t rc = (uint32_t)((r << 7) | c);
-            // phase 3 reads row << 7 | column; 0xFFFF = dropped; bit 14 = bright-side retry (single-entry cells only)
+            // ent >> 3 = dword index * 4 + byte (b >> 3) inside its dword; + 4 for the second dword of the run (bit 1 of b)
+            const uint32_t t0 = (ent >> 3) + ((ent << 1) & 4u);
+            const int s = fast_score_side_raw<kTileP>(&tile_b[t0], ent & 1u);
+            const uint32_t so = t0 - (uint32_t)soff0;
+            // phase 3 reads the score offset; 0xFFFF = dropped; bit 14 = bright-side retry (single-entry cells only)
             if (s >= thr1) {  // thr1 = max(thr, 1): a corner at the threshold, and never a zero score
-              score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
-              queue[q] = (uint16_t)rc;
+              score[so] = (uint8_t)s;
+              queue[q] = (uint16_t)so;
             } else {
-              queue[q] = (uint16_t)((ent & 0x8000u) ? (rc | 0x4000u) : 0xFFFFu);
+              queue[q] = (uint16_t)((ent & 4u) ? 0xFFFFu : (so | 0x4000u));
             }
           }
           __syncthreads();
@@ -972,10 +984,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             for (int q = tid; q < nq; q += NT) {
               const uint32_t ent = queue[q];
               if ((ent >> 14) != 1u) continue;  // bright side, retry flag: the dark side did not score
-              const int r = (ent >> 7) & 127, c = ent & 127;
-              const int s = fast_score_side<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr, 0u);
+              const uint32_t so = ent & 0x3FFFu;
+              const int s = fast_score_side<kTileP>(&tile_b[so + (uint32_t)soff0], thr, 0u);
               if (s)
-                score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
+                score[so] = (uint8_t)s, queue[q] = (uint16_t)so;
               else
                 queue[q] = 0xFFFFu;
             }
@@ -989,19 +1001,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
           // ---- phase 3: non-max suppression inside the cell
           keep = 0;  // bit per loop iteration: queued pixel survives NMS
           int it = 0;
+          int nbias = kScoreP + 1;  // the 3 x 3 neighbourhood at non-negative offsets from one register (see kBias)
+          asm volatile("" : "+s"(nbias));
+          const uint8_t *score_b = score - nbias;
           for (int q = tid; q < nq; q += NT, it++) {
             const uint32_t ent = queue[q];
             if (ent == 0xFFFFu) continue;
-            const int r = (ent >> 7) & 127, c = ent & 127;
-            const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
-            const int s = sp[0];
-            int mx = max(max((int)sp[-1], (int)sp[1]), (int)sp[-kScoreP - 1]);
-            mx = max(max(mx, (int)sp[-kScoreP]), (int)sp[-kScoreP + 1]);
-            mx = max(max(mx, (int)sp[kScoreP - 1]), (int)sp[kScoreP]);
-            mx = max(mx, (int)sp[kScoreP + 1]);
+            const uint8_t *sp = &score_b[ent] + (kScoreP + 1);
+            // nine reads back to back, one wait (see fast_score_side_raw)
+            int s = sp[0], n0 = sp[-kScoreP - 1], n1 = sp[-kScoreP], n2 = sp[-kScoreP + 1], n3 = sp[-1], n4 = sp[1],
+                n5 = sp[kScoreP - 1], n6 = sp[kScoreP], n7 = sp[kScoreP + 1];
+            asm volatile("" : "+v"(s), "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7));
+            const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
             if (s > mx) {
               if (seg) {
-                seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell_x0 + c - kFastBorder, cell_y0 + r - kFastBorder, s);
+                const int r1 = div_small((int)ent, 1.0f / kScoreP), c1 = (int)ent - r1 * kScoreP;  // row + 1, column + 1
+                seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell_x0 + c1 - 1 - kFastBorder, cell_y0 + r1 - 1 - kFastBorder, s);
               } else {
                 keep |= 1u << it;
                 atomicAdd(&s_cnt[0], 1);
@@ -1031,10 +1046,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
         for (int q = tid; q < nq; q += NT, it++) {
           if (!(keep & (1u << it))) continue;
           const uint32_t ent = queue[q];
-          const int r = (ent >> 7) & 127, c = ent & 127;
-          const int s = score[(r + 1) * kScoreP + (c + 1)];
+          const int r1 = div_small((int)ent, 1.0f / kScoreP), c1 = (int)ent - r1 * kScoreP;
+          const int s = score[ent];
           const int slot = base + atomicAdd(&s_cnt[2], 1);
-          if (slot < L.cand_cap) out[slot] = pack_cand(cell_x0 + c - kFastBorder, cell_y0 + r - kFastBorder, s);
+          if (slot < L.cand_cap) out[slot] = pack_cand(cell_x0 + c1 - 1 - kFastBorder, cell_y0 + r1 - 1 - kFastBorder, s);
         }
       }
     }
@@ -2143,13 +2158,14 @@ void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const
                  const FastCellRec *d_recs, const Src0 &s0,
                  uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea,
                  int nframes) {
-  // tile row = up to 3 alignment bytes + vw + 6 ring bytes, rounded up to dwords; score row = vw + 2
+  // tile row = up to 3 alignment bytes + vw + 6 ring bytes, rounded up to dwords; score rows (vw + 2 used) have the
+  // tile's pitch: a pixel's score sits a constant away from its tile byte (k_fast_cells phase 2)
   if (maxVw <= 40)
-    launch_fast_t<VSG_FAST_NT, 52, 44, 2>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 52, 52, 2>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
   else if (maxVw <= 56)
-    launch_fast_t<VSG_FAST_NT, 68, 60, 3>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 68, 68, 3>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
   else
-    launch_fast_t<VSG_FAST_NT, 84, 76, 4>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 84, 84, 4>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
 }
 // dynamic LDS of one octree workgroup (also what every blur workgroup of the fused launch is charged)
 size_t octree_lds_bytes(const FrameGeom &fg, int maxQuota, int maxCellsPerLevel) {
