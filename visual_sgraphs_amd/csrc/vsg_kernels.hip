@@ -835,7 +835,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
         const int g0 = C.g0(), nrun = C.nrun(), nruns = nrun * vh;
         uint16_t *runI = (uint16_t *)(runF + nruns);  // 6 bytes per run <= the score row pitch (static_assert at the launcher)
         const float inv_nrun = __builtin_amdgcn_rcpf((float)nrun);
-        const uint32_t first_mask = C.first_mask, last_mask = C.last_mask;
+        // Phase 1 lane layout, fixed for the cell: lane -> (row r0 of a band of rows_it rows, run rr of the row); a lane's
+        // run masks, tile offset and the "left of column 0" fix are then per-cell values and the loop over bands adds a
+        // uniform stride -- per iteration that was a division, three multiplies and six mask instructions per lane.
+        const int rows_it = __builtin_amdgcn_readfirstlane(div_small(NT, inv_nrun));  // whole rows per iteration (nrun <= 15: >= 8)
+        const int p1_row = div_small(tid, inv_nrun), p1_rr = tid - p1_row * nrun;
+        const int p1_r0 = p1_row < rows_it ? p1_row : 1 << 20;  // lanes past the last whole row idle
+        const uint32_t p1_mask = (p1_rr == 0 ? C.first_mask : 0xF0F0F0F0u) & (p1_rr == nrun - 1 ? C.last_mask : 0xF0F0F0F0u);
+        const uint32_t p1_left = g0 == 0 && p1_rr == 0 ? 0u : ~0u;  // and-mask of the dword left of the run (see below)
+        const int p1_off = (p1_row + 3) * kTileP + 4 * (g0 + 2 * p1_rr);
         uint32_t keep = 0;
         int nq = 0, thr = iniTh;
         for (int pass = 0; pass < 2; pass++) {
@@ -851,20 +859,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
           {
             const int t6 = thr <= 2 ? 0 : min(64, (thr + 1) >> 2);  // ceil((t - 2) / 4)
             const uint32_t K = (uint32_t)(128 - t6) * 0x01010101u, H = 0x80808080u;
-            for (int i0 = 0; i0 < nruns; i0 += NT) {
-              const int i = i0 + tid;
+            for (int rb = 0; rb < vh; rb += rows_it) {
               uint32_t F = 0;
-              int runB = 0;
-              if (i < nruns) {
-                const int r = div_small(i, inv_nrun), rr = i - r * nrun;
-                runB = (r + 3) * kTileP + 4 * (g0 + 2 * rr);  // the run's first byte in the tile
+              const int runB = p1_off + rb * kTileP;  // the run's first byte in the tile
+              if (rb + p1_r0 < vh) {
                 const uint32_t *pc = (const uint32_t *)&qtile[runB];
                 const uint32_t *pu = pc - 3 * (kTileP / 4), *pd = pc + 3 * (kTileP / 4);
                 uint32_t qc[4] = {pc[-1], pc[0], pc[1], pc[2]};
                 // Bytes of the 6-bit tile that were never staged (beyond a row's last staged dword) may hold anything, and
                 // a byte above 63 carries into the bytes ABOVE it.  Those are pixels further right, invalid like the
                 // byte itself -- except in the dword left of tile column 0, whose bytes sit BELOW a valid pixel's neighbour
-                if (g0 == 0 && rr == 0) qc[0] = 0;
+                qc[0] &= p1_left;
                 uint32_t f[2];
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
@@ -878,7 +883,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
                 }
                 F = VSG_BITOP3(f[1], f[0] >> 2, 0xC0C0C0C0u, (A & C) | (B & ~C));
                 // the run masks hold flag bits only (0xF0 per byte), so they also clear what the merges above left below them
-                F &= (rr == 0 ? first_mask : 0xF0F0F0F0u) & (rr == nrun - 1 ? last_mask : 0xF0F0F0F0u);
+                F &= p1_mask;
               }
               const uint64_t hit = __ballot(F != 0);
               if (hit) {
