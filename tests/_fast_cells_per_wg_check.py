@@ -32,7 +32,10 @@ def main():
                                     (416, 300, 700, 5, 20, 7),
                                     # 40 x 69-pixel cells: their tiles (75 rows of 4 chunks) exceed the two prefetch chunks
                                     # per thread of the narrow tile class, so these cells are staged when their turn comes
-                                    (151, 101, 200, 2, 20, 7)):
+                                    (151, 101, 200, 2, 20, 7),
+                                    # one column of 69-pixel-wide cells: the widest tile class (84-byte rows, 4 chunks per
+                                    # thread); and 45 x 51 cells: the middle one (68-byte rows)
+                                    (101, 151, 200, 2, 20, 7), (165, 133, 300, 2, 20, 7)):
         imgs = frames(w, h)
         ex = orb.ORBextractor(nf, 1.2, nl, ini, mn, max_batch=len(imgs))
         ref = ol.OracleExtractor(nf, 1.2, nl, ini, mn)
