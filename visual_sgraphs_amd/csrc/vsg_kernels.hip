@@ -776,16 +776,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
   // Every lane loads (the ones past the last chunk load it again): the kPre loads of a thread stay one block of
   // back-to-back instructions -- behind per-load branches the compiler put a vmcnt(0) in front of each.
   // Not for slivers (rows shorter than a chunk) or tiles beyond kPre chunks per thread: staged when their turn comes.
+  // (row, first dword) of a thread's chunks only depend on the chunks per row, which rarely change from cell to cell: kept
+  // across cells in the narrow tile class (the wider ones have no registers to spare) and clamped per cell instead of
+  // divided out again
+  constexpr bool kKeepRC = kPre == 2;
+  int rc_nq4 = 0, rc_r[kKeepRC ? kPre : 1], rc_c[kKeepRC ? kPre : 1];
   auto fetch = [&](const FastCell &N) -> bool {
     const int n = N.nq4() * N.th();
     if (!N.live() || N.tdw() < 4 || n > kPre * NT) return false;
-    const float inv_nq4 = __builtin_amdgcn_rcpf((float)N.nq4());
+    if constexpr (kKeepRC) {
+      if (N.nq4() != rc_nq4) {  // workgroup-uniform
+        rc_nq4 = N.nq4();
+        const float inv_nq4 = __builtin_amdgcn_rcpf((float)rc_nq4);
 #pragma unroll
-    for (int k = 0; k < kPre; k++) {
-      const int i = min(tid + k * NT, n - 1);
-      const int r = div_small(i, inv_nq4), c = min(4 * (i - r * N.nq4()), N.tdw() - 4);
-      pre[k] = *(const u32x4u *)(N.tsrc + (uint32_t)(r * N.pitch + 4 * c));
-      pre_off[k] = r * kTileP + 4 * c;
+        for (int k = 0; k < kPre; k++) {
+          rc_r[k] = div_small(tid + k * NT, inv_nq4);
+          rc_c[k] = 4 * (tid + k * NT - rc_r[k] * rc_nq4);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kPre; k++) {
+        // chunks past the tile's last (tid + k NT >= n: never committed) re-read a chunk of its last row
+        const int r = min(rc_r[k], N.th() - 1), c = min(rc_c[k], N.tdw() - 4);
+        pre[k] = *(const u32x4u *)(N.tsrc + (uint32_t)(r * N.pitch + 4 * c));
+        pre_off[k] = r * kTileP + 4 * c;
+      }
+    } else {
+      const float inv_nq4 = __builtin_amdgcn_rcpf((float)N.nq4());
+#pragma unroll
+      for (int k = 0; k < kPre; k++) {
+        const int i = min(tid + k * NT, n - 1);
+        const int r = div_small(i, inv_nq4), c = min(4 * (i - r * N.nq4()), N.tdw() - 4);
+        pre[k] = *(const u32x4u *)(N.tsrc + (uint32_t)(r * N.pitch + 4 * c));
+        pre_off[k] = r * kTileP + 4 * c;
+      }
     }
     return true;
   };
