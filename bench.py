@@ -232,6 +232,9 @@ def main():
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--ramp-steps", type=int, default=150,
+                    help="untimed steps BEFORE the W warm-up steps: the GPU needs ~0.1-0.2 s of load to reach its steady "
+                         "clocks (K = 20 after W = 5: 317.7 k frames/s, after 100+ steps of load: 325.1 k; DESIGN.md section 5)")
     ap.add_argument("--no-rotate-inputs", action="store_true",
                     help="N = 1: extract the same resident batch every step instead of alternating between two")
     ap.add_argument("--match-stream", type=int, default=0, choices=[0, 1],
@@ -498,6 +501,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(max(args.ramp_steps, 0)):  # clock ramp: the same count on every rank (steps may hold collectives)
+        step()
     for _ in range(Wu):
         step()
     barrier()
@@ -728,6 +733,8 @@ def main():
                                         "k + 1 (two alternating output sets); all K matches end inside the timed region"}
                       if overlap_match["on"] else {}),
                    "keypoints_per_frame": round(n_kp, 1),
+                   "clock_ramp": f"{max(args.ramp_steps, 0)} untimed steps before the {Wu} warm-up steps (the GPU reaches its "
+                                 "steady clocks after ~0.1-0.2 s of load)",
                    "inputs": "resident in HBM" + (": two batches (the frames in forward / reverse order) alternate from step to "
                                                   "step" if rotate else "")},
         "parity": {"bit_exact_vs_oracle": parity, "checked_frames": [0, B - 1]},
