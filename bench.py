@@ -189,8 +189,9 @@ def device_rate(workload, batch, steps, device, cpu_seconds=3.0):
     L = orb.load_library()
     vp = C.c_void_p
     with torch.cuda.stream(st):
-        for i in range(steps + 3):
-            if i == 3:
+        warm = 150  # untimed: the GPU's clocks have dropped during the CPU legs before this one (see --ramp-steps)
+        for i in range(steps + warm):
+            if i == warm:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             d_desc[0].copy_(d_desc[batch])
