@@ -210,7 +210,12 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ p
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int ci = min(max(4 * cg + k - (dx0 - dx0a), 0), dw - 1);  // columns outside the needed range: any value
-        const Short4 tx = txv[ci];
+        // the whole 8-byte entry in ONE aligned LDS read: left alone the compiler fetches the three fields it needs as
+        // ds_read_i16 + ds_read_b32 at offset 2 -- a mis-aligned dword read, which the LDS serves one lane at a time
+        // (64 cycles, profiles/r03_g_ubench_lds_rates.txt); the empty asm makes it need all 64 bits
+        uint2 tw = *(const uint2 *)&txv[ci];
+        asm volatile("" : "+v"(tw.x), "+v"(tw.y));
+        const Short4 tx = {(int16_t)(tw.x & 0xFFFFu), (int16_t)(tw.x >> 16), (int16_t)(tw.y & 0xFFFFu), 0};
         if (k == 0) o = tx.a;
         const uint32_t f = (uint32_t)(tx.a - o);  // 0..6 (vsg_geometry.h checks the span)
         sel[k] = f | (0x0Cu << 8) | ((f + 1) << 16) | (0x0Cu << 24);
