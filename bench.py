@@ -224,6 +224,67 @@ def device_rate(workload, batch, steps, device, cpu_seconds=3.0):
             "parity": bool(ok), "cpu_oracle": {"frames_per_s": round(v1, 2), "threads": 1, "kind": "port", "frames": n1}}
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT initialising HIP (the launcher below must not touch the GPU before it starts its
+    ranks): the visibility variables if set, else the KFD topology (nodes with SIMDs), else torch's device count (which
+    does not initialise the runtime on this image)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    n = 0
+    try:
+        for node in Path("/sys/class/kfd/kfd/topology/nodes").iterdir():
+            props = dict(line.split()[:2] for line in (node / "properties").read_text().splitlines() if " " in line)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        if n:
+            return n
+    except (OSError, ValueError):
+        pass
+    import torch
+    return torch.cuda.device_count()
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment): start the N ranks -- one process per GPU,
+    `python -m torch.distributed.run` -- as a CHILD process before this one imports torch or touches a GPU, relay rank
+    0's JSON line, and fail loudly (non-zero exit, no line) if fewer than N devices are visible, a rank fails, or the line
+    does not say n_gpus == N.  Never a silent one-rank line for an N-GPU request."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.one_device:
+        have = visible_gpu_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) visible on this node\n")
+            return 2
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    for x in r.stdout.splitlines():
+        if not x.startswith("{"):
+            sys.stderr.write(x + "\n")
+    if r.returncode != 0:
+        sys.stderr.write(f"bench.py: the {n}-rank run failed (exit code {r.returncode}); no result line\n")
+        return r.returncode
+    try:
+        d = json.loads(lines[-1])
+    except (IndexError, ValueError):
+        sys.stderr.write("bench.py: the ranks printed no JSON line\n")
+        return 3
+    if d.get("n_gpus") != n:
+        sys.stderr.write(f"bench.py: asked for {n} GPUs, the line says n_gpus = {d.get('n_gpus')}\n")
+        return 3
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,12 +319,19 @@ def main():
     ap.add_argument("--one-device", action="store_true",
                     help="dry run of the multi-rank path on a single GPU: every rank uses device 0 (needs gloo)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))  # before torch / HIP are touched in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:  # a launcher / flag mismatch is an error, never a line with the wrong n_gpus
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} "
+                         "(or plain `python bench.py --gpus N`, which starts the ranks itself)")
 
     import torch
     import torch.distributed as dist
     from visual_sgraphs_amd import orb, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
@@ -271,6 +339,8 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the ORB front-end has no CPU fallback)")
     if args.one_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants device {local_rank} but only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -728,7 +798,9 @@ def main():
                    **({"exchange": args.exchange,
                        "exchange_bytes_in_per_gpu_per_step": int((world - 1) * B * rec_bytes if args.exchange == "allgather"
                                                                  else rec_bytes),
+                       # ncclCommCount / ncclCommUserRank on the live communicator (not an echo of the arguments)
                        "rccl_ranks_seen": comm.world_seen() if comm is not None else None,
+                       "rccl_rank_seen": comm.rank_seen() if comm is not None else None,
                        "dist_world_size": dist.get_world_size()} if exchange else {}),
                    **({"match_overlap": "the match of step k runs on a second HIP stream under the extraction of step "
                                         "k + 1 (two alternating output sets); all K matches end inside the timed region"}

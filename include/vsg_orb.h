@@ -29,6 +29,7 @@ extern "C" {
 #define VSG_ERR_NO_DEVICE (-4)     /* no usable HIP device / HIP runtime error at start-up */
 #define VSG_ERR_HIP (-5)           /* a HIP call failed; see vsg_last_error() */
 #define VSG_ERR_INVALID (-6)       /* bad argument */
+#define VSG_ERR_BUSY (-7)          /* submitted batches are still un-waited: vsg_orb_wait them, then retry (nothing to grow) */
 
 /* cv::KeyPoint-compatible record: pt.x pt.y size angle response octave class_id (28 bytes),
  * so a C++ adaptor can memcpy into std::vector<cv::KeyPoint>. */
@@ -61,6 +62,12 @@ int vsg_orb_get_tables(const vsg_orb *h, float *scale, float *inv_scale, float *
  * Default {18,34,49,55,49,34,18} (OpenCV 4.2.0 independent rounding); OpenCV >= 4.3 normalises to
  * {18,34,48,56,48,34,18}.  Version-sensitive, hence data. */
 int vsg_orb_set_blur_taps(vsg_orb *h, const uint16_t taps[7]);
+
+/* Launch form of ComputePyramid (ORBextractor.cc:1171-1195): -1 (default) = the fused chain kernel with the tiling the
+ * handle timed faster for its image size, 0 / 1 = the fused kernel with the 32- / 36-pixel top-level tiling, 2 = one
+ * launch per level.  Every form produces the same bytes (tests/test_gpu_extract.py runs all four against the oracle);
+ * the setter exists so that each form stays a tested path instead of an environment switch. */
+int vsg_orb_set_pyramid_tiling(vsg_orb *h, int which);
 
 /* Keypoint capacity a caller must provide per frame for images of this size (>= nfeatures + 3*nlevels,
  * ORBextractor.cc:692,753-754), or a VSG_ERR_* code. */
@@ -320,14 +327,15 @@ int vsg_host_unregister(void *ptr);
 
 /* ---- Asynchronous operator() batches (caller: Frame::ExtractORB, Frame.cc:555-563, in a throughput pipeline) -----
  * vsg_orb_submit_batch enqueues H2D + the stage chain + the output export of one batch into one of the handle's
- * vsg_orb_slots() (= 3) pipeline slots and returns at once with a ticket (>= 0); VSG_ERR_CAPACITY when every slot
- * holds a batch that has not been waited for.  H2D of batch k+1 runs beside the kernels of batch k and the export of
+ * vsg_orb_slots() (= 3) pipeline slots and returns at once with a ticket (>= 0); VSG_ERR_BUSY when every slot
+ * holds a batch that has not been waited for, and when the image size differs from the handle's current one while any
+ * ticket is still un-waited (a new size rebuilds the slots those tickets live in).  H2D of batch k+1 runs beside the kernels of batch k and the export of
  * batch k-1 (three streams).  kps / desc ([nframes][capacity] records, host memory) must stay valid until the wait
  * returns; if they are pinned (vsg_host_register) the device writes the n[i] records of every frame straight into
  * them, otherwise they are filled from the slot's pinned staging inside vsg_orb_wait -- either way only n[i] records
  * per frame cross PCIe, not `capacity`.  `gray` must stay valid until the wait returns if it is pinned; unpinned
- * input is copied before submit returns (batches of 16 frames and more: by the calling thread and up to three helper
- * threads the handle keeps asleep between batches; environment VSG_STAGE_THREADS=n, 0 = the calling thread only).  vsg_orb_wait(ticket) blocks until that batch is complete and delivers n[]
+ * input is copied before submit returns (batches of 16 frames and more: by the calling thread and three helper
+ * threads the handle keeps asleep between batches).  vsg_orb_wait(ticket) blocks until that batch is complete and delivers n[]
  * and mono_index[] (nframes entries each).  Tickets are waited for in submission order. */
 int vsg_orb_slots(const vsg_orb *h);
 /* Latency path of the BLOCKING entry points (vsg_orb_extract, vsg_orb_extract_batch with <= 8 frames; the reference
@@ -531,7 +539,10 @@ int vsg_shard_all_gather(vsg_shard *s, const int *d_counts, const vsg_keypoint *
                          int src_capacity, int nframes, void *stream);
 int vsg_shard_record(vsg_shard *s, int rank, int frame, const int **d_counts, const vsg_keypoint **d_kps,
                      const uint8_t **d_desc);
-int vsg_shard_world(const vsg_shard *s); /* ranks of the communicator */
+/* Size of the communicator and this process's rank in it AS RCCL REPORTS THEM (ncclCommCount / ncclCommUserRank on the
+ * live communicator -- not an echo of what vsg_shard_create was given); VSG_ERR_UNSUPPORTED if the loaded RCCL lacks them. */
+int vsg_shard_world(const vsg_shard *s);
+int vsg_shard_rank(const vsg_shard *s);
 /* Neighbour-only exchange for chunk-partitioned sequences (rank r owns frames [r B, (r + 1) B) of a step): matching
  * needs ONE remote record per rank and step, the predecessor rank's last frame.  Packs frame `frame` of this rank's
  * batch and sends it to rank + 1 while receiving the record of rank - 1 (cyclic): one ncclSend / ncclRecv pair on the

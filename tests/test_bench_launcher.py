@@ -1,0 +1,36 @@
+"""bench.py's --gpus handling, the parts that need no GPU: a request for more ranks than visible devices and a
+launcher / flag mismatch both end non-zero without a result line."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(args, **env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, capture_output=True, text=True, timeout=300,
+                          env=env, cwd=str(ROOT))
+
+
+def test_more_ranks_than_devices_is_refused_before_anything_starts():
+    r = _run(["--gpus", "4"], HIP_VISIBLE_DEVICES="0,1")
+    assert r.returncode == 2 and "only 2 GPU" in r.stderr and "{" not in r.stdout
+
+
+def test_world_size_and_gpus_flag_must_agree():
+    r = _run(["--gpus", "4"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and "{" not in r.stdout
+    r = _run(["--gpus", "1"], WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    assert r.returncode != 0 and "{" not in r.stdout
+
+
+def test_visible_gpu_count_reads_the_visibility_variables(monkeypatch):
+    sys.path.insert(0, str(ROOT))
+    import bench
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0

@@ -40,7 +40,7 @@ def test_submit_wait_three_batches_in_flight(pinned):
     tickets = [ex.submit_batch(batches[i], *outs[i]) for i in range(3)]
     with pytest.raises(orb.VsgError) as e:  # every slot holds an un-waited batch
         ex.submit_batch(batches[3], *outs[3])
-    assert e.value.code == -2
+    assert e.value.code == -7  # VSG_ERR_BUSY: nothing the caller could grow
     res = [ex.wait(tickets[0])]
     tickets.append(ex.submit_batch(batches[3], *outs[3]))  # the freed slot is reused while 1 and 2 are in flight
     res.append(ex.wait(tickets[1]))
@@ -69,7 +69,7 @@ def test_new_image_size_is_refused_while_tickets_are_pending():
     cap2 = ex.capacity(H, W) + 100
     with pytest.raises(orb.VsgError) as e:
         ex.submit_batch(other, np.zeros((B, cap2), orb.KP_DTYPE), np.zeros((B, cap2, 32), np.uint8))
-    assert e.value.code == -2 and "waited" in str(e.value)
+    assert e.value.code == -7 and "waited" in str(e.value)  # VSG_ERR_BUSY, not the capacity code
     n, mono = ex.wait(t)
     _check(fr, kps, desc, n, mono)
     outs = ex.extract_batch(other)  # with nothing pending the new size is taken

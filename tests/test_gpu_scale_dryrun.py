@@ -31,3 +31,28 @@ def test_two_ranks_on_one_device(exchange):
     assert d["parity"]["bit_exact_vs_oracle"] is True          # incl. the boundary match against the remote frame
     assert d["config"]["exchange"] == exchange and d["config"]["dist_world_size"] == 2
     assert d["cpu_baseline"] and d["cpu_baseline"]["value"] > 0   # N > 1 lines carry the CPU baseline too
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` WITHOUT an outer torchrun: bench.py starts the two ranks as a child process before it
+    touches the GPU and relays rank 0's line (VERDICT r3 #3: --gpus used to be parsed and never read)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--one-device", "--dist-backend", "gloo", "--exchange",
+           "boundary", "--batch", "16", "--steps", "3", "--warmup", "2", "--ramp-steps", "2", "--cpu-seconds", "1",
+           "--no-stage-timing"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["dist_world_size"] == 2 and d["parity"]["bit_exact_vs_oracle"] is True
+
+
+def test_gpus_flag_refuses_more_ranks_than_devices():
+    """One GPU on the test box: --gpus 2 (without --one-device) must fail loudly, not print a one-rank line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = "0"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
+    assert r.returncode != 0 and not [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert "only 1 GPU" in r.stderr

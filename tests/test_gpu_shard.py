@@ -142,7 +142,7 @@ def test_boundary_send_recv_world1():
         if e.code == -3:
             pytest.skip("RCCL not loadable on this box")
         raise
-    assert comm.world_seen() == 1
+    assert comm.world_seen() == 1 and comm.rank_seen() == 0  # ncclCommCount / ncclCommUserRank on the live communicator
     ex.extract_batch_device(d_gray.data_ptr(), B, H * W, H, W, W, d_kps.data_ptr(), d_desc.data_ptr(),
                             d_counts.data_ptr(), cap, (0, 0), st.cuda_stream)
     comm.send_recv_boundary(d_counts.data_ptr(), d_kps.data_ptr(), d_desc.data_ptr(), cap, B - 1, st.cuda_stream)

@@ -1,0 +1,62 @@
+"""Every environment switch the library still reads, run against the oracle (a switch without a test is an
+untested code path one variable away from a production run).  VSG_FAST_K: test_gpu_fast_multicell.py; VSG_SUBBATCH:
+test_gpu_extract.py::test_large_batch_and_sub_batches; here VSG_NO_OVERLAP (every kernel on one stream: the form the
+profiling scripts use), VSG_GRAPH (hipGraph replay of the blocking one-frame chain) and VSG_ROCTX (roctx ranges around
+the stages).  The launch forms of ComputePyramid are an API (vsg_orb_set_pyramid_tiling), tested in-process."""
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from test_gpu_extract import assert_same_output
+from visual_sgraphs_amd import orb, synth
+
+CHILD = Path(__file__).parent / "_switch_check.py"
+CSRC = Path(__file__).resolve().parent.parent / "visual_sgraphs_amd" / "csrc"
+TESTED_SWITCHES = {"VSG_FAST_K", "VSG_SUBBATCH", "VSG_NO_OVERLAP", "VSG_GRAPH", "VSG_ROCTX"}
+
+
+def test_no_untested_environment_switch_in_the_library():
+    """CPU-side guard: the set of getenv() names under csrc/ is exactly the tested set."""
+    names = set()
+    for f in list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")):
+        names |= set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', f.read_text()))
+    assert names == TESTED_SWITCHES, names ^ TESTED_SWITCHES
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["VSG_NO_OVERLAP", "VSG_GRAPH", "VSG_ROCTX", ""])
+def test_switch_gives_the_oracles_output(switch):
+    env = {k: v for k, v in os.environ.items() if k not in TESTED_SWITCHES}
+    if switch:
+        env[switch] = "1"
+    r = subprocess.run([sys.executable, str(CHILD)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ok, checked, launches = r.stdout.strip().splitlines()[-1].split()
+    assert ok == "OK" and int(checked) == 18
+    # the graph path really replayed (slots record on their second call), and only under its switch
+    assert (int(launches) >= 3) if switch == "VSG_GRAPH" else int(launches) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [-1, 0, 1, 2])
+@pytest.mark.parametrize("w,h,nl,B", [(640, 480, 8, 1), (1280, 720, 8, 1), (320, 240, 4, 40)])
+def test_every_pyramid_launch_form(which, w, h, nl, B):
+    """ComputePyramid (ORBextractor.cc:1171-1195) as the fused chain kernel with either tiling, or as one launch per level:
+    the same level bytes and the same operator() output."""
+    imgs = np.stack([synth.sequence_frame(w, h, 21, t) for t in range(B)])
+    ex = orb.ORBextractor(1000, 1.2, nl, 20, 7, max_batch=B)
+    ex.set_pyramid_tiling(which)
+    ref = ol.OracleExtractor(1000, 1.2, nl, 20, 7)
+    outs = ex.extract_batch(imgs)
+    for t in sorted({0, B // 2, B - 1}):
+        assert_same_output(outs[t], ref(imgs[t]), f"tiling {which} frame {t}")
+        for l in range(nl):
+            assert np.array_equal(ex.image_pyramid(l, frame=t), ref.pyramid_level(l)), (which, t, l)
+    with pytest.raises(orb.VsgError):
+        ex.set_pyramid_tiling(3)

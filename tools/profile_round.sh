@@ -36,7 +36,7 @@ cp $OUT/stats_abi/*/*kernel_stats.csv $OUT/abi_kernel_stats.csv 2>/dev/null
 tools/_bin/config_chain 2 4 > $OUT/config_chain.json 2>> $OUT/rocprof.err
 rocprofv3 --kernel-trace --output-format csv -d $OUT/lt -- tools/_bin/extract_latency 300 > $OUT/extract_latency.json 2>> $OUT/rocprof.err
 python3 tools/latency_timeline.py $OUT/lt > $OUT/frame_timeline.txt 2>&1
-for e in "" VSG_GRAPH=1 VSG_BLUR_STREAM=1 VSG_EXPORT_KERNEL=1 VSG_INGEST_DMA=1; do echo "== ${e:-default}"; env $e tools/_bin/extract_latency 1000; done > $OUT/frame_latency_ab.txt 2>&1
+for e in "" VSG_GRAPH=1; do echo "== ${e:-default}"; env $e tools/_bin/extract_latency 1000; done > $OUT/frame_latency_ab.txt 2>&1
 rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/stats_abi/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp $OUT/lt
 cat $OUT/bench.json | cut -c1-1200
 cat $OUT/pmc_traffic.txt $OUT/pmc_sq.txt

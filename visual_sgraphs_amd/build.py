@@ -2,6 +2,7 @@
 
 `python -m visual_sgraphs_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -15,6 +16,20 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-Wno-unused-value",
          # MFMA results in VGPRs (the matcher's epilogue is VALU): no v_accvgpr_read per accumulator register
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
+
+
+STAMP = CSRC / "_obj" / "linked_flags.txt"  # flag key of the objects libvsg_orb.so was last linked from
+
+
+def _flag_key(extra):
+    return hashlib.sha256(" ".join(FLAGS + ["--"] + list(extra)).encode()).hexdigest()[:12]
+
+
+def _flag_stamp():
+    try:
+        return STAMP.read_text().strip()
+    except OSError:
+        return ""
 
 
 def _hipcc():
@@ -34,21 +49,24 @@ def needs_build():
 
 def build(force=False, verbose=False):
     """Per-source objects compiled in parallel (only the sources that changed, or all of them after a header change),
-    then one link.  Objects live in csrc/_obj (git-ignored)."""
-    if not force and not needs_build():
+    then one link.  Objects live in csrc/_obj/<hash of the full flag string> (git-ignored): an object compiled with
+    VSG_EXTRA_FLAGS (experiment builds, tools/build_variant.sh) can never be linked into a later normal build.  A
+    build with extra flags always links (the library on disk may come from other flags)."""
+    extra = os.environ.get("VSG_EXTRA_FLAGS", "").split()
+    if not force and not extra and not needs_build() and _flag_stamp() == _flag_key([]):
         return LIB
     from concurrent.futures import ThreadPoolExecutor
-    obj_dir = CSRC / "_obj"
-    obj_dir.mkdir(exist_ok=True)
-    hipcc = _hipcc()
     cflags = [f for f in FLAGS if f != "-shared"]
+    key = _flag_key(extra)
+    obj_dir = CSRC / "_obj" / key
+    obj_dir.mkdir(parents=True, exist_ok=True)
+    hipcc = _hipcc()
     headers = list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [PKG.parent / "include" / "vsg_orb.h", Path(__file__)]
     hdr_time = max(h.stat().st_mtime for h in headers)
-    extra = os.environ.get("VSG_EXTRA_FLAGS", "").split()
 
     def compile_one(src):
         obj = obj_dir / (src + ".o")
-        if not force and not extra and obj.exists() and obj.stat().st_mtime > max(hdr_time, (CSRC / src).stat().st_mtime):
+        if not force and obj.exists() and obj.stat().st_mtime > max(hdr_time, (CSRC / src).stat().st_mtime):
             return obj
         cmd = [hipcc] + cflags + extra + ["-c", "-o", str(obj), str(CSRC / src)]
         if verbose:
@@ -61,6 +79,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=str(CSRC))
+    STAMP.write_text(key + "\n")
     return LIB
 
 

@@ -284,111 +284,13 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ p
 // FAST-9-16 ([OCV] fast.cpp FAST_t<16>, fast_score.cpp cornerScore<16>) on an LDS tile of row pitch kTileP.
 //   score = max over the 16 contiguous 9-arcs of min(+-(v - ring)) - 1;  corner-at-t <=> score >= t, and the
 //   score does not depend on t.
-// The LDS row pitches are template parameters (52/44, 68/60, 84/76 bytes for cells up to 40, 56, 70 px wide) so that
+// The LDS row pitches are template parameters (52, 68, 84 bytes for cells up to 40, 56, 70 px wide) so that
 // the 16 ring offsets stay instruction immediates while the footprint follows the geometry.
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ s16x2 pk_swap(s16x2 a) { return a.yx; }
-
-// Exact score with packed 16-bit min/max: lane pair P[k] = (d[k], d[k+8]) so one v_pk_min/max_i16 advances the
-// sliding 9-arc minimum/maximum of two opposite arcs at once.  Returns 0 below `floor_t`.
-template <int kTileP>
-__device__ __forceinline__ int fast_score(const uint8_t *c, int floor_t) {
-  const int P = kTileP;
-  const short v = c[0];
-  s16x2 D[8];
-  D[0] = (s16x2){(short)(v - c[3 * P]), (short)(v - c[-3 * P])};
-  D[1] = (s16x2){(short)(v - c[3 * P + 1]), (short)(v - c[-3 * P - 1])};
-  D[2] = (s16x2){(short)(v - c[2 * P + 2]), (short)(v - c[-2 * P - 2])};
-  D[3] = (s16x2){(short)(v - c[P + 3]), (short)(v - c[-P - 3])};
-  D[4] = (s16x2){(short)(v - c[3]), (short)(v - c[-3])};
-  D[5] = (s16x2){(short)(v - c[-P + 3]), (short)(v - c[P - 3])};
-  D[6] = (s16x2){(short)(v - c[-2 * P + 2]), (short)(v - c[2 * P - 2])};
-  D[7] = (s16x2){(short)(v - c[-3 * P + 1]), (short)(v - c[3 * P - 1])};
-  // X[k] for k = 0..15 with X[k+8] = swap(X[k])
-#define DX(k) ((k) < 8 ? D[(k)] : pk_swap(D[(k)-8]))
-  s16x2 mn2[8], mx2[8], mn4[8], mx4[8], mn8[8], mx8[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    mn2[k] = pk_min(D[k], DX(k + 1));
-    mx2[k] = pk_max(D[k], DX(k + 1));
-  }
-#define M2N(k) ((k) < 8 ? mn2[(k)] : pk_swap(mn2[(k)-8]))
-#define M2X(k) ((k) < 8 ? mx2[(k)] : pk_swap(mx2[(k)-8]))
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    mn4[k] = pk_min(mn2[k], M2N(k + 2));
-    mx4[k] = pk_max(mx2[k], M2X(k + 2));
-  }
-#define M4N(k) ((k) < 8 ? mn4[(k)] : pk_swap(mn4[(k)-8]))
-#define M4X(k) ((k) < 8 ? mx4[(k)] : pk_swap(mx4[(k)-8]))
-  s16x2 A = (s16x2){-256, -256}, B = (s16x2){256, 256};
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    mn8[k] = pk_min(mn4[k], M4N(k + 4));
-    mx8[k] = pk_max(mx4[k], M4X(k + 4));
-    A = pk_max(A, pk_min(mn8[k], pk_swap(D[k])));  // arcs k..k+8 and k+8..k+16
-    B = pk_min(B, pk_max(mx8[k], pk_swap(D[k])));
-  }
-#undef DX
-#undef M2N
-#undef M2X
-#undef M4N
-#undef M4X
-  const int a = max((int)A.x, (int)A.y), bb = min((int)B.x, (int)B.y);
-  const int s = max(a, -bb) - 1;
-  return s >= floor_t ? s : 0;
-}
-
-// Necessary condition on two opposing ring pairs (same idea as the tab[] pre-test of FAST_t): a pixel can only be a
-// corner at threshold t if one of its N/S ring pixels AND one of its W/E ring pixels is darker than v - t, or one of
-// each is brighter than v + t.  Evaluated for a run of kRun dwords (4 px each) with SWAR arithmetic on plain 32-bit
-// adds / logic ops (2.3 issue cycles per wave64 instruction; the byte-select SDWA forms cost 4.2): every dword is
-// split into its even and odd bytes as two 16-bit lanes (x & 0x00FF00FF, (x >> 8) & 0x00FF00FF), and per lane
-//   dark   n < v - t  <=>  bit 9 of (v + 511 - t) - n      (value in [256 - t, 766 - t]: no borrow across lanes)
-//   bright n > v + t  <=>  bit 9 of (511 - t - v) + n
-// c points at the first centre dword of the run in the LDS tile; the dwords left and right of the run supply the
-// W/E neighbours (columns -3 / +3), which in split form are just lane-shifted neighbours of the centre splits.
-// Returns bit 4 * k + j = pixel j of dword k may be a corner.
-template <int kRun, int kTileP>
-__device__ __forceinline__ uint32_t fast_quick_run(const uint8_t *c, int t) {
-  const uint32_t K = 0x00FF00FFu, M9 = 0x02000200u;
-  const uint32_t bias = (uint32_t)(511 - t) * 0x00010001u;
-  uint32_t Ce[kRun + 2], Co[kRun + 2];
-#pragma unroll
-  for (int k = 0; k < kRun + 2; k++) {
-    const uint32_t w = *(const uint32_t *)(c + 4 * (k - 1));
-    Ce[k] = w & K;
-    Co[k] = (w >> 8) & K;
-  }
-  uint32_t m = 0, T = 0;
-#pragma unroll
-  for (int k = 0; k < kRun; k++) {
-    const uint32_t U = *(const uint32_t *)(c - 3 * kTileP + 4 * k), Dn = *(const uint32_t *)(c + 3 * kTileP + 4 * k);
-    uint32_t P[2];
-#pragma unroll
-    for (int par = 0; par < 2; par++) {  // even / odd pixels of the dword
-      const uint32_t v = par ? Co[k + 1] : Ce[k + 1];
-      const uint32_t u = par ? (U >> 8) & K : U & K, d = par ? (Dn >> 8) & K : Dn & K;
-      // column -3: even pixels <- odd bytes of the previous dword; odd pixels <- (prev byte 2, own byte 0)
-      const uint32_t w = par ? __builtin_amdgcn_alignbit(Ce[k + 1], Ce[k], 16) : Co[k];
-      // column +3: even pixels <- (own byte 3, next byte 1); odd pixels <- even bytes of the next dword
-      const uint32_t e = par ? Ce[k + 2] : __builtin_amdgcn_alignbit(Co[k + 2], Co[k + 1], 16);
-      const uint32_t A = v + bias, B = bias - v;
-      const uint32_t dark = ((A - u) | (A - d)) & ((A - w) | (A - e));
-      const uint32_t bright = ((B + u) | (B + d)) & ((B + w) | (B + e));
-      P[par] = (dark | bright) & M9;
-    }
-    T |= (P[0] | (P[1] << 1)) << (4 * (k & 1));  // bits 9,10,25,26 (k even) / 13,14,29,30 (k odd)
-    if ((k & 1) || k == kRun - 1) {
-      m |= (((T >> 9) | (T >> 23)) & 0xFFu) << (8 * (k >> 1));
-      T = 0;
-    }
-  }
-  return m;
-}
 
 // inclusive wave scan on the DPP path (no LDS round trips): Hillis-Steele inside each 16-lane row with zero-filled
 // row shifts, then lane 15 / lane 31 broadcasts carry the row totals across rows
@@ -406,209 +308,14 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
 #define VSG_FAST_NT 128  // threads per FAST cell: 2 waves keep more cells resident per CU than 4 (measured: 0.47 ->
                          // 0.38 ms per 256 frames); 1 wave runs out of LDS before it runs out of wave slots
 #endif
-#ifndef VSG_FAST_RUN
-#define VSG_FAST_RUN 2
-#endif
-constexpr int kFastRun = VSG_FAST_RUN;  // dwords per thread in the necessary test (2 or 4)
-static_assert(kFastRun == 2 || kFastRun == 4, "the run queue (4 bytes per run) must fit the score rows it aliases");
-
-// One workgroup per FAST cell.  The cell's valid region (3 px inside the reference's sub-image) is staged in LDS
-// with aligned 32-bit loads; a cheap necessary test runs on 8 pixels per thread from packed dwords and the pixels
-// that pass are COMPACTED into an LDS queue, so the exact score (packed 16-bit min/max) and the non-max suppression
-// run on dense wavefronts.  The compaction has two levels: phase 1 appends one entry per RUN that has a passer (one
-// ballot, no per-lane loop: the run test executes ~3.6 sparse wave-iterations per cell), and one dense pass over
-// those entries (a wave scan of their popcounts) unpacks them into the pixel queue.  Like the reference the cell is first searched at iniThFAST and only if that yields
-// nothing at minThFAST (ORBextractor.cc:832-851); NMS only looks at neighbours INSIDE the valid region (outside
-// counts as 0, exactly like the zeroed row buffers of FAST_t).  Emission order is irrelevant (the octree ranks
-// candidates).
-template <int NT, int kTileP, int kScoreP>
-__global__ __launch_bounds__(NT) void k_fast_cells_v2(const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
-                                                    const CellDesc *__restrict__ cells, Src0 s0,
-                                                    uint32_t *__restrict__ cand, int *__restrict__ cand_count,
-                                                    int *__restrict__ cell_count, int tile_bytes, int score_bytes) {
-  // LDS is sized by the launch for the largest cell of THIS geometry (rows x fixed pitches, queue = largest
-  // valid area), not for the 70 x 70 worst case: more cells resident per CU.
-  extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
-  uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
-  uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);
-  uint32_t *runq = (uint32_t *)score;  // run entries (mask << 16 | row << 8 | column + 3); consumed before the score rows are cleared
-  __shared__ int s_cnt[5];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base [4]=run entries
-  const BlockXY blk = frame_major_block();
-  const CellDesc cell = cells[blk.x];
-  const int frame = blk.y;
-  const LevelGeom &L = fg->lv[cell.level];
-  const int vw = cell.x1 - cell.x0, vh = cell.y1 - cell.y0;
-  const int tid = threadIdx.x, lane = tid & 63;
-  // Segmented candidate lists (the normal case): the cell owns a fixed segment of its level's slice, as long as its
-  // worst-case survivor count, and reports its count; survivors are written the moment non-max suppression finds
-  // them.  No returning global atomic at the end of the cell's dependency chain (a timing-only ablation put that
-  // round trip at 6 % of the kernel), no second pass over the queue.  k_octree gathers through the cell counts.
-  const bool seg = fg->cand_segmented != 0;
-  int *my_count = cell_count + (size_t)frame * fg->total_cells + blk.x;
-  if (vw <= 0 || vh <= 0) {
-    if (seg && tid == 0) *my_count = 0;
-    return;
-  }
-  uint32_t *seg_out = cand + (size_t)frame * fg->cand_frame + L.cand_off + cell.cand_off;
-  int pitch;
-  const uint8_t *img = level_ptr(fg, s0, pyr, frame, cell.level, pitch);
-  // tile column 0 <-> image column ax (4-byte aligned); valid-region column c sits at tile column c + 3 + ox
-  const int ax = (cell.x0 - 3) & ~3, ox = (cell.x0 - 3) - ax;
-  const int tdw = (ox + vw + 6 + 3) >> 2, th = vh + 6;  // dwords per tile row (<= 21)
-  const float inv_tdw = __builtin_amdgcn_rcpf((float)tdw);  // div_small has a margin of 0.5 / tdw: 1 ulp is plenty
-  {
-    // wave-uniform base + 32-bit lane offset (rows x pitch < 2^18): no 64-bit multiply per element
-    const uint8_t *tsrc = img + (ptrdiff_t)(cell.y0 - 3) * pitch + ax;
-#ifdef VSG_FAST_STAGE1
-    const bool narrow = true;
-#else
-    const bool narrow = tdw < 4;  // a sliver of a cell at the right edge of a level (cell-uniform)
-#endif
-    if (narrow) {
-      for (int i = tid; i < tdw * th; i += NT) {
-        const int r = div_small(i, inv_tdw), c = i - r * tdw;
-        *(uint32_t *)&tile[r * kTileP + 4 * c] = *(const uint32_t *)(tsrc + (uint32_t)(r * pitch + 4 * c));
-      }
-    } else {
-    // 16 bytes per lane: a tile row is nq4 <= 6 (4-byte aligned, otherwise unaligned) dwordx4 loads, the last one
-    // pulled back so that it ENDS with the row (it re-writes a few dwords of its neighbour with the same values
-    // instead of reading past the row -- level 0 is the caller's buffer): 2 rounds of loads per cell instead of 5,
-    // and a quarter of the address arithmetic (staging was 19 % of the kernel's instructions)
-    typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
-    const int nq4 = (tdw + 3) >> 2;
-    const float inv_nq4 = __builtin_amdgcn_rcpf((float)nq4);
-    for (int i = tid; i < nq4 * th; i += NT) {
-      const int r = div_small(i, inv_nq4), c = min(4 * (i - r * nq4), tdw - 4);
-      const u32x4u v = *(const u32x4u *)(tsrc + (uint32_t)(r * pitch + 4 * c));
-      uint32_t *d = (uint32_t *)&tile[r * kTileP + 4 * c];
-      d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
-    }
-    }
-  }
-  // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1
-  const int g0 = (3 + ox) >> 2, g1 = (3 + ox + vw + 3) >> 2, ng = g1 - g0;
-  const int nrun = (ng + kFastRun - 1) / kFastRun, nruns = nrun * vh;  // runs of kFastRun dwords per row
-  const float inv_nrun = __builtin_amdgcn_rcpf((float)nrun);
-  // first run: its bit 0 is valid-region column cb0 >= -3; last run: `over` of its 4 * kFastRun columns lie beyond vw
-  const int cb0 = 4 * g0 - 3 - ox, over = 4 * (g0 + (nrun - 1) * kFastRun) - 3 - ox + 4 * kFastRun - vw;
-  const uint32_t first_mask = cb0 < 0 ? ~0u << (-cb0) : ~0u;
-  const uint32_t last_mask = over <= 0 ? ~0u : over >= 4 * kFastRun ? 0u : (1u << (4 * kFastRun - over)) - 1u;
-  uint32_t keep = 0;
-  int nq = 0, thr = fg->iniTh;
-  for (int pass = 0; pass < 2; pass++) {
-    if (tid < 5) s_cnt[tid] = 0;
-    __syncthreads();
-    // ---- phase 1: necessary test on kFastRun dwords (4 px each) per thread; runs with a passer are appended to the
-    // run queue.  A longer run amortises the index arithmetic and the neighbour loads over more pixels.
-    for (int i0 = 0; i0 < nruns; i0 += NT) {
-      const int i = i0 + tid;
-      uint32_t m = 0;
-      int r = 0, cb = 0;
-      if (i < nruns) {
-        r = div_small(i, inv_nrun);
-        const int rr = i - r * nrun, g = g0 + rr * kFastRun;
-        const uint8_t *t = &tile[(r + 3) * kTileP + 4 * g];
-        m = fast_quick_run<kFastRun, kTileP>(t, thr);
-        cb = 4 * g - 3 - ox;  // valid-region column of bit 0 of this run (>= -3)
-        // pixels outside [0, vw) can only sit in the first and in the last run of a row: cell-uniform masks
-        if (rr == 0) m &= first_mask;
-        if (rr == nrun - 1) m &= last_mask;
-      }
-      const uint64_t hit = __ballot(m != 0);
-      if (hit) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&s_cnt[4], __popcll(hit));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (m) runq[base + __popcll(hit & ((1ull << lane) - 1))] = (m << 16) | (uint32_t)((r << 8) + cb + 3);
-      }
-    }
-    __syncthreads();
-    // ---- run entries -> pixel queue (entry = row << 8 | column, both < 70: no division to unpack)
-    const int nr = s_cnt[4];
-    for (int e0 = 0; e0 < nr; e0 += NT) {
-      const int e = e0 + tid;
-      const uint32_t ent = e < nr ? runq[e] : 0u;
-      uint32_t m = ent >> 16;
-      const int cnt = __popc(m);
-      const int incl = wave_inclusive_scan_i32(cnt);
-      const int wtotal = __builtin_amdgcn_readlane(incl, 63);
-      if (wtotal) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&s_cnt[1], wtotal);
-        int pos = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
-        const int pix = (int)(ent & 0xFFFFu) - 3;
-        while (m) {
-          queue[pos++] = (uint16_t)(pix + __builtin_ctz(m));
-          m &= m - 1;
-        }
-      }
-    }
-    __syncthreads();
-    nq = s_cnt[1];
-    // (vh + 2) score rows, cleared 16 bytes per lane (the region is allocated in multiples of 16 bytes)
-    for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    // ---- phase 2: exact score of the queued pixels
-    for (int q = tid; q < nq; q += NT) {
-      const int i = queue[q];
-      const int r = i >> 8, c = i & 255;
-      const int s = fast_score<kTileP>(&tile[(r + 3) * kTileP + (c + 3 + ox)], thr);
-      if (s) score[(r + 1) * kScoreP + (c + 1)] = (uint8_t)s;
-    }
-    __syncthreads();
-    // ---- phase 3: non-max suppression inside the cell
-    keep = 0;  // bit per loop iteration: queued pixel survives NMS
-    int it = 0;
-    for (int q = tid; q < nq; q += NT, it++) {
-      const int i = queue[q];
-      const int r = i >> 8, c = i & 255;
-      const uint8_t *sp = &score[(r + 1) * kScoreP + (c + 1)];
-      // all eight neighbours in one round of LDS reads (no short-circuit chain); a zero score is never a maximum
-      const int s = sp[0];
-      int mx = max(max((int)sp[-1], (int)sp[1]), (int)sp[-kScoreP - 1]);
-      mx = max(max(mx, (int)sp[-kScoreP]), (int)sp[-kScoreP + 1]);
-      mx = max(max(mx, (int)sp[kScoreP - 1]), (int)sp[kScoreP]);
-      mx = max(mx, (int)sp[kScoreP + 1]);
-      const bool is_max = s > mx;
-      if (is_max) {
-        if (seg) {
-          seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
-        } else {
-          keep |= 1u << it;
-          atomicAdd(&s_cnt[0], 1);
-        }
-      }
-    }
-    __syncthreads();
-    if (s_cnt[0] > 0 || pass == 1 || fg->minTh >= thr) break;
-    thr = fg->minTh;  // vKeysCell.empty() -> retry with minThFAST (:848-851)
-    __syncthreads();
-  }
-  const int nEmit = s_cnt[0];
-  if (seg) {
-    if (tid == 0) *my_count = nEmit;
-    return;
-  }
-  if (nEmit == 0) return;
-  if (tid == 0) s_cnt[3] = atomicAdd(&cand_count[frame * kMaxLevels + cell.level], nEmit);
-  __syncthreads();
-  const int base = s_cnt[3];
-  uint32_t *out = cand + (size_t)frame * fg->cand_frame + L.cand_off;
-  int it = 0;
-  for (int q = tid; q < nq; q += NT, it++) {
-    if (!(keep & (1u << it))) continue;
-    const int i = queue[q];
-    const int r = i >> 8, c = i & 255;
-    const int s = score[(r + 1) * kScoreP + (c + 1)];
-    const int slot = base + atomicAdd(&s_cnt[2], 1);
-    if (slot < L.cand_cap) out[slot] = pack_cand(cell.x0 + c - kFastBorder, cell.y0 + r - kFastBorder, s);
-  }
-}
-
 
 // ------------------------------------------------------------------------------------------------
-// Round 3 form of the cell kernel.  Same decomposition per cell as k_fast_cells_v2 (tile in LDS, compaction, exact score
-// on dense wavefronts, cell-confined NMS, per-cell candidate segments); what changed:
+// The cell kernel.  Per cell: the valid region (3 px inside the reference's sub-image) staged in LDS, a cheap necessary
+// test whose passers are COMPACTED into an LDS queue, the exact score and the non-max suppression on dense wavefronts,
+// survivors into the cell's own segment of the level's candidate slice.  Like the reference the cell is first searched at
+// iniThFAST and only if that yields nothing at minThFAST (ORBextractor.cc:832-851); NMS only looks at neighbours INSIDE
+// the valid region (outside counts as 0, exactly like the zeroed row buffers of FAST_t).  Emission order is irrelevant
+// (the octree ranks candidates).
 //
 //  * The necessary test runs on 6-BIT pixels, four per 32-bit operation.  With q(x) = x >> 2 per byte,
 //        n < v - t   =>   q(v) - q(n) >= T6 := ceil((t - 2) / 4)        (4 (qv - qn) >= v - n - 3 >= t - 2)
@@ -777,7 +484,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
     dq[0] = (v.x >> 2) & 0x3F3F3F3Fu, dq[1] = (v.y >> 2) & 0x3F3F3F3Fu;
     dq[2] = (v.z >> 2) & 0x3F3F3F3Fu, dq[3] = (v.w >> 2) & 0x3F3F3F3Fu;
   };
-  // 16 bytes per lane and chunk, the last chunk of a row pulled back so that it ENDS with the row (see k_fast_cells_v2).
+  // 16 bytes per lane and chunk, the last chunk of a row pulled back so that it ENDS with the row (it re-writes a few dwords
+  // of its neighbour with the same values instead of reading past the row -- level 0 is the caller's buffer).
   // Every lane loads (the ones past the last chunk load it again): the kPre loads of a thread stay one block of
   // back-to-back instructions -- behind per-load branches the compiler put a vmcnt(0) in front of each.
   // Not for slivers (rows shorter than a chunk) or tiles beyond kPre chunks per thread: staged when their turn comes.
@@ -878,11 +586,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
         for (int pass = 0; pass < 2; pass++) {
           if (tid < 5) s_cnt[tid] = 0;
           __syncthreads();  // the tile is staged / the previous pass is done with the score rows
-#if defined(VSG_FAST_ABL) && (VSG_FAST_ABL == 1 || VSG_FAST_ABL == 6)  // timing-only ablations: the results are wrong
-          { int keep_alive = tile[7 + tid]; asm volatile("" : : "v"(keep_alive)); }
-          if (seg && tid == 0) *my_count = 0;
-          goto cell_done;
-#endif
           // ---- phase 1: 6-bit necessary test, 8 pixels (2 dwords) per thread; runs with a passer are appended (flag word
           // + run index) to the run list: one ballot and one LDS atomic per wave and iteration
           {
@@ -924,11 +627,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             }
           }
           __syncthreads();
-#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 2
-          { int keep_alive = s_cnt[4]; asm volatile("" : : "v"(keep_alive)); }
-          if (seg && tid == 0) *my_count = 0;
-          goto cell_done;
-#endif
           // ---- run list -> pixel queue.  Entry = the run's dword index in the tile << 5 | bit position of the flag in the
           // run's word (bit 0 of the position: dark side; bit 2, set in every flag position, cleared = retry); phase 2 turns
           // an entry into the pixel's byte offset in the tile -- two shifts and two masks, no division by the run count, no
@@ -981,11 +679,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             __syncthreads();
           }
           nq = s_cnt[1];
-#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 3
-          { int keep_alive = nq + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
-          if (seg && tid == 0) *my_count = 0;
-          goto cell_done;
-#endif
           for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
           __syncthreads();
           // ---- phase 2: exact score of the queued pixels on their flagged side; entries that do not score are dropped
@@ -1027,11 +720,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             }
             __syncthreads();
           }
-#if defined(VSG_FAST_ABL) && VSG_FAST_ABL == 4
-          { int keep_alive = score[50 + tid] + queue[tid]; asm volatile("" : : "v"(keep_alive)); }
-          if (seg && tid == 0) *my_count = 0;
-          goto cell_done;
-#endif
           // ---- phase 3: non-max suppression inside the cell
           keep = 0;  // bit per loop iteration: queued pixel survives NMS
           int it = 0;
@@ -1087,9 +775,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
         }
       }
     }
-#if defined(VSG_FAST_ABL)
-  cell_done:
-#endif
     __syncthreads();  // the cell is done with the tile, the score rows and the queue: the next one may be written
     C = N;
   }
@@ -2156,23 +1841,17 @@ void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sh
                      d_tile_tab, s0, d_tiles, a16, ab16, cand_count);
 }
 template <int NT, int TP, int SP, int PRE>
-static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells,
-                          const FastCellRec *d_recs, const Src0 &s0, uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg,
-                          int maxVh, int maxArea, int nframes) {
+static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const FastCellRec *d_recs,
+                          const Src0 &s0, uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh,
+                          int maxArea, int nframes, int cus) {
   // Cells per workgroup: the first cell of a workgroup waits for its tile, the others find theirs fetched -- 2, 3 and 4
   // measure the same (0.425 ms per 512 C2 frames against 0.446 with 1; 6: 0.432, 8: 0.440, the tail of a launch grows).
   // Launches that would not fill the workgroup slots a few times over (16 per CU) keep one cell per workgroup: a
-  // single frame is 577 workgroups on 256 CUs.  VSG_FAST_K overrides.
+  // single frame is 577 workgroups on 256 CUs.  `cus` = the CU count of the handle's device (queried once per handle).
+  // VSG_FAST_K overrides (tests/test_gpu_fast_multicell.py runs every count against the oracle).
   static const int kenv = getenv("VSG_FAST_K") ? atoi(getenv("VSG_FAST_K")) : 0;
-  int dev = 0, cus = 256;
-  static int s_cus = 0;
-  if (!s_cus) {
-    hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    s_cus = cus;
-  }
   const long long cells_total = (long long)fg.total_cells * nframes;
-  const int kauto = cells_total >= 3LL * 4 * 16 * s_cus ? 3 : 1;
+  const int kauto = cells_total >= 3LL * 4 * 16 * (cus > 0 ? cus : 256) ? 3 : 1;
   const int cells_per_wg = std::max(1, std::min(kenv > 0 ? kenv : kauto, fg.total_cells));
   dim3 grid((fg.total_cells + cells_per_wg - 1) / cells_per_wg, nframes), block(NT);
   // + one spare row: the necessary test reads (masked) dwords just past the last tile row
@@ -2180,26 +1859,20 @@ static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_
   // the pixel queue's region also holds the 6-bit copy of the tile during the necessary test
   const size_t queue_bytes = std::max<size_t>(((size_t)maxArea * 2 + 15) & ~(size_t)15, (size_t)tile_bytes);
   const size_t lds = (size_t)tile_bytes + score_bytes + queue_bytes;
-  static const bool v2 = getenv("VSG_FAST_V2") != nullptr;  // A/B switch: the round-2 kernel (exact 9-bit test, two-sided score)
-  if (v2)
-    hipLaunchKernelGGL((k_fast_cells_v2<NT, TP, SP>), dim3(fg.total_cells, nframes), block, lds, s, pyr, d_fg, d_cells, s0,
-                       cand, cand_count, cell_count, tile_bytes, score_bytes);
-  else
-    hipLaunchKernelGGL((k_fast_cells<NT, TP, SP, PRE>), grid, block, lds, s, pyr, d_fg, d_recs, s0, cand, cand_count,
-                       cell_count, tile_bytes, score_bytes, maxArea, cells_per_wg);
+  hipLaunchKernelGGL((k_fast_cells<NT, TP, SP, PRE>), grid, block, lds, s, pyr, d_fg, d_recs, s0, cand, cand_count,
+                     cell_count, tile_bytes, score_bytes, maxArea, cells_per_wg);
 }
-void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const CellDesc *d_cells,
-                 const FastCellRec *d_recs, const Src0 &s0,
+void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const FastCellRec *d_recs, const Src0 &s0,
                  uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea,
-                 int nframes) {
+                 int nframes, int cus) {
   // tile row = up to 3 alignment bytes + vw + 6 ring bytes, rounded up to dwords; score rows (vw + 2 used) have the
   // tile's pitch: a pixel's score sits a constant away from its tile byte (k_fast_cells phase 2)
   if (maxVw <= 40)
-    launch_fast_t<VSG_FAST_NT, 52, 52, 2>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 52, 52, 2>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
   else if (maxVw <= 56)
-    launch_fast_t<VSG_FAST_NT, 68, 68, 3>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 68, 68, 3>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
   else
-    launch_fast_t<VSG_FAST_NT, 84, 84, 4>(s, pyr, d_fg, d_cells, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes);
+    launch_fast_t<VSG_FAST_NT, 84, 84, 4>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
 }
 // dynamic LDS of one octree workgroup (also what every blur workgroup of the fused launch is charged)
 size_t octree_lds_bytes(const FrameGeom &fg, int maxQuota, int maxCellsPerLevel) {
@@ -2223,8 +1896,9 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   if (blur_out) {  // the blur of the same frames as extra workgroups of this launch (latency path)
     lds_limit_ensure(2, dev, (const void *)k_octree_blur, lds);
     // octree workgroups `lead` frames ahead of the blur's (see the kernel); only for launches long enough to have a tail
-    static const int lead_env = getenv("VSG_OB_LEAD") ? atoi(getenv("VSG_OB_LEAD")) : 64;
-    const int lead = nframes >= 4 * lead_env && lead_env > 0 ? (lead_env + 7) & ~7 : 0;  // multiple of 8: whole XCD rounds
+    // (64 rows, a multiple of 8 = whole XCD rounds: 317.5 -> 320.5 k frames/s at 512 C2 frames; 32 and 128 measured the same +-0.3 %)
+    constexpr int kLead = 64;
+    const int lead = nframes >= 4 * kLead ? kLead : 0;
     hipLaunchKernelGGL(k_octree_blur, dim3(fg.nlevels + fg.total_blur_blocks, nframes + lead), dim3(kOctThreads), lds, s, a,
                        blur_pyr, blur_out, *blur_s0, fg.nlevels, nframes, lead);
     return;

@@ -76,76 +76,15 @@ __global__ void k_hamming_pairs(const uint8_t *a, const uint8_t *b, const int *i
   dist[i] = hamming256(a0, a1, b0, b1);
 }
 
-// ---- brute-force best / second best: 4 lanes share TWO rows of A (row, row + 64 of a 128-row block) and scan
-// interleaved quarters of B, which is streamed through LDS in 256-row tiles; each B row read from LDS serves both
-// A rows.  Packed keys (dist << 20 | index) are unique and keep the reference's strict-'<' scan semantics: the
-// smallest key is the first minimum, the second smallest is "bestDist2".  With k1 <= k2 the update is
+// ---- brute-force best / second best.  Packed keys (dist << 20 | index) are unique and keep the reference's strict-'<'
+// scan semantics: the smallest key is the first minimum, the second smallest is "bestDist2".  With k1 <= k2 the update is
 // k2 = median(k1, k2, key), k1 = min(k1, key): one v_med3_u32 and one v_min_u32 per pair.
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
   return min(max(a, b), max(min(a, b), c));  // folded to v_med3_u32
 }
 enum { kBest2Rows = 128 };  // A rows per workgroup
 
-__global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, const uint8_t *b_base, size_t block_stride,
-                                                     const int *counts_a, const int *counts_b, int count_stride,
-                                                     int fixed_na, int fixed_nb, int max_rows, int *best, int *second,
-                                                     int *argbest) {
-  __shared__ uint4 tile[256 * 2];
-  const int blk = blockIdx.y;
-  const int na = counts_a ? min(counts_a[blk * count_stride], max_rows) : fixed_na;
-  const int nb = counts_b ? min(counts_b[blk * count_stride], max_rows) : fixed_nb;
-  const uint8_t *A = a_base + (size_t)blk * block_stride, *B = b_base + (size_t)blk * block_stride;
-  if (blockIdx.x * kBest2Rows >= na) return;
-  const int row0 = blockIdx.x * kBest2Rows + (threadIdx.x >> 2), row1 = row0 + 64, sub = threadIdx.x & 3;
-  uint4 a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-  if (row0 < na) load_desc(A, row0, a0, a1);
-  if (row1 < na) load_desc(A, row1, c0, c1);
-  uint32_t k1 = KEY_NONE, k2 = KEY_NONE, m1 = KEY_NONE, m2 = KEY_NONE;
-  for (int t0 = 0; t0 < nb; t0 += 256) {
-    const int nt = min(256, nb - t0);
-    __syncthreads();
-    if ((int)threadIdx.x < nt) {
-      uint4 lo, hi;
-      load_desc(B, t0 + threadIdx.x, lo, hi);
-      tile[threadIdx.x * 2] = lo;
-      tile[threadIdx.x * 2 + 1] = hi;
-    }
-    __syncthreads();
-    for (int j = sub; j < nt; j += 4) {
-      const uint4 b0 = tile[2 * j], b1 = tile[2 * j + 1];
-      const uint32_t idx = (uint32_t)(t0 + j);
-      const uint32_t key = ((uint32_t)hamming256(a0, a1, b0, b1) << 20) | idx;
-      const uint32_t kez = ((uint32_t)hamming256(c0, c1, b0, b1) << 20) | idx;
-      k2 = umed3(k1, k2, key);
-      k1 = min(k1, key);
-      m2 = umed3(m1, m2, kez);
-      m1 = min(m1, kez);
-    }
-  }
-#pragma unroll
-  for (int d = 1; d <= 2; d <<= 1) {
-    const uint32_t o1 = __shfl_xor(k1, d), o2 = __shfl_xor(k2, d);
-    merge2(k1, k2, o1, o2);
-    const uint32_t p1 = __shfl_xor(m1, d), p2 = __shfl_xor(m2, d);
-    merge2(m1, m2, p1, p2);
-  }
-  if (sub == 0) {
-    if (row0 < na) {
-      const size_t o = (size_t)blk * max_rows + row0;
-      best[o] = (int)(k1 >> 20);
-      second[o] = (int)(k2 >> 20);
-      argbest[o] = key_is_none(k1) ? -1 : (int)(k1 & 0xFFFFF);
-    }
-    if (row1 < na) {
-      const size_t o = (size_t)blk * max_rows + row1;
-      best[o] = (int)(m1 >> 20);
-      second[o] = (int)(m2 >> 20);
-      argbest[o] = key_is_none(m1) ? -1 : (int)(m1 & 0xFFFFF);
-    }
-  }
-}
-
-// ---- the same best / second-best scan on the matrix cores.  A Hamming distance matrix is a GEMM over +-1 vectors:
+// ---- the best / second-best scan on the matrix cores.  A Hamming distance matrix is a GEMM over +-1 vectors:
 // with s(x) = 2*bit - 1, sum_k s(a_k) * s(b_k) = 256 - 2 * dist.  The train rows are expanded with their bits
 // INVERTED (so each product is negated) and the accumulator starts at 256, hence
 //     D[i][j] = 256 + sum_k (-s(train_i,k)) * s(query_j,k) = 2 * dist(train_i, query_j)          (exact, int32)
@@ -154,7 +93,8 @@ __global__ __launch_bounds__(256) void k_block_best2(const uint8_t *a_base, cons
 // four waves.  C/D layout: lane = column + 32 * h, register g holds row (g & 3) + 8 * (g >> 2) + 4 * h, so a lane
 // folds its 16 rows into the packed-key best/second pair with v_lshl_or + v_min_u32 + v_med3_u32 per pair; the
 // two lanes of a column merge at the end.  Keys (2 * dist << 19 | index == dist << 20 | index) and therefore tie
-// handling are identical to the VALU kernel above.
+// handling follow the packed-key rule above (an xor + popcount form of this scan measured 0.182 ms per 256 x 1006^2
+// pairs against 0.088 ms here: DESIGN 8, round 1).
 #ifndef VSG_MATCH_TR
 #define VSG_MATCH_TR 1
 #endif
@@ -287,11 +227,6 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
     second[o] = (int)(k2 >> 20);
     argbest[o] = key_is_none(k1) ? -1 : (int)(k1 & 0xFFFFF);
   }
-}
-
-static bool match_on_valu() {
-  static const bool v = getenv("VSG_MATCH_VALU") != nullptr;  // A/B switch: the xor + popcount kernel
-  return v;
 }
 
 // ---- SearchByBoW: one wavefront per shared vocabulary node (node pairs merged on the host).
@@ -715,12 +650,8 @@ int vsg_hamming_block_best2_device(int device, const uint8_t *d_a, const uint8_t
   dim3 grid((max_rows + kBest2Rows - 1) / kBest2Rows, nblocks);
   // stream == NULL is the caller's NULL stream (see vsg_orb_extract_batch_device for how the extractor orders itself
   // against it)
-  if (match_on_valu())
-    hipLaunchKernelGGL(k_block_best2, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes,
-                       d_counts_a, d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
-  else
-    hipLaunchKernelGGL(k_block_best2_mfma, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes,
-                       d_counts_a, d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
+  hipLaunchKernelGGL(k_block_best2_mfma, grid, dim3(256), 0, (hipStream_t)stream, d_a, d_b, block_stride_bytes,
+                     d_counts_a, d_counts_b, count_stride, max_rows, max_rows, max_rows, d_best, d_second, d_argbest);
   M_TRY(hipGetLastError());
   return VSG_OK;
 }
@@ -745,12 +676,8 @@ int vsg_hamming_block_best2(int device, const uint8_t *a, int na, const uint8_t 
   const uint8_t *d = c->d_buf;
   int *d1 = (int *)(c->d_pin + o1), *d2 = (int *)(c->d_pin + o2), *d3 = (int *)(c->d_pin + o3);
   const dim3 grid((na + kBest2Rows - 1) / kBest2Rows, 1);
-  if (match_on_valu())
-    hipLaunchKernelGGL(k_block_best2, grid, dim3(256), 0, c->stream, d + oA, d + oB, (size_t)0, (const int *)nullptr,
-                       (const int *)nullptr, 0, na, nb, na, d1, d2, d3);
-  else
-    hipLaunchKernelGGL(k_block_best2_mfma, grid, dim3(256), 0, c->stream, d + oA, d + oB, (size_t)0,
-                       (const int *)nullptr, (const int *)nullptr, 0, na, nb, na, d1, d2, d3);
+  hipLaunchKernelGGL(k_block_best2_mfma, grid, dim3(256), 0, c->stream, d + oA, d + oB, (size_t)0,
+                     (const int *)nullptr, (const int *)nullptr, 0, na, nb, na, d1, d2, d3);
   M_TRY(hipGetLastError());
   M_TRY(hipStreamSynchronize(c->stream));
   memcpy(best, h + o1, (size_t)na * 4);

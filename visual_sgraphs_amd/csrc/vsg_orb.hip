@@ -70,8 +70,7 @@ struct Slot {
 
 // Helper threads for the pageable-input path of vsg_orb_submit_batch: the frames of a batch are copied into the slot's
 // pinned staging by the calling thread AND three sleeping helpers (one core copies ~20 GB/s, a 64-frame C2 batch is
-// 20 MB; the copy was the whole cost of that path: 63 k -> 113 k frames/s on the GPU box, flat beyond 3-4 helpers;
-// VSG_STAGE_THREADS=n overrides, 0 = none).  The helpers are created at the first pageable batch of a handle,
+// 20 MB; the copy was the whole cost of that path: 63 k -> 113 k frames/s on the GPU box, flat beyond 3-4 helpers).  The helpers are created at the first pageable batch of a handle,
 // sleep on a condition variable between batches and are joined by vsg_orb_destroy.
 struct StagePool {
   struct Job {
@@ -187,6 +186,8 @@ struct vsg_orb {
   int *d_cell_count = nullptr;    // [max_batch][fg.total_cells] FAST survivors per cell (segmented candidate lists)
   uint32_t *d_cand2 = nullptr;    // [max_batch][fg.cand_frame] compacted candidates of levels too large for the octree's registers
   int pyr_tiling = 0;                   // the tiling calibration found faster for a full batch of this geometry
+  int force_tiling = -1;                // vsg_orb_set_pyramid_tiling (tests: every launch form against the oracle)
+  int cus = 256;                        // compute units of `device` (k_fast_cells' cells-per-workgroup choice)
   PyrTile *d_ptiles[kPyrTilings] = {};  // Geometry::pyr[i].tiles
   Short4 *d_ptab[kPyrTilings] = {};     // Geometry::pyr[i].tab
   uint8_t *d_in = nullptr;  // level-0 staging for unaligned / colour device images (device API), pitch in_pitch
@@ -343,7 +344,7 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   for (int i = 0; i < kSlots; i++)
     if (h->slot[i].busy) {
       set_err("image size changed while submitted batches have not been waited for (vsg_orb_wait them first)");
-      return VSG_ERR_CAPACITY;
+      return VSG_ERR_BUSY;
     }
   rc = quiesce(h);
   if (rc != VSG_OK) return rc;
@@ -461,14 +462,16 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   FrameHeader *hdr = h->d_hdr + F;
   Range r_all("vsg_orb: enqueue stage chain");
   if (tm) HIP_TRY(hipEventRecord(h->ev[0], s));
-  static const bool per_level = getenv("VSG_PYR_PER_LEVEL") != nullptr;  // A/B switch: 7 chained launches
-  // tiling: the coarser one when it still gives the chip enough workgroups and leaves three of them per CU
+  // tiling: the coarser one when it still gives the chip enough workgroups and leaves three of them per CU; without a
+  // usable tiling (scale factors > 2, LDS) the chain runs as one k_resize launch per level
   int ti = -1;
-  if (!per_level && fg.nlevels > 1) {
+  if (fg.nlevels > 1) {
     const PyrTiling &P0 = h->G.pyr[0], &P1 = h->G.pyr[1];
-    static const int forced = getenv("VSG_PYR_TILING") ? atoi(getenv("VSG_PYR_TILING")) : -1;  // A/B switch
-    if (forced == 0 || forced == 1)
-      ti = h->G.pyr[forced].ok ? forced : -1;
+    const int forced = h->force_tiling;  // vsg_orb_set_pyramid_tiling: -1 = calibrated choice, 0 / 1, 2 = per-level launches
+    if (forced == 2)
+      ti = -1;
+    else if (forced == 0 || forced == 1)
+      ti = h->G.pyr[forced].ok && h->G.pyr[forced].lds_bytes() <= kPyrLdsLimit ? forced : -1;
     else if (h->pyr_tiling == 1 && (long long)P1.tiles.size() * nf >= 2048)  // calibrated choice, large launches only
       ti = 1;
     else if (P0.ok && P0.lds_bytes() <= kPyrLdsLimit)
@@ -488,26 +491,23 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   // The blur only needs the pyramid and runs on its own stream.  It is released AFTER FAST, beside the
   // latency-bound octree (+ slots): FAST and the blur are both issue-bound, so running them side by side only
   // shares the CUs, while the octree leaves most issue slots free.  Measured on MI355X (C2, one batch of 256):
-  // 254 k frames/s against 250 k with the blur released right after the pyramid (VSG_BLUR_EARLY=1).
-  static const bool blur_early = getenv("VSG_BLUR_EARLY") != nullptr && getenv("VSG_BLUR_LATE") == nullptr;
-  if (!blur_early) {
-    if (tm || tmf) HIP_TRY(hipEventRecord(h->ev[8], s));
-    launch_fast(s, pyr, h->d_fg, h->d_cells, h->d_fast, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
-    if (tm || tmf) HIP_TRY(hipEventRecord(h->ev[2], s));
-  }
+  // 254 k frames/s against 250 k with the blur released right after the pyramid.
+  if (tm || tmf) HIP_TRY(hipEventRecord(h->ev[8], s));
+  launch_fast(s, pyr, h->d_fg, h->d_fast, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw,
+              h->G.fastMaxArea, nf, h->cus);
+  if (tm || tmf) HIP_TRY(hipEventRecord(h->ev[2], s));
   // The blur's workgroups ride in the octree's launch (k_octree_blur): both need only the pyramid, the octree is a
   // latency-bound handful of workgroups per frame and the blur issue-bound filler, and inside ONE kernel (one register
   // allocation) the two kinds of waves co-reside on a SIMD -- as two kernels on two streams the octree's 96-register
   // waves left no room for an 80-register blur wave, so the two shared the CUs in time.  Measured: + 1.6-2.7 % on the
   // 512-frame step (295.0 -> 299.8 k frames/s, 302.9 k on a second box), and on the one-frame latency path no fork /
-  // join events (each cross-stream wait cost the chain 5-7 us of idle GPU): 0.127 -> 0.108 ms.  VSG_BLUR_STREAM=1: A/B
-  // switch back to the blur on its own stream; timed / serialised runs keep the two kernels apart.
+  // join events (each cross-stream wait cost the chain 5-7 us of idle GPU): 0.127 -> 0.108 ms.  Timed / serialised runs
+  // keep the two kernels apart.
   // Throughput batches only take the fused launch while five of its workgroups (the 5 waves per SIMD it is compiled
   // for) still fit a CU's 160 KB of LDS: every blur workgroup is charged the octree's workspace, and at 1280x720 /
   // 2000 features (33 KB) the fifth no longer fits -- 93.1 -> 90.1 k frames/s there, so that geometry keeps two streams.
-  static const bool blur_stream = getenv("VSG_BLUR_STREAM") != nullptr;
   const bool lds_fits = 5 * octree_lds_bytes(fg, h->G.maxQuota, h->G.maxCellsPerLevel) <= 160 * 1024;
-  const bool fused_blur = !tm && !blur_early && !blur_stream && sb != s && (lds_fits || (h->one_stream && nf <= 8));
+  const bool fused_blur = !tm && sb != s && (lds_fits || (h->one_stream && nf <= 8));
   if (fused_blur) {
     Range r_tail("DistributeOctTree (+ blur workgroups) + slots + IC_Angle / rBRIEF");
     launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel,
@@ -517,7 +517,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   HIP_TRY(hipEventRecord(ev_pyr, s));
   // Host enqueue order: the latency-critical launch (the octree) goes out BEFORE the three calls that fork the blur onto
   // its stream.  Serialised runs (sb == s, per-stage timing) keep stream order = stage order: blur, then octree.
-  const bool octree_first = !blur_early && sb != s;
+  const bool octree_first = sb != s;
   if (octree_first) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
     launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel,
@@ -530,11 +530,6 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   if (tm) HIP_TRY(hipEventRecord(h->ev[7], sb));
   HIP_TRY(hipEventRecord(ev_blur, sb));
   Range r_tail("DistributeOctTree + slots + IC_Angle / rBRIEF");
-  if (blur_early) {
-    if (tm) HIP_TRY(hipEventRecord(h->ev[8], s));
-    launch_fast(s, pyr, h->d_fg, h->d_cells, h->d_fast, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw, h->G.fastMaxArea, nf);
-    if (tm) HIP_TRY(hipEventRecord(h->ev[2], s));
-  }
   if (!octree_first) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
     launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel,
@@ -697,6 +692,10 @@ int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fa
     vsg_orb_destroy(h);
     return VSG_ERR_NO_DEVICE;
   }
+  if (hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->cus <= 0) {
+    (void)hipGetLastError();
+    h->cus = 256;
+  }
   for (int i = 0; i < kEv; i++) hipEventCreate(&h->ev[i]);
   hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   for (int j = 0; j < kMaxSub; j++) {
@@ -782,6 +781,13 @@ int vsg_orb_set_blur_taps(vsg_orb *h, const uint16_t taps[7]) {
     if (rc != VSG_OK) return rc;
     HIP_TRY(hipMemcpy(h->d_fg, &h->G.fg, sizeof(FrameGeom), hipMemcpyHostToDevice));
   }
+  return VSG_OK;
+}
+
+int vsg_orb_set_pyramid_tiling(vsg_orb *h, int which) {
+  if (!h || which < -1 || which > 2) return VSG_ERR_INVALID;
+  h->force_tiling = which;
+  free_chain_graphs(h);  // a recorded chain holds the launch form it was recorded with
   return VSG_OK;
 }
 
@@ -879,8 +885,6 @@ static int tail_stream_work(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1
                             bool mirror_out = false) {
   const FrameGeom &fg = h->G.fg;
   const Src0 s0 = {S.d_in, (size_t)h->rows * h->in_pitch, h->in_pitch};
-  static const bool dma_out_ = getenv("VSG_D2H_DMA") != nullptr, export_kernel = getenv("VSG_EXPORT_KERNEL") != nullptr;
-  mirror_out = mirror_out && !dma_out_ && !export_kernel;  // VSG_EXPORT_KERNEL=1: A/B switch, the separate export launch
   if (mirror_out) {
     // latency path: k_orient_desc writes the records into the pinned destination as it produces them
     h->mirror.kps = (KeyPointPOD *)(E.direct ? E.dk : (void *)S.h_kps), h->mirror.desc = (uint8_t *)(E.direct ? E.dd : (void *)S.h_desc);
@@ -896,12 +900,7 @@ static int tail_stream_work(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1
     HIP_TRY(hipStreamWaitEvent(h->s_d2h, S.ev_done, 0));
   }
   // export: n records per frame, written by the device into pinned host memory
-  static const bool dma_out = getenv("VSG_D2H_DMA") != nullptr;  // A/B switch: copy-engine D2H of out_cap-sized buffers
-  if (dma_out) {
-    HIP_TRY(hipMemcpyAsync(S.h_counts, S.d_counts, (size_t)nframes * 2 * sizeof(int), hipMemcpyDeviceToHost, s_out));
-    HIP_TRY(hipMemcpyAsync(S.h_kps, S.d_kps, (size_t)nframes * fg.out_cap * sizeof(KeyPointPOD), hipMemcpyDeviceToHost, s_out));
-    HIP_TRY(hipMemcpyAsync(S.h_desc, S.d_desc, (size_t)nframes * fg.out_cap * 32, hipMemcpyDeviceToHost, s_out));
-  } else if (E.direct) {
+  if (E.direct) {
     launch_export(s_out, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, E.dk, E.dd, S.h_counts, capacity, nframes);
   } else {
     launch_export(s_out, S.d_kps, S.d_desc, S.d_counts, fg.out_cap, S.h_kps, S.h_desc, S.h_counts, fg.out_cap, nframes);
@@ -912,8 +911,7 @@ static int tail_stream_work(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1
 
 // bookkeeping of a submitted batch; records the completion event behind whatever was enqueued / launched
 static int finish_submit(vsg_orb *h, Slot &S, int nframes, vsg_keypoint *kps, uint8_t *desc, int capacity, bool direct) {
-  static const bool dma_out = getenv("VSG_D2H_DMA") != nullptr;
-  S.direct = direct && !dma_out;
+  S.direct = direct;
   S.out_kps = kps, S.out_desc = desc, S.out_cap = capacity;
   HIP_TRY(hipEventRecord(S.ev_out, h->one_stream ? h->s_main : h->s_d2h));
   S.busy = true;
@@ -1005,7 +1003,7 @@ static int acquire_slot(vsg_orb *h, Slot **out) {
   Slot &S = h->slot[i];
   if (S.busy) {
     set_err("every pipeline slot holds a batch that has not been waited for (vsg_orb_wait)");
-    return VSG_ERR_CAPACITY;
+    return VSG_ERR_BUSY;
   }
   int rc = ensure_slot(h, i);
   if (rc != VSG_OK) return rc;
@@ -1028,8 +1026,7 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
   const size_t fbytes = (size_t)rows * ip;
   const bool packed = stride == ip && (nframes == 1 || frame_stride == fbytes);
   const hipStream_t s_in = h->one_stream ? h->s_main : h->s_h2d;
-  static const bool ingest_dma = getenv("VSG_INGEST_DMA") != nullptr;  // A/B switch: copy engine on the blocking path too
-  if (h->one_stream && nframes <= 8 && !ingest_dma) {
+  if (h->one_stream && nframes <= 8) {
     // Blocking call, small batch (the reference's one frame per operator()): the latency path.  Pageable images are
     // staged into the slot's pinned buffer by this thread; the device then reads the pinned image itself (ingest
     // kernel) and the whole call's stream work is one graph launch.
@@ -1068,9 +1065,9 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
     // pageable memory: bounce through the slot's pinned staging.  Small batches: in chunks, so that the copy engine
     // works on chunk i while this thread copies chunk i + 1.  Large batches: the frames are dealt to this thread and
     // the handle's helper threads, then ONE DMA (which overlaps the staging of the next batch, another slot).
-    static const int n_helpers = getenv("VSG_STAGE_THREADS") ? atoi(getenv("VSG_STAGE_THREADS")) : 3;
-    if (nframes >= 16 && n_helpers > 0) {
-      if (!h->pool) h->pool = new StagePool(n_helpers < 8 ? n_helpers : 8);
+    constexpr int kStageHelpers = 3;  // flat beyond 3-4 (63 k frames/s alone, 113 k with 3 helpers: DESIGN 8, round 2)
+    if (nframes >= 16) {
+      if (!h->pool) h->pool = new StagePool(kStageHelpers);
       StagePool::Job j;
       j.src = gray, j.dst = S.h_in, j.frame_stride = frame_stride, j.fbytes = fbytes;
       j.stride = stride, j.ip = ip, j.rows = rows, j.cols = cols, j.nframes = nframes;

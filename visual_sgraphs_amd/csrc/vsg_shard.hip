@@ -36,6 +36,8 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   bool ok = false;
 };
 // record layout for a capacity
@@ -63,6 +65,8 @@ const Rccl &rccl() {
     g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(g_rccl.lib, "ncclGroupStart");
     g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(g_rccl.lib, "ncclGroupEnd");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(g_rccl.lib, "ncclGetErrorString");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(g_rccl.lib, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(g_rccl.lib, "ncclCommUserRank");
     g_rccl.ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllGather;
   });
   return g_rccl;
@@ -257,8 +261,41 @@ int vsg_shard_boundary_record(vsg_shard *s, const int **d_counts, const vsg_keyp
   return VSG_OK;
 }
 
-// number of ranks of the communicator (what ncclCommInitRank was given): bench lines report it as rccl_ranks_seen
-int vsg_shard_world(const vsg_shard *s) { return s ? s->world : VSG_ERR_INVALID; }
+// Number of ranks of the communicator AS RCCL REPORTS IT (ncclCommCount on the live communicator, not the `world` the
+// caller passed to ncclCommInitRank): bench lines report it as rccl_ranks_seen.  VSG_ERR_UNSUPPORTED when the loaded
+// RCCL does not export ncclCommCount -- never an echo of the argument.
+int vsg_shard_world(const vsg_shard *s) {
+  if (!s || !s->comm) return VSG_ERR_INVALID;
+  const Rccl &R = rccl();
+  if (!R.CommCount) {
+    t_serr = "the loaded RCCL does not export ncclCommCount";
+    return VSG_ERR_UNSUPPORTED;
+  }
+  int n = 0;
+  const ncclResult_t r = R.CommCount(s->comm, &n);
+  if (r != ncclSuccess) {
+    t_serr = std::string("ncclCommCount: ") + (R.GetErrorString ? R.GetErrorString(r) : "error");
+    return VSG_ERR_HIP;
+  }
+  return n;
+}
+
+// This process's rank in the communicator as RCCL reports it (ncclCommUserRank).
+int vsg_shard_rank(const vsg_shard *s) {
+  if (!s || !s->comm) return VSG_ERR_INVALID;
+  const Rccl &R = rccl();
+  if (!R.CommUserRank) {
+    t_serr = "the loaded RCCL does not export ncclCommUserRank";
+    return VSG_ERR_UNSUPPORTED;
+  }
+  int n = -1;
+  const ncclResult_t r = R.CommUserRank(s->comm, &n);
+  if (r != ncclSuccess) {
+    t_serr = std::string("ncclCommUserRank: ") + (R.GetErrorString ? R.GetErrorString(r) : "error");
+    return VSG_ERR_HIP;
+  }
+  return n;
+}
 
 int vsg_shard_record(vsg_shard *s, int rank, int frame, const int **d_counts, const vsg_keypoint **d_kps,
                      const uint8_t **d_desc) {

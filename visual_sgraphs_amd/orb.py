@@ -26,7 +26,7 @@ assert KP_DTYPE.itemsize == 28
 
 VSG_OK = 0
 ERRORS = {-1: "VSG_ERR_EMPTY_IMAGE", -2: "VSG_ERR_CAPACITY", -3: "VSG_ERR_UNSUPPORTED", -4: "VSG_ERR_NO_DEVICE",
-          -5: "VSG_ERR_HIP", -6: "VSG_ERR_INVALID"}
+          -5: "VSG_ERR_HIP", -6: "VSG_ERR_INVALID", -7: "VSG_ERR_BUSY"}
 
 _u8p = C.POINTER(C.c_uint8)
 _i32p = C.POINTER(C.c_int32)
@@ -60,6 +60,8 @@ EXPORTS = [
     "vsg_shard_stream_owner", "vsg_shard_unique_id", "vsg_shard_create", "vsg_shard_destroy", "vsg_shard_all_gather",
     "vsg_shard_record", "vsg_shard_world", "vsg_shard_send_recv_boundary", "vsg_shard_boundary_record",
     "vsg_copy_d2d_async", "vsg_orb_chain_graph_launches",
+    # round 4
+    "vsg_orb_set_pyramid_tiling", "vsg_shard_rank",
 ]
 
 
@@ -123,6 +125,7 @@ def load_library():
     L.vsg_orb_get_tables.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _i32p, _i32p]
     L.vsg_orb_set_blur_taps.argtypes = [C.c_void_p, _u16p]
     L.vsg_orb_capacity.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.vsg_orb_set_pyramid_tiling.argtypes = [C.c_void_p, C.c_int]
     L.vsg_orb_extract.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p,
                                   C.c_int, _i32p]
     L.vsg_orb_extract_batch.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -239,6 +242,7 @@ def load_library():
     L.vsg_shard_all_gather.argtypes = [vp, vp, vp, vp, ci, ci, vp]
     L.vsg_shard_record.argtypes = [vp, ci, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.vsg_shard_world.argtypes = [vp]
+    L.vsg_shard_rank.argtypes = [vp]
     L.vsg_shard_send_recv_boundary.argtypes = [vp, vp, vp, vp, ci, ci, vp]
     L.vsg_shard_boundary_record.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.vsg_copy_d2d_async.argtypes = [ci, vp, vp, C.c_size_t, vp]
@@ -339,6 +343,10 @@ class ORBextractor:
         t = np.ascontiguousarray(taps, dtype=np.uint16)
         assert t.shape == (7,)
         _check(self._L.vsg_orb_set_blur_taps(self._h, _p(t, _u16p)), "vsg_orb_set_blur_taps")
+
+    def set_pyramid_tiling(self, which):
+        """ComputePyramid's launch form: -1 calibrated (default), 0 / 1 the two fused tilings, 2 one launch per level."""
+        _check(self._L.vsg_orb_set_pyramid_tiling(self._h, int(which)), "vsg_orb_set_pyramid_tiling")
 
     def capacity(self, rows, cols):
         return _check(self._L.vsg_orb_capacity(self._h, int(rows), int(cols)), "vsg_orb_capacity")

@@ -184,7 +184,18 @@ class ShardComm:
             raise self._orb.VsgError(rc, "vsg_shard_all_gather", self._L.vsg_shard_last_error().decode())
 
     def world_seen(self):
-        return self._L.vsg_shard_world(self._h)
+        """Communicator size as RCCL reports it (ncclCommCount), not the world this object was created with."""
+        n = self._L.vsg_shard_world(self._h)
+        if n < 0:
+            raise self._orb.VsgError(n, "vsg_shard_world", self._L.vsg_shard_last_error().decode())
+        return n
+
+    def rank_seen(self):
+        """This process's rank as RCCL reports it (ncclCommUserRank)."""
+        n = self._L.vsg_shard_rank(self._h)
+        if n < 0:
+            raise self._orb.VsgError(n, "vsg_shard_rank", self._L.vsg_shard_last_error().decode())
+        return n
 
     def send_recv_boundary(self, d_counts, d_kps, d_desc, src_capacity, frame, stream):
         """Neighbour-only exchange: this rank's record of `frame` goes to rank + 1, the predecessor's arrives in the
