@@ -200,6 +200,15 @@ int or_search_for_initialization(const uint8_t *desc1, const float *angle1, cons
  * with one node and no greedy state): strict '<' scan order ties (Appendix B). */
 void or_block_best2(const uint8_t *a, int na, const uint8_t *b, int nb, int *best, int *second, int *argbest);
 
+/* ---- camera undistortion (undistort_oracle.cpp): Frame::UndistortKeyPoints (Frame.cc:891-921), Frame::ComputeImageBounds
+ * (Frame.cc:924-955) and the [OCV 4.2] cv::undistortPoints(src, dst, K, D, Mat(), K) they call (5 fixed iterations, double).
+ * K4 = {fx, fy, cx, cy} as the floats of mK; dist = the 4 or 5 floats of mDistCoef (k1, k2, p1, p2[, k3]).  Harness code
+ * for the grid / search parity tests; parity unpinned like every OpenCV piece. */
+void or_undistort_points(const float *xy_in, int n, const float K4[4], const float *dist, int ndist, float *xy_out);
+void or_undistort_keypoints(const OrKeyPoint *keys, int n, const float K4[4], const float *dist, int ndist,
+                            OrKeyPoint *keys_un);
+void or_image_bounds(int cols, int rows, const float K4[4], const float *dist, int ndist, float out[4]);
+
 /* ---- routine-level restatements on a flattened Frame / KeyFrame (routines_oracle.cpp): the functions follow the
  * reference's loops from the point where a map point has been projected; see the comments there. ---- */
 typedef struct OrFrame OrFrame;

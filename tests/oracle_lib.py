@@ -497,6 +497,77 @@ def distinctive_descriptors(desc, off):
 
 
 # ---------------------------------------------------------------- routine-level oracle (oracle/routines_oracle.cpp)
+# ---- cameras of the reference's settings files whose mDistCoef(0) != 0 (Frame::UndistortKeyPoints / ComputeImageBounds
+# do real work): K4 = (fx, fy, cx, cy), dist = mDistCoef, size = (cols, rows)
+CAMERAS = {
+    # config/RGB-D/TUM1.yaml:11-23 (BASELINE config C1)
+    "tum1": dict(K4=(517.306408, 516.469215, 318.643040, 255.313989),
+                 dist=(0.262383, -0.953104, -0.005358, 0.002628, 1.163314), size=(640, 480)),
+    # config/RGB-D-Inertial/RealSense_D435i.yaml:11-23 (BASELINE config C5)
+    "d435i": dict(K4=(6.165911254882812e+02, 6.166796264648438e+02, 3.242193603515625e+02, 2.3942701721191406e+02),
+                  dist=(1.25323e-01, -2.51452e-01, 7.12e-04, 6.217e-03), size=(640, 480)),
+}
+
+
+def scaled_camera(name, cols, rows):
+    """The camera `name` for another image size (focal lengths and principal point scale with the image, the distortion
+    coefficients live in normalised coordinates and stay): tests extract on small frames."""
+    c = CAMERAS[name]
+    sx, sy = cols / c["size"][0], rows / c["size"][1]
+    fx, fy, cx, cy = c["K4"]
+    return dict(K4=(fx * sx, fy * sy, cx * sx, cy * sy), dist=c["dist"], size=(cols, rows))
+
+
+def _cam_args(cam):
+    K4 = np.asarray(cam["K4"], np.float32)
+    dist = np.asarray(cam["dist"], np.float32)
+    return K4, dist
+
+
+def _bind_undistort(L):
+    if getattr(L, "_undistort_bound", False):
+        return L
+    L.or_undistort_points.argtypes = [_f32p, C.c_int, _f32p, _f32p, C.c_int, _f32p]
+    L.or_undistort_points.restype = None
+    L.or_undistort_keypoints.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.c_int, C.c_void_p]
+    L.or_undistort_keypoints.restype = None
+    L.or_image_bounds.argtypes = [C.c_int, C.c_int, _f32p, _f32p, C.c_int, _f32p]
+    L.or_image_bounds.restype = None
+    L._undistort_bound = True
+    return L
+
+
+def undistort_points(xy, cam):
+    """cv::undistortPoints(xy, K, D, Mat(), K) restated (oracle/undistort_oracle.cpp); xy [n, 2] float32."""
+    L = _bind_undistort(lib())
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    K4, dist = _cam_args(cam)
+    out = np.zeros_like(xy)
+    L.or_undistort_points(_ptr(xy, _f32p), len(xy), _ptr(K4, _f32p), _ptr(dist, _f32p), len(dist), _ptr(out, _f32p))
+    return out
+
+
+def undistort_keypoints(kps, cam):
+    """Frame::UndistortKeyPoints (Frame.cc:891-921): mvKeysUn."""
+    L = _bind_undistort(lib())
+    k = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    out = k.copy()
+    K4, dist = _cam_args(cam)
+    L.or_undistort_keypoints(k.ctypes.data_as(C.c_void_p), len(k), _ptr(K4, _f32p), _ptr(dist, _f32p), len(dist),
+                             out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def image_bounds(cam):
+    """Frame::ComputeImageBounds (Frame.cc:924-955): (mnMinX, mnMinY, mnMaxX, mnMaxY) as float32 values."""
+    L = _bind_undistort(lib())
+    K4, dist = _cam_args(cam)
+    out = np.zeros(4, np.float32)
+    L.or_image_bounds(int(cam["size"][0]), int(cam["size"][1]), _ptr(K4, _f32p), _ptr(dist, _f32p), len(dist),
+                      _ptr(out, _f32p))
+    return tuple(float(v) for v in out)
+
+
 def _rl():
     L = lib()
     if getattr(L, "_routines_bound", False):
