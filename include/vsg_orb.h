@@ -375,6 +375,21 @@ int vsg_frame_upload(vsg_frame *f, const vsg_keypoint *keys, const uint8_t *desc
  * call delivered) -- nothing is downloaded. */
 int vsg_frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_keypoint *kps_host, int n, float min_x,
                              float min_y, float max_x, float max_y);
+/* Frame::ComputeImageBounds (Frame.cc:924-955) for a pinhole camera: K4 = {fx, fy, cx, cy} (the floats of mK), dist = the
+ * 4 or 5 floats of mDistCoef (k1, k2, p1, p2[, k3]; Tracking.cc:742-787); out = {mnMinX, mnMinY, mnMaxX, mnMaxY} -- the
+ * image rectangle when mDistCoef(0) == 0, otherwise the four corners through cv::undistortPoints(.., K, D, Mat(), K)
+ * ([OCV 4.2]: five fixed iterations in double).  Four points, once per camera (mbInitialComputations, Frame.cc:373-392):
+ * host arithmetic, no device needed. */
+int vsg_camera_image_bounds(int cols, int rows, const float K4[4], const float *dist, int ndist, float out[4]);
+/* vsg_frame_from_extractor for a DISTORTED camera (mDistCoef(0) != 0: config/RGB-D/TUM1.yaml, config/RGB-D-Inertial/
+ * RealSense_D435i.yaml -- BASELINE configs C1 and C5): Frame::UndistortKeyPoints (Frame.cc:891-921) runs on the device,
+ * in double, inside the launch that builds the grid -- the frame's keypoints are mvKeysUn, the grid indexes them with
+ * the bounds of vsg_camera_image_bounds, and keys_un_out (n records, may be NULL) receives mvKeysUn for the host's own
+ * use (Tracking, the optimizer).  The frame stays resident: no D2H -> cv::undistortPoints -> H2D hop.  With
+ * mDistCoef(0) == 0 this is vsg_frame_from_extractor (keys_un_out = kps_host). */
+int vsg_frame_from_extractor_undistort(vsg_frame *f, vsg_orb *h, int index, const vsg_keypoint *kps_host, int n,
+                                       const float K4[4], const float *dist, int ndist, float min_x, float min_y,
+                                       float max_x, float max_y, vsg_keypoint *keys_un_out);
 int vsg_frame_size(const vsg_frame *f);
 /* test / debug read-back of the device copy: grid CSR (cell_start[64*48+1], entries[n]) of the left (0) or right (1) grid */
 int vsg_frame_copy_grid(vsg_frame *f, int right, int32_t *cell_start, int32_t *entries);

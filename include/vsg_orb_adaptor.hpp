@@ -430,6 +430,21 @@ class ResidentFrame {
     check(vsg_frame_from_extractor(f_, ex.handle(), index, keys.data(), (int)keys.size(), mnMinX, mnMinY, mnMaxX, mnMaxY),
           "vsg_frame_from_extractor");
   }
+  // The same for a distorted pinhole camera (mDistCoef(0) != 0: TUM1.yaml, RealSense_D435i.yaml): UndistortKeyPoints
+  // (Frame.cc:891-921) runs on the device inside the grid launch; mvKeysUn comes back for the host's own use.
+  // K4 = {fx, fy, cx, cy} of mK, dist = mDistCoef's 4 or 5 floats, bounds = ImageBounds(...) below.
+  void FromExtractorUndistort(const ORBextractor &ex, const std::vector<vsg_keypoint> &mvKeys, const float K4[4],
+                              const float *dist, int ndist, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY,
+                              std::vector<vsg_keypoint> *mvKeysUn, int index = 0) {
+    if (mvKeysUn) mvKeysUn->resize(mvKeys.size());
+    check(vsg_frame_from_extractor_undistort(f_, ex.handle(), index, mvKeys.data(), (int)mvKeys.size(), K4, dist, ndist,
+                                             mnMinX, mnMinY, mnMaxX, mnMaxY, mvKeysUn ? mvKeysUn->data() : nullptr),
+          "vsg_frame_from_extractor_undistort");
+  }
+  // Frame::ComputeImageBounds (Frame.cc:924-955): {mnMinX, mnMinY, mnMaxX, mnMaxY}
+  static void ImageBounds(int cols, int rows, const float K4[4], const float *dist, int ndist, float out[4]) {
+    check(vsg_camera_image_bounds(cols, rows, K4, dist, ndist, out), "vsg_camera_image_bounds");
+  }
   int N() const { return vsg_frame_size(f_); }
   vsg_frame *handle() const { return f_; }
 

@@ -15,14 +15,45 @@ SCALE = np.float32(1.2) ** np.arange(8, dtype=np.float32)
 _T = ol.OracleExtractor(1000, 1.2, 8, 20, 7).tables()
 SCALE_FACTORS = _T["scale"]          # mvScaleFactors
 INV_SIGMA2 = _T["inv_sigma2"]        # mvInvLevelSigma2
-BOUNDS = (0.0, 0.0, 320.0, 240.0)
+# The camera the scenario frames are seen through: "image" = no distortion (mDistCoef(0) == 0: mvKeysUn =
+# mvKeys, bounds = the image rectangle), "tum1" / "d435i" = the two BASELINE cameras whose Frame constructor really
+# undistorts (config/RGB-D/TUM1.yaml, config/RGB-D-Inertial/RealSense_D435i.yaml, scaled to the 320x240 scenario frames):
+# keys = mvKeysUn through oracle/undistort_oracle.cpp, BOUNDS = Frame::ComputeImageBounds -- fractional, negative
+# (D435i) or inside the image (TUM1: features near the edge fall outside the grid).  use_camera() switches all of it.
+W, H = 320, 240
+CAMERA_NAMES = ("image", "tum1", "d435i")
+CAMERA = "image"
+CAM = None                        # oracle_lib camera dict of the current camera (None: no distortion)
+BOUNDS = (0.0, 0.0, float(W), float(H))
+
+
+def use_camera(name):
+    global CAMERA, CAM, BOUNDS
+    assert name in CAMERA_NAMES
+    CAMERA = name
+    CAM = None if name == "image" else ol.scaled_camera(name, W, H)
+    BOUNDS = (0.0, 0.0, float(W), float(H)) if CAM is None else ol.image_bounds(CAM)
 
 
 @functools.lru_cache(maxsize=None)
-def features(seed, t, w=320, h=240, nfeat=600):
+def features_raw(seed, t, w=W, h=H, nfeat=600):
+    """(mvKeys, mDescriptors) of the oracle extractor on a scenario frame."""
     ex = ol.OracleExtractor(nfeat, 1.2, 8, 20, 7)
     _, k, d = ex(synth.sequence_frame(w, h, seed, t))
     return k, d
+
+
+@functools.lru_cache(maxsize=None)
+def _features_un(camera, seed, t, w, h, nfeat):
+    k, d = features_raw(seed, t, w, h, nfeat)
+    return ol.undistort_keypoints(k, ol.scaled_camera(camera, w, h)), d
+
+
+def features(seed, t, w=W, h=H, nfeat=600):
+    """(mvKeysUn, mDescriptors) under the current camera (Frame::UndistortKeyPoints, Frame.cc:891-921)."""
+    if CAMERA == "image":
+        return features_raw(seed, t, w, h, nfeat)
+    return _features_un(CAMERA, seed, t, w, h, nfeat)
 
 
 def stereo_pair(seed):
@@ -40,8 +71,9 @@ def u_right_for(kps, rng, frac=0.6):
     return ur
 
 
-def projections(rng, src_kps, shift=(-3.0, -2.0), noise=1.5, n_far=20, bounds=BOUNDS):
+def projections(rng, src_kps, shift=(-3.0, -2.0), noise=1.5, n_far=20, bounds=None):
     """(u, v) of the source keypoints in the target frame + a few points far from any feature / outside the image."""
+    bounds = BOUNDS if bounds is None else bounds
     n = len(src_kps)
     u = src_kps["x"] + np.float32(shift[0]) + rng.normal(0, noise, n).astype(np.float32)
     v = src_kps["y"] + np.float32(shift[1]) + rng.normal(0, noise, n).astype(np.float32)

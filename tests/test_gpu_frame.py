@@ -12,6 +12,17 @@ from visual_sgraphs_amd import orb, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=sc.CAMERA_NAMES)
+def camera(request):
+    """Every test of this file runs under three cameras: no distortion (bounds = the image rectangle) and
+    the two BASELINE cameras whose Frame constructor undistorts -- TUM1 (C1) and RealSense D435i (C5): the frame's keys
+    are mvKeysUn, the grid bounds Frame::ComputeImageBounds' fractional / negative values, mfGridElementWidthInv no
+    longer 64 / W (Frame.cc:378-379, 870-880, 891-955)."""
+    sc.use_camera(request.param)
+    yield request.param
+    sc.use_camera("image")
+
+
 def _frame(keys, desc, u_right=None, nleft=-1, cap=None):
     return orb.Frame(cap or max(len(keys), 1)).upload(keys, desc, sc.BOUNDS, u_right, nleft)
 
@@ -34,7 +45,19 @@ def test_device_built_grid_from_extractor_equals_oracle():
     ex = orb.ORBextractor(600, 1.2, 8, 20, 7, max_batch=3)
     outs = ex.extract_batch(imgs)
     for i, (_, k, d) in enumerate(outs):
-        f = orb.Frame(ex.capacity(240, 320)).from_extractor(ex, i, k, sc.BOUNDS)
+        if sc.CAM is None:
+            f = orb.Frame(ex.capacity(240, 320)).from_extractor(ex, i, k, sc.BOUNDS)
+        else:
+            # distorted camera: Frame::UndistortKeyPoints runs on the device inside the grid launch; the bounds come
+            # from the library's own ComputeImageBounds and must be the oracle's bit for bit
+            bounds = orb.camera_image_bounds(320, 240, sc.CAM["K4"], sc.CAM["dist"])
+            assert bounds == sc.BOUNDS
+            f = orb.Frame(ex.capacity(240, 320)).from_extractor_undistort(ex, i, k, sc.CAM["K4"], sc.CAM["dist"], bounds)
+            k = ol.undistort_keypoints(k, sc.CAM)   # mvKeysUn by the oracle
+            assert f.kps.tobytes() == k.tobytes()   # ... equals what the device computed, bit for bit
+            # and the upload route (host undistortion, then vsg_frame_upload) builds the same grid
+            fu = orb.Frame(ex.capacity(240, 320)).upload(k, d, sc.BOUNDS)
+            assert all(np.array_equal(a, b) for a, b in zip(f.grid(), fu.grid()))
         o = ol.OracleFrame(k, d, sc.BOUNDS)
         cs, en = f.grid()
         ocs, oen = o.grid()

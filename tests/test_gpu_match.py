@@ -208,12 +208,23 @@ def test_matchers_on_empty_inputs():
 
 
 # ----------------------------------------------------------------------------- the Frame grid on the device
+def _camera_view(name, keys, w=640, h=480):
+    """(mvKeysUn, bounds) of `keys` seen through camera `name`: "image" = no distortion, "tum1" / "d435i" = the BASELINE
+    cameras whose Frame constructor undistorts (Frame.cc:891-955; C1 and C5)."""
+    if name == "image":
+        return keys, (0.0, 0.0, float(w), float(h))
+    cam = ol.scaled_camera(name, w, h)
+    return ol.undistort_keypoints(keys, cam), ol.image_bounds(cam)
+
+
+@pytest.mark.parametrize("camera", ["image", "tum1", "d435i"])
 @pytest.mark.parametrize("seed", [0, 1])
-def test_device_grid_query_equals_reference_order(frames, seed):
+def test_device_grid_query_equals_reference_order(frames, seed, camera):
     (k0, d0), (k1, d1) = frames
     rng = np.random.default_rng(seed)
-    g_ref = ol.OracleGrid(k1, 0.0, 0.0, 640.0, 480.0)
-    g = orb.FrameGrid(k1, 0.0, 0.0, 640.0, 480.0)
+    k1, bounds = _camera_view(camera, k1)
+    g_ref = ol.OracleGrid(k1, *bounds)
+    g = orb.FrameGrid(k1, *bounds)
     nq = 400
     x = rng.uniform(-20, 660, nq).astype(np.float32)
     y = rng.uniform(-20, 500, nq).astype(np.float32)
@@ -230,16 +241,20 @@ def test_device_grid_query_equals_reference_order(frames, seed):
     assert off[-1] > 1000
 
 
-def test_device_grid_edge_cases():
+@pytest.mark.parametrize("camera", ["image", "tum1", "d435i"])
+def test_device_grid_edge_cases(camera):
     e32 = np.zeros(0, orb.KP_DTYPE)
-    g = orb.FrameGrid(e32, 0.0, 0.0, 640.0, 480.0)
+    _, bounds = _camera_view(camera, e32)
+    g = orb.FrameGrid(e32, *bounds)
     off, idx = g.GetFeaturesInArea([10.0, 700.0], [10.0, 10.0], [5.0, 5.0])
     assert off.tolist() == [0, 0, 0] and len(idx) == 0
     kp = np.zeros(3, orb.KP_DTYPE)
     kp["x"], kp["y"], kp["octave"] = [5.0, 5.0, 639.9], [5.0, 5.0, 479.9], [0, 3, 1]
-    g = orb.FrameGrid(kp, 0.0, 0.0, 640.0, 480.0)
-    ref = ol.OracleGrid(kp, 0.0, 0.0, 640.0, 480.0)
-    for q in [(5.0, 5.0, 1.0, -1, -1), (5.0, 5.0, 1.0, 2, 4), (639.0, 479.0, 3.0, -1, -1), (-50.0, 5.0, 10.0, -1, -1)]:
+    kp, bounds = _camera_view(camera, kp)  # TUM1: (5, 5) undistorts to outside the grid -- PosInGrid drops it
+    g = orb.FrameGrid(kp, *bounds)
+    ref = ol.OracleGrid(kp, *bounds)
+    for q in [(5.0, 5.0, 1.0, -1, -1), (5.0, 5.0, 1.0, 2, 4), (639.0, 479.0, 3.0, -1, -1), (-50.0, 5.0, 10.0, -1, -1),
+              (12.0, 15.0, 9.0, -1, -1), (bounds[0], bounds[1], 0.5, -1, -1), (bounds[2], bounds[3], 2.0, -1, -1)]:
         off, idx = g.GetFeaturesInArea([q[0]], [q[1]], [q[2]], [q[3]], [q[4]])
         assert idx.tolist() == ref.query(*q).tolist()
 

@@ -105,8 +105,35 @@ def case_bow(rng):
     return ok, ("bow", k, L, n, lv)
 
 
+def _rand_camera(rng, w, h):
+    """None (mDistCoef(0) == 0: bounds = the image) a third of the time, otherwise a random pinhole camera with 4 or 5
+    distortion coefficients in the range of the reference's settings files (TUM1: k1 0.26, k2 -0.95, k3 1.16; D435i:
+    k1 0.125, k2 -0.25): Frame::ComputeImageBounds then gives fractional bounds, negative or inside the image."""
+    if rng.random() < 0.34:
+        return None
+    f = float(rng.uniform(0.6, 1.1)) * w
+    dist = [float(rng.uniform(-0.3, 0.3)) or 0.1, float(rng.uniform(-1.0, 1.0)), float(rng.uniform(-0.008, 0.008)),
+            float(rng.uniform(-0.008, 0.008))]
+    if rng.random() < 0.5:
+        dist.append(float(rng.uniform(-1.2, 1.2)))
+    return dict(K4=(f, f * float(rng.uniform(0.98, 1.02)), w / 2 + float(rng.uniform(-12, 12)),
+                    h / 2 + float(rng.uniform(-12, 12))), dist=tuple(dist), size=(w, h))
+
+
+def _camera_view(cam, keys, w, h):
+    """(mvKeysUn, bounds) -- Frame::UndistortKeyPoints / ComputeImageBounds (Frame.cc:891-955) through the oracle harness;
+    a camera whose bounds come out degenerate (wild coefficients) falls back to the image rectangle"""
+    if cam is None:
+        return keys, (0.0, 0.0, float(w), float(h))
+    b = ol.image_bounds(cam)
+    if not (np.all(np.isfinite(b)) and b[2] - b[0] > w / 4 and b[3] - b[1] > h / 4):
+        return keys, (0.0, 0.0, float(w), float(h))
+    return ol.undistort_keypoints(keys, cam), b
+
+
 def case_window(rng):
-    """Frame grid -> candidate lists -> the four windowed searches, random blocking state and thresholds."""
+    """Frame grid -> candidate lists -> the four windowed searches, random blocking state and thresholds; the target
+    frame seen through a random (often distorted) camera."""
     w, h = int(rng.integers(300, 800)), int(rng.integers(240, 600))
     nf = int(rng.integers(100, 1500))
     seq = int(rng.integers(0, 1 << 16))
@@ -115,8 +142,11 @@ def case_window(rng):
     _, k1, d1 = ref(synth.sequence_frame(w, h, seq, 1))
     if len(k0) == 0 or len(k1) == 0:
         return True, ("window-empty",)
-    g = orb.FrameGrid(k1, 0.0, 0.0, float(w), float(h))
-    og = ol.OracleGrid(k1, 0.0, 0.0, float(w), float(h))
+    cam = _rand_camera(rng, w, h)
+    k1, bounds = _camera_view(cam, k1, w, h)
+    k0, _ = _camera_view(cam, k0, w, h)
+    g = orb.FrameGrid(k1, *bounds)
+    og = ol.OracleGrid(k1, *bounds)
     r = rng.uniform(3, 40, len(k0)).astype(np.float32)
     qx = (k0["x"] + rng.uniform(-8, 8, len(k0))).astype(np.float32)
     qy = (k0["y"] + rng.uniform(-8, 8, len(k0))).astype(np.float32)
@@ -128,7 +158,7 @@ def case_window(rng):
         widx += og.query(qx[i], qy[i], r[i], int(lo[i]), int(hi[i])).tolist()
         woff.append(len(widx))
     if not (np.array_equal(off, woff) and np.array_equal(idx, widx)):
-        return False, ("grid", w, h, nf, seq)
+        return False, ("grid", w, h, nf, seq, cam)
     qb = (rng.random(len(k0)) < 0.7).astype(np.uint8)
     tb = (rng.random(len(k1)) < 0.2).astype(np.uint8)
     th = int(rng.choice([50, 100, 255]))  # 256 would make the reference index [-1] when every candidate is blocked
@@ -147,7 +177,7 @@ def case_window(rng):
     a = m.SearchForInitialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"])
     b = ol.search_for_initialization(d0, k0["angle"], k0["octave"], off, idx, d1, k1["angle"], ratio, ori)
     ok = ok and a[0] == b[0] and np.array_equal(a[1], b[1])
-    return ok, ("window", w, h, nf, seq, th, ratio, ori)
+    return ok, ("window", w, h, nf, seq, th, ratio, ori, cam)
 
 
 def _rand_frame_pair(rng, stereo2):
@@ -163,6 +193,10 @@ def _rand_frame_pair(rng, stereo2):
         _, k2, d2 = ref(synth.sequence_frame(w, h, seq, 2))
         keys, desc, nleft, ur = np.concatenate([k1, k2]), np.concatenate([d1, d2]), len(k1), None
     else:
+        cam = _rand_camera(rng, w, h)
+        if cam is not None:  # Nleft == -1: the frame holds mvKeysUn and Frame::ComputeImageBounds' bounds
+            k1, bounds = _camera_view(cam, k1, w, h)
+            k0, _ = _camera_view(cam, k0, w, h)
         keys, desc, nleft = k1, d1, -1
         ur = np.where(rng.random(len(k1)) < 0.5, k1["x"] - rng.uniform(1, 30, len(k1)), -1).astype(np.float32)
         if rng.random() < 0.3:
@@ -275,6 +309,43 @@ def case_resident(rng):
     return ok, tag
 
 
+def case_undistort(rng):
+    """A frame straight out of the extractor through a random distorted camera: vsg_frame_from_extractor_undistort
+    (Frame::UndistortKeyPoints on the device, FP64) against the oracle harness -- mvKeysUn bit for bit, the library's own
+    ComputeImageBounds, the device-built grid, and one windowed search on the resident frame."""
+    w, h = int(rng.integers(300, 800)), int(rng.integers(240, 600))
+    nf = int(rng.integers(100, 1500))
+    seq = int(rng.integers(0, 1 << 16))
+    cam = _rand_camera(rng, w, h) or dict(K4=(0.8 * w, 0.8 * w, w / 2, h / 2), dist=(0.0, 0.3, 0.0, 0.0), size=(w, h))
+    img = synth.sequence_frame(w, h, seq, 1)
+    ex = orb.ORBextractor(nf, 1.2, 8, 20, 7)
+    _, k, d = ex(img)
+    if len(k) == 0:
+        return True, ("undistort-empty",)
+    bounds = orb.camera_image_bounds(w, h, cam["K4"], cam["dist"])
+    tag = ("undistort", w, h, nf, seq, cam)
+    if bounds != ol.image_bounds(cam):
+        return False, tag
+    if not (np.all(np.isfinite(bounds)) and bounds[2] - bounds[0] > w / 4 and bounds[3] - bounds[1] > h / 4):
+        return True, ("undistort-degenerate",)
+    f = orb.Frame(ex.capacity(h, w)).from_extractor_undistort(ex, 0, k, cam["K4"], cam["dist"], bounds)
+    kun = ol.undistort_keypoints(k, cam)
+    if f.kps.tobytes() != kun.tobytes():
+        return False, tag
+    o = ol.OracleFrame(kun, d, bounds)
+    ok = all(np.array_equal(a, b) for a, b in zip(f.grid(), o.grid()))
+    import scenarios as sc
+    n = len(kun)
+    u = (kun["x"] - 3 + rng.normal(0, 2, n)).astype(np.float32)
+    v = (kun["y"] - 2 + rng.normal(0, 2, n)).astype(np.float32)
+    lvl = np.clip(kun["octave"] + rng.integers(-1, 2, n), 0, 7).astype(np.int32)
+    rad = (np.float32(rng.choice([3.0, 7.0])) * sc.SCALE_FACTORS[lvl]).astype(np.float32)
+    qd = sc.noisy_desc(rng, d, 8)
+    m0 = np.full(n, -1, np.int32)
+    a, b = f.SearchByProjection_Sim3(qd, u, v, rad, lvl, 1.0, m0), o.search_by_projection_sim3(qd, u, v, rad, lvl, 1.0, m0)
+    return bool(ok and a[0] == b[0] and np.array_equal(a[1], b[1])), tag
+
+
 def case_async(rng):
     """vsg_orb_submit_batch / vsg_orb_wait with random batch sizes, strides, pinned / pageable buffers, lapping areas."""
     w, h, nf, sc_, nl, ini, mn = geometry(rng)
@@ -320,7 +391,7 @@ def _finish(ex, ref, ticket, buf, lap, pinned):
     return bool(ok)
 
 
-CASES = {"resident": case_resident, "async": case_async, "window": case_window, "batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow}
+CASES = {"undistort": case_undistort, "resident": case_resident, "async": case_async, "window": case_window, "batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow}
 
 
 def main():

@@ -18,12 +18,14 @@
 #include <stdlib.h>
 #include <time.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "vsg_frame_int.h"
 #include "vsg_math.h"
+#include "vsg_undistort.h"
 
 using namespace vsg;
 
@@ -57,21 +59,35 @@ __global__ __launch_bounds__(1024) void k_frame_grid_build(const KeyPointPOD *__
                                                             KeyPointPOD *__restrict__ kps_copy,
                                                             const uint8_t *__restrict__ desc_src,
                                                             uint8_t *__restrict__ desc_copy,
-                                                            int *__restrict__ zero_cells) {
+                                                            int *__restrict__ zero_cells, CamModel cam,
+                                                            KeyPointPOD *__restrict__ kps_un_host) {
   __shared__ int s_cnt[kGridCells + 1];
   __shared__ int s_fill[kGridCells];
   __shared__ int s_wtot[16];
   const int tid = threadIdx.x;
   // making a frame resident straight out of the extractor is ONE launch: the keypoint / descriptor records are copied
   // into the frame's block and the (absent) right-camera grid is emptied by the threads that build the grid
-  if (kps_copy)
+  // Frame::UndistortKeyPoints (Frame.cc:891-921) on the way: with a distorted camera the frame's keypoints are mvKeysUn
+  // -- every pt through cv::undistortPoints' five double-precision iterations (vsg_undistort.h) -- and the grid below is
+  // built from THEM; the host's copy of mvKeysUn is written to pinned memory by the same threads
+  const bool undist = kps_copy && cam.distorted;
+  if (undist) {
+    for (int i = tid; i < n; i += 1024) {
+      KeyPointPOD kp = kps[i0 + i];
+      undistort_point(cam, kp.x, kp.y, &kp.x, &kp.y);
+      kps_copy[i] = kp;
+      if (kps_un_host) kps_un_host[i] = kp;
+    }
+  } else if (kps_copy) {
     for (int i = tid; i < n * 7; i += 1024) ((uint32_t *)kps_copy)[i] = ((const uint32_t *)(kps + i0))[i];
+  }
   if (desc_copy)
     for (int i = tid; i < n * 8; i += 1024) ((uint32_t *)desc_copy)[i] = ((const uint32_t *)desc_src)[i];
   if (zero_cells)
     for (int c = tid; c <= kGridCells; c += 1024) zero_cells[c] = 0;
   for (int c = tid; c <= kGridCells; c += 1024) s_cnt[c] = 0;
-  __syncthreads();
+  __syncthreads();  // (also: the undistorted records above are visible to the whole workgroup)
+  const KeyPointPOD *gsrc = undist ? kps_copy : kps + i0;  // the keypoints the grid indexes (mvKeysUn)
   // PosInGrid (Frame.cc:870-880): round() = half away from zero
   auto cell_of = [&](const KeyPointPOD &kp) -> int {
     const int px = cvt_int_x86(roundf(fmul(fsub(kp.x, minX), invW)));
@@ -79,7 +95,7 @@ __global__ __launch_bounds__(1024) void k_frame_grid_build(const KeyPointPOD *__
     return (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? -1 : px * kGridRows + py;
   };
   for (int i = tid; i < n; i += 1024) {
-    const int c = cell_of(kps[i0 + i]);
+    const int c = cell_of(gsrc[i]);
     if (c >= 0) atomicAdd(&s_cnt[c], 1);
   }
   __syncthreads();
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(1024) void k_frame_grid_build(const KeyPointPOD *__
   __syncthreads();
   for (int c = tid; c <= kGridCells; c += 1024) cell_start[c] = s_cnt[c];
   for (int i = tid; i < n; i += 1024) {
-    const KeyPointPOD kp = kps[i0 + i];
+    const KeyPointPOD kp = gsrc[i];
     const int c = cell_of(kp);
     if (c < 0) continue;
     const int slot = atomicAdd(&s_fill[c], 1);
@@ -578,26 +594,74 @@ int vsg_frame_upload(vsg_frame *f, const vsg_keypoint *keys, const uint8_t *desc
   return VSG_OK;
 }
 
-int vsg_frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_keypoint *kps_host, int n, float min_x,
-                             float min_y, float max_x, float max_y) {
-  if (frame_check(f) != VSG_OK || !h || n < 0 || n > f->capacity || (n > 0 && !kps_host)) return VSG_ERR_INVALID;
+// one launch: [undistortion +] grid from the keypoints where they already are (the extractor's output) + the two record
+// copies + an empty right-camera grid
+static int frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_keypoint *kps_host, int n,
+                                const CamModel &cam, float min_x, float min_y, float max_x, float max_y,
+                                vsg_keypoint *keys_un_out) {
   OrbOutputView v;
   int rc = vsg_orb_output_view(h, index, &v);
   if (rc != VSG_OK) return rc;
   if (v.device != f->device) return VSG_ERR_INVALID;
   ThreadCtx *c = thread_ctx(f->device, &rc);
   if (!c) return rc;
+  KeyPointPOD *un_pin = nullptr, *un_dev = nullptr;
+  if (cam.distorted) {  // mvKeysUn comes back through the calling thread's pinned arena (written by the kernel itself)
+    rc = ctx_reserve(c, (size_t)(n + 1) * sizeof(KeyPointPOD), 0);
+    if (rc != VSG_OK) return rc;
+    un_pin = (KeyPointPOD *)c->h_pin, un_dev = (KeyPointPOD *)c->d_pin;
+  }
   set_bounds(f, min_x, min_y, max_x, max_y);
   f->n = n, f->nleft = -1, f->has_uright = false;
-  f->h_kps.assign(kps_host, kps_host + n);
   if (v.done) F_TRY(hipStreamWaitEvent(c->stream, v.done, 0));
-  // one launch: grid from the keypoints where they already are (the extractor's output) + the two record copies +
-  // an empty right-camera grid
   hipLaunchKernelGGL(k_frame_grid_build, dim3(1), dim3(1024), 0, c->stream, v.d_kps, 0, n, f->minX, f->minY, f->invW,
-                     f->invH, f->d_cell_start[0], f->d_ent[0], f->d_kps, v.d_desc, f->d_desc, f->d_cell_start[1]);
+                     f->invH, f->d_cell_start[0], f->d_ent[0], f->d_kps, v.d_desc, f->d_desc, f->d_cell_start[1], cam,
+                     un_dev);
   F_TRY(hipGetLastError());
+  if (!cam.distorted) f->h_kps.assign(kps_host, kps_host + n);  // beside the kernel
   F_TRY(hipStreamSynchronize(c->stream));
+  if (cam.distorted) {
+    f->h_kps.assign((const vsg_keypoint *)un_pin, (const vsg_keypoint *)un_pin + n);
+    if (keys_un_out && n) memcpy(keys_un_out, un_pin, (size_t)n * sizeof(vsg_keypoint));
+  } else if (keys_un_out && n && keys_un_out != kps_host) {
+    memcpy(keys_un_out, kps_host, (size_t)n * sizeof(vsg_keypoint));  // mvKeysUn = mvKeys (Frame.cc:893-897)
+  }
   return VSG_OK;
+}
+
+int vsg_frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_keypoint *kps_host, int n, float min_x,
+                             float min_y, float max_x, float max_y) {
+  if (frame_check(f) != VSG_OK || !h || n < 0 || n > f->capacity || (n > 0 && !kps_host)) return VSG_ERR_INVALID;
+  CamModel cam = {};
+  return frame_from_extractor(f, h, index, kps_host, n, cam, min_x, min_y, max_x, max_y, nullptr);
+}
+
+int vsg_camera_image_bounds(int cols, int rows, const float K4[4], const float *dist, int ndist, float out[4]) {
+  CamModel cam;
+  if (!out || cols < 1 || rows < 1 || !make_cam_model(K4, dist, ndist, &cam)) return VSG_ERR_INVALID;
+  if (!cam.distorted) {  // Frame.cc:948-954
+    out[0] = 0.0f, out[1] = 0.0f, out[2] = (float)cols, out[3] = (float)rows;
+    return VSG_OK;
+  }
+  // the four corners through cv::undistortPoints (Frame.cc:928-946): four points, once per camera -- host arithmetic,
+  // the same source the device runs per keypoint
+  float x[4], y[4];
+  const float cx[4] = {0.f, (float)cols, 0.f, (float)cols}, cy[4] = {0.f, 0.f, (float)rows, (float)rows};
+  for (int i = 0; i < 4; i++) undistort_point(cam, cx[i], cy[i], &x[i], &y[i]);
+  out[0] = std::min(x[0], x[2]);  // mnMinX = min(mat(0,0), mat(2,0))
+  out[2] = std::max(x[1], x[3]);  // mnMaxX = max(mat(1,0), mat(3,0))
+  out[1] = std::min(y[0], y[1]);  // mnMinY = min(mat(0,1), mat(1,1))
+  out[3] = std::max(y[2], y[3]);  // mnMaxY = max(mat(2,1), mat(3,1))
+  return VSG_OK;
+}
+
+int vsg_frame_from_extractor_undistort(vsg_frame *f, vsg_orb *h, int index, const vsg_keypoint *kps_host, int n,
+                                       const float K4[4], const float *dist, int ndist, float min_x, float min_y,
+                                       float max_x, float max_y, vsg_keypoint *keys_un_out) {
+  if (frame_check(f) != VSG_OK || !h || n < 0 || n > f->capacity || (n > 0 && !kps_host)) return VSG_ERR_INVALID;
+  CamModel cam;
+  if (!make_cam_model(K4, dist, ndist, &cam)) return VSG_ERR_INVALID;
+  return frame_from_extractor(f, h, index, kps_host, n, cam, min_x, min_y, max_x, max_y, keys_un_out);
 }
 
 int vsg_frame_copy_grid(vsg_frame *f, int right, int32_t *cell_start, int32_t *entries) {

@@ -61,7 +61,7 @@ EXPORTS = [
     "vsg_shard_record", "vsg_shard_world", "vsg_shard_send_recv_boundary", "vsg_shard_boundary_record",
     "vsg_copy_d2d_async", "vsg_orb_chain_graph_launches",
     # round 4
-    "vsg_orb_set_pyramid_tiling", "vsg_shard_rank",
+    "vsg_orb_set_pyramid_tiling", "vsg_shard_rank", "vsg_camera_image_bounds", "vsg_frame_from_extractor_undistort",
 ]
 
 
@@ -72,6 +72,16 @@ class VsgError(RuntimeError):
 
 
 _lib = None
+
+
+def camera_image_bounds(cols, rows, K4, dist):
+    """Frame::ComputeImageBounds (Frame.cc:924-955): (mnMinX, mnMinY, mnMaxX, mnMaxY); host arithmetic in the library."""
+    L = load_library()
+    K4, dist = np.ascontiguousarray(K4, np.float32), np.ascontiguousarray(dist, np.float32)
+    out = np.zeros(4, np.float32)
+    _check(L.vsg_camera_image_bounds(int(cols), int(rows), _p(K4, _f32p), _p(dist, _f32p), len(dist), _p(out, _f32p)),
+           "vsg_camera_image_bounds")
+    return tuple(float(v) for v in out)
 
 
 def debug_device_sort(items, device=0):
@@ -202,6 +212,8 @@ def load_library():
     L.vsg_frame_destroy.restype = None
     L.vsg_frame_upload.argtypes = [vp, vp, _u8p, _f32p, ci, ci, cf, cf, cf, cf]
     L.vsg_frame_from_extractor.argtypes = [vp, vp, ci, vp, ci, cf, cf, cf, cf]
+    L.vsg_frame_from_extractor_undistort.argtypes = [vp, vp, ci, vp, ci, _f32p, _f32p, ci, cf, cf, cf, cf, vp]
+    L.vsg_camera_image_bounds.argtypes = [ci, ci, _f32p, _f32p, ci, _f32p]
     L.vsg_frame_size.argtypes = [vp]
     L.vsg_frame_copy_grid.argtypes = [vp, ci, _i32p, _i32p]
     L.vsg_frame_features_in_area.argtypes = [vp, _f32p, _f32p, _f32p, _i32p, _i32p, ci, ci, _i32p, _i32p, ci]
@@ -856,6 +868,18 @@ class Frame:
         _check(self._L.vsg_frame_from_extractor(self._h, ex.handle, int(index), k.ctypes.data_as(C.c_void_p), len(k),
                                                 *[float(b) for b in bounds]), "vsg_frame_from_extractor")
         self.kps, self.nleft = k, -1
+        return self
+
+    def from_extractor_undistort(self, ex, index, kps, K4, dist, bounds):
+        """The same for a distorted pinhole camera: Frame::UndistortKeyPoints (Frame.cc:891-921) on the device inside the
+        grid launch.  self.kps = mvKeysUn afterwards."""
+        k = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+        K4, dist = _f32(np.asarray(K4)), _f32(np.asarray(dist))
+        un = np.zeros(len(k), KP_DTYPE)
+        _check(self._L.vsg_frame_from_extractor_undistort(
+            self._h, ex.handle, int(index), k.ctypes.data_as(C.c_void_p), len(k), _p(K4, _f32p), _p(dist, _f32p), len(dist),
+            *[float(b) for b in bounds], un.ctypes.data_as(C.c_void_p)), "vsg_frame_from_extractor_undistort")
+        self.kps, self.nleft = un, -1
         return self
 
     def grid(self, right=False):
