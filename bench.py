@@ -165,20 +165,24 @@ def config_chain_leg(seconds=2.0, pipelines=4):
         return {"error": str(e)}
 
 
-def device_rate(workload, batch, steps, device, cpu_seconds=3.0):
-    """Another BASELINE config on the main bench's terms (frames resident in HBM, one batch per step): extract +
-    brute-force best2 match of every frame against its predecessor, the first and last frame and the last match
-    bit-compared with the CPU oracle, the oracle's own rate on one host thread beside it."""
+def device_rate(workload, batch, steps, device, cpu_seconds=3.0, uniq=None, label=None, ex=None):
+    """Another BASELINE config -- or another CONTENT CLASS of the headline config (`uniq`: the distinct frames the batch
+    cycles through) -- on the main bench's terms (frames resident in HBM, one batch per step): extract + brute-force
+    best2 match of every frame against its predecessor, the first and last frame and the last match bit-compared with
+    the CPU oracle, the oracle's own rate on one host thread beside it, the FAST kernel's launch duration by HIP events
+    around its launches inside the timed steps."""
     import ctypes as C
     import torch
     import oracle_lib as ol
     from visual_sgraphs_amd import orb, synth
     W, H, nfeat = WORKLOADS[workload]
     dev = torch.device("cuda", device)
-    ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, device=device, max_batch=batch)
+    if ex is None:
+        ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, device=device, max_batch=batch)
     cap = ex.capacity(H, W)
-    nuniq = min(batch, 16)
-    uniq = np.stack([synth.sequence_frame(W, H, 3000, t) for t in range(nuniq)])
+    if uniq is None:
+        uniq = np.stack([synth.sequence_frame(W, H, 3000, t) for t in range(min(batch, 16))])
+    nuniq = len(uniq)
     frames = np.concatenate([uniq] * ((batch + nuniq - 1) // nuniq))[:batch]
     d_gray = torch.from_numpy(frames).to(dev)
     d_kps = torch.zeros((batch + 1, cap, 28), dtype=torch.uint8, device=dev)
@@ -193,6 +197,7 @@ def device_rate(workload, batch, steps, device, cpu_seconds=3.0):
         for i in range(steps + warm):
             if i == warm:
                 torch.cuda.synchronize()
+                ex.enable_timing(2)  # events around the FAST launches only
                 t0 = time.perf_counter()
             d_desc[0].copy_(d_desc[batch])
             d_counts[0].copy_(d_counts[batch])
@@ -205,6 +210,8 @@ def device_rate(workload, batch, steps, device, cpu_seconds=3.0):
             assert rc == 0, rc
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    fast_ms = ex.timing_ms().get("fast")
+    ex.enable_timing(0)
     counts, kps_h, desc_h = d_counts.cpu().numpy(), d_kps.cpu().numpy(), d_desc.cpu().numpy()
     ref = ol.OracleExtractor(nfeat, 1.2, 8, 20, 7)
     ok = True
@@ -218,10 +225,38 @@ def device_rate(workload, batch, steps, device, cpu_seconds=3.0):
     ok &= np.array_equal(d_best[batch - 1, :n].cpu().numpy(), rb) and np.array_equal(d_arg[batch - 1, :n].cpu().numpy(), ra)
     ok &= np.array_equal(d_second[batch - 1, :n].cpu().numpy(), rs)
     v1, n1 = ol.bench_throughput(uniq, nfeat, 1, cpu_seconds, do_match=True)
-    return {"workload": f"{workload}: {W}x{H}, nFeatures={nfeat}, extract + brute-force best2 match vs previous frame, "
-                        f"{batch}-frame batches resident in HBM", "unit": "frames/s", "frames_per_step": batch,
+    return {"workload": label or f"{workload}: {W}x{H}, nFeatures={nfeat}, extract + brute-force best2 match vs previous "
+                                 f"frame, {batch}-frame batches resident in HBM", "unit": "frames/s", "frames_per_step": batch,
             "frames_per_s": round(batch * steps / dt, 1), "keypoints_per_frame": round(float(counts[1:, 0].mean()), 1),
+            "fast_ms": round(fast_ms, 4) if fast_ms else None,
             "parity": bool(ok), "cpu_oracle": {"frames_per_s": round(v1, 2), "threads": 1, "kind": "port", "frames": n1}}
+
+
+def content_sweep_leg(device, batch=512, steps=12, nuniq=32, cpu_seconds=1.0):
+    """The headline workload (C2: 640x480 / 1000, extract + match, `batch`-frame batches resident in HBM) on every
+    content class of synth.CONTENT_CLASSES: frames/s, the FAST kernel's launch time, the parity flag and the CPU oracle's
+    rate per class -- the spread of `value` over image statistics (a headline measured on rectangles +
+    noise alone has no error bar).  The batch cycles through `nuniq` distinct frames of the class (consecutive frames of
+    one translated sequence)."""
+    from visual_sgraphs_amd import orb, synth
+    W, H, nfeat = WORKLOADS["C2"]
+    ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, device=device, max_batch=batch)
+    out = {}
+    for kind in synth.CONTENT_CLASSES:
+        uniq = np.stack([synth.content_frame(kind, W, H, 5000, t) for t in range(nuniq)])
+        try:
+            r = device_rate("C2", batch, steps, device, cpu_seconds, uniq=uniq, label=kind, ex=ex)
+            out[kind] = {k: r[k] for k in ("frames_per_s", "fast_ms", "keypoints_per_frame", "parity")}
+            out[kind]["cpu_oracle_frames_per_s"] = r["cpu_oracle"]["frames_per_s"]
+        except Exception as e:  # noqa: BLE001
+            out[kind] = {"error": str(e)}
+    good = [v["frames_per_s"] for v in out.values() if "frames_per_s" in v]
+    fast = [v["fast_ms"] for v in out.values() if v.get("fast_ms")]
+    return {"workload": f"C2 geometry, extract + match, {batch}-frame batches resident in HBM ({nuniq} distinct frames per "
+                        "class, cycled), one entry per content class of synth.CONTENT_CLASSES",
+            "classes": out, "frames_per_s_min": min(good) if good else None, "frames_per_s_max": max(good) if good else None,
+            "fast_ms_min": min(fast) if fast else None, "fast_ms_max": max(fast) if fast else None,
+            "all_parity": all(v.get("parity") is True for v in out.values())}
 
 
 def visible_gpu_count():
@@ -833,6 +868,10 @@ def main():
             other.append({"workload": "C4", "error": str(e)})
         other.append(chain.get("C5", {"workload": "C5", **chain}))
         out["other_configs"] = other
+        try:
+            out["content_sweep"] = content_sweep_leg(local_rank, cpu_seconds=min(1.0, max(0.3, args.cpu_seconds / 8)))
+        except Exception as e:  # noqa: BLE001
+            out["content_sweep"] = {"error": str(e)}
         # the call pattern the reference has: ONE frame per blocking operator() (System.cc:359, Tracking.cc:1583,
         # Frame.cc:344,555-563), from plain C++ through the C ABI, with the CPU oracle's chain beside each figure
         fl = dict(chain.get("frame_latency") or {"error": chain.get("error", "config_chain gave no frame_latency")})

@@ -23,6 +23,9 @@ def frames(w, h):
     out.append(np.full((h, w), 77, np.uint8))
     out.append(rng.integers(0, 256, (h, w), dtype=np.uint8))
     out.append(np.clip(128 + rng.integers(-12, 13, (h, w)), 0, 255).astype(np.uint8))
+    # content classes that fill the queue (one-sided: checkerboard; two-sided: the steep ramp), that leave whole levels to
+    # the minThFAST pass (value noise) and that scatter isolated corners (salt and pepper)
+    out += [synth.content_frame(kind, w, h, 13, 2) for kind in ("checker1", "sawtooth", "value_noise", "salt_pepper")]
     return np.stack(out)
 
 

@@ -17,4 +17,4 @@ def test_every_cells_per_workgroup_count_gives_the_oracles_output(k):
     env = dict(os.environ, VSG_FAST_K=k)
     r = subprocess.run([sys.executable, str(CHILD)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert r.stdout.strip().splitlines()[-1].startswith("OK 63"), r.stdout[-500:]
+    assert r.stdout.strip().splitlines()[-1].startswith("OK 91"), r.stdout[-500:]

@@ -303,15 +303,45 @@ static std::string run_c3(double seconds, int npipes) {
   return b;
 }
 
+// ------------------------------------------------------------------------------------------------ cameras
+// The two BASELINE cameras whose Frame constructor really undistorts (mDistCoef(0) != 0): Frame::UndistortKeyPoints
+// (Frame.cc:891-921) gives mvKeysUn, Frame::ComputeImageBounds (Frame.cc:924-955) fractional grid bounds.
+struct Camera {
+  const char *name;
+  float K4[4], dist[5];
+  int ndist;
+  float bounds[4];  // mnMinX, mnMinY, mnMaxX, mnMaxY (vsg_camera_image_bounds, checked against the oracle's)
+  void init(int cols, int rows) {
+    CHECK(vsg_camera_image_bounds(cols, rows, K4, dist, ndist, bounds) == VSG_OK);
+    float ob[4];
+    or_image_bounds(cols, rows, K4, dist, ndist, ob);
+    CHECK(!memcmp(ob, bounds, sizeof ob));
+  }
+};
+// config/RGB-D-Inertial/RealSense_D435i.yaml:11-23 (C5) and config/RGB-D/TUM1.yaml:11-23 (C1; 640x480 / 1000 = the frame
+// latency workload)
+static Camera cam_d435i() {
+  return {"RealSense D435i (k1 0.125, k2 -0.251, p1 0.0007, p2 0.0062)",
+          {6.165911254882812e+02f, 6.166796264648438e+02f, 3.242193603515625e+02f, 2.3942701721191406e+02f},
+          {1.25323e-01f, -2.51452e-01f, 7.12e-04f, 6.217e-03f, 0.f}, 4, {0, 0, 0, 0}};
+}
+static Camera cam_tum1() {
+  return {"TUM1 (k1 0.262, k2 -0.953, p1 -0.0054, p2 0.0026, k3 1.163)",
+          {517.306408f, 516.469215f, 318.643040f, 255.313989f},
+          {0.262383f, -0.953104f, -0.005358f, 0.002628f, 1.163314f}, 5, {0, 0, 0, 0}};
+}
+
 // ------------------------------------------------------------------------------------------------ C5
 static const int W5 = 640, H5 = 480, NF5 = 1250, NSTREAM = 5 - 1;
 
 struct TrackResult {
   int n = 0, n_last = 0, n_local = 0;
-  std::vector<vsg_keypoint> kp;
+  std::vector<vsg_keypoint> kp, kpun;  // mvKeys, mvKeysUn
   std::vector<uint8_t> ds, tb;
   std::vector<int32_t> tm_last, tm_local;
-  void size_for(int cap) { kp.resize(cap), ds.resize((size_t)cap * 32), tb.resize(cap), tm_last.resize(cap), tm_local.resize(cap); }
+  void size_for(int cap) {
+    kp.resize(cap), kpun.resize(cap), ds.resize((size_t)cap * 32), tb.resize(cap), tm_last.resize(cap), tm_local.resize(cap);
+  }
 };
 
 // the projections of the previous frame's features into the current one: the scene moves by (-3, -2) px per frame
@@ -321,8 +351,8 @@ struct Queries {
   std::vector<uint8_t> obs;
   void from(const TrackResult &P) {
     u.resize(P.n), v.resize(P.n), ang.resize(P.n), vc.assign(P.n, 0.9f), oct.resize(P.n), obs.assign(P.n, 1);
-    for (int i = 0; i < P.n; i++)
-      u[i] = P.kp[i].x - 3.f, v[i] = P.kp[i].y - 2.f, ang[i] = P.kp[i].angle, oct[i] = P.kp[i].octave;
+    for (int i = 0; i < P.n; i++)  // projected from the previous frame's UNDISTORTED keypoints, like the reference's geometry
+      u[i] = P.kpun[i].x - 3.f, v[i] = P.kpun[i].y - 2.f, ang[i] = P.kpun[i].angle, oct[i] = P.kpun[i].octave;
   }
 };
 
@@ -334,7 +364,9 @@ struct C5Gpu {
   TrackResult res[2];
   Queries q;
   long frames = 0;
+  Camera cam = cam_d435i();
   void init(int dev) {
+    cam.init(W5, H5);
     CHECK(vsg_orb_create(NF5, 1.2f, 8, 20, 7, dev, 1, &ex) == VSG_OK);
     cap = vsg_orb_capacity(ex, H5, W5);
     CHECK(cap > 0);
@@ -347,7 +379,9 @@ struct C5Gpu {
   void frame(const uint8_t *img, int t, bool have_prev) {
     TrackResult &R = res[t & 1], &P = res[(t + 1) & 1];
     CHECK(vsg_orb_extract(ex, img, H5, W5, W5, 0, 0, R.kp.data(), R.ds.data(), cap, &R.n) >= 0);
-    CHECK(vsg_frame_from_extractor(F[t & 1], ex, 0, R.kp.data(), R.n, 0.f, 0.f, (float)W5, (float)H5) == VSG_OK);
+    // Frame::UndistortKeyPoints on the device, inside the launch that builds the grid; mvKeysUn comes back for the host
+    CHECK(vsg_frame_from_extractor_undistort(F[t & 1], ex, 0, R.kp.data(), R.n, cam.K4, cam.dist, cam.ndist, cam.bounds[0],
+                                             cam.bounds[1], cam.bounds[2], cam.bounds[3], R.kpun.data()) == VSG_OK);
     R.n_last = R.n_local = 0;
     if (have_prev) {
       q.from(P);
@@ -377,7 +411,9 @@ struct C5Cpu {
   TrackResult res[2];
   Queries q;
   long frames = 0;
+  Camera cam = cam_d435i();
   explicit C5Cpu(int cap_) : cap(cap_) {
+    cam.init(W5, H5);
     ex = or_create(NF5, 1.2f, 8, 20, 7);
     or_get_tables(ex, sf, nullptr, nullptr, nullptr, nullptr, nullptr);
     res[0].size_for(cap), res[1].size_for(cap);
@@ -385,7 +421,9 @@ struct C5Cpu {
   void frame(const uint8_t *img, int t, bool have_prev) {
     TrackResult &R = res[t & 1], &P = res[(t + 1) & 1];
     or_extract(ex, img, H5, W5, W5, 0, 0, (OrKeyPoint *)R.kp.data(), R.ds.data(), cap, &R.n);
-    OrFrame *f = or_frame_create((const OrKeyPoint *)R.kp.data(), R.ds.data(), nullptr, R.n, -1, 0.f, 0.f, (float)W5, (float)H5);
+    or_undistort_keypoints((const OrKeyPoint *)R.kp.data(), R.n, cam.K4, cam.dist, cam.ndist, (OrKeyPoint *)R.kpun.data());
+    OrFrame *f = or_frame_create((const OrKeyPoint *)R.kpun.data(), R.ds.data(), nullptr, R.n, -1, cam.bounds[0], cam.bounds[1],
+                                 cam.bounds[2], cam.bounds[3]);
     R.n_last = R.n_local = 0;
     if (have_prev) {
       q.from(P);
@@ -406,6 +444,7 @@ struct C5Cpu {
 
 static bool same_track(const TrackResult &a, const TrackResult &b) {
   return a.n == b.n && a.n_last == b.n_last && a.n_local == b.n_local && !memcmp(a.kp.data(), b.kp.data(), (size_t)a.n * 28) &&
+         !memcmp(a.kpun.data(), b.kpun.data(), (size_t)a.n * 28) &&
          !memcmp(a.ds.data(), b.ds.data(), (size_t)a.n * 32) && !memcmp(a.tm_last.data(), b.tm_last.data(), (size_t)a.n * 4) &&
          !memcmp(a.tm_local.data(), b.tm_local.data(), (size_t)a.n * 4);
 }
@@ -475,15 +514,17 @@ static std::string run_c5(double seconds) {
     for (auto &x : th) x.join();
     cpu_fps = total / ((now_ms() - t0) * 1e-3);
   }
-  char b[2048];
+  char b[3072];
   snprintf(b, sizeof b,
            "{\"workload\": \"C5: %d concurrent 640x480 camera streams, nFeatures=1250, one extractor + one host thread per "
-           "stream, per frame operator() -> resident frame -> SearchByProjection(Cur, Last) -> SearchByProjection(F, local "
+           "stream, camera = %s: per frame operator() -> UndistortKeyPoints on the device + resident frame on the grid bounds "
+           "(%.3f, %.3f, %.3f, %.3f) of ComputeImageBounds -> SearchByProjection(Cur, Last) -> SearchByProjection(F, local "
            "map points); stream s on device s mod %d\", \"unit\": \"frames/s\", \"frames_per_s\": %.1f, "
            "\"frames_per_s_one_stream\": %.1f, \"ms_per_frame_one_stream\": %.4f, \"streams\": %d, \"devices\": %d, "
            "\"parity\": %s, \"frames_checked\": %d, \"per_frame\": {\"keypoints\": %.1f, \"matches_last_frame\": %.1f, "
            "\"matches_local_map\": %.1f}, \"cpu_oracle\": {\"frames_per_s\": %.2f, \"threads\": %d, \"kind\": \"port\"}}",
-           NSTREAM, ndev, fps4, fps1, 1e3 / fps1, NSTREAM, ndev, parity ? "true" : "false", NSTREAM * T,
+           NSTREAM, g[0].cam.name, g[0].cam.bounds[0], g[0].cam.bounds[1], g[0].cam.bounds[2], g[0].cam.bounds[3], ndev, fps4, fps1,
+           1e3 / fps1, NSTREAM, ndev, parity ? "true" : "false", NSTREAM * T,
            (double)kps / (NSTREAM * T), (double)m_last / (NSTREAM * (T - 1)), (double)m_local / (NSTREAM * (T - 1)), cpu_fps,
            NSTREAM);
   return b;
@@ -515,12 +556,23 @@ static std::string run_latency(double seconds) {
   }
   Queries q;
   bool parity = true;
-  // one frame of each chain; level: 0 = operator() only, 1 = + resident frame, 2 = + the two tracking searches
-  auto gpu = [&](int t, int level) {
+  Camera cam = cam_tum1();  // C1's camera (TUM1.yaml: 640x480 / 1000 features): mDistCoef(0) != 0
+  cam.init(W, H);
+  // one frame of each chain; level: 0 = operator() only, 1 = + UndistortKeyPoints + resident frame, 2 = + the two tracking
+  // searches; `upload` = the other route to the same resident frame: mvKeysUn on the HOST (the reference's
+  // cv::undistortPoints; here the oracle's restatement stands in for it), then vsg_frame_upload(mvKeysUn, bounds)
+  auto gpu = [&](int t, int level, bool upload = false) {
     TrackResult &C = R[t & 1], &P = R[(t + 1) & 1];
     CHECK(vsg_orb_extract(ex, img[t % T].data(), H, W, W, 0, 0, C.kp.data(), C.ds.data(), cap, &C.n) >= 0);
     if (level < 1) return;
-    CHECK(vsg_frame_from_extractor(F[t & 1], ex, 0, C.kp.data(), C.n, 0.f, 0.f, (float)W, (float)H) == VSG_OK);
+    if (upload) {
+      or_undistort_keypoints((const OrKeyPoint *)C.kp.data(), C.n, cam.K4, cam.dist, cam.ndist, (OrKeyPoint *)C.kpun.data());
+      CHECK(vsg_frame_upload(F[t & 1], C.kpun.data(), C.ds.data(), nullptr, C.n, -1, cam.bounds[0], cam.bounds[1], cam.bounds[2],
+                             cam.bounds[3]) == VSG_OK);
+    } else {
+      CHECK(vsg_frame_from_extractor_undistort(F[t & 1], ex, 0, C.kp.data(), C.n, cam.K4, cam.dist, cam.ndist, cam.bounds[0],
+                                               cam.bounds[1], cam.bounds[2], cam.bounds[3], C.kpun.data()) == VSG_OK);
+    }
     if (level < 2 || P.n == 0) return;
     q.from(P);
     std::fill(C.tb.begin(), C.tb.begin() + C.n, 0), std::fill(C.tm_last.begin(), C.tm_last.begin() + C.n, -1);
@@ -537,7 +589,9 @@ static std::string run_latency(double seconds) {
     TrackResult &C = O[t & 1], &P = O[(t + 1) & 1];
     or_extract(oe, img[t % T].data(), H, W, W, 0, 0, (OrKeyPoint *)C.kp.data(), C.ds.data(), cap, &C.n);
     if (level < 1) return;
-    OrFrame *f = or_frame_create((const OrKeyPoint *)C.kp.data(), C.ds.data(), nullptr, C.n, -1, 0.f, 0.f, (float)W, (float)H);
+    or_undistort_keypoints((const OrKeyPoint *)C.kp.data(), C.n, cam.K4, cam.dist, cam.ndist, (OrKeyPoint *)C.kpun.data());
+    OrFrame *f = or_frame_create((const OrKeyPoint *)C.kpun.data(), C.ds.data(), nullptr, C.n, -1, cam.bounds[0], cam.bounds[1],
+                                 cam.bounds[2], cam.bounds[3]);
     if (level >= 2 && P.n > 0) {
       q.from(P);
       std::fill(C.tb.begin(), C.tb.begin() + C.n, 0), std::fill(C.tm_last.begin(), C.tm_last.begin() + C.n, -1);
@@ -551,30 +605,43 @@ static std::string run_latency(double seconds) {
     }
     or_frame_destroy(f);
   };
-  for (int t = 0; t < 2 * T; t++) {  // parity over two laps of the sequence (the second one runs on recorded graphs)
-    gpu(t, 2), cpu(t, 2);
+  for (int t = 0; t < 3 * T; t++) {  // parity over three laps of the sequence, the last one on the upload route
+    gpu(t, 2, t >= 2 * T), cpu(t, 2);
     parity = parity && same_track(R[t & 1], O[t & 1]);
   }
-  double g_ms[3], c_ms[3];
+  double g_ms[3], c_ms[3], up_ms[2];
   for (int level = 0; level < 3; level++) {
     int t = 0, n = 0;
     for (int w = 0; w < 12; w++) gpu(t++, level);
     double t0 = now_ms();
     while (now_ms() - t0 < seconds * 400) gpu(t++, level), n++;
     g_ms[level] = (now_ms() - t0) / n;
+    if (level >= 1) {  // the same level through host undistortion + vsg_frame_upload
+      t = 0, n = 0;
+      for (int w = 0; w < 12; w++) gpu(t++, level, true);
+      t0 = now_ms();
+      while (now_ms() - t0 < seconds * 400) gpu(t++, level, true), n++;
+      up_ms[level - 1] = (now_ms() - t0) / n;
+    }
     t = 0, n = 0;
     t0 = now_ms();
     while (now_ms() - t0 < seconds * 400) cpu(t++, level), n++;
     c_ms[level] = (now_ms() - t0) / n;
   }
-  char b[1024];
+  char b[3072];
   snprintf(b, sizeof b,
            "{\"workload\": \"one 640x480 / 1000-feature frame per blocking operator() call through the C ABI, host image in, "
-           "host records out\", \"extract_ms\": %.4f, \"extract_plus_resident_ms\": %.4f, \"track_chain_ms\": %.4f, "
+           "host records out; camera = %s, grid bounds (%.3f, %.3f, %.3f, %.3f) from ComputeImageBounds\", "
+           "\"extract_ms\": %.4f, \"extract_plus_resident_ms\": %.4f, \"track_chain_ms\": %.4f, "
+           "\"upload_route\": {\"extract_plus_resident_ms\": %.4f, \"track_chain_ms\": %.4f, \"what\": \"mvKeysUn on the host "
+           "(stand-in for cv::undistortPoints: the oracle's restatement) -> vsg_frame_upload(mvKeysUn, bounds) instead of the "
+           "on-device UndistortKeyPoints\"}, "
            "\"cpu_oracle_1_thread\": {\"extract_ms\": %.3f, \"extract_plus_resident_ms\": %.3f, \"track_chain_ms\": %.3f}, "
-           "\"parity\": %s, \"graph_launches\": %ld, \"track_chain\": \"operator() -> resident frame -> "
-           "SearchByProjection(Cur, Last) -> SearchByProjection(F, local map points)\"}",
-           g_ms[0], g_ms[1], g_ms[2], c_ms[0], c_ms[1], c_ms[2], parity ? "true" : "false", vsg_orb_chain_graph_launches(ex));
+           "\"parity\": %s, \"graph_launches\": %ld, \"track_chain\": \"operator() -> UndistortKeyPoints (on the device, "
+           "FP64, inside the grid launch) -> resident frame -> SearchByProjection(Cur, Last) -> SearchByProjection(F, local map "
+           "points)\"}",
+           cam.name, cam.bounds[0], cam.bounds[1], cam.bounds[2], cam.bounds[3], g_ms[0], g_ms[1], g_ms[2], up_ms[0], up_ms[1],
+           c_ms[0], c_ms[1], c_ms[2], parity ? "true" : "false", vsg_orb_chain_graph_launches(ex));
   for (int i = 0; i < 2; i++) vsg_frame_destroy(F[i]);
   vsg_orb_destroy(ex);
   or_destroy(oe);

@@ -40,12 +40,16 @@ def case_batch(rng):
     w, h, nf, sc, nl, ini, mn = geometry(rng)
     B = int(rng.integers(1, 7))
     lap = (int(rng.integers(-10, w)), int(rng.integers(-10, w + 50)))
-    imgs = np.stack([synth.frame(w, h, int(rng.integers(0, 1 << 20)), amplitude_div=int(rng.choice([1, 1, 4])))
-                     for _ in range(B)])
+    # half of the cases: the default rectangles + noise frames; the other half: a random content class per frame
+    # (synth.CONTENT_CLASSES: value noise, checkerboards, gratings, defocus, saturation, ramps, salt and pepper)
+    kinds = [str(rng.choice(synth.CONTENT_CLASSES)) if rng.random() < 0.5 else "" for _ in range(B)]
+    imgs = np.stack([synth.content_frame(k, w, h, int(rng.integers(0, 1 << 20)), int(rng.integers(0, 40))) if k else
+                     synth.frame(w, h, int(rng.integers(0, 1 << 20)), amplitude_div=int(rng.choice([1, 1, 4])))
+                     for k in kinds])
     ex = orb.ORBextractor(nf, sc, nl, ini, mn, max_batch=B)
     ref = ol.OracleExtractor(nf, sc, nl, ini, mn)
     outs = ex.extract_batch(imgs, lap)
-    return all(same(outs[i], ref(imgs[i], lap)) for i in range(B)), ("batch", w, h, nf, sc, nl, ini, mn, B, lap)
+    return all(same(outs[i], ref(imgs[i], lap)) for i in range(B)), ("batch", w, h, nf, sc, nl, ini, mn, B, lap, kinds)
 
 
 def case_colour(rng):

@@ -5,6 +5,8 @@ quota, most FAST cells pass iniThFAST and some fall back to minThFAST.  The
 generator is pure integer arithmetic on a SplitMix64 stream, so host, tests
 and bench agree byte for byte.
 """
+import functools
+
 import numpy as np
 
 _GAMMA = np.uint64(0x9E3779B97F4A7C15)
@@ -58,6 +60,107 @@ def sequence_frame(w, h, seq, t, amplitude_div=1, noise=6):
 def frame(w, h, index, amplitude_div=1, noise=6):
     """Independent frame number `index` (seed 0x5EED0000 + index)."""
     return sequence_frame(w, h, index, 0, amplitude_div=amplitude_div, noise=noise)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Content classes (VERDICT r3 #2): the rectangles + noise frames above are ONE class of image statistics.  The classes
+# below stand in for what real sequences add -- gradients, defocus, 1-2 px texture, saturation, impulse noise -- and are
+# chosen to reach the paths of the FAST kernel the default class leaves cold: the pixel queue's overflow / `single`
+# re-unpack (most pixels of a cell pass the necessary test on both sides), the whole-frame minThFAST second pass (no cell
+# holds a corner at iniThFAST), empty cells and empty frames.  Seeded integer arithmetic on the same SplitMix64 streams;
+# frame t of a sequence is the class's canvas translated by (3, 2) px per step, like sequence_frame.
+CONTENT_CLASSES = ("rectangles", "value_noise", "checker1", "checker2", "grating", "defocus", "saturated", "ramp",
+                   "sawtooth", "salt_pepper")
+
+
+def _lattice_noise(cw, ch, seed, octaves=6):
+    """Multi-octave value noise: per octave a random lattice of spacing 64 >> o, bilinearly interpolated in integers,
+    amplitudes halving -- gradients at every scale, few exact corners (natural-image like)."""
+    acc = np.zeros((ch, cw), np.int64)
+    wsum = 0
+    for o in range(octaves):
+        sp = 64 >> o
+        gw, gh = cw // sp + 2, ch // sp + 2
+        lat = (splitmix64(seed ^ (0x0C7A << 32) ^ (o + 1), gw * gh) % np.uint64(256)).astype(np.int64).reshape(gh, gw)
+        ys, xs = np.arange(ch), np.arange(cw)
+        iy, fy = ys // sp, (ys % sp)[:, None]
+        ix, fx = xs // sp, (xs % sp)[None, :]
+        a, b = lat[iy][:, ix], lat[iy][:, ix + 1]
+        c, d = lat[iy + 1][:, ix], lat[iy + 1][:, ix + 1]
+        v = ((sp - fy) * ((sp - fx) * a + fx * b) + fy * ((sp - fx) * c + fx * d)) // (sp * sp)
+        wgt = 1 << (octaves - 1 - o)
+        acc += wgt * v
+        wsum += wgt
+    return (acc // wsum).astype(np.int32)
+
+
+def _box_blur(img, radius):
+    """Integer box filter (2 r + 1)^2 with edge replication (defocus)."""
+    k = 2 * radius + 1
+    p = np.pad(img.astype(np.int64), radius, mode="edge")
+    cs = np.cumsum(np.pad(p, ((1, 0), (0, 0))), axis=0)
+    p = cs[k:] - cs[:-k]
+    cs = np.cumsum(np.pad(p, ((0, 0), (1, 0))), axis=1)
+    p = cs[:, k:] - cs[:, :-k]
+    return (p // (k * k)).astype(np.int32)
+
+
+@functools.lru_cache(maxsize=8)
+def _content_canvas(kind, w, h, seq):
+    seed = SEED_BASE + seq
+    cw, ch = w + 2 * _MARGIN, h + 2 * _MARGIN
+    r = splitmix64(seed ^ (0xC0DE << 32), 8)
+    if kind == "value_noise":
+        return np.clip(_lattice_noise(cw, ch, seed), 0, 255).astype(np.uint8)
+    if kind in ("checker1", "checker2"):
+        sp = 1 if kind == "checker1" else 2
+        lo = int(r[0] % np.uint64(100))
+        hi = lo + 60 + int(r[1] % np.uint64(96))  # contrast 60..155: far above iniThFAST
+        yy, xx = np.mgrid[0:ch, 0:cw]
+        return np.where(((xx // sp) + (yy // sp)) & 1, hi, lo).astype(np.uint8)
+    if kind == "grating":
+        period = 2 + int(r[0] % np.uint64(3))   # 2..4 px, slanted by one pixel every 8 rows
+        lo = int(r[1] % np.uint64(90))
+        hi = lo + 70 + int(r[2] % np.uint64(90))
+        yy, xx = np.mgrid[0:ch, 0:cw]
+        return np.where(((xx + yy // 8) % period) * 2 < period, hi, lo).astype(np.uint8)
+    if kind == "defocus":
+        return np.clip(_box_blur(_scene(w, h, seed), 6), 0, 255).astype(np.uint8)
+    if kind == "saturated":
+        return np.where(_scene(w, h, seed) >= 128, 255, 0).astype(np.uint8)
+    if kind == "ramp":
+        yy, xx = np.mgrid[0:ch, 0:cw]
+        gx, gy = 1 + int(r[0] % np.uint64(3)), 1 + int(r[1] % np.uint64(3))
+        return ((xx * gx * 255 // (3 * cw) + yy * gy * 255 // (3 * ch)) % 256).astype(np.uint8)
+    if kind == "sawtooth":
+        # a STEEP diagonal ramp (7..10 grey levels per pixel, wrapping): N / W ring pixels darker AND S / E brighter than
+        # the centre by more than iniThFAST, so nearly every pixel passes the necessary test on BOTH sides (the queue's
+        # overflow path) while only the wrap lines hold corners
+        yy, xx = np.mgrid[0:ch, 0:cw]
+        g = 7 + int(r[0] % np.uint64(4))
+        return ((xx * g + yy * g) % 256).astype(np.uint8)
+    if kind == "salt_pepper":
+        u = splitmix64(seed ^ (0x5A17 << 32), cw * ch).reshape(ch, cw)
+        base = np.full((ch, cw), 128, np.uint8)
+        base[(u % np.uint64(100)) == 0] = 0
+        base[(u % np.uint64(100)) == 1] = 255
+        return base
+    raise ValueError(kind)
+
+
+def content_frame(kind, w, h, seq, t=0):
+    """Frame t of sequence `seq` of content class `kind` (CONTENT_CLASSES)."""
+    if kind == "rectangles":
+        return sequence_frame(w, h, seq, t)
+    canvas = _content_canvas(kind, w, h, seq)
+    ox = _MARGIN + (3 * t) % _MARGIN
+    oy = _MARGIN + (2 * t) % _MARGIN
+    img = canvas[oy:oy + h, ox:ox + w]
+    noise = {"value_noise": 2, "defocus": 2, "ramp": 1}.get(kind, 0)  # sensor noise on the smooth classes
+    if noise:
+        nz = splitmix64((SEED_BASE + seq) ^ (0xA5A5 << 32) ^ (t + 1), w * h).reshape(h, w)
+        img = np.clip(img.astype(np.int32) + (nz % np.uint64(2 * noise + 1)).astype(np.int32) - noise, 0, 255)
+    return np.ascontiguousarray(img).astype(np.uint8)
 
 
 def constant_frame(w, h, value=128):
