@@ -627,6 +627,49 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             }
           }
           __syncthreads();
+#ifndef VSG_FAST_NO_STAGE_B
+          // ---- phase 1b, dense cells only: the same necessary test on the two DIAGONAL ring pairs (ring positions 2 / 10
+          // and 6 / 14: offsets (+-2, +-2)), run entry by run entry.  A 9-arc holds one pixel of every opposite pair, so a
+          // corner on a side needs that side on all four tested pairs.  On the frames the pipeline is tuned on a cell
+          // queues 60-190 pixels and this pass would cost more than the scores it saves (the reason the test above stops at
+          // two pairs); on fine texture -- 1-2 px checkerboards, gratings, steep ramps -- EVERY pixel passes the N / S / W / E
+          // test, on ramps on both sides, and the cell scored its whole area two or three times per threshold (FAST launch
+          // 1.05-2.47 ms instead of 0.39 per 512 frames: profiles/r04_b_bench_content_sweep_before_stage_b.json).  The
+          // diagonals see the other phase of a checkerboard and the iso-line of a ramp.  Cell-uniform trigger: more than
+          // three quarters of the cell's runs hold a passer.
+          if (4 * s_cnt[4] > 3 * nruns) {
+            const int nr1 = s_cnt[4];
+            const int t6 = thr <= 2 ? 0 : min(64, (thr + 1) >> 2);
+            const uint32_t K = (uint32_t)(128 - t6) * 0x01010101u, H = 0x80808080u;
+            for (int e = tid; e < nr1; e += NT) {
+              const uint32_t F0 = runF[e];
+              const int runB = runI[e];
+              const uint32_t *pc = (const uint32_t *)&qtile[runB];
+              const uint32_t *pu = pc - 2 * (kTileP / 4), *pd = pc + 2 * (kTileP / 4);
+              uint32_t qu[4] = {pu[-1], pu[0], pu[1], pu[2]}, qd[4] = {pd[-1], pd[0], pd[1], pd[2]};
+              const uint32_t qc[2] = {pc[0], pc[1]};
+              // the dword left of tile column 0 (see phase 1): only the first run of a row reads it, and only when g0 == 0
+              const int col = runB - kTileP * div_small(runB, 1.0f / kTileP);
+              const uint32_t left = (g0 == 0 && col == 0) ? 0u : ~0u;
+              qu[0] &= left, qd[0] &= left;
+              uint32_t g[2];
+#pragma unroll
+              for (int k = 0; k < 2; k++) {
+                const uint32_t nw = __builtin_amdgcn_alignbyte(qu[k + 1], qu[k], 2);      // row -2, columns -2
+                const uint32_t ne = __builtin_amdgcn_alignbyte(qu[k + 2], qu[k + 1], 2);  // row -2, columns +2
+                const uint32_t sw = __builtin_amdgcn_alignbyte(qd[k + 1], qd[k], 2);      // row +2, columns -2
+                const uint32_t se = __builtin_amdgcn_alignbyte(qd[k + 2], qd[k + 1], 2);  // row +2, columns +2
+                const uint32_t A = qc[k] + K, B = K - qc[k];
+                const uint32_t dark = VSG_BITOP3(A - nw, A - se, (A - ne) | (A - sw), (A | B) & C);
+                const uint32_t bright = VSG_BITOP3(B + nw, B + se, (B + ne) | (B + sw), (A | B) & C);
+                g[k] = VSG_BITOP3(dark, bright >> 1, H, (A & C) | (B & ~C));
+              }
+              // same flag layout as F; F0 already carries the run masks, so the bits the merge leaves below the flags die
+              runF[e] = F0 & VSG_BITOP3(g[1], g[0] >> 2, 0xC0C0C0C0u, (A & C) | (B & ~C));
+            }
+            __syncthreads();
+          }
+#endif
           // ---- run list -> pixel queue.  Entry = the run's dword index in the tile << 5 | bit position of the flag in the
           // run's word (bit 0 of the position: dark side; bit 2, set in every flag position, cleared = retry); phase 2 turns
           // an entry into the pixel's byte offset in the tile -- two shifts and two masks, no division by the run count, no
