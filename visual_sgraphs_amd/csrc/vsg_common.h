@@ -40,7 +40,13 @@ struct LevelGeom {
   int sel_off, sel_cap;     // slice of the per-frame selected-keypoint array
   int tab_x_off, tab_y_off; // resize tables (short4 units) for producing THIS level from level-1
   int blur_block_base;      // first workgroup of this level in the blur launch
-  int blur_nxg, blur_nys;   // 4-pixel column groups per row / row strips of kBlurStrip rows
+  int blur_nxg, blur_nys;   // 4-pixel column groups per row (4 per tile column, padding included) / row strips of kBlurStrip rows
+  // The BLURRED level is stored as 16 x 4-pixel tiles, one 64-byte line each (x fastest inside a tile, tiles row-major):
+  // k_orient_desc's 37 x 37 patch then touches ~33 lines instead of ~58 row segments (tools/ubench_tile.hip).
+  int btx, bty;             // tile columns = ceil(w / 16), tile rows = ceil(h / 4)
+  int boff;                 // byte offset of the level inside one frame's blurred block (blur_frame_bytes)
+  int blur_int_tc;          // tile columns 1 .. blur_int_tc are interior for the blur (all 12 source bytes of their four
+                            // column groups exist): their threads come first, the edge tile columns' threads last
   float scale;              // mvScaleFactor[level]
   float kp_size;            // (float)(int)(31 * scale)   (ORBextractor.cc:884,893)
   // octree (ORBextractor.cc:562-593)
@@ -54,6 +60,7 @@ struct FrameGeom {
   int nlevels;
   int rows, cols;
   int pyr_frame_bytes;   // bytes of one frame's pyramid block (all levels)
+  int blur_frame_bytes;  // bytes of one frame's blurred block (all levels, tiled: LevelGeom::boff)
   int cand_frame;        // uint32 per frame in the candidate array
   int sel_frame;         // uint32 per frame in the selected array
   int total_cells;       // FAST cells per frame (all levels)
@@ -94,7 +101,17 @@ struct PyrView {
   int w[kMaxLevels], h[kMaxLevels];
 };
 
-enum { kBlurStrip = 36 };  // output rows per thread in k_blur (36 + 6 halo rows = 6 x 7-row window turns)
+enum { kBlurStrip = 36 };  // output rows per thread in k_blur (36 + 6 halo rows = 6 x 7-row window turns; 9 tile rows)
+enum { kBlurTileW = 16, kBlurTileH = 4, kBlurTileBytes = 64 };
+// byte offset of pixel (x, y) inside a tiled blurred level with `btx` tile columns
+__attribute__((always_inline)) inline
+#if defined(__HIPCC__)
+    __host__ __device__
+#endif
+    int
+    blur_tiled_offset(int x, int y, int btx) {
+  return ((y >> 2) * btx + (x >> 4)) * kBlurTileBytes + (y & 3) * kBlurTileW + (x & 15);
+}
 
 // cv::KeyPoint-compatible record (28 bytes): pt.x pt.y size angle response octave class_id
 struct KeyPointPOD {

@@ -169,7 +169,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   fg.lap1 = lap1;
   for (int k = 0; k < 7; k++) fg.taps[k] = taps[k];
   if (T.iniTh < 1 || T.minTh < 1 || T.iniTh > 255 || T.minTh > 255) return -3;
-  int img_off = 0, cand_off = 0, sel_off = 0, out_cap = 0, blur_blocks = 0;
+  int img_off = 0, cand_off = 0, sel_off = 0, out_cap = 0, blur_blocks = 0, blur_off = 0;
   int prev_w = 0, prev_h = 0;
   for (int l = 0; l < T.nlevels; l++) {
     LevelGeom &L = fg.lv[l];
@@ -237,8 +237,15 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
     prev_w = L.w;
     prev_h = L.h;
     // blur launch: thread = 4 px x kBlurStrip rows, 256 threads per workgroup, workgroups never straddle levels
+    // (strips are 9 tile rows; the four column groups of a tile column are four adjacent lanes)
+    static_assert(kBlurStrip % kBlurTileH == 0, "a blur strip is a whole number of tile rows");
+    L.btx = (L.w + kBlurTileW - 1) / kBlurTileW;
+    L.bty = (L.h + kBlurTileH - 1) / kBlurTileH;
+    L.boff = blur_off;
+    blur_off += L.btx * L.bty * kBlurTileBytes;
+    L.blur_int_tc = L.w >= 36 ? (L.w - 20) / 16 : 0;  // tile columns tc >= 1 with 16 tc + 12 + 8 <= w
     L.blur_block_base = blur_blocks;
-    L.blur_nxg = (L.w + 3) / 4;
+    L.blur_nxg = 4 * L.btx;
     L.blur_nys = (L.h + kBlurStrip - 1) / kBlurStrip;
     blur_blocks += (L.blur_nxg * L.blur_nys + 255) / 256;
     L.scale = T.scale[l];
@@ -399,6 +406,7 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   // prefix of the cell counts in LDS) as long as a level's cells fit that prefix; beyond: one list per level
   fg.cand_segmented = G.maxCellsPerLevel <= kOctMaxCells ? 1 : 0;
   fg.total_blur_blocks = blur_blocks;
+  fg.blur_frame_bytes = blur_off;
   // output capacity: what operator() can produce = sum over levels of final list sizes
   fg.out_cap = out_cap;
   return 0;

@@ -1193,41 +1193,57 @@ __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint
   const LevelGeom &L = fg->lv[level];
   const int t = (blk.x - L.blur_block_base) * 256 + (int)threadIdx.x;
   if (t >= L.blur_nxg * L.blur_nys) return;
-  // Interior column groups first, the three edge groups (which need per-byte REFLECT_101 loads) last, so that
-  // whole wavefronts take either the fast or the slow load path instead of every wave diverging at a row end.
-  const int nI = L.blur_nxg - 3, nInt = nI * L.blur_nys;
+  // Four adjacent lanes own the four column groups of one 16-pixel TILE column (the output is tiled: 16 x 4 pixels per
+  // 64-byte line), so a quad's stores of one row are 16 contiguous bytes and four rows fill the line.  The threads of
+  // the interior tile columns (all four groups read 12 existing bytes) come first, those of the edge tile columns --
+  // column 0, the last one or two, with the REFLECT_101 selectors and, past the image, padding -- last, so that whole
+  // wavefronts take either the fast or the slow load path instead of every wave diverging at a row end.
+  const int nI = 4 * L.blur_int_tc, nInt = nI * L.blur_nys;
   int gx, sy;
   if (t < nInt) {
     sy = t / nI;
-    gx = 1 + (t - sy * nI);
+    gx = 4 + (t - sy * nI);
   } else {
-    const int e = t - nInt;
-    sy = e / 3;
-    const int k = e - sy * 3;
-    gx = k == 0 ? 0 : L.blur_nxg - 3 + k;
+    const int nE = L.blur_nxg - nI, e = t - nInt;
+    sy = e / nE;
+    const int k = e - sy * nE;
+    gx = k < 4 ? k : nI + k;
   }
   const int x0 = gx * 4, y0 = sy * kBlurStrip;
   const int w = L.w, h = L.h;
   int spitch;
   const uint8_t *img = level_ptr(fg, s0, pyr, blk.y, level, spitch);
-  uint8_t *dst = blur + (size_t)blk.y * fg->pyr_frame_bytes + L.img_off;
+  // Stores: four output rows of a quad are a 4 x 4 matrix of dwords (row, column group) = one tile.  It is transposed
+  // inside the quad (two rounds of DPP quad permutes + selects) so that lane q holds ROW q of the tile -- 16 contiguous
+  // bytes -- and the quad writes the whole 64-byte line with one dwordx4 store per lane: a wave's store is 16 full lines.
+  // (Storing each row's dword where it belongs -- 16-byte pieces of 16 different lines per instruction, 4 times the
+  // write requests -- cost the blur 0.267 -> 0.323 ms per 512 C2 frames: profiles/r04_d_*.)
+  const int q = gx & 3;
+  uint8_t *dst = blur + (size_t)blk.y * fg->blur_frame_bytes + L.boff + (uint32_t)blur_tiled_offset(x0 & ~15, y0, L.btx) +
+                 q * kBlurTileW;
+  const uint32_t tile_row_bytes = (uint32_t)L.btx * kBlurTileBytes;
+  const bool q_odd = q & 1, q_hi = q & 2;
+  uint32_t trow[4] = {0, 0, 0, 0};  // the thread's dwords of the four rows of the current tile
   const uint32_t T0 = fg->taps[0] | (fg->taps[1] << 8) | (fg->taps[2] << 16) | ((uint32_t)fg->taps[3] << 24);
   const uint32_t T1 = fg->taps[4] | (fg->taps[5] << 8) | (fg->taps[6] << 16);
   uint32_t k[7];
 #pragma unroll
   for (int j = 0; j < 7; j++) k[j] = fg->taps[j];
   const bool interior = x0 >= 4 && x0 + 8 <= w;  // all 12 source bytes exist: aligned dword loads
+  // column groups past the image (the padding of the last tile column) compute on clamped addresses and store garbage
+  // into bytes nothing reads
   // Edge groups (the first and the last two of a row) also fetch 12 contiguous bytes per row -- columns 0..11 on
   // the left, w-12..w-1 on the right (w >= 16, checked with the geometry) -- which hold every REFLECT_101 source
   // column they need; the 12 wanted bytes are then picked with v_perm selectors that are computed once per thread.
   const int base = interior ? x0 - 4 : (x0 == 0 ? 0 : w - 12);
+  const int xr = x0 < w ? x0 : w - 4;  // reflected columns of a padding group: anything inside the row
   uint32_t selLo[3] = {0, 0, 0}, selHi[3] = {0, 0, 0};
   if (!interior) {
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
       for (int b = 0; b < 4; b++) {
-        const uint32_t sidx = (uint32_t)(reflect101(x0 - 4 + 4 * q + b, w) - base);  // 0..11
+        const uint32_t sidx = (uint32_t)(reflect101(xr - 4 + 4 * q + b, w) - base);  // 0..11
         selLo[q] |= (sidx < 8 ? sidx : 0x0Cu) << (8 * b);
         selHi[q] |= (sidx >= 8 ? sidx - 8 : 0x0Cu) << (8 * b);
       }
@@ -1297,7 +1313,19 @@ __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint
         }
         const uint32_t out = __builtin_amdgcn_perm(cl[1], cl[0], 0x0C0C0602u) |
                              (__builtin_amdgcn_perm(cl[3], cl[2], 0x0C0C0602u) << 16);
-        *(uint32_t *)(dst + (uint32_t)(yo * L.pitch + x0)) = out;
+        trow[(rr - 6) & 3] = out;
+      }
+      const int o = rr - 6;  // output row of the strip: tile row o / 4, line row o % 4
+      if ((o & 3) == 3 && y0 + o - 3 < h) {  // the tile row is complete (rows past the level's last one: padding)
+        auto x1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); };  // quad_perm [1,0,3,2]
+        auto x2 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); };  // quad_perm [2,3,0,1]
+        const uint32_t p01 = x1(trow[1]), p10 = x1(trow[0]), p23 = x1(trow[3]), p32 = x1(trow[2]);
+        const uint32_t c0 = q_odd ? p01 : trow[0], c1 = q_odd ? trow[1] : p10;
+        const uint32_t c2 = q_odd ? p23 : trow[2], c3 = q_odd ? trow[3] : p32;
+        const uint32_t r02 = x2(c2), r13 = x2(c3), r20 = x2(c0), r31 = x2(c1);
+        u32x4 line;
+        line.x = q_hi ? r02 : c0, line.y = q_hi ? r13 : c1, line.z = q_hi ? c2 : r20, line.w = q_hi ? c3 : r31;
+        *(u32x4 *)(dst + (uint32_t)(o >> 2) * tile_row_bytes) = line;
       }
     }
   }
@@ -1404,7 +1432,8 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
 // One wavefront per keypoint: intensity-centroid angle on the un-blurred level, steered rBRIEF-256 on
 // the blurred level, keypoint record + 32 descriptor bytes written to the keypoint's output slot.
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-enum { kPatchR = 18, kPatchW = 2 * kPatchR + 1, kPatchP = 40 };  // rBRIEF patch radius / width / LDS row pitch
+// rBRIEF patch radius / width; the LDS copy holds the 10 x (3 or 4) blurred TILES the patch touches: 40 rows of 64 bytes
+enum { kPatchR = 18, kPatchW = 2 * kPatchR + 1, kPatchP = 64, kPatchRows = 40 };
 
 // IC_Angle lane layout: 16 rows x 4 (unaligned) qwords per load instruction (lane = 4 * row + column), 2 instructions
 // cover the 31 x 31 patch (rows 16 * it + row - 15, pixels u = 8 * column + 4 * half + b - 15).  Per (it, lane, half)
@@ -1470,7 +1499,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
                                                      OutMirror mir) {
   __shared__ f32x4 patf[256];            // test k: (x0, y0, x1, y1) of bit_pattern_31_ as floats
   __shared__ int s_hdr[kMaxLevels + 3];  // n, mono, level_start[0..kMaxLevels]
-  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchW * kPatchP];
+  __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchRows * kPatchP];
   __shared__ u32x4 s_ic[2 * 64];  // c_disc, one 16-byte entry per (it, lane)
   const BlockXY blk = frame_major_block();
   const int frame = blk.y, tid = threadIdx.x;
@@ -1502,7 +1531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   const int lane = tid & 63;
   // everything derived from the keypoint index is wave-uniform: keep it in SGPRs so the per-level geometry comes
   // through the scalar cache in one round trip instead of a chain of dependent vector loads
-  uint8_t *patch = &s_patch[(tid >> 6) * (kPatchW * kPatchP)];
+  uint8_t *patch = &s_patch[(tid >> 6) * (kPatchRows * kPatchP)];
 #pragma unroll
   for (int j = 0; j < kOdKpPerWave; j++) {
   // the workgroup's keypoints: wave w takes blk.x * 4 * G + 4 * j + w  (adjacent keypoints run side by side)
@@ -1513,7 +1542,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane(rec[j].x);
   const int slot = __builtin_amdgcn_readfirstlane(rec[j].y);
   const int cx = VSG_CAND_X(c) + kFastBorder, cy = VSG_CAND_Y(c) + kFastBorder;
-  const size_t foff = (size_t)frame * fg->pyr_frame_bytes + L.img_off;
   int upitch;
   const uint8_t *unblurred = level_ptr(fg, s0, pyr, frame, l, upitch);
   // ---- IC_Angle: 16 rows x 4 (unaligned) qwords per load instruction, 2 instructions per patch; the disc mask and
@@ -1542,43 +1570,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   const float angle = fast_atan2_deg((float)m01, (float)m10);
   float a, b;
   brief_rotation(angle, &a, &b);
-  // ---- descriptor.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38), so the 37x37 blurred
-  // patch is staged in LDS with row-major (coalesced) byte loads; the 8 samples per lane are then LDS reads.
+  // ---- descriptor.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38).  The blurred level is TILED
+  // (16 x 4 pixels per 64-byte line, LevelGeom::btx): the 37 x 37 patch touches 10 tile rows x 3 or 4 tile columns, and
+  // the load's lanes are mapped to whole tiles -- lane = 4 * tile + row of the tile, 16 bytes per lane -- so every group of
+  // four lanes reads ONE full line and a keypoint costs ~33 line requests in 2 or 3 load instructions instead of ~58
+  // row segments in 4 (tools/ubench_tile.hip: 175 against 358 CU-cycles per patch with the LDS side included).  The
+  // tiles land in LDS where they lie (aligned b128 rows of a 40 x 64-byte image), so no byte shifting is left.
+  const int px0 = cx - kPatchR, py0 = cy - kPatchR;
+  const int tx0 = px0 >> 4, ty0 = py0 >> 2;
   {
-    // 37 rows x 5 qwords, 12 rows (60 lanes) per trip, 4 trips.  Rows are fetched from the patch origin rounded DOWN
-    // to 4 bytes (origin % 4 + 37 <= 40 bytes: still 5 qwords) -- the L1 moves 4-byte-aligned qwords, 5 lanes per row,
-    // in 104 cycles per patch against 144 for unaligned dwords, 10 lanes per row (tools/ubench_tcp.hip) -- and the
-    // shift is undone in registers: the bytes to the right of a lane's qword are the next lane's (DPP), one
-    // v_alignbyte per dword.  The last qword of a row only feeds the unused columns 37..39, so what its right
-    // neighbour holds does not matter.
-    constexpr int kQw = kPatchP / 8, kRows = 64 / kQw, kIt = (kPatchW + kRows - 1) / kRows;
-    static_assert(kPatchP % 8 == 0 && (kIt - 1) * kRows == kPatchW - 1, "the last trip holds exactly one patch row");
-    const int r0 = lane / kQw, cc = lane - r0 * kQw;
-    const int pitch = L.pitch;
-    const int ox = cx - kPatchR, sh = ox & 3;
-    const uint8_t *gp = blur + foff + (size_t)(cy - kPatchR) * pitch + (ox - sh) + 8 * cc;
-    uint8_t *lp = patch + r0 * kPatchP + 8 * cc;
-    const bool act = r0 < kRows;
-    u32x2 pv[kIt];
+    const int ntx = ((px0 + 2 * kPatchR) >> 4) - tx0 + 1;  // 3 (three quarters of the origins) or 4; always 10 tile rows
+    const int nt = 10 * ntx;
+    const float inv_ntx = ntx == 3 ? 1.0f / 3.0f : 0.25f;
+    const int sub = lane & 3, tg = lane >> 2;
+    const uint8_t *gp = blur + (size_t)frame * fg->blur_frame_bytes + L.boff + (uint32_t)((ty0 * L.btx + tx0) * kBlurTileBytes) +
+                        sub * kBlurTileW;
+    const uint32_t trow = (uint32_t)L.btx * kBlurTileBytes;
+    u32x4 pv[3];
+    int lo[3];
 #pragma unroll
-    for (int it = 0; it < kIt; it++) {
-      // the last trip holds one patch row (r0 = 0); its other lanes re-read that row: inside the image, never stored
-      const int r = it < kIt - 1 ? it * kRows + r0 : kPatchW - 1;
-      pv[it] = act ? *(const u64_global_4aligned *)(gp + (ptrdiff_t)r * pitch) : (u32x2){0u, 0u};
+    for (int it = 0; it < 3; it++) {
+      if (it == 2 && ntx == 3) break;  // wave-uniform: 30 tiles fit two instructions
+      const int t = min(it * 16 + tg, nt - 1);  // lanes past the last tile re-read it (never stored)
+      const int tyi = div_small(t, inv_ntx), txi = t - tyi * ntx;
+      pv[it] = *(const __attribute__((address_space(1))) u32x4 *)(gp + (uint32_t)tyi * trow + (uint32_t)(txi * kBlurTileBytes));
+      lo[it] = (4 * tyi + sub) * kPatchP + kBlurTileW * txi;
     }
 #pragma unroll
-    for (int it = 0; it < kIt; it++) {
-      const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pv[it].x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-      u32x2 v;
-      v.x = __builtin_amdgcn_alignbyte(pv[it].y, pv[it].x, (uint32_t)sh);
-      v.y = __builtin_amdgcn_alignbyte(nx, pv[it].y, (uint32_t)sh);
-      if (act && (it < kIt - 1 || r0 == 0)) *(u32x2 *)(lp + it * kRows * kPatchP) = v;
+    for (int it = 0; it < 3; it++) {
+      if (it == 2 && ntx == 3) break;
+      if (it * 16 + tg < nt) *(u32x4 *)(patch + lo[it]) = pv[it];
     }
   }
   // the patch is private to this wavefront: LDS writes complete in order before the reads below
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  const uint8_t *center = patch + kPatchR * kPatchP + kPatchR;
+  const uint8_t *center = patch + (cy - 4 * ty0) * kPatchP + (cx - 16 * tx0);
   uint64_t word = 0;
 #pragma unroll
   for (int r = 0; r < 4; r++) {  // lane handles tests lane, lane+64, lane+128, lane+192

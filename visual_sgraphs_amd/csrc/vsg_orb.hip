@@ -371,9 +371,9 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
       HIP_TRY(hipMemcpy(h->d_ptab[i], PT.tab.data(), sizeof(Short4) * PT.tab.size(), hipMemcpyHostToDevice));
   }
   HIP_TRY(hipMalloc(&h->d_pyr, B * fg.pyr_frame_bytes));
-  HIP_TRY(hipMalloc(&h->d_blur, B * fg.pyr_frame_bytes));
+  HIP_TRY(hipMalloc(&h->d_blur, B * fg.blur_frame_bytes));
   HIP_TRY(hipMemset(h->d_pyr, 0, B * fg.pyr_frame_bytes));
-  HIP_TRY(hipMemset(h->d_blur, 0, B * fg.pyr_frame_bytes));
+  HIP_TRY(hipMemset(h->d_blur, 0, B * fg.blur_frame_bytes));
   HIP_TRY(hipMalloc(&h->d_cand, B * fg.cand_frame * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&h->d_cand2, B * fg.cand_frame * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&h->d_cell_count, B * fg.total_cells * sizeof(int)));
@@ -451,7 +451,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   const FrameGeom &fg = h->G.fg;
   const size_t F = (size_t)f0;
   const Src0 s0 = {src.base + F * src.frame_stride, src.frame_stride, src.pitch};
-  uint8_t *pyr = h->d_pyr + F * fg.pyr_frame_bytes, *blur = h->d_blur + F * fg.pyr_frame_bytes;
+  uint8_t *pyr = h->d_pyr + F * fg.pyr_frame_bytes, *blur = h->d_blur + F * fg.blur_frame_bytes;
   uint32_t *cand = h->d_cand + F * fg.cand_frame, *sel = h->d_sel + F * fg.sel_frame;
   uint16_t *nodeof = h->d_nodeof + F * fg.cand_frame;
   int *cell_count = h->d_cell_count + F * fg.total_cells;
@@ -1238,8 +1238,24 @@ static int copy_level(vsg_orb *h, const uint8_t *base, int frame, int level, int
 int vsg_orb_copy_pyramid_level(vsg_orb *h, int frame, int level, int with_border, uint8_t *dst, int dst_stride) {
   return copy_level(h, h ? h->d_pyr : nullptr, frame, level, with_border, dst, dst_stride);
 }
+// The blurred levels are stored as 16 x 4-pixel tiles (LevelGeom::btx / boff, vsg_common.h): the level comes down as it
+// lies and is de-tiled into the caller's rows here (a test / debug read-back, not on any hot path).
 int vsg_orb_copy_blurred_level(vsg_orb *h, int frame, int level, uint8_t *dst, int dst_stride) {
-  return copy_level(h, h ? h->d_blur : nullptr, frame, level, 0, dst, dst_stride);
+  if (!h || !h->rows || !dst || level < 0 || level >= h->T.nlevels || frame < 0 || frame >= h->max_batch)
+    return VSG_ERR_INVALID;
+  HIP_TRY(hipSetDevice(h->device));
+  const FrameGeom &fg = h->G.fg;
+  const LevelGeom &L = fg.lv[level];
+  int rc = wait_last(h);
+  if (rc != VSG_OK) return rc;
+  const size_t bytes = (size_t)L.btx * L.bty * kBlurTileBytes;
+  std::vector<uint8_t> tiled(bytes);
+  HIP_TRY(hipMemcpy(tiled.data(), h->d_blur + (size_t)frame * fg.blur_frame_bytes + L.boff, bytes, hipMemcpyDeviceToHost));
+  for (int y = 0; y < L.h; y++)
+    for (int x = 0; x < L.w; x += kBlurTileW)
+      memcpy(dst + (size_t)y * dst_stride + x, &tiled[(size_t)blur_tiled_offset(x, y, L.btx)],
+             (size_t)std::min<int>(kBlurTileW, L.w - x));
+  return VSG_OK;
 }
 
 // One D2H for mvImagePyramid (ORBextractor.h:93) of frame `frame`: every level WITH its 19 px REFLECT_101 border,
