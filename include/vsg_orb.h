@@ -64,9 +64,10 @@ int vsg_orb_get_tables(const vsg_orb *h, float *scale, float *inv_scale, float *
 int vsg_orb_set_blur_taps(vsg_orb *h, const uint16_t taps[7]);
 
 /* Launch form of ComputePyramid (ORBextractor.cc:1171-1195): -1 (default) = the fused chain kernel with the tiling the
- * handle timed faster for its image size, 0 / 1 = the fused kernel with the 32- / 36-pixel top-level tiling, 2 = one
- * launch per level.  Every form produces the same bytes (tests/test_gpu_extract.py runs all four against the oracle);
- * the setter exists so that each form stays a tested path instead of an environment switch. */
+ * handle picks (the one it timed faster for its image size; 16-pixel top tiles for calls of one or two frames),
+ * 0 / 1 / 2 = the fused kernel with the 32- / 36- / 16-pixel top-level tiling, 3 = one launch per level.  Every form
+ * produces the same bytes (tests/test_gpu_switches.py runs all five against the oracle); the setter exists so that each
+ * form stays a tested path instead of an environment switch. */
 int vsg_orb_set_pyramid_tiling(vsg_orb *h, int which);
 
 /* Keypoint capacity a caller must provide per frame for images of this size (>= nfeatures + 3*nlevels,

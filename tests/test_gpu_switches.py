@@ -44,10 +44,11 @@ def test_switch_gives_the_oracles_output(switch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", [-1, 0, 1, 2])
+@pytest.mark.parametrize("which", [-1, 0, 1, 2, 3])
 @pytest.mark.parametrize("w,h,nl,B", [(640, 480, 8, 1), (1280, 720, 8, 1), (320, 240, 4, 40)])
 def test_every_pyramid_launch_form(which, w, h, nl, B):
-    """ComputePyramid (ORBextractor.cc:1171-1195) as the fused chain kernel with either tiling, or as one launch per level:
+    """ComputePyramid (ORBextractor.cc:1171-1195) as the fused chain kernel with any of its three tilings (the 16-pixel one
+    is what single-frame calls take by default), or as one launch per level:
     the same level bytes and the same operator() output."""
     imgs = np.stack([synth.sequence_frame(w, h, 21, t) for t in range(B)])
     ex = orb.ORBextractor(1000, 1.2, nl, 20, 7, max_batch=B)
@@ -59,4 +60,4 @@ def test_every_pyramid_launch_form(which, w, h, nl, B):
         for l in range(nl):
             assert np.array_equal(ex.image_pyramid(l, frame=t), ref.pyramid_level(l)), (which, t, l)
     with pytest.raises(orb.VsgError):
-        ex.set_pyramid_tiling(3)
+        ex.set_pyramid_tiling(4)

@@ -86,8 +86,11 @@ struct PyrTile {
 // Candidate top-level tile edges of the fused pyramid.  A larger tile recomputes less halo but needs more LDS and
 // yields fewer workgroups: 36 is ahead for >= ~2000 workgroups per launch (0.214 -> 0.194 ms per 256 C2 frames),
 // 32 for small batches and for geometries whose 36-tiling would not leave three workgroups per CU.
-enum { kPyrTilings = 2 };
-constexpr int kPyrTileEdge[kPyrTilings] = {32, 36};
+// Tiling 2 (16-pixel top tiles) is for the LATENCY path: one frame is 30 workgroups at edge 32 on a 256-CU part, each
+// walking a ~130 x 130-pixel level-0 cone alone; at edge 16 it is 108 workgroups with a third of the work each (the
+// recomputed halo grows, which a launch that does not fill the chip does not pay for).
+enum { kPyrTilings = 3, kPyrTilingSmall = 2 };
+constexpr int kPyrTileEdge[kPyrTilings] = {32, 36, 16};
 
 struct PyrTiling {
   std::vector<PyrTile> tiles;

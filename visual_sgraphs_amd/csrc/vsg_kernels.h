@@ -42,8 +42,8 @@ void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGe
 void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, const int *sel_count, int *flags,
                   int4 *slots, FrameHeader *hdr, int lap0, int lap1, int nframes);
 void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
-                        const uint32_t *sel, const int4 *slots, const FrameHeader *hdr, const int8_t *pattern,
-                        KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes,
-                        const OutMirror &mir);
+                        const uint32_t *sel, const int *sel_count, const int4 *slots, const FrameHeader *hdr,
+                        const int8_t *pattern, KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity,
+                        const FrameGeom &fg, int nframes, const OutMirror &mir, bool self_slots);
 void launch_border_copy(hipStream_t s, const uint8_t *img, int w, int h, int pitch, uint8_t *dst, int dpitch, int b);
 }  // namespace vsg

@@ -1489,10 +1489,13 @@ constexpr int kOdKpPerWave = VSG_OD_G;
 #ifndef VSG_OD_SGPRS
 #define VSG_OD_SGPRS 72
 #endif
-template <bool kMirror>
+// kSelf (latency path, no lapping area: RGB-D / stereo, vLappingArea = {0, 0}): the kernel derives what k_slots would have
+// handed it -- the level starts from the octree's per-level counts, slot = keypoint index -- in its own prologue, and the
+// 8 us k_slots launch leaves the one-frame chain (two dependent loads in front of a keypoint instead of a kernel).
+template <bool kMirror, bool kSelf>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS))) void k_orient_desc(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                      const FrameGeom *__restrict__ fg, Src0 s0,
-                                                     const uint32_t *__restrict__ sel,
+                                                     const uint32_t *__restrict__ sel, const int *__restrict__ sel_count,
                                                      const int4 *__restrict__ slots, const FrameHeader *__restrict__ hdr,
                                                      const int8_t *__restrict__ pattern, KeyPointPOD *__restrict__ kps,
                                                      uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity,
@@ -1507,7 +1510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   // table loads below: header -> level search -> selected list -> keypoint used to be a chain of dependent round trips
   // in front of every keypoint's patch loads.  Records at or past the frame's count are stale but inside the array.
   int4 rec[kOdKpPerWave];
-  {
+  if (!kSelf) {
     const int cap1 = fg->out_cap - 1;
 #pragma unroll
     for (int j = 0; j < kOdKpPerWave; j++) {
@@ -1520,7 +1523,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
     const uint32_t pw = ((const uint32_t *)pattern)[tid];
     patf[tid] = (f32x4){(float)(int8_t)pw, (float)(int8_t)(pw >> 8), (float)(int8_t)(pw >> 16), (float)(int8_t)(pw >> 24)};
   }
-  if (tid < kMaxLevels + 3) s_hdr[tid] = ((const int *)&hdr[frame])[tid];
+  if (kSelf) {
+    if (tid == 0) {  // the slot kernel's scan (slots_of_frame) with an empty lapping set: n = monoIndex = the total
+      int cnt[kMaxLevels];
+#pragma unroll
+      for (int l = 0; l < kMaxLevels; l++) cnt[l] = l < fg->nlevels ? min(sel_count[frame * kMaxLevels + l], fg->lv[l].sel_cap) : 0;
+      int run = 0;
+#pragma unroll
+      for (int l = 0; l < kMaxLevels; l++) {
+        s_hdr[2 + l] = run;
+        run += cnt[l];
+      }
+      s_hdr[2 + kMaxLevels] = run;
+      s_hdr[0] = run, s_hdr[1] = run;
+    }
+  } else if (tid < kMaxLevels + 3) {
+    s_hdr[tid] = ((const int *)&hdr[frame])[tid];
+  }
   __syncthreads();
   const int n = s_hdr[0];
   if (blk.x == 0 && tid == 0) {
@@ -1537,10 +1556,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   // the workgroup's keypoints: wave w takes blk.x * 4 * G + 4 * j + w  (adjacent keypoints run side by side)
   const int g = __builtin_amdgcn_readfirstlane((blk.x * kOdKpPerWave + j) * 4 + (tid >> 6));
   if (g >= n) break;
-  const int l = __builtin_amdgcn_readfirstlane(rec[j].z);
+  int l, slot;
+  uint32_t c;
+  if (kSelf) {
+    l = 0;
+    while (g >= s_hdr[3 + l]) l++;  // wave-uniform (g < n = s_hdr[2 + kMaxLevels])
+    l = __builtin_amdgcn_readfirstlane(l);
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)sel[(size_t)frame * fg->sel_frame + fg->lv[l].sel_off + (g - s_hdr[2 + l])]);
+    slot = g;
+  } else {
+    l = __builtin_amdgcn_readfirstlane(rec[j].z);
+    c = (uint32_t)__builtin_amdgcn_readfirstlane(rec[j].x);
+    slot = __builtin_amdgcn_readfirstlane(rec[j].y);
+  }
   const LevelGeom &L = fg->lv[l];
-  const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane(rec[j].x);
-  const int slot = __builtin_amdgcn_readfirstlane(rec[j].y);
   const int cx = VSG_CAND_X(c) + kFastBorder, cy = VSG_CAND_Y(c) + kFastBorder;
   int upitch;
   const uint8_t *unblurred = level_ptr(fg, s0, pyr, frame, l, upitch);
@@ -1990,16 +2019,22 @@ void launch_slots(hipStream_t s, const FrameGeom *d_fg, const uint32_t *sel, con
   hipLaunchKernelGGL(k_slots, dim3(nframes), dim3(256), 0, s, d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1);
 }
 void launch_orient_desc(hipStream_t s, const uint8_t *pyr, const uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
-                        const uint32_t *sel, const int4 *slots, const FrameHeader *hdr, const int8_t *pattern,
-                        KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity, const FrameGeom &fg, int nframes,
-                        const OutMirror &mir) {
+                        const uint32_t *sel, const int *sel_count, const int4 *slots, const FrameHeader *hdr,
+                        const int8_t *pattern, KeyPointPOD *kps, uint8_t *desc, int *counts, int capacity,
+                        const FrameGeom &fg, int nframes, const OutMirror &mir, bool self_slots) {
   dim3 grid((fg.out_cap + 4 * kOdKpPerWave - 1) / (4 * kOdKpPerWave), nframes), block(256);
-  if (mir.kps)
-    hipLaunchKernelGGL(k_orient_desc<true>, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
-                       counts, capacity, mir);
+  if (self_slots && mir.kps)
+    hipLaunchKernelGGL((k_orient_desc<true, true>), grid, block, 0, s, pyr, blur, d_fg, s0, sel, sel_count, slots, hdr, pattern,
+                       kps, desc, counts, capacity, mir);
+  else if (self_slots)
+    hipLaunchKernelGGL((k_orient_desc<false, true>), grid, block, 0, s, pyr, blur, d_fg, s0, sel, sel_count, slots, hdr, pattern,
+                       kps, desc, counts, capacity, mir);
+  else if (mir.kps)
+    hipLaunchKernelGGL((k_orient_desc<true, false>), grid, block, 0, s, pyr, blur, d_fg, s0, sel, sel_count, slots, hdr, pattern,
+                       kps, desc, counts, capacity, mir);
   else
-    hipLaunchKernelGGL(k_orient_desc<false>, grid, block, 0, s, pyr, blur, d_fg, s0, sel, slots, hdr, pattern, kps, desc,
-                       counts, capacity, mir);
+    hipLaunchKernelGGL((k_orient_desc<false, false>), grid, block, 0, s, pyr, blur, d_fg, s0, sel, sel_count, slots, hdr, pattern,
+                       kps, desc, counts, capacity, mir);
 }
 void launch_border_copy(hipStream_t s, const uint8_t *img, int w, int h, int pitch, uint8_t *dst, int dpitch, int b) {
   dim3 grid((w + 2 * b + 255) / 256, h + 2 * b), block(256);

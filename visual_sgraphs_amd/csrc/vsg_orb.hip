@@ -403,7 +403,7 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
         (long long)P1.tiles.size() * nf >= 2048) {
       const Src0 s0 = {h->d_in, (size_t)rows * h->in_pitch, h->in_pitch};
       float best = 0.f;
-      for (int ti = 0; ti < kPyrTilings; ti++) {
+      for (int ti = 0; ti < 2; ti++) {  // the two throughput tilings; kPyrTilingSmall serves the small launches
         const PyrTiling &PT = h->G.pyr[ti];
         float ms = 0.f;
         for (int rep = 0; rep < 2; rep++) {  // first launch warms up, second is timed
@@ -467,11 +467,14 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   int ti = -1;
   if (fg.nlevels > 1) {
     const PyrTiling &P0 = h->G.pyr[0], &P1 = h->G.pyr[1];
-    const int forced = h->force_tiling;  // vsg_orb_set_pyramid_tiling: -1 = calibrated choice, 0 / 1, 2 = per-level launches
-    if (forced == 2)
+    const PyrTiling &PS = h->G.pyr[kPyrTilingSmall];
+    const int forced = h->force_tiling;  // vsg_orb_set_pyramid_tiling: -1 = automatic, 0 / 1 / 2 = a tiling, 3 = per-level launches
+    if (forced == 3)
       ti = -1;
-    else if (forced == 0 || forced == 1)
+    else if (forced >= 0 && forced < kPyrTilings)
       ti = h->G.pyr[forced].ok && h->G.pyr[forced].lds_bytes() <= kPyrLdsLimit ? forced : -1;
+    else if (PS.ok && PS.lds_bytes() <= kPyrLdsLimit && (long long)P0.tiles.size() * nf <= 256)
+      ti = kPyrTilingSmall;  // the coarse tiling would leave most CUs without a workgroup (one or two frames per call)
     else if (h->pyr_tiling == 1 && (long long)P1.tiles.size() * nf >= 2048)  // calibrated choice, large launches only
       ti = 1;
     else if (P0.ok && P0.lds_bytes() <= kPyrLdsLimit)
@@ -508,11 +511,15 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   // 2000 features (33 KB) the fifth no longer fits -- 93.1 -> 90.1 k frames/s there, so that geometry keeps two streams.
   const bool lds_fits = 5 * octree_lds_bytes(fg, h->G.maxQuota, h->G.maxCellsPerLevel) <= 160 * 1024;
   const bool fused_blur = !tm && sb != s && (lds_fits || (h->one_stream && nf <= 8));
+  // Latency path without a lapping area (every keypoint has x >= 19, so lap1 < 19 -- the {0, 0} of the RGB-D / stereo
+  // callers, Frame.cc:108,344 -- selects nothing): k_orient_desc derives slots and level starts itself, k_slots is not
+  // launched (8 us of the one-frame chain)
+  const bool self_slots = !tm && h->one_stream && nf <= 8 && (lap1 < kEdgeThreshold || lap0 > lap1);
   if (fused_blur) {
     Range r_tail("DistributeOctTree (+ blur workgroups) + slots + IC_Angle / rBRIEF");
     launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel,
                   sel_count, fg, h->G.maxQuota, h->G.maxCellsPerLevel, nf, pyr, blur, &s0);
-    launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
+    if (!self_slots) launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
   } else {
   HIP_TRY(hipEventRecord(ev_pyr, s));
   // Host enqueue order: the latency-critical launch (the octree) goes out BEFORE the three calls that fork the blur onto
@@ -543,8 +550,8 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   }
   OutMirror mir = h->mirror;
   if (mir.kps) mir.kps += F * mir.capacity, mir.desc += F * mir.capacity * 32, mir.counts += F * 2;
-  launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, slots, hdr, h->d_pattern, d_kps + F * capacity,
-                     d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf, mir);
+  launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, sel_count, slots, hdr, h->d_pattern, d_kps + F * capacity,
+                     d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf, mir, self_slots && fused_blur);
   if (tm) HIP_TRY(hipEventRecord(h->ev[5], s));
   return VSG_OK;
 }
@@ -785,7 +792,7 @@ int vsg_orb_set_blur_taps(vsg_orb *h, const uint16_t taps[7]) {
 }
 
 int vsg_orb_set_pyramid_tiling(vsg_orb *h, int which) {
-  if (!h || which < -1 || which > 2) return VSG_ERR_INVALID;
+  if (!h || which < -1 || which > kPyrTilings) return VSG_ERR_INVALID;
   h->force_tiling = which;
   free_chain_graphs(h);  // a recorded chain holds the launch form it was recorded with
   return VSG_OK;

@@ -357,7 +357,8 @@ class ORBextractor:
         _check(self._L.vsg_orb_set_blur_taps(self._h, _p(t, _u16p)), "vsg_orb_set_blur_taps")
 
     def set_pyramid_tiling(self, which):
-        """ComputePyramid's launch form: -1 calibrated (default), 0 / 1 the two fused tilings, 2 one launch per level."""
+        """ComputePyramid's launch form: -1 automatic (default), 0 / 1 / 2 the fused tilings (32 / 36 / 16 px), 3 one launch
+        per level."""
         _check(self._L.vsg_orb_set_pyramid_tiling(self._h, int(which)), "vsg_orb_set_pyramid_tiling")
 
     def capacity(self, rows, cols):
