@@ -512,16 +512,21 @@ def main():
                                     o_counts[1].data_ptr(), cap, (0, 0), stream)
             ms = mstream if side else tstream
             if side:
+                # the last frame of the previous batch into slot 0 ON THE EXTRACTION STREAM: the next step extracts into
+                # the set these two copies read, and it only waits for the match recorded two steps ago -- on the match
+                # stream they could still be reading while that extraction writes
+                o_desc[0].copy_(p_desc[B])
+                o_counts[0].copy_(p_counts[B])
                 ev_ext.record(tstream)
                 mstream.wait_event(ev_ext)
             with torch.cuda.stream(ms):
                 if time_match:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(ms)
-                # the last frame of the previous batch into slot 0 (its extraction is earlier work of tstream, which
-                # ev_ext orders before this)
-                o_desc[0].copy_(p_desc[B])
-                o_counts[0].copy_(p_counts[B])
+                if not side:
+                    # the last frame of the previous batch into slot 0 (its extraction is earlier work of this stream)
+                    o_desc[0].copy_(p_desc[B])
+                    o_counts[0].copy_(p_counts[B])
                 best2(o_desc[1].data_ptr(), o_desc[0].data_ptr(), o_counts[1].data_ptr(), o_counts[0].data_ptr(), B,
                       cap * 32, d_best.data_ptr(), d_second.data_ptr(), d_arg.data_ptr(), on_stream=ms.cuda_stream)
                 if time_match:
@@ -701,7 +706,7 @@ def main():
             sys.path.insert(0, str(ROOT / "tools"))
             from source_hash import source_hash
             doc, traffic_source = {}, None
-            for name in ("traffic_r03.json",):
+            for name in ("traffic_r04.json",):
                 if (ROOT / "profiles" / name).exists():
                     doc = json.load(open(ROOT / "profiles" / name))
                     traffic_source = f"profiles/{name}"
@@ -712,8 +717,8 @@ def main():
                                 f"{source_hash()}: PMC figures withheld (re-run tools/profile_round.sh)")
                 doc = {}
             isa = {}
-            if (ROOT / "profiles" / "r03_isa_mix.json").exists():
-                isa = json.load(open(ROOT / "profiles" / "r03_isa_mix.json"))
+            if (ROOT / "profiles" / "r04_isa_mix.json").exists():
+                isa = json.load(open(ROOT / "profiles" / "r04_isa_mix.json"))
                 if isa.get("source_hash") != source_hash():
                     isa = {}
             per_stage = doc.get(f"{args.workload}/{B}", {})
@@ -731,7 +736,7 @@ def main():
             # Issue roofline per stage.  MI355X: 1024 SIMDs; a wave64 VALU instruction holds its SIMD's vector issue
             # for 2.3 cycles (plain 32-bit add / logic / fp32) or 4.2 (everything else these kernels use; measured:
             # profiles/r01_c_ubench_valu_rates.txt).  frac_at_4_cycles prices every instruction at the classic 4
-            # cycles; frac_priced uses the kernel's STATIC full-rate / half-rate mix (profiles/r03_isa_mix.json).
+            # cycles; frac_priced uses the kernel's STATIC full-rate / half-rate mix (profiles/r04_isa_mix.json).
             # wait_any = share of resident wave-cycles parked at s_waitcnt / barriers (SQ_WAIT_ANY / SQ_WAVE_CYCLES),
             # issue_stall = SQ_WAIT_INST_ANY share (the instruction buffer has work, the pipe is not free).
             for k, v in per_stage.items():
@@ -750,7 +755,9 @@ def main():
                     issue[k] = e
             if issue:
                 issue["_source"] = (f"{traffic_source} (rocprofv3 --pmc SQ_* passes of tools/profile_round.sh, source hash "
-                                    f"{doc.get('source_hash')}); durations = stage_ms of this run")
+                                    f"{doc.get('source_hash')}); durations = stage_ms of this run; both describe the "
+                                    "SERIALISED step (VSG_NO_OVERLAP: k_octree and k_blur as separate launches) -- in the "
+                                    "timed region the blur's workgroups ride in k_octree_blur")
             # PMC traffic over algorithmic bytes per stage: well above 1 = wasted re-reads (the first thing to fix)
             for k, v in per_stage.items():
                 if k in stages and stages[k] > 0 and "fetch_bytes" in v:

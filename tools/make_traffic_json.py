@@ -56,7 +56,8 @@ def main():
                     "counter values in bytes (counter unit KB x 1024); gfx950 caveat (MI355X_MICROARCH.md): FETCH_SIZE "
                     "under-reports wide (16 B/lane) streaming reads by 2x and is uncalibrated for the 4-12 B per lane "
                     "loads used here, so fetch_bytes is a lower bound; Infinity-Cache hits are counted. valu_insts = "
-                    "SQ_INSTS_VALU per launch."}
+                    "SQ_INSTS_VALU per launch.  Collected under VSG_NO_OVERLAP=1 (tools/profile_round.sh): octree and blur "
+                    "are the SEPARATE-LAUNCH forms k_octree / k_blur, not the fused k_octree_blur of the timed region."}
     doc[tag] = res
     doc["source_hash"] = source_hash()  # tools/source_hash.py: the sources these counters were measured on
     out.write_text(json.dumps(doc, indent=1))

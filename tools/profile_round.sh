@@ -11,6 +11,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 B="python3 bench.py --cpu-seconds 0 --no-stage-timing --no-extras"
 VSG_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B > $OUT/bench_rocprof.json 2> $OUT/rocprof.err
+# the same command WITHOUT the serialisation: the kernels of the timed region as the bench runs them (the blur's workgroups
+# ride in k_octree_blur; the counters below describe the separate-launch forms k_octree / k_blur)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_timed -- $B > $OUT/bench_rocprof_timed.json 2>> $OUT/rocprof.err
 P="--steps 3 --warmup 1"
 pass() {  # name, counters...
   local name=$1; shift
@@ -22,14 +25,18 @@ pass sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES
 pass wait SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 pass active SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
+# one counter pass of the un-serialised step: the fused k_octree_blur launch the timed region really runs
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES --output-format csv -d $OUT/pmc_fused -- $B $P > /dev/null 2>>$OUT/rocprof.err
+python3 tools/pmc_summary.py $OUT/pmc_fused > $OUT/pmc_sq_timed_region_fused_octree_blur.txt 2>&1
 cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+cp $OUT/stats_timed/*/*kernel_stats.csv $OUT/kernel_stats_timed_region.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > $OUT/pmc_sq.txt 2>&1
 python3 tools/make_traffic_json.py C2/512 $OUT/traffic.json $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > /dev/null 2>&1
 # the un-profiled bench line LAST among the bench runs, with this build's own counters in place (bench.py only quotes a
 # traffic file whose source hash is the hash of the sources it runs on): the copies under profiles/ on this box are scratch
-cp $OUT/traffic.json profiles/traffic_r03.json
-python3 tools/isa_mix.py > $OUT/isa_mix.json 2>> $OUT/rocprof.err && cp $OUT/isa_mix.json profiles/r03_isa_mix.json
+cp $OUT/traffic.json profiles/traffic_r04.json
+python3 tools/isa_mix.py > $OUT/isa_mix.json 2>> $OUT/rocprof.err && cp $OUT/isa_mix.json profiles/r04_isa_mix.json
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_abi -- tools/_bin/abi_latency 300 > $OUT/abi_latency.json 2>> $OUT/rocprof.err
 cp $OUT/stats_abi/*/*kernel_stats.csv $OUT/abi_kernel_stats.csv 2>/dev/null
@@ -37,6 +44,6 @@ tools/_bin/config_chain 2 4 > $OUT/config_chain.json 2>> $OUT/rocprof.err
 rocprofv3 --kernel-trace --output-format csv -d $OUT/lt -- tools/_bin/extract_latency 300 > $OUT/extract_latency.json 2>> $OUT/rocprof.err
 python3 tools/latency_timeline.py $OUT/lt > $OUT/frame_timeline.txt 2>&1
 for e in "" VSG_GRAPH=1; do echo "== ${e:-default}"; env $e tools/_bin/extract_latency 1000; done > $OUT/frame_latency_ab.txt 2>&1
-rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/stats_abi/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp $OUT/lt
+rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/stats_timed/*/*kernel_trace.csv $OUT/pmc_fused $OUT/stats_abi/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp $OUT/lt
 cat $OUT/bench.json | cut -c1-1200
 cat $OUT/pmc_traffic.txt $OUT/pmc_sq.txt

@@ -453,7 +453,11 @@ __device__ __forceinline__ FastCell load_fast_cell(const FastCellRec *__restrict
 // L2 (profiles/r03_c_fast_ablation.txt: 0.065 / 0.074 / 0.108 / 0.221 ms for workgroups that end at once / after the
 // descriptors / after a staging pass without loads / after the real staging pass, of 0.441 ms).
 template <int NT, int kTileP, int kScoreP, int kPre>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS), amdgpu_waves_per_eu(8, 8))) void k_fast_cells(
+#ifndef VSG_FAST_WAVES_MIN
+#define VSG_FAST_WAVES_MIN 8
+#define VSG_FAST_WAVES_MAX 8
+#endif
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS), amdgpu_waves_per_eu(VSG_FAST_WAVES_MIN, VSG_FAST_WAVES_MAX))) void k_fast_cells(
     const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg, const FastCellRec *__restrict__ recs, Src0 s0,
     uint32_t *__restrict__ cand, int *__restrict__ cand_count, int *__restrict__ cell_count, int tile_bytes,
     int score_bytes, int queue_cap, int cells_per_wg) {
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
   // (row, first dword) of a thread's chunks only depend on the chunks per row, which rarely change from cell to cell: kept
   // across cells in the narrow tile class (the wider ones have no registers to spare) and clamped per cell instead of
   // divided out again
-  constexpr bool kKeepRC = kPre == 2;
+  constexpr bool kKeepRC = kPre * NT == 256;
   int rc_nq4 = 0, rc_r[kKeepRC ? kPre : 1], rc_c[kKeepRC ? kPre : 1];
   auto fetch = [&](const FastCell &N) -> bool {
     const int n = N.nq4() * N.th();
@@ -1967,11 +1971,11 @@ void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const
   // tile row = up to 3 alignment bytes + vw + 6 ring bytes, rounded up to dwords; score rows (vw + 2 used) have the
   // tile's pitch: a pixel's score sits a constant away from its tile byte (k_fast_cells phase 2)
   if (maxVw <= 40)
-    launch_fast_t<VSG_FAST_NT, 52, 52, 2>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
+    launch_fast_t<VSG_FAST_NT, 52, 52, 2 * (128 / VSG_FAST_NT)>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
   else if (maxVw <= 56)
-    launch_fast_t<VSG_FAST_NT, 68, 68, 3>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
+    launch_fast_t<VSG_FAST_NT, 68, 68, 3 * (128 / VSG_FAST_NT)>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
   else
-    launch_fast_t<VSG_FAST_NT, 84, 84, 4>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
+    launch_fast_t<VSG_FAST_NT, 84, 84, 4 * (128 / VSG_FAST_NT)>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
 }
 // dynamic LDS of one octree workgroup (also what every blur workgroup of the fused launch is charged)
 size_t octree_lds_bytes(const FrameGeom &fg, int maxQuota, int maxCellsPerLevel) {
