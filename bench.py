@@ -888,6 +888,10 @@ def main():
             fl["stereo_pair_ms"] = round(st["extract_2_eyes"] + st["make_resident_2"] + st["stereo_matches"], 4)
             fl["stereo_pair"] = ("752x480 / 1200: two handles on two host threads (Frame.cc:129-132) -> both eyes resident "
                                  "-> ComputeStereoMatches (Frame.cc:957)")
+            bp = c3.get("batched_pair") or {}
+            if "extract_2_eyes" in bp:
+                fl["stereo_pair_batched_ms"] = round(bp["extract_2_eyes"] + bp["make_resident_2"] + bp["stereo_matches"], 4)
+                fl["stereo_pair_batched"] = bp.get("what", "") + f"; parity {bp.get('parity')}"
         out["frame_latency"] = fl
     print(json.dumps(out))
     if distributed:

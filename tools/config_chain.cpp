@@ -125,7 +125,11 @@ struct PairResult {  // everything the chain produces for one pair
 };
 
 struct C3Gpu {
-  vsg_orb *exL = nullptr, *exR = nullptr;
+  vsg_orb *exL = nullptr, *exR = nullptr, *ex2 = nullptr;  // ex2: ONE handle that takes both eyes as a 2-frame batch
+  std::vector<uint8_t> both;                               // the two eyes back to back (the batch's input layout)
+  std::vector<vsg_keypoint> kp2;
+  std::vector<uint8_t> ds2;
+  double batched_ms[3] = {0, 0, 0};
   vsg_frame *FL[2] = {nullptr, nullptr}, *FR = nullptr;
   vsg_vocab *voc = nullptr;  // shared, not owned
   int cap = 0, device = 0;
@@ -144,18 +148,45 @@ struct C3Gpu {
       res[i].size_for(cap);
     }
     CHECK(vsg_frame_create(dev, cap, &FR) == VSG_OK);
+    CHECK(vsg_orb_create(NF3, 1.2f, 8, 20, 7, dev, 2, &ex2) == VSG_OK);
+    CHECK(vsg_orb_capacity(ex2, H3, W3) == cap);
+    both.resize((size_t)2 * W3 * H3), kp2.resize((size_t)2 * cap), ds2.resize((size_t)2 * cap * 32);
+  }
+  // The same first three stages with ONE handle and ONE call for both eyes (a rectified pair has the same lapping area
+  // {0, 0} for both, Frame.cc:108-132): one chain of launches over two frames instead of two chains from two host threads.
+  // Results go through the same checks (left / right keypoints, descriptors, mvuRight, mvDepth).
+  bool pair_batched(const uint8_t *left, const uint8_t *right, const PairResult &want) {
+    double t0 = now_ms();
+    memcpy(both.data(), left, (size_t)W3 * H3), memcpy(both.data() + (size_t)W3 * H3, right, (size_t)W3 * H3);
+    int n[2], mono[2];
+    CHECK(vsg_orb_extract_batch(ex2, both.data(), 2, (size_t)W3 * H3, H3, W3, W3, 0, 0, kp2.data(), ds2.data(), cap, n, mono) == VSG_OK);
+    double t1 = now_ms();
+    CHECK(vsg_frame_from_extractor(FL[0], ex2, 0, kp2.data(), n[0], 0.f, 0.f, (float)W3, (float)H3) == VSG_OK);
+    CHECK(vsg_frame_from_extractor(FR, ex2, 1, kp2.data() + cap, n[1], 0.f, 0.f, (float)W3, (float)H3) == VSG_OK);
+    double t2 = now_ms();
+    std::vector<float> uR(cap), depth(cap);
+    const int ns = vsg_frame_stereo_matches(ex2, 0, ex2, 1, FL[0], FR, MB, MBF, uR.data(), depth.data());
+    double t3 = now_ms();
+    batched_ms[0] += t1 - t0, batched_ms[1] += t2 - t1, batched_ms[2] += t3 - t2;
+    return ns == want.nstereo && n[0] == want.nL && n[1] == want.nR && !memcmp(kp2.data(), want.kpL.data(), (size_t)n[0] * 28) &&
+           !memcmp(kp2.data() + cap, want.kpR.data(), (size_t)n[1] * 28) && !memcmp(ds2.data(), want.dsL.data(), (size_t)n[0] * 32) &&
+           !memcmp(ds2.data() + (size_t)cap * 32, want.dsR.data(), (size_t)n[1] * 32) &&
+           !memcmp(uR.data(), want.uR.data(), (size_t)n[0] * 4) && !memcmp(depth.data(), want.depth.data(), (size_t)n[0] * 4);
   }
   // one stereo pair through the chain; `have_prev`: a previous pair exists to search against
   void pair(const uint8_t *left, const uint8_t *right, int t, bool have_prev) {
     PairResult &R = res[t & 1], &P = res[(t + 1) & 1];
     vsg_frame *cur = FL[t & 1], *prev = FL[(t + 1) & 1];
     double t0 = now_ms();
-    right_eye.run([&] { CHECK(vsg_orb_extract(exR, right, H3, W3, W3, 0, 0, R.kpR.data(), R.dsR.data(), cap, &R.nR) >= 0); });
+    // each eye's thread extracts AND makes its features resident (the two eyes are independent until ComputeStereoMatches)
+    right_eye.run([&] {
+      CHECK(vsg_orb_extract(exR, right, H3, W3, W3, 0, 0, R.kpR.data(), R.dsR.data(), cap, &R.nR) >= 0);
+      CHECK(vsg_frame_from_extractor(FR, exR, 0, R.kpR.data(), R.nR, 0.f, 0.f, (float)W3, (float)H3) == VSG_OK);
+    });
     CHECK(vsg_orb_extract(exL, left, H3, W3, W3, 0, 0, R.kpL.data(), R.dsL.data(), cap, &R.nL) >= 0);
-    right_eye.wait();
     double t1 = now_ms();
     CHECK(vsg_frame_from_extractor(cur, exL, 0, R.kpL.data(), R.nL, 0.f, 0.f, (float)W3, (float)H3) == VSG_OK);
-    CHECK(vsg_frame_from_extractor(FR, exR, 0, R.kpR.data(), R.nR, 0.f, 0.f, (float)W3, (float)H3) == VSG_OK);
+    right_eye.wait();
     double t2 = now_ms();
     R.nstereo = vsg_frame_stereo_matches(exL, 0, exR, 0, cur, FR, MB, MBF, R.uR.data(), R.depth.data());
     CHECK(R.nstereo >= 0);
@@ -178,7 +209,7 @@ struct C3Gpu {
   ~C3Gpu() {
     for (int i = 0; i < 2; i++) vsg_frame_destroy(FL[i]);
     vsg_frame_destroy(FR);
-    vsg_orb_destroy(exL), vsg_orb_destroy(exR);
+    vsg_orb_destroy(exL), vsg_orb_destroy(exR), vsg_orb_destroy(ex2);
   }
 };
 
@@ -279,23 +310,39 @@ static std::string run_c3(double seconds, int npipes) {
     for (auto &x : th) x.join();
     multi = total / ((now_ms() - tm0) * 1e-3);
   }
+  // ---- both eyes as one 2-frame batch on one handle (parity against the oracle's pair, then timed)
+  bool batched_parity = true;
+  for (int tt = 0; tt < T; tt++) {
+    c.pair(in.left[tt].data(), in.right[tt].data(), tt, false);
+    batched_parity = batched_parity && g[0].pair_batched(in.left[tt].data(), in.right[tt].data(), c.res[tt & 1]);
+  }
+  memset(g[0].batched_ms, 0, sizeof g[0].batched_ms);
+  long nb = 0;
+  t0 = now_ms();
+  for (t = 0; now_ms() - t0 < seconds * 500; t++, nb++) g[0].pair_batched(in.left[t % T].data(), in.right[t % T].data(), c.res[0]);
+  double bst[3];
+  for (int i = 0; i < 3; i++) bst[i] = g[0].batched_ms[i] / nb;
   // ---- the oracle's chain
   c.pairs = 0;
   t0 = now_ms();
   t = T;
   while (now_ms() - t0 < seconds * 1e3) c.pair(in.left[t % T].data(), in.right[t % T].data(), t, true), t++;
   const double cpu_ms = (now_ms() - t0) / c.pairs;
-  char b[2048];
+  char b[4096];
   snprintf(b, sizeof b,
-           "{\"workload\": \"C3: stereo 752x480, nFeatures=1200; per pair 2 x operator() on two host threads -> resident "
-           "frames -> ComputeStereoMatches -> ComputeBoW (k=%d, L=%d vocabulary, %d nodes, levelsup 4) -> SearchByBoW(KF = "
+           "{\"workload\": \"C3: stereo 752x480, nFeatures=1200; per pair 2 x (operator() -> resident frame) on two host threads "
+           "(stage extract_2_eyes = the left eye's operator(), make_resident_2 = until both eyes are resident) "
+           "-> ComputeStereoMatches -> ComputeBoW (k=%d, L=%d vocabulary, %d nodes, levelsup 4) -> SearchByBoW(KF = "
            "previous pair, F)\", \"unit\": \"stereo pairs/s\", \"pairs_per_s\": %.1f, \"ms_per_pair\": %.4f, "
            "\"stage_ms\": {\"extract_2_eyes\": %.4f, \"make_resident_2\": %.4f, \"stereo_matches\": %.4f, \"compute_bow\": %.4f, "
-           "\"search_by_bow\": %.4f}, \"pipelines\": %d, \"pairs_per_s_all_pipelines\": %.1f, \"parity\": %s, "
+           "\"search_by_bow\": %.4f}, \"batched_pair\": {\"what\": \"both eyes as ONE 2-frame vsg_orb_extract_batch on one handle "
+           "(rectified pair: one lapping area) instead of two handles on two host threads\", \"extract_2_eyes\": %.4f, "
+           "\"make_resident_2\": %.4f, \"stereo_matches\": %.4f, \"parity\": %s}, \"pipelines\": %d, \"pairs_per_s_all_pipelines\": %.1f, \"parity\": %s, "
            "\"pairs_checked\": %d, \"per_pair\": {\"stereo_matches\": %.1f, \"feature_vector_nodes\": %.1f, \"bow_matches\": %.1f}, "
            "\"cpu_oracle\": {\"pairs_per_s\": %.2f, \"ms_per_pair\": %.3f, \"threads\": 2, \"kind\": \"port\"}, "
            "\"vocabulary_load_ms\": %.1f}",
-           vk, vL, vn, 1e3 / one_ms, one_ms, st[0], st[1], st[2], st[3], st[4], npipes, multi, parity ? "true" : "false", T,
+           vk, vL, vn, 1e3 / one_ms, one_ms, st[0], st[1], st[2], st[3], st[4], bst[0], bst[1], bst[2],
+           batched_parity ? "true" : "false", npipes, multi, parity ? "true" : "false", T,
            (double)stereo / T, (double)nodes / T, (double)matches / (T - 1), 1e3 / cpu_ms, cpu_ms, voc_load_ms);
   g.clear();
   vsg_vocab_destroy(voc);
