@@ -391,6 +391,15 @@ int vsg_camera_image_bounds(int cols, int rows, const float K4[4], const float *
 int vsg_frame_from_extractor_undistort(vsg_frame *f, vsg_orb *h, int index, const vsg_keypoint *kps_host, int n,
                                        const float K4[4], const float *dist, int ndist, float min_x, float min_y,
                                        float max_x, float max_y, vsg_keypoint *keys_un_out);
+/* The Frame constructor's front end in ONE call and ONE wait (Frame.cc:344-358: ExtractORB -> UndistortKeyPoints ->
+ * AssignFeaturesToGrid): vsg_orb_extract + vsg_frame_from_extractor_undistort, with the grid launch enqueued on the
+ * extractor's stream right behind its stage chain (it reads the keypoint count on the device), so the blocking call's
+ * single wait covers both.  Arguments as the two calls'; K4 == NULL: no distortion.  Returns monoIndex like
+ * vsg_orb_extract, *n = the keypoint count; VSG_ERR_CAPACITY when the frame's capacity is below *n. */
+int vsg_orb_extract_to_frame(vsg_orb *h, const uint8_t *gray, int rows, int cols, int stride, int lap0, int lap1,
+                             vsg_keypoint *kps, uint8_t *desc, int capacity, int *n, vsg_frame *f, const float K4[4],
+                             const float *dist, int ndist, float min_x, float min_y, float max_x, float max_y,
+                             vsg_keypoint *keys_un_out);
 int vsg_frame_size(const vsg_frame *f);
 /* test / debug read-back of the device copy: grid CSR (cell_start[64*48+1], entries[n]) of the left (0) or right (1) grid */
 int vsg_frame_copy_grid(vsg_frame *f, int right, int32_t *cell_start, int32_t *entries);

@@ -441,6 +441,25 @@ class ResidentFrame {
                                              mnMinX, mnMinY, mnMaxX, mnMaxY, mvKeysUn ? mvKeysUn->data() : nullptr),
           "vsg_frame_from_extractor_undistort");
   }
+  // ExtractORB + UndistortKeyPoints + AssignFeaturesToGrid in one call and one wait (vsg_orb_extract_to_frame): the
+  // front end of the monocular / RGB-D Frame constructors.  Returns monoIndex; mvKeys / descriptors sized to N.
+  int ExtractInto(ORBextractor &ex, const uint8_t *gray, int rows, int cols, int stride, const int lapping[2],
+                  std::vector<vsg_keypoint> &mvKeys, std::vector<uint8_t> &descriptors, const float K4[4],
+                  const float *dist, int ndist, float mnMinX, float mnMinY, float mnMaxX, float mnMaxY,
+                  std::vector<vsg_keypoint> *mvKeysUn) {
+    const int cap = vsg_orb_capacity(ex.handle(), rows, cols);
+    check(cap, "vsg_orb_capacity");
+    mvKeys.resize(cap), descriptors.resize((size_t)cap * 32);
+    if (mvKeysUn) mvKeysUn->resize(cap);
+    int n = 0;
+    const int mono = vsg_orb_extract_to_frame(ex.handle(), gray, rows, cols, stride, lapping[0], lapping[1], mvKeys.data(),
+                                              descriptors.data(), cap, &n, f_, K4, dist, ndist, mnMinX, mnMinY, mnMaxX,
+                                              mnMaxY, mvKeysUn ? mvKeysUn->data() : nullptr);
+    check(mono, "vsg_orb_extract_to_frame");
+    mvKeys.resize(n), descriptors.resize((size_t)n * 32);
+    if (mvKeysUn) mvKeysUn->resize(n);
+    return mono;
+  }
   // Frame::ComputeImageBounds (Frame.cc:924-955): {mnMinX, mnMinY, mnMaxX, mnMaxY}
   static void ImageBounds(int cols, int rows, const float K4[4], const float *dist, int ndist, float out[4]) {
     check(vsg_camera_image_bounds(cols, rows, K4, dist, ndist, out), "vsg_camera_image_bounds");

@@ -71,6 +71,35 @@ def test_device_built_grid_from_extractor_equals_oracle():
         assert n == n2 and np.array_equal(m, m2)
 
 
+def test_extract_into_frame_is_operator_plus_resident_frame():
+    """vsg_orb_extract_to_frame (the Frame constructor's front end in one call and one wait: operator() -> UndistortKeyPoints
+    -> AssignFeaturesToGrid) against the oracle and against the two separate calls, under the current camera; repeated calls
+    on the same frame object (sizes change from call to call) and the empty frame."""
+    ex = orb.ORBextractor(600, 1.2, 8, 20, 7)
+    ref = ol.OracleExtractor(600, 1.2, 8, 20, 7)
+    f = orb.Frame(ex.capacity(240, 320))
+    K4, dist = (sc.CAM["K4"], sc.CAM["dist"]) if sc.CAM is not None else (None, None)
+    for t, img in enumerate([synth.sequence_frame(320, 240, 12, 0), synth.content_frame("ramp", 320, 240, 12, 1),
+                             synth.sequence_frame(320, 240, 12, 2), np.full((240, 320), 90, np.uint8)]):
+        mono, k, d = f.extract_into(ex, img, sc.BOUNDS, K4, dist)
+        rm, rk, rd = ref(img)
+        assert mono == rm and k.tobytes() == rk.tobytes() and np.array_equal(d, rd), t
+        kun = ol.undistort_keypoints(rk, sc.CAM) if sc.CAM is not None else rk
+        assert f.N == len(rk) and f.kps.tobytes() == kun.tobytes(), t
+        o = ol.OracleFrame(kun, rd, sc.BOUNDS)
+        assert all(np.array_equal(a, b) for a, b in zip(f.grid(), o.grid())), t
+        if len(rk):
+            s = sc.kf_projection_scenario(3)
+            m0 = np.full(len(rk), -1, np.int32)
+            got = f.SearchByProjection_Sim3(s["q_desc"], s["u"], s["v"], s["radius"], s["level"], 1.0, m0)
+            want = o.search_by_projection_sim3(s["q_desc"], s["u"], s["v"], s["radius"], s["level"], 1.0, m0)
+            assert got[0] == want[0] and np.array_equal(got[1], want[1]), t
+    # a lapping area (the mono case: everything from the back) goes through k_slots and the same hook
+    mono, k, d = f.extract_into(ex, synth.sequence_frame(320, 240, 12, 3), sc.BOUNDS, K4, dist, vLappingArea=(0, 1000))
+    rm, rk, rd = ref(synth.sequence_frame(320, 240, 12, 3), (0, 1000))
+    assert mono == rm and k.tobytes() == rk.tobytes() and np.array_equal(d, rd)
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_features_in_area_order_and_filters(seed):
     keys, desc, nleft = sc.stereo_pair(seed)

@@ -425,10 +425,10 @@ struct C5Gpu {
   }
   void frame(const uint8_t *img, int t, bool have_prev) {
     TrackResult &R = res[t & 1], &P = res[(t + 1) & 1];
-    CHECK(vsg_orb_extract(ex, img, H5, W5, W5, 0, 0, R.kp.data(), R.ds.data(), cap, &R.n) >= 0);
-    // Frame::UndistortKeyPoints on the device, inside the launch that builds the grid; mvKeysUn comes back for the host
-    CHECK(vsg_frame_from_extractor_undistort(F[t & 1], ex, 0, R.kp.data(), R.n, cam.K4, cam.dist, cam.ndist, cam.bounds[0],
-                                             cam.bounds[1], cam.bounds[2], cam.bounds[3], R.kpun.data()) == VSG_OK);
+    // the Frame constructor's front end in one call and one wait: operator() -> UndistortKeyPoints on the device (inside the
+    // launch that builds the grid, right behind the extractor's chain) -> resident frame; mvKeysUn comes back for the host
+    CHECK(vsg_orb_extract_to_frame(ex, img, H5, W5, W5, 0, 0, R.kp.data(), R.ds.data(), cap, &R.n, F[t & 1], cam.K4, cam.dist,
+                                   cam.ndist, cam.bounds[0], cam.bounds[1], cam.bounds[2], cam.bounds[3], R.kpun.data()) >= 0);
     R.n_last = R.n_local = 0;
     if (have_prev) {
       q.from(P);
@@ -564,7 +564,7 @@ static std::string run_c5(double seconds) {
   char b[3072];
   snprintf(b, sizeof b,
            "{\"workload\": \"C5: %d concurrent 640x480 camera streams, nFeatures=1250, one extractor + one host thread per "
-           "stream, camera = %s: per frame operator() -> UndistortKeyPoints on the device + resident frame on the grid bounds "
+           "stream, camera = %s: per frame vsg_orb_extract_to_frame (operator() -> UndistortKeyPoints on the device + resident frame, one wait) on the grid bounds "
            "(%.3f, %.3f, %.3f, %.3f) of ComputeImageBounds -> SearchByProjection(Cur, Last) -> SearchByProjection(F, local "
            "map points); stream s on device s mod %d\", \"unit\": \"frames/s\", \"frames_per_s\": %.1f, "
            "\"frames_per_s_one_stream\": %.1f, \"ms_per_frame_one_stream\": %.4f, \"streams\": %d, \"devices\": %d, "
@@ -610,15 +610,18 @@ static std::string run_latency(double seconds) {
   // cv::undistortPoints; here the oracle's restatement stands in for it), then vsg_frame_upload(mvKeysUn, bounds)
   auto gpu = [&](int t, int level, bool upload = false) {
     TrackResult &C = R[t & 1], &P = R[(t + 1) & 1];
-    CHECK(vsg_orb_extract(ex, img[t % T].data(), H, W, W, 0, 0, C.kp.data(), C.ds.data(), cap, &C.n) >= 0);
+    if (level >= 1 && !upload) {  // the fused front end (vsg_orb_extract_to_frame): one call, one wait
+      CHECK(vsg_orb_extract_to_frame(ex, img[t % T].data(), H, W, W, 0, 0, C.kp.data(), C.ds.data(), cap, &C.n, F[t & 1], cam.K4,
+                                     cam.dist, cam.ndist, cam.bounds[0], cam.bounds[1], cam.bounds[2], cam.bounds[3],
+                                     C.kpun.data()) >= 0);
+    } else {
+      CHECK(vsg_orb_extract(ex, img[t % T].data(), H, W, W, 0, 0, C.kp.data(), C.ds.data(), cap, &C.n) >= 0);
+    }
     if (level < 1) return;
     if (upload) {
       or_undistort_keypoints((const OrKeyPoint *)C.kp.data(), C.n, cam.K4, cam.dist, cam.ndist, (OrKeyPoint *)C.kpun.data());
       CHECK(vsg_frame_upload(F[t & 1], C.kpun.data(), C.ds.data(), nullptr, C.n, -1, cam.bounds[0], cam.bounds[1], cam.bounds[2],
                              cam.bounds[3]) == VSG_OK);
-    } else {
-      CHECK(vsg_frame_from_extractor_undistort(F[t & 1], ex, 0, C.kp.data(), C.n, cam.K4, cam.dist, cam.ndist, cam.bounds[0],
-                                               cam.bounds[1], cam.bounds[2], cam.bounds[3], C.kpun.data()) == VSG_OK);
     }
     if (level < 2 || P.n == 0) return;
     q.from(P);
@@ -684,9 +687,9 @@ static std::string run_latency(double seconds) {
            "(stand-in for cv::undistortPoints: the oracle's restatement) -> vsg_frame_upload(mvKeysUn, bounds) instead of the "
            "on-device UndistortKeyPoints\"}, "
            "\"cpu_oracle_1_thread\": {\"extract_ms\": %.3f, \"extract_plus_resident_ms\": %.3f, \"track_chain_ms\": %.3f}, "
-           "\"parity\": %s, \"graph_launches\": %ld, \"track_chain\": \"operator() -> UndistortKeyPoints (on the device, "
-           "FP64, inside the grid launch) -> resident frame -> SearchByProjection(Cur, Last) -> SearchByProjection(F, local map "
-           "points)\"}",
+           "\"parity\": %s, \"graph_launches\": %ld, \"track_chain\": \"vsg_orb_extract_to_frame = operator() -> "
+           "UndistortKeyPoints (on the device, FP64, inside the grid launch behind the extractor's chain: one call, one wait) -> "
+           "resident frame; then SearchByProjection(Cur, Last) -> SearchByProjection(F, local map points)\"}",
            cam.name, cam.bounds[0], cam.bounds[1], cam.bounds[2], cam.bounds[3], g_ms[0], g_ms[1], g_ms[2], up_ms[0], up_ms[1],
            c_ms[0], c_ms[1], c_ms[2], parity ? "true" : "false", vsg_orb_chain_graph_launches(ex));
   for (int i = 0; i < 2; i++) vsg_frame_destroy(F[i]);

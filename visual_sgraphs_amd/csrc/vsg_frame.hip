@@ -60,7 +60,11 @@ __global__ __launch_bounds__(1024) void k_frame_grid_build(const KeyPointPOD *__
                                                             const uint8_t *__restrict__ desc_src,
                                                             uint8_t *__restrict__ desc_copy,
                                                             int *__restrict__ zero_cells, CamModel cam,
-                                                            KeyPointPOD *__restrict__ kps_un_host) {
+                                                            KeyPointPOD *__restrict__ kps_un_host,
+                                                            const int *__restrict__ n_dev, int n_cap) {
+  // n_dev: the keypoint count where the extractor's chain left it ({n, monoIndex} of the frame) -- the launch that rides
+  // behind operator()'s chain (vsg_orb_extract_to_frame) is enqueued before the host knows it
+  if (n_dev) n = min(*n_dev, n_cap);
   __shared__ int s_cnt[kGridCells + 1];
   __shared__ int s_fill[kGridCells];
   __shared__ int s_wtot[16];
@@ -616,7 +620,7 @@ static int frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_k
   if (v.done) F_TRY(hipStreamWaitEvent(c->stream, v.done, 0));
   hipLaunchKernelGGL(k_frame_grid_build, dim3(1), dim3(1024), 0, c->stream, v.d_kps, 0, n, f->minX, f->minY, f->invW,
                      f->invH, f->d_cell_start[0], f->d_ent[0], f->d_kps, v.d_desc, f->d_desc, f->d_cell_start[1], cam,
-                     un_dev);
+                     un_dev, (const int *)nullptr, 0);
   F_TRY(hipGetLastError());
   if (!cam.distorted) f->h_kps.assign(kps_host, kps_host + n);  // beside the kernel
   F_TRY(hipStreamSynchronize(c->stream));
@@ -634,6 +638,62 @@ int vsg_frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_keyp
   if (frame_check(f) != VSG_OK || !h || n < 0 || n > f->capacity || (n > 0 && !kps_host)) return VSG_ERR_INVALID;
   CamModel cam = {};
   return frame_from_extractor(f, h, index, kps_host, n, cam, min_x, min_y, max_x, max_y, nullptr);
+}
+
+// ---- Frame::Frame(...) in ONE call and ONE wait: ExtractORB (operator()) -> UndistortKeyPoints -> AssignFeaturesToGrid
+// (Frame.cc:344-358 for RGB-D).  The grid launch is enqueued on the extractor's stream right behind its stage chain -- it
+// reads the keypoint count from the device -- so the blocking call's single wait covers both, instead of
+// operator() [wait] -> vsg_frame_from_extractor* [launch, wait].
+namespace {
+struct ToFrameHook {
+  vsg_frame *f;
+  CamModel cam;
+  KeyPointPOD *un_dev;
+};
+int to_frame_hook(void *ctx, hipStream_t s, const OrbOutputView &v) {
+  const ToFrameHook *H = (const ToFrameHook *)ctx;
+  vsg_frame *f = H->f;
+  hipLaunchKernelGGL(k_frame_grid_build, dim3(1), dim3(1024), 0, s, v.d_kps, 0, 0, f->minX, f->minY, f->invW, f->invH,
+                     f->d_cell_start[0], f->d_ent[0], f->d_kps, v.d_desc, f->d_desc, f->d_cell_start[1], H->cam, H->un_dev,
+                     v.d_counts, f->capacity);
+  return hipGetLastError() == hipSuccess ? VSG_OK : VSG_ERR_HIP;
+}
+}  // namespace
+
+int vsg_orb_extract_to_frame(vsg_orb *h, const uint8_t *gray, int rows, int cols, int stride, int lap0, int lap1,
+                             vsg_keypoint *kps, uint8_t *desc, int capacity, int *n, vsg_frame *f, const float K4[4],
+                             const float *dist, int ndist, float min_x, float min_y, float max_x, float max_y,
+                             vsg_keypoint *keys_un_out) {
+  if (n) *n = 0;
+  if (frame_check(f) != VSG_OK || !h || !kps || !desc || !n) return VSG_ERR_INVALID;
+  ToFrameHook H;
+  H.f = f, H.un_dev = nullptr;
+  H.cam = CamModel();
+  if (K4 && !make_cam_model(K4, dist, ndist, &H.cam)) return VSG_ERR_INVALID;
+  int rc = VSG_OK;
+  ThreadCtx *c = thread_ctx(f->device, &rc);
+  if (!c) return rc;
+  KeyPointPOD *un_pin = nullptr;
+  if (H.cam.distorted) {
+    rc = ctx_reserve(c, (size_t)(f->capacity + 1) * sizeof(KeyPointPOD), 0);
+    if (rc != VSG_OK) return rc;
+    un_pin = (KeyPointPOD *)c->h_pin, H.un_dev = (KeyPointPOD *)c->d_pin;
+  }
+  set_bounds(f, min_x, min_y, max_x, max_y);
+  vsg_orb_set_post_chain(h, to_frame_hook, &H);
+  const int mono = vsg_orb_extract(h, gray, rows, cols, stride, lap0, lap1, kps, desc, capacity, n);
+  vsg_orb_set_post_chain(h, nullptr, nullptr);  // (a call that failed before its submit leaves the hook unconsumed)
+  if (mono < 0) return mono;
+  if (*n > f->capacity) return VSG_ERR_CAPACITY;
+  f->n = *n, f->nleft = -1, f->has_uright = false;
+  if (H.cam.distorted) {
+    f->h_kps.assign((const vsg_keypoint *)un_pin, (const vsg_keypoint *)un_pin + *n);
+    if (keys_un_out && *n) memcpy(keys_un_out, un_pin, (size_t)*n * sizeof(vsg_keypoint));
+  } else {
+    f->h_kps.assign(kps, kps + *n);
+    if (keys_un_out && *n && keys_un_out != kps) memcpy(keys_un_out, kps, (size_t)*n * sizeof(vsg_keypoint));
+  }
+  return mono;
 }
 
 int vsg_camera_image_bounds(int cols, int rows, const float K4[4], const float *dist, int ndist, float out[4]) {

@@ -104,3 +104,8 @@ struct OrbOutputView {
 }  // namespace vsg
 
 int vsg_orb_output_view(vsg_orb *h, int index, vsg::OrbOutputView *v);
+// Work a blocking extract call enqueues on the handle's stream BEHIND its stage chain and in front of the completion event
+// the call waits for (vsg_orb_extract_to_frame: the resident frame's grid launch rides in operator()'s one wait).  The
+// hook is consumed by the next submit; `v` = frame 0 of that call's outputs.
+typedef int (*vsg_post_chain_fn)(void *ctx, hipStream_t stream, const vsg::OrbOutputView &v);
+void vsg_orb_set_post_chain(vsg_orb *h, vsg_post_chain_fn fn, void *ctx);

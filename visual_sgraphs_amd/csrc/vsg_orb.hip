@@ -187,6 +187,8 @@ struct vsg_orb {
   uint32_t *d_cand2 = nullptr;    // [max_batch][fg.cand_frame] compacted candidates of levels too large for the octree's registers
   int pyr_tiling = 0;                   // the tiling calibration found faster for a full batch of this geometry
   int force_tiling = -1;                // vsg_orb_set_pyramid_tiling (tests: every launch form against the oracle)
+  vsg_post_chain_fn post_fn = nullptr;  // vsg_orb_set_post_chain: enqueued behind the next submit's chain, then cleared
+  void *post_ctx = nullptr;
   int cus = 256;                        // compute units of `device` (k_fast_cells' cells-per-workgroup choice)
   PyrTile *d_ptiles[kPyrTilings] = {};  // Geometry::pyr[i].tiles
   Short4 *d_ptab[kPyrTilings] = {};     // Geometry::pyr[i].tab
@@ -918,6 +920,17 @@ static int tail_stream_work(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1
 
 // bookkeeping of a submitted batch; records the completion event behind whatever was enqueued / launched
 static int finish_submit(vsg_orb *h, Slot &S, int nframes, vsg_keypoint *kps, uint8_t *desc, int capacity, bool direct) {
+  if (h->post_fn) {  // e.g. the resident frame's grid launch: on the chain's stream, covered by the call's one wait
+    const vsg_post_chain_fn fn = h->post_fn;
+    void *ctx = h->post_ctx;
+    h->post_fn = nullptr, h->post_ctx = nullptr;
+    OrbOutputView v;
+    int rc = vsg_orb_output_view(h, 0, &v);
+    if (rc != VSG_OK) return rc;
+    v.done = nullptr;  // same stream: ordered behind the chain already
+    rc = fn(ctx, h->one_stream ? h->s_main : h->s_d2h, v);
+    if (rc != VSG_OK) return rc;
+  }
   S.direct = direct;
   S.out_kps = kps, S.out_desc = desc, S.out_cap = capacity;
   HIP_TRY(hipEventRecord(S.ev_out, h->one_stream ? h->s_main : h->s_d2h));
@@ -1365,6 +1378,10 @@ static int pyr_view(vsg_orb *h, int frame, PyrView &v) {
     }
   }
   return VSG_OK;
+}
+
+void vsg_orb_set_post_chain(vsg_orb *h, vsg_post_chain_fn fn, void *ctx) {
+  if (h) h->post_fn = fn, h->post_ctx = ctx;
 }
 
 int vsg_orb_output_view(vsg_orb *h, int index, OrbOutputView *v) {

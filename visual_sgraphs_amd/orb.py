@@ -62,6 +62,7 @@ EXPORTS = [
     "vsg_copy_d2d_async", "vsg_orb_chain_graph_launches",
     # round 4
     "vsg_orb_set_pyramid_tiling", "vsg_shard_rank", "vsg_camera_image_bounds", "vsg_frame_from_extractor_undistort",
+    "vsg_orb_extract_to_frame",
 ]
 
 
@@ -214,6 +215,8 @@ def load_library():
     L.vsg_frame_from_extractor.argtypes = [vp, vp, ci, vp, ci, cf, cf, cf, cf]
     L.vsg_frame_from_extractor_undistort.argtypes = [vp, vp, ci, vp, ci, _f32p, _f32p, ci, cf, cf, cf, cf, vp]
     L.vsg_camera_image_bounds.argtypes = [ci, ci, _f32p, _f32p, ci, _f32p]
+    L.vsg_orb_extract_to_frame.argtypes = [vp, _u8p, ci, ci, ci, ci, ci, vp, _u8p, ci, _i32p, vp, _f32p, _f32p, ci, cf, cf,
+                                           cf, cf, vp]
     L.vsg_frame_size.argtypes = [vp]
     L.vsg_frame_copy_grid.argtypes = [vp, ci, _i32p, _i32p]
     L.vsg_frame_features_in_area.argtypes = [vp, _f32p, _f32p, _f32p, _i32p, _i32p, ci, ci, _i32p, _i32p, ci]
@@ -882,6 +885,24 @@ class Frame:
             *[float(b) for b in bounds], un.ctypes.data_as(C.c_void_p)), "vsg_frame_from_extractor_undistort")
         self.kps, self.nleft = un, -1
         return self
+
+    def extract_into(self, ex, image, bounds, K4=None, dist=None, vLappingArea=(0, 0)):
+        """Frame::Frame front end in one call and one wait: operator() -> UndistortKeyPoints -> AssignFeaturesToGrid
+        (vsg_orb_extract_to_frame).  Returns (monoIndex, mvKeys, descriptors); self.kps = mvKeysUn."""
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        rows, cols = img.shape
+        cap = ex.capacity(rows, cols)
+        kps, desc, un = np.zeros(cap, KP_DTYPE), np.zeros((cap, 32), np.uint8), np.zeros(cap, KP_DTYPE)
+        n = C.c_int32(0)
+        k4 = _f32(np.asarray(K4)) if K4 is not None else None
+        d = _f32(np.asarray(dist)) if dist is not None else None
+        mono = _check(self._L.vsg_orb_extract_to_frame(
+            ex.handle, _p(img, _u8p), rows, cols, img.strides[0], int(vLappingArea[0]), int(vLappingArea[1]),
+            kps.ctypes.data_as(C.c_void_p), _p(desc, _u8p), cap, C.byref(n), self._h, _p(k4, _f32p) if k4 is not None else None,
+            _p(d, _f32p) if d is not None else None, len(d) if d is not None else 0, *[float(b) for b in bounds],
+            un.ctypes.data_as(C.c_void_p)), "vsg_orb_extract_to_frame")
+        self.kps, self.nleft = un[:n.value].copy(), -1
+        return mono, kps[:n.value].copy(), desc[:n.value].copy()
 
     def grid(self, right=False):
         cs, en = np.zeros(64 * 48 + 1, np.int32), np.zeros(max(self.N, 1), np.int32)
