@@ -27,11 +27,10 @@ void launch_export(hipStream_t s, const KeyPointPOD *kps, const uint8_t *desc, c
 void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tab, const Src0 &s0,
                    const FrameGeom &fg, int level, int nframes);
 void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tile_tab, const Src0 &s0,
-                    const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes, int *cand_count,
-                    int *ovf_count = nullptr);
+                    const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes, int *cand_count);
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const FastCellRec *d_recs, const Src0 &s0,
                  uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea,
-                 int nframes, int cus, uint32_t *ovf_list, int *ovf_count);
+                 int nframes, int cus);
 void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, const int *cand_count,
                    const CellDesc *d_cells, const int *cell_count, uint32_t *cand2, uint16_t *node_of, uint32_t *sel,
                    int *sel_count, const FrameGeom &fg, int maxQuota, int maxCellsPerLevel, int nframes,

@@ -109,7 +109,7 @@ constexpr int kPyrThreads = VSG_PYR_NT;  // threads per pyramid tile (512: 0.196
 __global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg,
                                                  const Short4 *__restrict__ tile_tab, Src0 s0,
                                                  const PyrTile *__restrict__ tiles, int ldsA, int ldsAB,
-                                                 int *__restrict__ cand_count, int *__restrict__ ovf_count) {
+                                                 int *__restrict__ cand_count) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pyr_lds[];
   const BlockXY blk = frame_major_block();
   const PyrTile &T = tiles[blk.x];
@@ -117,7 +117,6 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ p
   // the per-level FAST candidate counters of this frame start the call at zero (k_fast_cells adds to them after this
   // kernel): one workgroup per frame clears them here instead of a launch of its own
   if (cand_count && blk.x == 0 && tid < kMaxLevels) cand_count[frame * kMaxLevels + tid] = 0;
-  if (ovf_count && blk.x == 0 && frame == 0 && tid == 0) *ovf_count = 0;  // k_fast_cells' overflow list of this launch
   uint8_t *buf0 = pyr_lds, *buf1 = pyr_lds + ldsA;
   Short4 *s_tab = (Short4 *)(pyr_lds + ldsAB);  // the tile's slices of the resize tables, all levels
   // One round of independent global loads: the tile's (pre-rebased, contiguous) table slice and the level-0 region.
@@ -453,56 +452,41 @@ __device__ __forceinline__ FastCell load_fast_cell(const FastCellRec *__restrict
 // life of a workgroup, and ~3 us of a one-cell workgroup's 6 us were launch + descriptor chain + the tile's trip from
 // L2 (profiles/r03_c_fast_ablation.txt: 0.065 / 0.074 / 0.108 / 0.221 ms for workgroups that end at once / after the
 // descriptors / after a staging pass without loads / after the real staging pass, of 0.441 ms).
-// (register budgets: 8 waves per SIMD = 64 VGPRs for the two-wave form, whose 16 workgroups per CU are the 32 wave slots;
-// the one-wave form is resident 27 times per CU at C2's 5.8 KB of LDS = 6.75 waves per SIMD: 7 waves = 72 VGPRs)
-template <int NT, int kTileP, int kScoreP, int kPre, bool kList>
-__device__ __forceinline__ void fast_cells_body(
+template <int NT, int kTileP, int kScoreP, int kPre>
+#ifndef VSG_FAST_WAVES_MIN
+#define VSG_FAST_WAVES_MIN 8
+#define VSG_FAST_WAVES_MAX 8
+#endif
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS), amdgpu_waves_per_eu(VSG_FAST_WAVES_MIN, VSG_FAST_WAVES_MAX))) void k_fast_cells(
     const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg, const FastCellRec *__restrict__ recs, Src0 s0,
     uint32_t *__restrict__ cand, int *__restrict__ cand_count, int *__restrict__ cell_count, int tile_bytes,
-    int score_bytes, int queue_cap, int cells_per_wg, uint32_t *__restrict__ ovf_list, int *__restrict__ ovf_count) {
+    int score_bytes, int queue_cap, int cells_per_wg) {
   static_assert(kScoreP == kTileP, "a pixel's score offset is its tile offset minus a constant");
-  // Two forms of one source (profiles/r04_f / r04_h):
-  //  * NT = 128 -- two waves per cell, counters in LDS, a 6-bit copy of the tile, a queue slot for every pixel of the
-  //    largest cell: handles ANY cell.  Small launches (the latency path) and the overflow list of the other form.
-  //  * NT = 64 (kW1) -- ONE wave per cell: no cross-wave barriers, the counters wave-uniform registers, the 6-bit pixels
-  //    formed from the tile's dwords as the test loads them, the queue capped well below the cell's area -- 5.8 instead of
-  //    7.2 KB of LDS per cell, 27 instead of 16 cells in flight per CU (the kernel's speed is cells in flight over a
-  //    cell's dependency chain).  A cell that queues more than the cap is appended to ovf_list and redone by the
-  //    NT = 128 form in list mode, launched right behind.
-  constexpr bool kW1 = NT == 64;
-#ifndef VSG_W1_REGCNT
-#define VSG_W1_REGCNT 1
-#endif
-  constexpr bool kRC = kW1 && VSG_W1_REGCNT;  // counters in wave-uniform registers instead of LDS
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
-  uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);  // queue_cap entries (NT = 128: the largest cell's pixels)
-  // NT = 128: the tile once more as 6-bit pixels (x >> 2 per byte), read by the necessary test only: it lives where the
-  // pixel queue is built afterwards (the launcher sizes that region for both)
-  uint8_t *qtile = kW1 ? tile : (uint8_t *)queue;
-  auto q6 = [](uint32_t x) -> uint32_t { return kW1 ? (x >> 2) & 0x3F3F3F3Fu : x; };
-  int cnt_runs = 0, cnt_q = 0, cnt_surv = 0;  // kW1: run entries / queue length / NMS survivors of the current pass
+  uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);  // queue_cap entries = the largest cell's pixels
+  // the tile once more as 6-bit pixels (x >> 2 per byte), read by the necessary test only: it lives where the pixel
+  // queue is built afterwards (the launcher sizes that region for both)
+  uint8_t *qtile = (uint8_t *)queue;
   // flag word + index of every run with a passer; both lists are consumed before the score rows they alias are cleared
   uint32_t *runF = (uint32_t *)score;
   __shared__ int s_cnt[5];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base [4]=run entries
   const BlockXY blk = frame_major_block();
+  const int frame = blk.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const bool seg = fg->cand_segmented != 0;
   const int total_cells = fg->total_cells, pyr_frame_bytes = fg->pyr_frame_bytes, cand_frame = fg->cand_frame;
   const int iniTh = fg->iniTh, minTh = fg->minTh;
-  // direct mode: `cells_per_wg` consecutive cells of frame blk.y; list mode: the cells of ovf_list, one per turn
-  int frame = blk.y, c_begin = blk.x * cells_per_wg, c_end = min(c_begin + cells_per_wg, total_cells);
+  const int c_begin = blk.x * cells_per_wg, c_end = min(c_begin + cells_per_wg, total_cells);
   typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
   u32x4u pre[kPre];
   int pre_off[kPre];  // where the chunk goes in the tile
   auto put = [&](int off, const u32x4u &v) {
     uint32_t *d = (uint32_t *)&tile[off];
     d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
-    if constexpr (!kW1) {
-      uint32_t *dq = (uint32_t *)&qtile[off];
-      dq[0] = (v.x >> 2) & 0x3F3F3F3Fu, dq[1] = (v.y >> 2) & 0x3F3F3F3Fu;
-      dq[2] = (v.z >> 2) & 0x3F3F3F3Fu, dq[3] = (v.w >> 2) & 0x3F3F3F3Fu;
-    }
+    uint32_t *dq = (uint32_t *)&qtile[off];
+    dq[0] = (v.x >> 2) & 0x3F3F3F3Fu, dq[1] = (v.y >> 2) & 0x3F3F3F3Fu;
+    dq[2] = (v.z >> 2) & 0x3F3F3F3Fu, dq[3] = (v.w >> 2) & 0x3F3F3F3Fu;
   };
   // 16 bytes per lane and chunk, the last chunk of a row pulled back so that it ENDS with the row (it re-writes a few dwords
   // of its neighbour with the same values instead of reading past the row -- level 0 is the caller's buffer).
@@ -512,7 +496,7 @@ __device__ __forceinline__ void fast_cells_body(
   // (row, first dword) of a thread's chunks only depend on the chunks per row, which rarely change from cell to cell: kept
   // across cells in the narrow tile class (the wider ones have no registers to spare) and clamped per cell instead of
   // divided out again
-  constexpr bool kKeepRC = kTileP == 52;  // the narrow tile class
+  constexpr bool kKeepRC = kPre * NT == 256;
   int rc_nq4 = 0, rc_r[kKeepRC ? kPre : 1], rc_c[kKeepRC ? kPre : 1];
   auto fetch = [&](const FastCell &N) -> bool {
     const int n = N.nq4() * N.th();
@@ -546,14 +530,6 @@ __device__ __forceinline__ void fast_cells_body(
     }
     return true;
   };
-  // (kList is a compile-time form: the direct kernels carry no outer loop)
-  const int n_units = kList ? min(*ovf_count, cells_per_wg) : 1;  // list mode: cells_per_wg carries the list's capacity
-  for (int unit = kList ? (int)blockIdx.x : 0; unit < n_units; unit += kList ? (int)gridDim.x : 1) {
-  if constexpr (kList) {
-    const uint32_t lin = ovf_list[unit];
-    frame = (int)(lin / (uint32_t)total_cells);
-    c_begin = (int)(lin - (uint32_t)frame * (uint32_t)total_cells), c_end = c_begin + 1;
-  }
   FastCell C = load_fast_cell(recs, c_begin, s0, pyr, pyr_frame_bytes, frame);
   bool have_pre = fetch(C);  // the first cell of the workgroup waits for its tile
   for (int ci = c_begin; ci < c_end; ci++) {
@@ -567,7 +543,7 @@ __device__ __forceinline__ void fast_cells_body(
           const int r = div_small(i, inv_tdw), c = i - r * C.tdw();
           const uint32_t v = *(const uint32_t *)(C.tsrc + (uint32_t)(r * C.pitch + 4 * c));
           *(uint32_t *)&tile[r * kTileP + 4 * c] = v;
-          if constexpr (!kW1) *(uint32_t *)&qtile[r * kTileP + 4 * c] = (v >> 2) & 0x3F3F3F3Fu;
+          *(uint32_t *)&qtile[r * kTileP + 4 * c] = (v >> 2) & 0x3F3F3F3Fu;
         }
       } else {
         const int n = C.nq4() * C.th();
@@ -611,13 +587,8 @@ __device__ __forceinline__ void fast_cells_body(
         const int p1_off = (p1_row + 3) * kTileP + 4 * (g0 + 2 * p1_rr);
         uint32_t keep = 0;
         int nq = 0, thr = iniTh;
-        bool deferred = false;  // kW1: the cell queued more than the capped queue holds and went to the overflow list
         for (int pass = 0; pass < 2; pass++) {
-          if constexpr (kRC) {
-            cnt_runs = cnt_q = cnt_surv = 0;
-          } else {
-            if (tid < 5) s_cnt[tid] = 0;
-          }
+          if (tid < 5) s_cnt[tid] = 0;
           __syncthreads();  // the tile is staged / the previous pass is done with the score rows
           // ---- phase 1: 6-bit necessary test, 8 pixels (2 dwords) per thread; runs with a passer are appended (flag word
           // + run index) to the run list: one ballot and one LDS atomic per wave and iteration
@@ -630,7 +601,7 @@ __device__ __forceinline__ void fast_cells_body(
               if (rb + p1_r0 < vh) {
                 const uint32_t *pc = (const uint32_t *)&qtile[runB];
                 const uint32_t *pu = pc - 3 * (kTileP / 4), *pd = pc + 3 * (kTileP / 4);
-                uint32_t qc[4] = {q6(pc[-1]), q6(pc[0]), q6(pc[1]), q6(pc[2])};
+                uint32_t qc[4] = {pc[-1], pc[0], pc[1], pc[2]};
                 // Bytes of the 6-bit tile that were never staged (beyond a row's last staged dword) may hold anything, and
                 // a byte above 63 carries into the bytes ABOVE it.  Those are pixels further right, invalid like the
                 // byte itself -- except in the dword left of tile column 0, whose bytes sit BELOW a valid pixel's neighbour
@@ -638,7 +609,7 @@ __device__ __forceinline__ void fast_cells_body(
                 uint32_t f[2];
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                  const uint32_t qu = q6(pu[k]), qd = q6(pd[k]);
+                  const uint32_t qu = pu[k], qd = pd[k];
                   const uint32_t qw = __builtin_amdgcn_alignbyte(qc[k + 1], qc[k], 1);      // columns -3
                   const uint32_t qe = __builtin_amdgcn_alignbyte(qc[k + 2], qc[k + 1], 3);  // columns +3
                   const uint32_t A = qc[k + 1] + K, B = K - qc[k + 1];
@@ -653,14 +624,8 @@ __device__ __forceinline__ void fast_cells_body(
               const uint64_t hit = __ballot(F != 0);
               if (hit) {
                 int base = 0;
-                if constexpr (kRC) {  // the only wave of the cell: its counter is a register
-                  base = cnt_runs;
-                  cnt_runs += (int)__popcll(hit);
-                } else {
-                  if (lane == 0) base = lds_add_rtn(&s_cnt[4], __popcll(hit));
-                  base = __builtin_amdgcn_readfirstlane(base);
-                }
-                const int slot = base + mbcnt64(hit);
+                if (lane == 0) base = lds_add_rtn(&s_cnt[4], __popcll(hit));
+                const int slot = __builtin_amdgcn_readfirstlane(base) + mbcnt64(hit);
                 if (F) runF[slot] = F, runI[slot] = (uint16_t)runB;
               }
             }
@@ -676,9 +641,8 @@ __device__ __forceinline__ void fast_cells_body(
           // 1.05-2.47 ms instead of 0.39 per 512 frames: profiles/r04_b_bench_content_sweep_before_stage_b.json).  The
           // diagonals see the other phase of a checkerboard and the iso-line of a ramp.  Cell-uniform trigger: more than
           // three quarters of the cell's runs hold a passer.
-          const int nr_total = kRC ? cnt_runs : s_cnt[4];
-          if (4 * nr_total > 3 * nruns) {
-            const int nr1 = nr_total;
+          if (4 * s_cnt[4] > 3 * nruns) {
+            const int nr1 = s_cnt[4];
             const int t6 = thr <= 2 ? 0 : min(64, (thr + 1) >> 2);
             const uint32_t K = (uint32_t)(128 - t6) * 0x01010101u, H = 0x80808080u;
             for (int e = tid; e < nr1; e += NT) {
@@ -686,8 +650,8 @@ __device__ __forceinline__ void fast_cells_body(
               const int runB = runI[e];
               const uint32_t *pc = (const uint32_t *)&qtile[runB];
               const uint32_t *pu = pc - 2 * (kTileP / 4), *pd = pc + 2 * (kTileP / 4);
-              uint32_t qu[4] = {q6(pu[-1]), q6(pu[0]), q6(pu[1]), q6(pu[2])}, qd[4] = {q6(pd[-1]), q6(pd[0]), q6(pd[1]), q6(pd[2])};
-              const uint32_t qc[2] = {q6(pc[0]), q6(pc[1])};
+              uint32_t qu[4] = {pu[-1], pu[0], pu[1], pu[2]}, qd[4] = {pd[-1], pd[0], pd[1], pd[2]};
+              const uint32_t qc[2] = {pc[0], pc[1]};
               // the dword left of tile column 0 (see phase 1): only the first run of a row reads it, and only when g0 == 0
               const int col = runB - kTileP * div_small(runB, 1.0f / kTileP);
               const uint32_t left = (g0 == 0 && col == 0) ? 0u : ~0u;
@@ -718,7 +682,7 @@ __device__ __forceinline__ void fast_cells_body(
           // That can exceed the queue (one slot per pixel of the largest cell) when most of a cell passes on both sides;
           // such a cell is unpacked again with ONE entry per pixel: both-sided pixels flagged dark + retry, scored dark
           // first and, in a second pass of their own, bright.
-          const int nr = nr_total;
+          const int nr = s_cnt[4];
           auto unpack = [&](const bool single) {
             for (int e0 = 0; e0 < nr; e0 += NT) {
               const int e0t = e0 + tid;
@@ -729,15 +693,9 @@ __device__ __forceinline__ void fast_cells_body(
               const int incl = wave_inclusive_scan_i32(cnt);
               const int wtotal = __builtin_amdgcn_readlane(incl, 63);
               if (wtotal) {
-                int wbase;
-                if constexpr (kRC) {
-                  wbase = cnt_q;
-                  cnt_q += wtotal;
-                } else {
-                  int base = 0;
-                  if (lane == 0) base = lds_add_rtn(&s_cnt[1], wtotal);
-                  wbase = __builtin_amdgcn_readfirstlane(base);
-                }
+                int base = 0;
+                if (lane == 0) base = lds_add_rtn(&s_cnt[1], wtotal);
+                const int wbase = __builtin_amdgcn_readfirstlane(base);
                 // a wave whose entries would run past the queue writes none of them (wave-uniform test, nothing per entry):
                 // the total then exceeds the capacity and the cell is unpacked again below
                 if (wbase + wtotal <= queue_cap) {
@@ -759,29 +717,15 @@ __device__ __forceinline__ void fast_cells_body(
           };
           unpack(false);
           __syncthreads();
-          const bool single = (kRC ? cnt_q : s_cnt[1]) > queue_cap;  // cell-uniform; only cells where most pixels pass on both sides
+          const bool single = s_cnt[1] > queue_cap;  // cell-uniform; only cells where most pixels pass on both sides
           if (single) {
             __syncthreads();
-            if constexpr (kRC) {
-              cnt_q = 0;
-            } else {
-              if (tid == 0) s_cnt[1] = 0;
-            }
+            if (tid == 0) s_cnt[1] = 0;
             __syncthreads();
             unpack(true);
             __syncthreads();
           }
-          nq = kRC ? cnt_q : s_cnt[1];
-          if constexpr (kW1) {
-            if (nq > queue_cap) {  // more passers than the capped queue holds even at one entry per pixel: the two-wave form
-              if (tid == 0) {      // redoes the whole cell (both thresholds) from the overflow list
-                ovf_list[atomicAdd(ovf_count, 1)] = (uint32_t)frame * (uint32_t)total_cells + (uint32_t)ci;
-                *my_count = 0;
-              }
-              deferred = true;
-              break;
-            }
-          }
+          nq = s_cnt[1];
           for (int i = tid; i < ((vh + 2) * kScoreP + 15) / 16; i += NT) ((uint4 *)score)[i] = make_uint4(0, 0, 0, 0);
           __syncthreads();
           // ---- phase 2: exact score of the queued pixels on their flagged side; entries that do not score are dropped
@@ -829,52 +773,16 @@ __device__ __forceinline__ void fast_cells_body(
           int nbias = kScoreP + 1;  // the 3 x 3 neighbourhood at non-negative offsets from one register (see kBias)
           asm volatile("" : "+s"(nbias));
           const uint8_t *score_b = score - nbias;
-          if constexpr (!kRC) {
-            for (int q = tid; q < nq; q += NT, it++) {
-              const uint32_t ent = queue[q];
-              if (ent == 0xFFFFu) continue;
-              const uint8_t *sp = &score_b[ent] + (kScoreP + 1);
-              // nine reads back to back, one wait (see fast_score_side_raw)
-              int s = sp[0], n0 = sp[-kScoreP - 1], n1 = sp[-kScoreP], n2 = sp[-kScoreP + 1], n3 = sp[-1], n4 = sp[1],
-                  n5 = sp[kScoreP - 1], n6 = sp[kScoreP], n7 = sp[kScoreP + 1];
-              asm volatile("" : "+v"(s), "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7));
-              const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-              if (s > mx) {
-                if (seg) {
-                  const int r1 = div_small((int)ent, 1.0f / kScoreP), c1 = (int)ent - r1 * kScoreP;  // row + 1, column + 1
-                  seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell_x0 + c1 - 1 - kFastBorder, cell_y0 + r1 - 1 - kFastBorder, s);
-                } else {
-                  keep |= 1u << it;
-                  atomicAdd(&s_cnt[0], 1);
-                }
-              }
-            }
-          } else {
-          // every lane takes every turn (uniform trip count): in the one-wave form the survivor counter is a wave-uniform
-          // register fed by ballots, which only works where control flow is uniform
-          for (int q0 = 0; q0 < nq; q0 += NT, it++) {
-            const int q = q0 + tid;
-            const uint32_t ent = q < nq ? queue[q] : 0xFFFFu;
-            bool is_max = false;
-            int s = 0;
-            if (ent != 0xFFFFu) {
-              const uint8_t *sp = &score_b[ent] + (kScoreP + 1);
-              // nine reads back to back, one wait (see fast_score_side_raw)
-              int n0 = sp[-kScoreP - 1], n1 = sp[-kScoreP], n2 = sp[-kScoreP + 1], n3 = sp[-1], n4 = sp[1],
-                  n5 = sp[kScoreP - 1], n6 = sp[kScoreP], n7 = sp[kScoreP + 1];
-              s = sp[0];
-              asm volatile("" : "+v"(s), "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7));
-              const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
-              is_max = s > mx;
-            }
-            if constexpr (kRC) {  // (segmented candidate lists only: the launcher takes this form for nothing else)
-              const uint64_t sv = __ballot(is_max);
-              if (is_max) {
-                const int r1 = div_small((int)ent, 1.0f / kScoreP), c1 = (int)ent - r1 * kScoreP;  // row + 1, column + 1
-                seg_out[cnt_surv + mbcnt64(sv)] = pack_cand(cell_x0 + c1 - 1 - kFastBorder, cell_y0 + r1 - 1 - kFastBorder, s);
-              }
-              cnt_surv += (int)__popcll(sv);
-            } else if (is_max) {
+          for (int q = tid; q < nq; q += NT, it++) {
+            const uint32_t ent = queue[q];
+            if (ent == 0xFFFFu) continue;
+            const uint8_t *sp = &score_b[ent] + (kScoreP + 1);
+            // nine reads back to back, one wait (see fast_score_side_raw)
+            int s = sp[0], n0 = sp[-kScoreP - 1], n1 = sp[-kScoreP], n2 = sp[-kScoreP + 1], n3 = sp[-1], n4 = sp[1],
+                n5 = sp[kScoreP - 1], n6 = sp[kScoreP], n7 = sp[kScoreP + 1];
+            asm volatile("" : "+v"(s), "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7));
+            const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
+            if (s > mx) {
               if (seg) {
                 const int r1 = div_small((int)ent, 1.0f / kScoreP), c1 = (int)ent - r1 * kScoreP;  // row + 1, column + 1
                 seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell_x0 + c1 - 1 - kFastBorder, cell_y0 + r1 - 1 - kFastBorder, s);
@@ -884,22 +792,18 @@ __device__ __forceinline__ void fast_cells_body(
               }
             }
           }
-          }
           __syncthreads();
-          if ((kRC ? cnt_surv : s_cnt[0]) > 0 || pass == 1 || minTh >= thr) break;
+          if (s_cnt[0] > 0 || pass == 1 || minTh >= thr) break;
           thr = minTh;  // vKeysCell.empty() -> retry with minThFAST (:848-851)
           __syncthreads();
           // the queue was built over the 6-bit tile: derive it again (whole rows: unstaged bytes come out as 6-bit values too)
-          if constexpr (!kW1)
-            for (int i = tid; i < ((th + 1) * kTileP) / 4; i += NT)
-              ((uint32_t *)qtile)[i] = (((const uint32_t *)tile)[i] >> 2) & 0x3F3F3F3Fu;
+          for (int i = tid; i < ((th + 1) * kTileP) / 4; i += NT)
+            ((uint32_t *)qtile)[i] = (((const uint32_t *)tile)[i] >> 2) & 0x3F3F3F3Fu;
         }
 
 
-      const int nEmit = kRC ? cnt_surv : s_cnt[0];
-      if (deferred) {
-        // counted and filled by the overflow launch
-      } else if (seg) {
+      const int nEmit = s_cnt[0];
+      if (seg) {
         if (tid == 0) *my_count = nEmit;
       } else if (nEmit) {
         const LevelGeom &L = fg->lv[cell_level];
@@ -921,31 +825,6 @@ __device__ __forceinline__ void fast_cells_body(
     __syncthreads();  // the cell is done with the tile, the score rows and the queue: the next one may be written
     C = N;
   }
-  }  // work units
-}
-
-#ifndef VSG_FAST_W1_WMIN
-#define VSG_FAST_W1_WMIN 7
-#define VSG_FAST_W1_WMAX 7
-#endif
-// The two kernels of the one body.  Register budgets: 8 waves per SIMD = 64 VGPRs / 80 SGPRs for the two-wave form, whose 16
-// workgroups per CU are the 32 wave slots; the one-wave form is resident 27 times per CU at C2's 5.8 KB of LDS = 6.75 waves
-// per SIMD: 7 waves = 72 VGPRs, and at 7 waves the SGPR file has room for 102 per wave.
-template <int kTileP, int kScoreP, int kPre, bool kList>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS), amdgpu_waves_per_eu(8, 8))) void k_fast_cells(
-    const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg, const FastCellRec *__restrict__ recs, Src0 s0,
-    uint32_t *__restrict__ cand, int *__restrict__ cand_count, int *__restrict__ cell_count, int tile_bytes,
-    int score_bytes, int queue_cap, int cells_per_wg, uint32_t *__restrict__ ovf_list, int *__restrict__ ovf_count) {
-  fast_cells_body<128, kTileP, kScoreP, kPre, kList>(pyr, fg, recs, s0, cand, cand_count, cell_count, tile_bytes, score_bytes,
-                                                     queue_cap, cells_per_wg, ovf_list, ovf_count);
-}
-template <int kTileP, int kScoreP, int kPre>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(102), amdgpu_waves_per_eu(VSG_FAST_W1_WMIN, VSG_FAST_W1_WMAX))) void k_fast_cells_w1(
-    const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg, const FastCellRec *__restrict__ recs, Src0 s0,
-    uint32_t *__restrict__ cand, int *__restrict__ cand_count, int *__restrict__ cell_count, int tile_bytes,
-    int score_bytes, int queue_cap, int cells_per_wg, uint32_t *__restrict__ ovf_list, int *__restrict__ ovf_count) {
-  fast_cells_body<64, kTileP, kScoreP, kPre, false>(pyr, fg, recs, s0, cand, cand_count, cell_count, tile_bytes, score_bytes,
-                                                    queue_cap, cells_per_wg, ovf_list, ovf_count);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2054,8 +1933,7 @@ void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sho
   hipLaunchKernelGGL(k_resize, grid, block, 0, s, pyr, d_fg, d_tab, s0, level);
 }
 void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tile_tab, const Src0 &s0,
-                    const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes, int *cand_count,
-                    int *ovf_count) {
+                    const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes, int *cand_count) {
   const int a16 = (ldsA + 15) & ~15, ab16 = a16 + ((ldsB + 15) & ~15);
   const size_t lds = ab16 + tabMax * sizeof(Short4);
   // the raised limit is a per-DEVICE attribute of the function (vsg_ctx.h lds_limit_ensure)
@@ -2063,25 +1941,12 @@ void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sh
   hipGetDevice(&dev);
   lds_limit_ensure(0, dev, (const void *)k_pyramid, lds);
   hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(kPyrThreads), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
-                     d_tile_tab, s0, d_tiles, a16, ab16, cand_count, ovf_count);
+                     d_tile_tab, s0, d_tiles, a16, ab16, cand_count);
 }
-// LDS of one workgroup of k_fast_cells<NT = 128>: tile + score rows + a queue slot per pixel of the largest cell (the
-// region also holds the 6-bit copy of the tile during the necessary test)
-template <int TP, int SP>
-static size_t fast_lds_full(int maxVh, int maxArea, int *tile_bytes, int *score_bytes) {
-  // + one spare row: the necessary test reads (masked) dwords just past the last tile row
-  *tile_bytes = ((maxVh + 6 + 1) * TP + 15) & ~15, *score_bytes = ((maxVh + 2) * SP + 15) & ~15;
-  const size_t queue_bytes = std::max<size_t>(((size_t)maxArea * 2 + 15) & ~(size_t)15, (size_t)*tile_bytes);
-  return (size_t)*tile_bytes + *score_bytes + queue_bytes;
-}
-// queue entries of the one-wave form: half the largest cell's pixels, at least 512 (the frames the pipeline is tuned on
-// queue up to ~650 per cell on the upper levels; every cell beyond the cap goes to the overflow list)
-static int fast_queue_cap_w1(int maxArea) { return std::min(maxArea, std::max(512, maxArea / 2)); }
-
-template <int TP, int SP, int PRE>
+template <int NT, int TP, int SP, int PRE>
 static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const FastCellRec *d_recs,
                           const Src0 &s0, uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh,
-                          int maxArea, int nframes, int cus, uint32_t *ovf_list, int *ovf_count) {
+                          int maxArea, int nframes, int cus) {
   // Cells per workgroup: the first cell of a workgroup waits for its tile, the others find theirs fetched -- 2, 3 and 4
   // measure the same (0.425 ms per 512 C2 frames against 0.446 with 1; 6: 0.432, 8: 0.440, the tail of a launch grows).
   // Launches that would not fill the workgroup slots a few times over (16 per CU) keep one cell per workgroup: a
@@ -2091,54 +1956,26 @@ static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_
   const long long cells_total = (long long)fg.total_cells * nframes;
   const int kauto = cells_total >= 3LL * 4 * 16 * (cus > 0 ? cus : 256) ? 3 : 1;
   const int cells_per_wg = std::max(1, std::min(kenv > 0 ? kenv : kauto, fg.total_cells));
-  dim3 grid((fg.total_cells + cells_per_wg - 1) / cells_per_wg, nframes);
-  int tile_bytes, score_bytes;
-  const size_t lds_full = fast_lds_full<TP, SP>(maxVh, maxArea, &tile_bytes, &score_bytes);
-  // The one-wave form for every launch of several cells per workgroup (the throughput batches, and whatever VSG_FAST_K
-  // forces), the two-wave form for the small launches of the latency path -- where residency is not the limit and a
-  // second launch would cost the chain -- and for geometries whose levels do not have per-cell candidate segments.
-  // -- and only for the narrow tile class (cells up to 40 px wide: 640x480, 752x480, 1280x720, ... at 35-px cells) with
-  // tiles of at most 3 prefetch chunks per lane: there the one-wave kernel fits 7 waves per SIMD without spilling; wider
-  // cells hold so much LDS that the wave slots are not the limit in either form.
-#ifndef VSG_FAST_W1_PRE
-#define VSG_FAST_W1_PRE 3
-#endif
-  constexpr int kPreW1 = VSG_FAST_W1_PRE;
-  const int chunks = (maxVh + 6) * ((TP / 4 + 3) / 4);  // rows x 16-byte chunks per row of the largest tile
-#ifdef VSG_FAST_NO_W1  // experiment builds: the two-wave form everywhere
-  const bool one_wave = false;
-#else
-  const bool one_wave = TP == 52 && cells_per_wg > 1 && fg.cand_segmented && ovf_list && chunks <= 64 * kPreW1;
-#endif
-  if (!one_wave) {
-    hipLaunchKernelGGL((k_fast_cells<TP, SP, PRE, false>), grid, dim3(128), lds_full, s, pyr, d_fg, d_recs, s0, cand, cand_count,
-                       cell_count, tile_bytes, score_bytes, maxArea, cells_per_wg, (uint32_t *)nullptr, (int *)nullptr);
-    return;
-  }
-  if constexpr (TP == 52) {
-    const int cap = fast_queue_cap_w1(maxArea);
-    const size_t lds_w1 = (size_t)tile_bytes + score_bytes + (((size_t)cap * 2 + 15) & ~(size_t)15);
-    hipLaunchKernelGGL((k_fast_cells_w1<TP, SP, kPreW1>), grid, dim3(64), lds_w1, s, pyr, d_fg, d_recs, s0, cand, cand_count,
-                       cell_count, tile_bytes, score_bytes, cap, cells_per_wg, ovf_list, ovf_count);
-    // the overflow list (normally empty; capacity = every cell of the launch): persistent two-wave workgroups, one listed
-    // cell per turn
-    const int ovf_wgs = (int)std::min<long long>(cells_total, 4LL * (cus > 0 ? cus : 256));
-    hipLaunchKernelGGL((k_fast_cells<TP, SP, PRE, true>), dim3(ovf_wgs), dim3(128), lds_full, s, pyr, d_fg, d_recs, s0, cand,
-                       cand_count, cell_count, tile_bytes, score_bytes, maxArea,
-                       (int)std::min<long long>(cells_total, 0x7FFFFFFF), ovf_list, ovf_count);
-  }
+  dim3 grid((fg.total_cells + cells_per_wg - 1) / cells_per_wg, nframes), block(NT);
+  // + one spare row: the necessary test reads (masked) dwords just past the last tile row
+  const int tile_bytes = ((maxVh + 6 + 1) * TP + 15) & ~15, score_bytes = ((maxVh + 2) * SP + 15) & ~15;
+  // the pixel queue's region also holds the 6-bit copy of the tile during the necessary test
+  const size_t queue_bytes = std::max<size_t>(((size_t)maxArea * 2 + 15) & ~(size_t)15, (size_t)tile_bytes);
+  const size_t lds = (size_t)tile_bytes + score_bytes + queue_bytes;
+  hipLaunchKernelGGL((k_fast_cells<NT, TP, SP, PRE>), grid, block, lds, s, pyr, d_fg, d_recs, s0, cand, cand_count,
+                     cell_count, tile_bytes, score_bytes, maxArea, cells_per_wg);
 }
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const FastCellRec *d_recs, const Src0 &s0,
                  uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea,
-                 int nframes, int cus, uint32_t *ovf_list, int *ovf_count) {
+                 int nframes, int cus) {
   // tile row = up to 3 alignment bytes + vw + 6 ring bytes, rounded up to dwords; score rows (vw + 2 used) have the
   // tile's pitch: a pixel's score sits a constant away from its tile byte (k_fast_cells phase 2)
   if (maxVw <= 40)
-    launch_fast_t<52, 52, 2>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus, ovf_list, ovf_count);
+    launch_fast_t<VSG_FAST_NT, 52, 52, 2 * (128 / VSG_FAST_NT)>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
   else if (maxVw <= 56)
-    launch_fast_t<68, 68, 3>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus, ovf_list, ovf_count);
+    launch_fast_t<VSG_FAST_NT, 68, 68, 3 * (128 / VSG_FAST_NT)>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
   else
-    launch_fast_t<84, 84, 4>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus, ovf_list, ovf_count);
+    launch_fast_t<VSG_FAST_NT, 84, 84, 4 * (128 / VSG_FAST_NT)>(s, pyr, d_fg, d_recs, s0, cand, cand_count, cell_count, fg, maxVh, maxArea, nframes, cus);
 }
 // dynamic LDS of one octree workgroup (also what every blur workgroup of the fused launch is charged)
 size_t octree_lds_bytes(const FrameGeom &fg, int maxQuota, int maxCellsPerLevel) {

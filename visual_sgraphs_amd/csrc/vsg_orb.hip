@@ -184,8 +184,6 @@ struct vsg_orb {
   CellDesc *d_cells = nullptr;
   FastCellRec *d_fast = nullptr;  // one record per cell for k_fast_cells (vsg_common.h)
   int *d_cell_count = nullptr;    // [max_batch][fg.total_cells] FAST survivors per cell (segmented candidate lists)
-  uint32_t *d_ovf_list = nullptr; // [max_batch][fg.total_cells] cells the one-wave FAST form hands to the two-wave form
-  int *d_ovf_count = nullptr;     // [max_batch]: the list length of the launch whose first frame is f (sub-batches)
   uint32_t *d_cand2 = nullptr;    // [max_batch][fg.cand_frame] compacted candidates of levels too large for the octree's registers
   int pyr_tiling = 0;                   // the tiling calibration found faster for a full batch of this geometry
   int force_tiling = -1;                // vsg_orb_set_pyramid_tiling (tests: every launch form against the oracle)
@@ -262,8 +260,8 @@ static void free_chain_graphs(vsg_orb *h) {
 static void free_image_buffers(vsg_orb *h) {
   free_chain_graphs(h);  // their nodes point into the buffers below
   hipFree(h->d_fg), hipFree(h->d_tab), hipFree(h->d_cells), hipFree(h->d_fast), hipFree(h->d_in);
-  hipFree(h->d_cell_count), hipFree(h->d_cand2), hipFree(h->d_ovf_list), hipFree(h->d_ovf_count);
-  h->d_cell_count = nullptr, h->d_cand2 = nullptr, h->d_ovf_list = nullptr, h->d_ovf_count = nullptr;
+  hipFree(h->d_cell_count), hipFree(h->d_cand2);
+  h->d_cell_count = nullptr, h->d_cand2 = nullptr;
   for (int i = 0; i < kPyrTilings; i++) {
     hipFree(h->d_ptiles[i]), hipFree(h->d_ptab[i]);
     h->d_ptiles[i] = nullptr, h->d_ptab[i] = nullptr;
@@ -382,9 +380,6 @@ static int ensure_geometry(vsg_orb *h, int rows, int cols) {
   HIP_TRY(hipMalloc(&h->d_cand2, B * fg.cand_frame * sizeof(uint32_t)));
   HIP_TRY(hipMalloc(&h->d_cell_count, B * fg.total_cells * sizeof(int)));
   HIP_TRY(hipMemset(h->d_cell_count, 0, B * fg.total_cells * sizeof(int)));
-  HIP_TRY(hipMalloc(&h->d_ovf_list, B * fg.total_cells * sizeof(uint32_t)));
-  HIP_TRY(hipMalloc(&h->d_ovf_count, B * sizeof(int)));
-  HIP_TRY(hipMemset(h->d_ovf_count, 0, B * sizeof(int)));
   // the fills above ran on the NULL stream; the handle's streams are non-blocking, i.e. NOT ordered against it
   HIP_TRY(hipStreamSynchronize(nullptr));
   HIP_TRY(hipMalloc(&h->d_nodeof, B * fg.cand_frame * sizeof(uint16_t)));
@@ -487,17 +482,14 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
     else if (P0.ok && P0.lds_bytes() <= kPyrLdsLimit)
       ti = 0;
   }
-  uint32_t *ovf_list = h->d_ovf_list + F * fg.total_cells;
-  int *ovf_count = h->d_ovf_count + F;
   range_push("ComputePyramid");
   if (ti < 0) {
     launch_zero(s, cand_count, nf * kMaxLevels);  // the fused kernel clears the candidate counters itself
-    launch_zero(s, ovf_count, 1);
     for (int l = 1; l < fg.nlevels; l++) launch_resize(s, pyr, h->d_fg, h->d_tab, s0, fg, l, nf);
   } else {
     const PyrTiling &PT = h->G.pyr[ti];
     launch_pyramid(s, pyr, h->d_fg, h->d_ptab[ti], s0, h->d_ptiles[ti], (int)PT.tiles.size(), PT.ldsA, PT.ldsB,
-                   PT.tabMax, nf, cand_count, ovf_count);
+                   PT.tabMax, nf, cand_count);
   }
   range_pop();
   if (tm) HIP_TRY(hipEventRecord(h->ev[1], s));
@@ -507,7 +499,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   // 254 k frames/s against 250 k with the blur released right after the pyramid.
   if (tm || tmf) HIP_TRY(hipEventRecord(h->ev[8], s));
   launch_fast(s, pyr, h->d_fg, h->d_fast, s0, cand, cand_count, cell_count, fg, h->G.fastMaxVh, h->G.fastMaxVw,
-              h->G.fastMaxArea, nf, h->cus, ovf_list, ovf_count);
+              h->G.fastMaxArea, nf, h->cus);
   if (tm || tmf) HIP_TRY(hipEventRecord(h->ev[2], s));
   // The blur's workgroups ride in the octree's launch (k_octree_blur): both need only the pyramid, the octree is a
   // latency-bound handful of workgroups per frame and the blur issue-bound filler, and inside ONE kernel (one register
