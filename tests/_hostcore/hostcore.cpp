@@ -129,6 +129,9 @@ float hc_fast_atan2(float y, float x) { return fast_atan2_deg(y, x); }
 int hc_synth_frame(int w, int h, unsigned seq, int t, int div, int noise, uint8_t *out, size_t stride) {
   return vsg_synth_sequence_frame(w, h, seq, t, div, noise, out, stride);
 }
+int hc_synth_content_frame(int kind, int w, int h, unsigned seq, int t, uint8_t *out, size_t stride) {
+  return vsg_synth_content_frame(kind, w, h, seq, t, out, stride);
+}
 size_t hc_synth_vocabulary(int k, int L, unsigned seed, int scoring, int weighting, double stop_fraction, uint8_t *out,
                            size_t cap) {
   return vsg_synth_vocabulary(k, L, seed, scoring, weighting, stop_fraction, out, cap);

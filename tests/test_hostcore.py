@@ -347,6 +347,17 @@ def test_synth_header_matches_python(hc):
     assert hc.hc_synth_frame(0, 10, 0, 0, 1, 6, None, 0) == -1
 
 
+def test_synth_header_content_classes_match_python(hc):
+    """vsg_synth_content_frame (C) == synth.content_frame (Python) for every content class, byte for byte."""
+    hc.hc_synth_content_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_size_t]
+    for kind, name in enumerate(synth.CONTENT_CLASSES):
+        for (w, h, seq, t) in ((160, 120, 5, 0), (333, 241, 4099, 7)):
+            out = np.zeros((h, w + 5), np.uint8)
+            assert hc.hc_synth_content_frame(kind, w, h, seq, t, out.ctypes.data, out.strides[0]) == 0
+            assert np.array_equal(out[:, :w], synth.content_frame(name, w, h, seq, t)), (name, w, h, seq, t)
+    assert hc.hc_synth_content_frame(99, 10, 10, 0, 0, None, 0) == -1
+
+
 def test_synth_header_vocabulary_matches_python(hc):
     """vsg_synth_vocabulary (C) == synth.synthetic_vocabulary (Python), byte for byte, incl. the reference-scale tree."""
     hc.hc_synth_vocabulary.restype = C.c_size_t
