@@ -1484,10 +1484,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #ifndef VSG_OD_G
-#define VSG_OD_G 2
+#define VSG_OD_G 3
 #endif
 // keypoints a wavefront works through one after the other: amortises the workgroup prologue (pattern + disc tables
-// into LDS, one barrier).  2: 0.396 -> 0.386 ms per 512 frames; 4: no gain (fewer, longer workgroups)
+// into LDS, one barrier).  1: 0.343, 2: 0.296, 3 and 4: 0.291 ms per 512 C2 frames; workgroups of hundreds of keypoints (a
+// launch that fills the chip once) lose badly: 0.34-0.44 ms, the frames of the resident workgroups thrash the XCD's L2;
+// requesting the first keypoint's patches before the prologue's barrier: 0.293 -> 0.300 (profiles/r04_d_*, steps 4-5)
 constexpr int kOdKpPerWave = VSG_OD_G;
 
 #ifndef VSG_OD_SGPRS
