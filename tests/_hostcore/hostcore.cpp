@@ -139,5 +139,31 @@ size_t hc_synth_vocabulary(int k, int L, unsigned seed, int scoring, int weighti
 void hc_brief_rotation(float angle, float *a, float *b) { brief_rotation(angle, a, b); }
 void hc_brief_offset(int px, int py, float a, float b, int *dx, int *dy) { brief_offset(px, py, a, b, dx, dy); }
 float hc_sinf(float x, int fma) { return fma ? SinCosF<true>::eval(x, false) : SinCosF<false>::eval(x, false); }
+void hc_sincos_pair(float x, int fma, float *c, float *s) {
+  if (fma) sincos_pair<true>(x, c, s); else sincos_pair<false>(x, c, s);
+}
+// every float in [lo, hi] (bit patterns lo_bits .. hi_bits): the pair form against the two eval() calls; returns mismatches
+long hc_sincos_pair_sweep(uint32_t lo_bits, uint32_t hi_bits, int fma) {
+  long bad = 0;
+  for (uint32_t u = lo_bits; u <= hi_bits; u++) {
+    union { uint32_t u; float f; } v;
+    v.u = u;
+    float c, s, c0, s0;
+    if (fma) {
+      sincos_pair<true>(v.f, &c, &s);
+      c0 = SinCosF<true>::eval(v.f, true), s0 = SinCosF<true>::eval(v.f, false);
+    } else {
+      sincos_pair<false>(v.f, &c, &s);
+      c0 = SinCosF<false>::eval(v.f, true), s0 = SinCosF<false>::eval(v.f, false);
+    }
+    bad += (f2u(c) != f2u(c0)) + (f2u(s) != f2u(s0));
+    if (u == 0xFFFFFFFFu) break;
+  }
+  return bad;
+}
+float hc_fast_atan2_sel(float y, float x) { return fast_atan2_deg_sel(y, x); }
+void hc_brief_rotation_of_moments(float m01, float m10, float *angle, float *a, float *b) {
+  brief_rotation_of_moments(m01, m10, angle, a, b);
+}
 float hc_cosf(float x, int fma) { return fma ? SinCosF<true>::eval(x, true) : SinCosF<false>::eval(x, true); }
 }

@@ -266,6 +266,45 @@ def test_float_helpers_match_oracle_and_libm(hc):
             assert struct.pack("f", hc.hc_cosf(float(xv), fma)) == struct.pack("f", libm.cosf(float(xv)))
 
 
+def test_lane_parallel_rotation_equals_the_scalar_kernels(hc):
+    """k_orient_desc evaluates fastAtan2 -> cosf / sinf for a wavefront's keypoints at once with the branch-free forms of
+    vsg_math.h (fast_atan2_deg_sel, sincos_pair); they must give the bits of the branching forms, which are the ones
+    pinned against libm / the oracle above.  (The full sweep of every float in [0, 6.4] -- 1.09e9 values, both
+    contraction variants -- was run offline: 0 mismatches.)"""
+    import struct
+    hc.hc_sincos_pair_sweep.restype = C.c_long
+    hc.hc_sincos_pair_sweep.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+    hc.hc_fast_atan2_sel.restype = C.c_float
+    hc.hc_fast_atan2_sel.argtypes = [C.c_float, C.c_float]
+    hc.hc_brief_rotation_of_moments.argtypes = [C.c_float, C.c_float] + [C.POINTER(C.c_float)] * 3
+    bits = lambda f: struct.unpack("<I", struct.pack("<f", f))[0]
+    # windows of consecutive floats around every branch point of the scalar kernels, plus strided samples of the range
+    windows = [(0, 200000)]
+    for centre in (2.0 ** -12, 0.7853982, 1.5707964, 2.3561945, 3.1415927, 3.9269908, 4.712389, 5.4977875, 6.2831855):
+        b = bits(centre)
+        windows.append((b - 100000, b + 100000))
+    top = bits(6.4)
+    rng = np.random.default_rng(5)
+    for start in rng.integers(0, top - 50000, 40):
+        windows.append((int(start), int(start) + 50000))
+    for fma in (0, 1):
+        for lo, hi in windows:
+            assert hc.hc_sincos_pair_sweep(lo, hi, fma) == 0, (lo, hi, fma)
+    for _ in range(20000):
+        y, x = (int(v) for v in rng.integers(-200000, 200000, 2))
+        if rng.integers(0, 10) == 0:
+            x = y if rng.integers(0, 2) else -y  # |x| == |y|: the tie of the two-sided form
+        assert bits(hc.hc_fast_atan2_sel(y, x)) == bits(hc.hc_fast_atan2(y, x)), (y, x)
+    ang, a, b = C.c_float(), C.c_float(), C.c_float()
+    a0, b0 = C.c_float(), C.c_float()
+    for _ in range(2000):
+        y, x = (int(v) for v in rng.integers(-200000, 200000, 2))
+        hc.hc_brief_rotation_of_moments(y, x, C.byref(ang), C.byref(a), C.byref(b))
+        want = hc.hc_fast_atan2(y, x)
+        hc.hc_brief_rotation(want, C.byref(a0), C.byref(b0))
+        assert (bits(ang.value), bits(a.value), bits(b.value)) == (bits(want), bits(a0.value), bits(b0.value))
+
+
 @pytest.mark.parametrize("w,h,nf,nl,seeds", [(640, 480, 1000, 8, [0, 1]), (752, 480, 1200, 8, [2]),
                                               (320, 240, 500, 4, [3, 4, 5]), (1280, 720, 2000, 8, [6])])
 def test_octree_core_equals_oracle_on_real_candidates(hc, w, h, nf, nl, seeds):

@@ -90,6 +90,35 @@ __global__ void __launch_bounds__(256) k_mad64(uint64_t *out, int iters, uint32_
   out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3;
 }
 
+// FP64 vector ops (the glibc sinf / cosf kernels of k_orient_desc run in double) and the conversions around them
+template <int WHICH>
+__global__ void __launch_bounds__(256) k_f64(double *out, int iters, double b, double c) {
+  double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  if (WHICH == 0) { BODY(I8("v_fma_f64", F_ABC)) }
+  if (WHICH == 1) { BODY(I8("v_mul_f64", F_AB)) }
+  if (WHICH == 2) { BODY(I8("v_add_f64", F_AB)) }
+  out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+template <int WHICH>
+__global__ void __launch_bounds__(256) k_cvt64(uint32_t *out, int iters, double b) {
+  uint32_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double d[8];
+  for (int k = 0; k < 8; k++) d[k] = b + threadIdx.x + k;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (WHICH == 0) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(r[k]) : "v"(d[k]));
+        if (WHICH == 1) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(r[k]) : "v"(d[k]));
+        if (WHICH == 2) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[k]) : "v"(r[k]));
+      }
+  }
+  uint32_t acc = 0;
+  for (int k = 0; k < 8; k++) acc += r[k] + (uint32_t)d[k];
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 __global__ void __launch_bounds__(256) k_sdwa(uint32_t *out, int iters, uint32_t b, uint32_t c) {
   uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
 #define F_SDWA(n) "%" #n ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_2"
@@ -213,6 +242,12 @@ int main() {
   RUN(29) RUN(30) RUN(31) RUN(32) RUN(33) RUN(34) RUN(35) RUN(36) RUN(37) RUN(38) RUN(39) RUN(40) RUN(41) RUN(42)
   RUN(43) RUN(44) RUN(45)
   report("v_mad_u64_u32", time_ms([&] { hipLaunchKernelGGL(k_mad64, dim3(blocks), dim3(256), 0, 0, (uint64_t *)out, iters, 3u, 5u); }), iters * 64.0);
+  report("v_fma_f64", time_ms([&] { hipLaunchKernelGGL(k_f64<0>, dim3(blocks), dim3(256), 0, 0, (double *)out, iters, 1.25, 0.5); }), iters * 64.0);
+  report("v_mul_f64", time_ms([&] { hipLaunchKernelGGL(k_f64<1>, dim3(blocks), dim3(256), 0, 0, (double *)out, iters, 1.25, 0.5); }), iters * 64.0);
+  report("v_add_f64", time_ms([&] { hipLaunchKernelGGL(k_f64<2>, dim3(blocks), dim3(256), 0, 0, (double *)out, iters, 1.25, 0.5); }), iters * 64.0);
+  report("v_cvt_f32_f64", time_ms([&] { hipLaunchKernelGGL(k_cvt64<0>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.25); }), iters * 64.0);
+  report("v_cvt_i32_f64", time_ms([&] { hipLaunchKernelGGL(k_cvt64<1>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.25); }), iters * 64.0);
+  report("v_cvt_f64_f32", time_ms([&] { hipLaunchKernelGGL(k_cvt64<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.25); }), iters * 64.0);
   report("v_max_i32_sdwa", time_ms([&] { hipLaunchKernelGGL(k_sdwa, dim3(blocks), dim3(256), 0, 0, out, iters, 3u, 5u); }), iters * 64.0);
   report("v_cmp+v_cndmask", time_ms([&] { hipLaunchKernelGGL(k_cmpsel, dim3(blocks), dim3(256), 0, 0, out, iters, 3u, 5u); }), iters * 64.0);
   report("dep chain v_add", time_ms([&] { hipLaunchKernelGGL(k_chain<0>, dim3(blocks), dim3(256), 0, 0, out, iters, 3u, 5u); }), iters * 64.0);

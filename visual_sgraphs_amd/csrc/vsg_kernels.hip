@@ -1557,6 +1557,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   // everything derived from the keypoint index is wave-uniform: keep it in SGPRs so the per-level geometry comes
   // through the scalar cache in one round trip instead of a chain of dependent vector loads
   uint8_t *patch = &s_patch[(tid >> 6) * (kPatchRows * kPatchP)];
+  // Three passes over the wave's keypoints: (A) the moments of every keypoint, (B) fastAtan2 -> cosf / sinf of ALL of them in
+  // one evaluation -- keypoint j in lane j, the branch-free forms of vsg_math.h -- and (C) the descriptors.  The rotation
+  // is ~40 dependent FP32 / FP64 instructions (an IEEE division, the glibc kernels in double) that were issued once per
+  // keypoint with every lane computing the same value; FP64 issues at a fraction of the FP32 rate on this part.
+  int k_l[kOdKpPerWave], k_slot[kOdKpPerWave], k_m01[kOdKpPerWave], k_m10[kOdKpPerWave], nk = 0;
+  uint32_t k_c[kOdKpPerWave];
+#pragma unroll
+  for (int j = 0; j < kOdKpPerWave; j++) k_l[j] = 0, k_slot[j] = 0, k_m01[j] = 0, k_m10[j] = 0, k_c[j] = 0;
 #pragma unroll
   for (int j = 0; j < kOdKpPerWave; j++) {
   // the workgroup's keypoints: wave w takes blk.x * 4 * G + 4 * j + w  (adjacent keypoints run side by side)
@@ -1600,11 +1608,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
     m10 = (int)su - kHalfPatch * S;
     m01 = (row - kHalfPatch) * S + 16 * (int)s1p;
   }
-  m10 = wave_sum_i32(m10);
-  m01 = wave_sum_i32(m01);
-  const float angle = fast_atan2_deg((float)m01, (float)m10);
-  float a, b;
-  brief_rotation(angle, &a, &b);
+  k_m10[j] = wave_sum_i32(m10);
+  k_m01[j] = wave_sum_i32(m01);
+  k_l[j] = l, k_slot[j] = slot, k_c[j] = c;
+  nk = j + 1;
+  }
+  float ang_v, a_v, b_v;
+  {
+    float fm01 = 0.0f, fm10 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kOdKpPerWave; j++)
+      if (lane == j) fm01 = (float)k_m01[j], fm10 = (float)k_m10[j];
+    brief_rotation_of_moments(fm01, fm10, &ang_v, &a_v, &b_v);
+  }
+#pragma unroll
+  for (int j = 0; j < kOdKpPerWave; j++) {
+  if (j >= nk) break;
+  const int l = k_l[j], slot = k_slot[j];
+  const uint32_t c = k_c[j];
+  const LevelGeom &L = fg->lv[l];
+  const int cx = VSG_CAND_X(c) + kFastBorder, cy = VSG_CAND_Y(c) + kFastBorder;
+  const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_v), j));
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_v), j));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b_v), j));
   // ---- descriptor.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38).  The blurred level is TILED
   // (16 x 4 pixels per 64-byte line, LevelGeom::btx): the 37 x 37 patch touches 10 tile rows x 3 or 4 tile columns, and
   // the load's lanes are mapped to whole tiles -- lane = 4 * tile + row of the tile, 16 bytes per lane -- so every group of

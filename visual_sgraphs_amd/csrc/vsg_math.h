@@ -71,6 +71,16 @@ VSG_HD double dfma(double a, double b, double c) { return __builtin_fma(a, b, c)
 VSG_HD int round_half_even(float v) { return (int)__builtin_lrintf(v); }
 #endif
 
+// neg ? -v : v as ONE integer operation on the high word (the products with a run-time +-1.0 this replaces were a
+// v_mul_f64 each -- FP64 issues at a fraction of the FP32 rate on gfx950; x * -1.0 == -x exactly)
+VSG_HD double flip_sign(double v, bool neg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hiloint2double(__double2hiint(v) ^ (neg ? (int)0x80000000 : 0), __double2loint(v));
+#else
+  return neg ? -v : v;
+#endif
+}
+
 VSG_HD uint32_t f2u(float f) {
   union {
     float f;
@@ -124,12 +134,12 @@ struct SinCosF {
       double s = mad(x3, s1c, x);
       return (float)mad(x7, s1, s);
     } else {
-      const double sg = neg_table ? -1.0 : 1.0;  // __sincosf_table[1] negates the cosine coefficients
+      // __sincosf_table[1] negates the cosine coefficients
       double x4 = dmul(x2, x2);
-      double cc2 = mad(x2, sg * c4, sg * c3);
-      double cc1 = mad(x2, sg * c1, sg * c0);
+      double cc2 = mad(x2, flip_sign(c4, neg_table), flip_sign(c3, neg_table));
+      double cc1 = mad(x2, flip_sign(c1, neg_table), flip_sign(c0, neg_table));
       double x6 = dmul(x4, x2);
-      double c = mad(x4, sg * c2c, cc1);
+      double c = mad(x4, flip_sign(c2c, neg_table), cc1);
       return (float)mad(x6, cc2, c);
     }
   }
@@ -150,11 +160,53 @@ struct SinCosF {
     int n = ((int32_t)r + 0x800000) >> 24;
     double xr = USE_FMA ? dfma(-(double)n, hpi, x) : dsub(x, dmul((double)n, hpi));
     const int q = n & 3;
-    const double s = (q == 1 || q == 2) ? -1.0 : 1.0;  // sign[] = {1,-1,-1,1}
+    const bool sneg = q == 1 || q == 2;  // sign[] = {1,-1,-1,1}: x * sign[q] as a sign flip
     const bool neg = (n & 2) != 0;
-    return poly(dmul(xr, s), dmul(xr, xr), neg, is_cos ? (n ^ 1) : n);
+    return poly(flip_sign(xr, sneg), dmul(xr, xr), neg, is_cos ? (n ^ 1) : n);
   }
 };
+
+// cosf(y) AND sinf(y) of the kernels above in ONE branch-free evaluation, for 0 <= y < 120.  eval() reduces y twice and
+// runs one polynomial per call; but for a given y the two calls use the SAME reduction and the same two polynomial values
+// -- sinf takes the sine polynomial when n is even and the cosine one when n is odd, cosf (n ^ 1) the other -- so one
+// reduction and both polynomials give both results, swapped by n's parity.  The |y| < pi/4 shortcut of eval() is the general path
+// with n = 0 (x * hpi_inv < 2^23, so n = 0 and xr = fma(-0, hpi, x) = x - 0 * hpi = x exactly); the |y| < 2^-12 shortcut
+// stays as a select.  Without branches the evaluation can run with a DIFFERENT y in every lane: k_orient_desc evaluates
+// the rotations of a wavefront's keypoints in one go instead of one wave-uniform evaluation per keypoint (FP64 issues
+// at a fraction of the FP32 rate).  tests/test_hostcore.py compares it with eval() over the whole argument range.
+template <bool USE_FMA>
+VSG_HD void sincos_pair(float y, float *cos_out, float *sin_out) {
+  typedef SinCosF<USE_FMA> K;
+  const double x = y;
+  const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+  const double r = dmul(x, hpi_inv);
+  const int n = ((int32_t)r + 0x800000) >> 24;
+  const double xr = USE_FMA ? dfma(-(double)n, hpi, x) : dsub(x, dmul((double)n, hpi));
+  const int q = n & 3;
+  const bool sneg = q == 1 || q == 2, neg = (n & 2) != 0;
+  const double x2 = dmul(xr, xr);
+  const float ps = K::poly(flip_sign(xr, sneg), x2, neg, 0);  // the sine polynomial
+  const float pc = K::poly(xr, x2, neg, 1);                   // the cosine polynomial
+  float sv = (n & 1) ? pc : ps, cv = (n & 1) ? ps : pc;
+  if (K::abstop12(y) < K::abstop12(0x1p-12f)) sv = y, cv = 1.0f;
+  *cos_out = cv, *sin_out = sv;
+}
+
+// fast_atan2_deg without the two-sided branch (both sides are the same polynomial of min / max); bit-identical: when
+// ax == ay both forms divide the same values
+VSG_HD float fast_atan2_deg_sel(float y, float x) {
+  const float p1 = 0x1.ca44dep+5f, p3 = -0x1.2aaddcp+4f, p5 = 0x1.1d3f7ep+3f, p7 = -0x1.4515b2p+1f, eps = 0x1p-52f;
+  const float ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;
+  const bool swap = !(ax >= ay);
+  const float num = swap ? ax : ay, den = swap ? ay : ax;
+  const float c = fdiv(num, fadd(den, eps));
+  const float c2 = fmul(c, c);
+  float a = fmul(fadd(fmul(fadd(fmul(fadd(fmul(p7, c2), p5), c2), p3), c2), p1), c);
+  if (swap) a = fsub(90.f, a);
+  if (x < 0) a = fsub(180.f, a);
+  if (y < 0) a = fsub(360.f, a);
+  return a;
+}
 
 #ifndef VSG_SINCOS_FMA
 #define VSG_SINCOS_FMA 1
@@ -167,6 +219,14 @@ VSG_HD void brief_rotation(float angle_deg, float *a, float *b) {
   float ang = fmul(angle_deg, factorPI);
   *a = SinCos::eval(ang, true);
   *b = SinCos::eval(ang, false);
+}
+
+// the same from the moments, in a form every lane can run on its own values: angle = fastAtan2(m01, m10), then a, b
+VSG_HD void brief_rotation_of_moments(float m01, float m10, float *angle_deg, float *a, float *b) {
+  const float factorPI = 0x1.1df46ap-6f;
+  const float ang_deg = fast_atan2_deg_sel(m01, m10);
+  sincos_pair<(VSG_SINCOS_FMA != 0)>(fmul(ang_deg, factorPI), a, b);
+  *angle_deg = ang_deg;
 }
 
 // rotated, rounded sample offset of pattern point (px,py)  (ORBextractor.cc:113-115)
