@@ -1506,7 +1506,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
                                                      const int8_t *__restrict__ pattern, KeyPointPOD *__restrict__ kps,
                                                      uint8_t *__restrict__ desc, int *__restrict__ counts, int capacity,
                                                      OutMirror mir) {
-  __shared__ f32x4 patf[256];            // test k: (x0, y0, x1, y1) of bit_pattern_31_ as floats
+  __shared__ f32x4 patf[256];            // test k: (x0, x1, y0, y1) of bit_pattern_31_ as floats: the packed operands as they are used
   __shared__ int s_hdr[kMaxLevels + 3];  // n, mono, level_start[0..kMaxLevels]
   __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * kPatchRows * kPatchP];
   __shared__ u32x4 s_ic[2 * 64];  // c_disc, one 16-byte entry per (it, lane)
@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   if (tid < 128) s_ic[tid] = ((const u32x4 *)c_disc.w)[tid];
   {
     const uint32_t pw = ((const uint32_t *)pattern)[tid];
-    patf[tid] = (f32x4){(float)(int8_t)pw, (float)(int8_t)(pw >> 8), (float)(int8_t)(pw >> 16), (float)(int8_t)(pw >> 24)};
+    patf[tid] = (f32x4){(float)(int8_t)pw, (float)(int8_t)(pw >> 16), (float)(int8_t)(pw >> 8), (float)(int8_t)(pw >> 24)};
   }
   if (kSelf) {
     if (tid == 0) {  // the slot kernel's scan (slots_of_frame) with an empty lapping set: n = monoIndex = the total
@@ -1613,6 +1613,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   k_l[j] = l, k_slot[j] = slot, k_c[j] = c;
   nk = j + 1;
   }
+  // ---- descriptor patch.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38).  The blurred level is TILED
+  // (16 x 4 pixels per 64-byte line, LevelGeom::btx): the 37 x 37 patch touches 10 tile rows x 3 or 4 tile columns, and
+  // the load's lanes are mapped to whole tiles -- lane = 4 * tile + row of the tile, 16 bytes per lane -- so every group of
+  // four lanes reads ONE full line and a keypoint costs ~33 line requests in 2 or 3 load instructions instead of ~58
+  // row segments in 4 (tools/ubench_tile.hip: 175 against 358 CU-cycles per patch with the LDS side included).  The
+  // tiles land in LDS where they lie (aligned b128 rows of a 40 x 64-byte image), so no byte shifting is left.
+  struct TileLoad {
+    u32x4 pv[3];
+    int lo[3], nt;
+  };
+  const int sub = lane & 3, tg = lane >> 2;
+  auto issue_tiles = [&](int l, uint32_t c, TileLoad &T) {
+    const LevelGeom &L = fg->lv[l];
+    const int px0 = VSG_CAND_X(c) + kFastBorder - kPatchR, py0 = VSG_CAND_Y(c) + kFastBorder - kPatchR;
+    const int tx0 = px0 >> 4, ty0 = py0 >> 2;
+    const int ntx = ((px0 + 2 * kPatchR) >> 4) - tx0 + 1;  // 3 (three quarters of the origins) or 4; always 10 tile rows
+    const int nt = 10 * ntx;
+    const float inv_ntx = ntx == 3 ? 1.0f / 3.0f : 0.25f;
+    const uint8_t *gp = blur + (size_t)frame * fg->blur_frame_bytes + L.boff + (uint32_t)((ty0 * L.btx + tx0) * kBlurTileBytes) +
+                        sub * kBlurTileW;
+    const uint32_t trow = (uint32_t)L.btx * kBlurTileBytes;
+    T.nt = nt;
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+      if (it == 2 && ntx == 3) break;  // wave-uniform: 30 tiles fit two instructions
+      const int t = min(it * 16 + tg, nt - 1);  // lanes past the last tile re-read it (never stored)
+      const int tyi = div_small(t, inv_ntx), txi = t - tyi * ntx;
+      T.pv[it] = *(const __attribute__((address_space(1))) u32x4 *)(gp + (uint32_t)tyi * trow + (uint32_t)(txi * kBlurTileBytes));
+      T.lo[it] = (4 * tyi + sub) * kPatchP + kBlurTileW * txi;
+    }
+  };
+  auto commit_tiles = [&](const TileLoad &T) {
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+      if (it == 2 && T.nt == 30) break;
+      if (it * 16 + tg < T.nt) *(u32x4 *)(patch + T.lo[it]) = T.pv[it];
+    }
+  };
+  // the first keypoint's tiles are requested before the rotations are evaluated (~120 instructions with nothing in flight)
+  TileLoad T0;
+  if (nk > 0) issue_tiles(k_l[0], k_c[0], T0);
   float ang_v, a_v, b_v;
   {
     float fm01 = 0.0f, fm10 = 0.0f;
@@ -1631,56 +1672,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   const float angle = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ang_v), j));
   const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_v), j));
   const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b_v), j));
-  // ---- descriptor.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38).  The blurred level is TILED
-  // (16 x 4 pixels per 64-byte line, LevelGeom::btx): the 37 x 37 patch touches 10 tile rows x 3 or 4 tile columns, and
-  // the load's lanes are mapped to whole tiles -- lane = 4 * tile + row of the tile, 16 bytes per lane -- so every group of
-  // four lanes reads ONE full line and a keypoint costs ~33 line requests in 2 or 3 load instructions instead of ~58
-  // row segments in 4 (tools/ubench_tile.hip: 175 against 358 CU-cycles per patch with the LDS side included).  The
-  // tiles land in LDS where they lie (aligned b128 rows of a 40 x 64-byte image), so no byte shifting is left.
-  const int px0 = cx - kPatchR, py0 = cy - kPatchR;
-  const int tx0 = px0 >> 4, ty0 = py0 >> 2;
-  {
-    const int ntx = ((px0 + 2 * kPatchR) >> 4) - tx0 + 1;  // 3 (three quarters of the origins) or 4; always 10 tile rows
-    const int nt = 10 * ntx;
-    const float inv_ntx = ntx == 3 ? 1.0f / 3.0f : 0.25f;
-    const int sub = lane & 3, tg = lane >> 2;
-    const uint8_t *gp = blur + (size_t)frame * fg->blur_frame_bytes + L.boff + (uint32_t)((ty0 * L.btx + tx0) * kBlurTileBytes) +
-                        sub * kBlurTileW;
-    const uint32_t trow = (uint32_t)L.btx * kBlurTileBytes;
-    u32x4 pv[3];
-    int lo[3];
-#pragma unroll
-    for (int it = 0; it < 3; it++) {
-      if (it == 2 && ntx == 3) break;  // wave-uniform: 30 tiles fit two instructions
-      const int t = min(it * 16 + tg, nt - 1);  // lanes past the last tile re-read it (never stored)
-      const int tyi = div_small(t, inv_ntx), txi = t - tyi * ntx;
-      pv[it] = *(const __attribute__((address_space(1))) u32x4 *)(gp + (uint32_t)tyi * trow + (uint32_t)(txi * kBlurTileBytes));
-      lo[it] = (4 * tyi + sub) * kPatchP + kBlurTileW * txi;
-    }
-#pragma unroll
-    for (int it = 0; it < 3; it++) {
-      if (it == 2 && ntx == 3) break;
-      if (it * 16 + tg < nt) *(u32x4 *)(patch + lo[it]) = pv[it];
-    }
+  const int tx0 = (cx - kPatchR) >> 4, ty0 = (cy - kPatchR) >> 2;
+  if (j == 0) {
+    commit_tiles(T0);
+  } else {
+    TileLoad T;
+    issue_tiles(l, c, T);
+    commit_tiles(T);
   }
   // the patch is private to this wavefront: LDS writes complete in order before the reads below
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const uint8_t *center = patch + (cy - 4 * ty0) * kPatchP + (cx - 16 * tx0);
+  // both points of a test at once on the packed-fp32 path; every product and sum is rounded separately (no contraction:
+  // the file is built with -ffp-contract=off), exactly like the scalar code
+  //   dy = cvRound(x*b + y*a), dx = cvRound(x*a - y*b)     (ORBextractor.cc:113-115)
+  // lane handles tests lane, lane + 64, lane + 128, lane + 192
   uint64_t word = 0;
+  // cvRound (round half to even) of |v| <= 26 as ONE float addition: v + 1.5 * 2^23 has an ulp of 1, so the sum's rounding
+  // IS the rounding to the nearest integer, ties to even, and its bit pattern is 0x4B400000 + round(v) =: M + round(v).
+  // Both points at once (v_pk_add_f32), and the constant leaves through the base address: the byte of (dy, dx) sits at
+  // centre + (dy << 6) + dx = (centre - 65 M) + (By << 6) + Bx modulo 2^32 (v_rndne + v_cvt_i32 per coordinate before: 8
+  // instructions per pair of points, now 2).
+  {
+    const uint32_t cbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)center - 65u * 0x4B400000u;
+    const f32x2 kMagic = {12582912.0f, 12582912.0f};
 #pragma unroll
-  for (int r = 0; r < 4; r++) {  // lane handles tests lane, lane+64, lane+128, lane+192
-    // both points of the test at once on the packed-fp32 path; every product and sum is rounded separately
-    // (no contraction: the file is built with -ffp-contract=off), exactly like the scalar code
-    //   dy = cvRound(x*b + y*a), dx = cvRound(x*a - y*b)     (ORBextractor.cc:113-115)
-    const f32x4 pt = patf[r * 64 + lane];
-    const f32x2 X = pt.xz, Y = pt.yw;
-    const f32x2 fy = X * b + Y * a, fx = X * a - Y * b;
-    const int dy0 = round_half_even(fy.x), dy1 = round_half_even(fy.y);
-    const int dx0 = round_half_even(fx.x), dx1 = round_half_even(fx.y);
-    const int t0 = center[dy0 * kPatchP + dx0], t1 = center[dy1 * kPatchP + dx1];
-    const uint64_t m = __ballot(t0 < t1);
-    if (lane == r) word = m;
+    for (int r = 0; r < 4; r++) {
+      const f32x4 pt = patf[r * 64 + lane];
+      const f32x2 X = pt.xy, Y = pt.zw;
+      const f32x2 ry = (X * b + Y * a) + kMagic, rx = (X * a - Y * b) + kMagic;
+      // (the components through named floats: __builtin_bit_cast of `ry.y` itself read component x)
+      const float ry0 = ry.x, ry1 = ry.y, rx0 = rx.x, rx1 = rx.y;
+      const uint32_t o0 = cbase + (__builtin_bit_cast(uint32_t, ry0) << 6) + __builtin_bit_cast(uint32_t, rx0);
+      const uint32_t o1 = cbase + (__builtin_bit_cast(uint32_t, ry1) << 6) + __builtin_bit_cast(uint32_t, rx1);
+      const uint32_t t0 = *(const __attribute__((address_space(3))) uint8_t *)(uintptr_t)o0;
+      const uint32_t t1 = *(const __attribute__((address_space(3))) uint8_t *)(uintptr_t)o1;
+      const uint64_t m = __ballot(t0 < t1);  // 64 descriptor bits per ballot
+      if (lane == r) word = m;
+    }
   }
   if (slot < capacity) {
     if (lane < 4) *(uint64_t *)(desc + ((size_t)frame * capacity + slot) * 32 + lane * 8) = word;
