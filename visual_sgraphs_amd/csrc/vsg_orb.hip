@@ -513,10 +513,10 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   // 2000 features (33 KB) the fifth no longer fits -- 93.1 -> 90.1 k frames/s there, so that geometry keeps two streams.
   const bool lds_fits = 5 * octree_lds_bytes(fg, h->G.maxQuota, h->G.maxCellsPerLevel) <= 160 * 1024;
   const bool fused_blur = !tm && sb != s && (lds_fits || (h->one_stream && nf <= 8));
-  // Latency path without a lapping area (every keypoint has x >= 19, so lap1 < 19 -- the {0, 0} of the RGB-D / stereo
-  // callers, Frame.cc:108,344 -- selects nothing): k_orient_desc derives slots and level starts itself, k_slots is not
-  // launched (8 us of the one-frame chain)
-  const bool self_slots = !tm && h->one_stream && nf <= 8 && (lap1 < kEdgeThreshold || lap0 > lap1);
+  // Without a lapping area (every keypoint has x >= 19, so lap1 < 19 -- the {0, 0} of the RGB-D / stereo callers,
+  // Frame.cc:108,344 -- selects nothing): k_orient_desc derives slots and level starts itself, k_slots is not launched
+  // (8 us of the one-frame chain; for 512-frame batches + 0.4 % frames/s in the same run, round 4)
+  const bool self_slots = !tm && (lap1 < kEdgeThreshold || lap0 > lap1);
   if (fused_blur) {
     Range r_tail("DistributeOctTree (+ blur workgroups) + slots + IC_Angle / rBRIEF");
     launch_octree(s, h->d_fg, cand, cand_count, h->d_cells, cell_count, h->d_cand2 + F * fg.cand_frame, nodeof, sel,
