@@ -701,9 +701,10 @@ static std::string run_latency(double seconds) {
 int main(int argc, char **argv) {
   const double seconds = argc > 1 ? atof(argv[1]) : 2.0;
   const int npipes = argc > 2 ? atoi(argv[2]) : 4;
-  const std::string c3 = run_c3(seconds, npipes);
-  const std::string c5 = run_c5(seconds);
-  const std::string lat = run_latency(seconds);
+  const std::string only = argc > 3 ? argv[3] : "";  // "c5": that configuration alone (kernel traces of the four streams)
+  const std::string c3 = only.empty() || only == "c3" ? run_c3(seconds, npipes) : "null";
+  const std::string c5 = only.empty() || only == "c5" ? run_c5(seconds) : "null";
+  const std::string lat = only.empty() || only == "latency" ? run_latency(seconds) : "null";
   printf("{\"C3\": %s, \"C5\": %s, \"frame_latency\": %s}\n", c3.c_str(), c5.c_str(), lat.c_str());
   return 0;
 }

@@ -281,12 +281,22 @@ static void free_image_buffers(vsg_orb *h) {
   h->rows = h->cols = 0;
 }
 
+// one of the handle's auxiliary streams, created on first use (see vsg_orb_create)
+static int need_stream(vsg_orb *h, hipStream_t *ps) {
+  if (*ps) return VSG_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamCreateWithFlags(ps, hipStreamNonBlocking));
+  return VSG_OK;
+}
+// "the blur on a stream of the handle's own": resolved (and the stream created) only by a call that does not fuse the blur
+static const hipStream_t kOwnBlurStream = (hipStream_t)(uintptr_t)1;
+
 // every stream of the handle idle (before buffers are re-built or parameters change under running kernels)
 static int quiesce(vsg_orb *h) {
-  HIP_TRY(hipStreamSynchronize(h->s_h2d));
+  if (h->s_h2d) HIP_TRY(hipStreamSynchronize(h->s_h2d));
   HIP_TRY(hipStreamSynchronize(h->s_main));
-  HIP_TRY(hipStreamSynchronize(h->s_blur));
-  HIP_TRY(hipStreamSynchronize(h->s_d2h));
+  if (h->s_blur) HIP_TRY(hipStreamSynchronize(h->s_blur));
+  if (h->s_d2h) HIP_TRY(hipStreamSynchronize(h->s_d2h));
   if (h->have_last) HIP_TRY(hipEventSynchronize(h->ev_last));  // the last enqueue may sit on a caller stream
   return VSG_OK;
 }
@@ -526,6 +536,11 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   HIP_TRY(hipEventRecord(ev_pyr, s));
   // Host enqueue order: the latency-critical launch (the octree) goes out BEFORE the three calls that fork the blur onto
   // its stream.  Serialised runs (sb == s, per-stage timing) keep stream order = stage order: blur, then octree.
+  if (sb == kOwnBlurStream) {
+    const int rs = need_stream(h, &h->s_blur);
+    if (rs != VSG_OK) return rs;
+    sb = h->s_blur;
+  }
   const bool octree_first = sb != s;
   if (octree_first) {
     if (tm) HIP_TRY(hipEventRecord(h->ev[10], s));
@@ -576,7 +591,7 @@ static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, i
   if (tm || tmf) harvest_timing(h);
   if (nsub == 1) {
     int rc = enqueue_range(h, s0, 0, nframes, lap0, lap1, d_kps, d_desc, d_counts, capacity, s,
-                           no_overlap ? s : h->s_blur, h->ev_pyr, h->ev_blur, tm, tmf);
+                           no_overlap ? s : kOwnBlurStream, h->ev_pyr, h->ev_blur, tm, tmf);
     if (rc != VSG_OK) return rc;
     if (tm || tmf) h->ev_pending = true;
   } else {
@@ -585,6 +600,9 @@ static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, i
     for (int j = 0; j < nsub; j++) {
       const int f0 = j * per, nf = nframes - f0 < per ? nframes - f0 : per;
       if (nf <= 0) break;
+      int rs = need_stream(h, &h->sub_s[j]);
+      if (rs == VSG_OK) rs = need_stream(h, &h->sub_b[j]);
+      if (rs != VSG_OK) return rs;
       HIP_TRY(hipStreamWaitEvent(h->sub_s[j], h->ev_fork, 0));
       int rc = enqueue_range(h, s0, f0, nf, lap0, lap1, d_kps, d_desc, d_counts, capacity, h->sub_s[j], h->sub_b[j],
                              h->sub_ev_pyr[j], h->sub_ev_blur[j], false);
@@ -605,7 +623,7 @@ static int enqueue_pipeline(vsg_orb *h, const Src0 &s0, int nframes, int lap0, i
 // wait (on the host) for the last enqueue, whichever stream it went to
 static int wait_last(vsg_orb *h) {
   if (h->have_last) HIP_TRY(hipEventSynchronize(h->ev_last));
-  HIP_TRY(hipStreamSynchronize(h->s_blur));
+  if (h->s_blur) HIP_TRY(hipStreamSynchronize(h->s_blur));
   return VSG_OK;
 }
 
@@ -686,10 +704,11 @@ int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fa
     set_err("no usable HIP device (the extractor has no CPU fallback)");
     return VSG_ERR_NO_DEVICE;
   }
+  // ONE stream at creation; the blur / copy / sub-batch streams come when a path first needs them (need_stream).  The
+  // runtime deals a process's streams over a handful of hardware queues: with 20 streams per handle created up front,
+  // the main streams of four handles -- four camera streams, BASELINE's C5 -- all sat on the SAME queue and their
+  // kernels ran one after the other (profiles/r04_n_c5_stream_overlap.txt).
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->s_blur, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->s_h2d, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->s_d2h, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_pyr, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_blur, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_last, hipEventDisableTiming) != hipSuccess ||
@@ -708,8 +727,6 @@ int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fa
   for (int i = 0; i < kEv; i++) hipEventCreate(&h->ev[i]);
   hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   for (int j = 0; j < kMaxSub; j++) {
-    hipStreamCreateWithFlags(&h->sub_s[j], hipStreamNonBlocking);
-    hipStreamCreateWithFlags(&h->sub_b[j], hipStreamNonBlocking);
     hipEventCreateWithFlags(&h->sub_ev_pyr[j], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->sub_ev_blur[j], hipEventDisableTiming);
     hipEventCreateWithFlags(&h->sub_ev_done[j], hipEventDisableTiming);
@@ -903,6 +920,10 @@ static int tail_stream_work(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1
   h->mirror = OutMirror();
   if (rc != VSG_OK) return rc;
   if (mirror_out) return VSG_OK;
+  if (!h->one_stream) {
+    const int rs = need_stream(h, &h->s_d2h);
+    if (rs != VSG_OK) return rs;
+  }
   const hipStream_t s_out = h->one_stream ? h->s_main : h->s_d2h;
   if (!h->one_stream) {
     HIP_TRY(hipEventRecord(S.ev_done, h->s_main));
@@ -1045,6 +1066,10 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
   const int ip = h->in_pitch;
   const size_t fbytes = (size_t)rows * ip;
   const bool packed = stride == ip && (nframes == 1 || frame_stride == fbytes);
+  if (!h->one_stream) {
+    const int rs = need_stream(h, &h->s_h2d);
+    if (rs != VSG_OK) return rs;
+  }
   const hipStream_t s_in = h->one_stream ? h->s_main : h->s_h2d;
   if (h->one_stream && nframes <= 8) {
     // Blocking call, small batch (the reference's one frame per operator()): the latency path.  Pageable images are
