@@ -6,7 +6,7 @@ import collections, csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-40:], r.get("Queue_Id", r.get("Stream_Id", "?"))))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0][-40:], r.get("Queue_Id", r.get("Stream_Id", "?"))))
 rows.sort()
 t0, t1 = rows[0][0], rows[-1][1]
 lo = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0

@@ -120,6 +120,41 @@ __global__ __launch_bounds__(1024) void k_frame_grid_build(const KeyPointPOD *__
   }
   __syncthreads();
   for (int c = tid; c <= kGridCells; c += 1024) cell_start[c] = s_cnt[c];
+  // The reference's cells list their features in index order (mGrid[i][j].push_back in AssignFeaturesToGrid's loop,
+  // Frame.cc:521-533): the scatter's atomics do not, so every cell is put in order afterwards.  Up to kGridLdsMax
+  // keypoints that happens in LDS on the 4-byte (index | octave) words alone and the 12-byte entries are written once,
+  // coalesced, from the sorted words (sorting the entries where they lie -- global memory, a dependent round trip per
+  // comparison -- was a third of this launch's 18 us at 1250 keypoints).
+  __shared__ uint32_t s_io[kGridLdsMax];
+  if (n <= kGridLdsMax) {
+    for (int i = tid; i < n; i += 1024) {
+      const KeyPointPOD kp = gsrc[i];
+      const int c = cell_of(kp);
+      if (c < 0) continue;
+      s_io[atomicAdd(&s_fill[c], 1)] = (uint32_t)i | ((uint32_t)(kp.octave & 0xFFFF) << 16);
+    }
+    __syncthreads();
+    for (int c = tid; c < kGridCells; c += 1024) {  // insertion sort by index: cells hold a few entries
+      const int e0 = s_cnt[c], e1 = s_cnt[c + 1];
+      for (int a = e0 + 1; a < e1; a++) {
+        const uint32_t v = s_io[a];
+        int b = a - 1;
+        while (b >= e0 && (s_io[b] & 0xFFFFu) > (v & 0xFFFFu)) {
+          s_io[b + 1] = s_io[b];
+          b--;
+        }
+        s_io[b + 1] = v;
+      }
+    }
+    __syncthreads();
+    const int nin = s_cnt[kGridCells];
+    for (int e = tid; e < nin; e += 1024) {
+      const uint32_t io = s_io[e];
+      const KeyPointPOD kp = gsrc[io & 0xFFFFu];
+      ent[e] = {kp.x, kp.y, io};
+    }
+    return;
+  }
   for (int i = tid; i < n; i += 1024) {
     const KeyPointPOD kp = gsrc[i];
     const int c = cell_of(kp);

@@ -12,6 +12,7 @@
 #include "vsg_walks.h"
 
 enum { kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows };  // FRAME_GRID_COLS / ROWS (Frame.h:49-50)
+enum { kGridLdsMax = 4096 };  // keypoints per frame up to which k_frame_grid_build orders the cells in LDS
 
 namespace vsg {
 // One entry of a grid cell's vector (mGrid[ix][iy][j], Frame.h:290) with the keypoint fields GetFeaturesInArea tests
