@@ -162,6 +162,27 @@ __global__ void __launch_bounds__(256) k_chain(uint32_t *out, int iters, uint32_
 // MFMA i8 32x32x32: NACC independent accumulators per wave (1 = fully dependent chain)
 typedef int mi32x4 __attribute__((ext_vector_type(4)));
 typedef int mi32x16 __attribute__((ext_vector_type(16)));
+// the block-scaled FP4 form (e2m1: 0x2 = +1, 0xA = -1; scales 127 = 2^0): 32 x 32 x 64 per instruction, exact in fp32 for +-1 data
+typedef int mi32x8 __attribute__((ext_vector_type(8)));
+typedef float mf32x16 __attribute__((ext_vector_type(16)));
+template <int NACC>
+__global__ void __launch_bounds__(256) k_mfma_f4(float *out, int iters, int seed) {
+  mi32x8 a = {seed, seed + 1, seed + 2, seed + 3, 0, 0, 0, 0}, b = {seed + 4, seed + 5, seed + 6, (int)threadIdx.x, 0, 0, 0, 0};
+  mf32x16 acc[NACC];
+  for (int n = 0; n < NACC; n++)
+    for (int g = 0; g < 16; g++) acc[n][g] = 0;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+#pragma unroll
+      for (int n = 0; n < NACC; n++)
+        acc[n] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc[n], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+  }
+  float r = 0;
+  for (int n = 0; n < NACC; n++)
+    for (int g = 0; g < 16; g++) r += acc[n][g];
+  out[blockIdx.x * 256 + threadIdx.x] = r;
+}
 template <int NACC>
 __global__ void __launch_bounds__(256) k_mfma_i8(int *out, int iters, int seed) {
   mi32x4 a = {seed, seed + 1, seed + 2, seed + 3}, b = {seed + 4, seed + 5, seed + 6, (int)threadIdx.x};
@@ -255,6 +276,8 @@ int main() {
   report("mfma_i32_32x32x32_i8 x1", time_ms([&] { hipLaunchKernelGGL(k_mfma_i8<1>, dim3(blocks), dim3(256), 0, 0, (int *)out, iters / 8, 3); }), iters / 8 * 8.0);
   report("mfma_i32_32x32x32_i8 x2", time_ms([&] { hipLaunchKernelGGL(k_mfma_i8<2>, dim3(blocks), dim3(256), 0, 0, (int *)out, iters / 8, 3); }), iters / 8 * 16.0);
   report("mfma_i32_32x32x32_i8 x4", time_ms([&] { hipLaunchKernelGGL(k_mfma_i8<4>, dim3(blocks), dim3(256), 0, 0, (int *)out, iters / 8, 3); }), iters / 8 * 32.0);
+  report("mfma_scale_f32_32x32x64_f4 x1", time_ms([&] { hipLaunchKernelGGL(k_mfma_f4<1>, dim3(blocks), dim3(256), 0, 0, (float *)out, iters / 8, 3); }), iters / 8 * 8.0);
+  report("mfma_scale_f32_32x32x64_f4 x2", time_ms([&] { hipLaunchKernelGGL(k_mfma_f4<2>, dim3(blocks), dim3(256), 0, 0, (float *)out, iters / 8, 3); }), iters / 8 * 16.0);
   for (int w : {1, 2, 4})
     report(w == 1 ? "ds_read_b32" : w == 2 ? "ds_read_b64" : "ds_read_b128",
            time_ms([&] { hipLaunchKernelGGL(k_lds, dim3(blocks), dim3(256), 0, 0, out, iters, w); }), iters * 8.0);

@@ -86,40 +86,40 @@ enum { kBest2Rows = 128 };  // A rows per workgroup
 
 // ---- the best / second-best scan on the matrix cores.  A Hamming distance matrix is a GEMM over +-1 vectors:
 // with s(x) = 2*bit - 1, sum_k s(a_k) * s(b_k) = 256 - 2 * dist.  The train rows are expanded with their bits
-// INVERTED (so each product is negated) and the accumulator starts at 256, hence
-//     D[i][j] = 256 + sum_k (-s(train_i,k)) * s(query_j,k) = 2 * dist(train_i, query_j)          (exact, int32)
-// from eight v_mfma_i32_32x32x32_i8 per 32 x 32 tile (K = 256).  A wave owns 32 queries (the MFMA's columns, kept
-// expanded in 32 VGPRs for the whole scan); the workgroup expands each tile of 32 train rows once into LDS for its
+// INVERTED (so each product is negated), hence
+//     D[i][j] = sum_k (-s(train_i,k)) * s(query_j,k) = 2 * dist(train_i, query_j) - 256
+// The operands are FP4 (e2m1: +1 = 0x2, -1 = 0xA; block scales 2^0) for `v_mfma_scale_f32_32x32x64_f8f6f4`: K = 64 per
+// instruction at the 32 cycles of the i8 form's K = 32 (tools/ubench.hip), so a 32 x 32 tile of 256-bit distances is FOUR
+// instructions (round 4; rounds 1-3: eight v_mfma_i32_32x32x32_i8 -- 0.148 -> 0.111 ms per 512 x 1006^2 pairs, + 2.2 %
+// frames/s in the same run), a descriptor dword expands into ONE 16-byte operand through a byte -> 8-nibble table and a
+// tile of train rows is 4 KB of LDS.  Sums of +-1 products are exact in fp32.  A wave owns 32 queries (the MFMA's columns,
+// kept expanded in 16 VGPRs for the whole scan); the workgroup expands each tile of 32 train rows once into LDS for its
 // four waves.  C/D layout: lane = column + 32 * h, register g holds row (g & 3) + 8 * (g >> 2) + 4 * h, so a lane
-// folds its 16 rows into the packed-key best/second pair with v_lshl_or + v_min_u32 + v_med3_u32 per pair; the
-// two lanes of a column merge at the end.  Keys (2 * dist << 19 | index == dist << 20 | index) and therefore tie
-// handling follow the packed-key rule above (an xor + popcount form of this scan measured 0.182 ms per 256 x 1006^2
-// pairs against 0.088 ms here: DESIGN 8, round 1).
+// folds its 16 rows into a best/second pair of FLOAT keys 32 * acc + row offset (exact, lexicographic in (acc, row)) with
+// v_fma_f32 + v_min_f32 + v_med3_f32 per pair, turns the two survivors into the packed integer keys
+// (2 * dist << 19 | index == dist << 20 | index) and the two lanes of a column merge at the end: tie handling follows the
+// packed-key rule above (an xor + popcount form of this scan measured 0.182 ms per 256 x 1006^2 pairs against 0.088 ms
+// for the i8 form: DESIGN 8, round 1).
 #ifndef VSG_MATCH_TR
 #define VSG_MATCH_TR 1
 #endif
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
-
-// 4 bits -> 4 bytes: bit set -> 0x01 (+1), bit clear -> 0xFF (-1)
-__device__ __forceinline__ uint32_t expand_pm1(uint32_t nib) {
-  const uint32_t m = (nib * 0x00204081u) & 0x01010101u;  // bit i -> byte i (the four shifted copies do not overlap)
-  return m | ((m ^ 0x01010101u) * 0xFFu);
-}
-// 16 bits -> 16 bytes
-__device__ __forceinline__ i32x4 expand16_pm1(uint32_t h16) {
-  return (i32x4){(int)expand_pm1(h16 & 0xF), (int)expand_pm1((h16 >> 4) & 0xF), (int)expand_pm1((h16 >> 8) & 0xF),
-                 (int)expand_pm1((h16 >> 12) & 0xF)};
-}
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base, const uint8_t *b_base,
                                                           size_t block_stride, const int *counts_a, const int *counts_b,
                                                           int count_stride, int fixed_na, int fixed_nb, int max_rows,
                                                           int *best, int *second, int *argbest) {
   constexpr int TR = VSG_MATCH_TR;  // 32-row train tiles per iteration (independent MFMA chains, one barrier)
-  __shared__ i32x4 tiles[2][TR][8 * 2 * 32];  // double buffer of [tile][k-step s][half h][train row r]: 16 bytes each
-  __shared__ uint2 lut[256];                  // byte -> its 8 bits as +-1 bytes (expansion = 4 lookups per dword)
-  lut[threadIdx.x] = (uint2){expand_pm1(threadIdx.x & 0xF), expand_pm1(threadIdx.x >> 4)};
+  __shared__ i32x4 tiles[2][TR][8 * 32];  // double buffer of [tile][descriptor dword d = 2 * k-step + half][train row r]
+  __shared__ uint32_t lut[256];           // byte -> its 8 bits as FP4 nibbles
+  {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) m |= ((threadIdx.x >> i) & 1u) << (4 * i + 3);
+    lut[threadIdx.x] = 0xAAAAAAAAu ^ m;  // bit set -> 0x2 (+1), bit clear -> 0xA (-1)
+  }
   const int blk = blockIdx.y;
   const int na = counts_a ? min(counts_a[blk * count_stride], max_rows) : fixed_na;
   const int nb = counts_b ? min(counts_b[blk * count_stride], max_rows) : fixed_nb;
@@ -128,12 +128,12 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int q = blockIdx.x * kBest2Rows + wave * 32 + r;  // this lane's query (column)
   const bool wave_active = blockIdx.x * kBest2Rows + wave * 32 < na;
-  // queries: half h of every dword of the descriptor, expanded once
-  i32x4 Q[8];
+  // queries: dword 2 s + h of the descriptor is the lane's 32 K-values of k-step s (expanded below, once the table is there)
+  uint32_t qraw[4];
   {
     const uint32_t *qd = (const uint32_t *)(A + (size_t)(q < na ? q : 0) * 32);
 #pragma unroll
-    for (int s = 0; s < 8; s++) Q[s] = expand16_pm1((qd[s] >> (16 * h)) & 0xFFFFu);
+    for (int s = 0; s < 4; s++) qraw[s] = qd[2 * s + h];
   }
   uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
   // tile expansion: thread = (train row, dword); the row runs along the lanes so that a wave's 16-byte LDS stores
@@ -149,8 +149,15 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
   uint32_t wa[kPf], wn[kPf];
 #pragma unroll
   for (int j = 0; j < kPf; j++) wa[j] = fetch(32 * j), wn[j] = 0u;
-  const i32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   __syncthreads();  // lut
+  const f32x16 zerof = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  auto expand4 = [&](uint32_t w) {
+    return (i32x8){(int)lut[w & 255], (int)lut[(w >> 8) & 255], (int)lut[(w >> 16) & 255], (int)lut[w >> 24], 0, 0, 0, 0};
+  };
+  i32x8 Q[4];
+#pragma unroll
+  for (int s = 0; s < 4; s++) Q[s] = expand4(qraw[s]);
+  const int kScale = 0x7F7F7F7F;  // e8m0 block scales: 2^0
   int buf = 0;
   for (int tg = 0; tg < nb; tg += 32 * kPf) {
     if (tg + 32 * kPf < nb) {
@@ -165,46 +172,52 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
       for (int t = 0; t < TR; t++) {
         i32x4 *tile = tiles[buf][t];
         const uint32_t ww = wa[j + t];
-        const uint2 e0 = lut[ww & 255], e1 = lut[(ww >> 8) & 255], e2 = lut[(ww >> 16) & 255], e3 = lut[ww >> 24];
-        tile[(es * 2 + 0) * 32 + erow] = (i32x4){(int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y};
-        tile[(es * 2 + 1) * 32 + erow] = (i32x4){(int)e2.x, (int)e2.y, (int)e3.x, (int)e3.y};
+        tile[es * 32 + erow] = (i32x4){(int)lut[ww & 255], (int)lut[(ww >> 8) & 255], (int)lut[(ww >> 16) & 255], (int)lut[ww >> 24]};
       }
       // one barrier per iteration: nobody can overwrite this buffer before every wave has passed the NEXT
       // barrier, i.e. finished reading it
       __syncthreads();
       if (wave_active) {
         // acc = sum of negated products = 2 * dist - 256 (C operand: inline 0)
-        i32x16 acc[TR];
+        f32x16 acc[TR];
+        auto opA = [&](int t, int s) {
+          const i32x4 v = tiles[buf][t][(s * 2 + h) * 32 + r];
+          return (i32x8){v.x, v.y, v.z, v.w, 0, 0, 0, 0};
+        };
 #pragma unroll
         for (int t = 0; t < TR; t++)
-          acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tiles[buf][t][h * 32 + r], Q[0], zero, 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(opA(t, 0), Q[0], zerof, 4, 4, 0, kScale, 0, kScale);
 #pragma unroll
-        for (int s = 1; s < 8; s++)
+        for (int s = 1; s < 4; s++)
 #pragma unroll
           for (int t = 0; t < TR; t++)
-            acc[t] = __builtin_amdgcn_mfma_i32_32x32x32_i8(tiles[buf][t][(s * 2 + h) * 32 + r], Q[s], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(opA(t, s), Q[s], acc[t], 4, 4, 0, kScale, 0, kScale);
 #pragma unroll
         for (int t = 0; t < TR; t++) {
           const int tb = t0 + 32 * t + 4 * h;  // row of register 0 of this lane
           if (tb - 4 * h + 32 <= nb) {
             // full tile: best two of the lane's 16 rows on keys local to the tile -- (acc << 19) + (256 << 19 | row
             // offset), the constant living in an SGPR: one v_lshl_add_u32 -- then move them to absolute rows
-            uint32_t l1 = KEY_NONE, l2 = KEY_NONE;
+            // the same fold on FLOAT keys 32 * acc + row offset (exact: |32 acc + 27| < 2^14; the offset < 32 keeps (acc, row)
+            // in lexicographic order): one v_fma_f32, one v_min_f32, one v_med3_f32 per pair; the two survivors become the
+            // integer keys (dist << 20 | row) the rest of the kernel works on
+            float f1 = __builtin_inff(), f2 = __builtin_inff();
 #pragma unroll
             for (int g = 0; g < 16; g++) {
-              const uint32_t key = ((uint32_t)acc[t][g] << 19) + ((256u << 19) | (uint32_t)((g & 3) + 8 * (g >> 2)));
-              l2 = umed3(l1, l2, key);
-              l1 = min(l1, key);
+              const float kf = __builtin_fmaf(acc[t][g], 32.0f, (float)((g & 3) + 8 * (g >> 2)));
+              f2 = __builtin_amdgcn_fmed3f(f1, f2, kf);
+              f1 = __builtin_fminf(f1, kf);
             }
-            l1 += (uint32_t)tb;
-            l2 += (uint32_t)tb;
+            const int i1 = (int)f1, i2 = (int)f2;  // 32 acc + offset: acc = i >> 5 (floor), offset = i & 31
+            const uint32_t l1 = ((uint32_t)((i1 >> 5) + 256) << 19) + (uint32_t)((i1 & 31) + tb);
+            const uint32_t l2 = ((uint32_t)((i2 >> 5) + 256) << 19) + (uint32_t)((i2 & 31) + tb);
             k2 = min(max(k1, l1), min(k2, l2));
             k1 = min(k1, l1);
           } else {
 #pragma unroll
             for (int g = 0; g < 16; g++) {
               const int row = tb + (g & 3) + 8 * (g >> 2);
-              uint32_t key = ((uint32_t)(acc[t][g] + 256) << 19) | (uint32_t)row;
+              uint32_t key = ((uint32_t)((int)acc[t][g] + 256) << 19) | (uint32_t)row;
               if (row >= nb) key = KEY_NONE;
               k2 = umed3(k1, k2, key);
               k1 = min(k1, key);
