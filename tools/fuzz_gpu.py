@@ -350,6 +350,9 @@ def case_undistort(rng):
     return bool(ok and a[0] == b[0] and np.array_equal(a[1], b[1])), tag
 
 
+TRACE = False
+
+
 def case_async(rng):
     """vsg_orb_submit_batch / vsg_orb_wait with random batch sizes, strides, pinned / pageable buffers, lapping areas."""
     w, h, nf, sc_, nl, ini, mn = geometry(rng)
@@ -363,6 +366,8 @@ def case_async(rng):
     nb = int(rng.integers(1, 6))
     tickets, bufs = [], []
     ok = True
+    if TRACE:
+        print("  async", w, h, nf, sc_, nl, "B", B, "nb", nb, "pinned", pinned, "lap", lap, "cap", cap, flush=True)
     for k in range(nb):
         b = int(rng.integers(max(1, B - 4), B + 1))
         pad = int(rng.integers(0, 9))
@@ -376,6 +381,8 @@ def case_async(rng):
             view = big[:, :, :w]
         if len(tickets) == ex.slots():
             ok &= _finish(ex, ref, tickets.pop(0), bufs.pop(0), lap, pinned)
+        if TRACE:
+            print("    submit", k, "b", b, "pad", pad, hex(big.ctypes.data), big.nbytes, hex(kps.ctypes.data), kps.nbytes, hex(desc.ctypes.data), desc.nbytes, flush=True)
         tickets.append(ex.submit_batch(view, kps, desc, lap))
         bufs.append((imgs, big, kps, desc))
     while tickets:
@@ -403,12 +410,20 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", default="")
+    ap.add_argument("--trace", action="store_true", help="print every case's index and name before it runs (a GPU fault kills the process: the last line names the case)")
+    ap.add_argument("--stop-at", type=int, default=-1, help="run cases up to this index only (the random stream stays the same)")
     args = ap.parse_args()
+    global TRACE
+    TRACE = args.trace
     rng = np.random.default_rng(args.seed)
     names = [n for n in CASES if not args.only or n in args.only.split(",")]
     counts = {n: 0 for n in names}
     for i in range(args.cases):
         name = names[int(rng.integers(0, len(names)))]
+        if args.trace:
+            print("case", i, name, flush=True)
+        if 0 <= args.stop_at < i:
+            break
         try:
             ok, desc = CASES[name](rng)
         except orb.VsgError as e:
