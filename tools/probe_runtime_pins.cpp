@@ -39,5 +39,14 @@ int main() {
   show("the malloc'd buffer after hipHostRegister", h + 4096);
   hipHostUnregister(h);
   show("... after hipHostUnregister", h + 4096);
+  // a registration that starts and ends inside pages: what do the OTHER bytes of those pages report?
+  unsigned char *r0 = h + 8192 + 100;
+  const size_t rn = 5000;
+  hipHostRegister(r0, rn, hipHostRegisterMapped | hipHostRegisterPortable);
+  show("registered [page + 100, + 5000): inside", r0 + 10);
+  show("  same first page, 50 bytes BEFORE the range", r0 - 50);
+  show("  same last page, 10 bytes AFTER the range", r0 + rn + 10);
+  show("  the next page", r0 + rn + 4096);
+  hipHostUnregister(r0);
   return 0;
 }
