@@ -325,6 +325,11 @@ int vsg_debug_call_profile(float us[4]);
  * descriptor arrays of a ring of Frames).  Unpinned memory keeps working everywhere, through a staging memcpy. */
 int vsg_host_register(void *ptr, size_t bytes);
 int vsg_host_unregister(void *ptr);
+/* Pinned host memory from the runtime's own allocator (hipHostMalloc): the same direct paths as registered memory, without
+ * the user-pointer mapping of ordinary heap pages underneath (INTEGRATION.md "Pinned host buffers"; what the handle's own
+ * staging slots use).  For frame / keypoint / descriptor rings that live as long as the tracker. */
+int vsg_host_alloc(size_t bytes, void **out);
+int vsg_host_free(void *ptr);
 
 /* ---- Asynchronous operator() batches (caller: Frame::ExtractORB, Frame.cc:555-563, in a throughput pipeline) -----
  * vsg_orb_submit_batch enqueues H2D + the stage chain + the output export of one batch into one of the handle's

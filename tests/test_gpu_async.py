@@ -56,6 +56,28 @@ def test_submit_wait_three_batches_in_flight(pinned):
             orb.unpin(b), orb.unpin(k), orb.unpin(d)
 
 
+def test_host_alloc_buffers_take_the_direct_paths():
+    """vsg_host_alloc (hipHostMalloc) memory behaves like registered memory: the device reads the batch from it and writes the
+    n[f] records of every frame straight into it (rows beyond n[f] stay untouched: nothing was staged and copied)."""
+    B = 3
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    fr = _frames(77, B)
+    with orb.PinnedArray(fr.shape) as pin_in, orb.PinnedArray((B, cap), orb.KP_DTYPE) as pin_k, \
+            orb.PinnedArray((B, cap, 32)) as pin_d:
+        pin_in.a[...] = fr
+        pin_d.a[...] = 0xAB
+        for _ in range(3):
+            n, mono = ex.wait(ex.submit_batch(pin_in.a, pin_k.a, pin_d.a))
+            _check(fr, pin_k.a, pin_d.a, n, mono)
+            for f in range(B):
+                assert np.all(pin_d.a[f, n[f]:] == 0xAB)
+        # the blocking single-frame call (latency path: the device reads the pinned image itself)
+        mono, kps, desc = ex(pin_in.a[1])
+        rm, rk, rd = ol.OracleExtractor(NF, 1.2, 8, 20, 7)(fr[1])
+        assert mono == rm and kps.tobytes() == rk.tobytes() and np.array_equal(desc, rd)
+
+
 def test_new_image_size_is_refused_while_tickets_are_pending():
     """A different image size rebuilds the handle's buffers and frees the pipeline slots; with un-waited tickets that
     would drop their results silently, so the submit is refused and the pending batch stays intact."""

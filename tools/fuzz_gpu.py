@@ -351,6 +351,7 @@ def case_undistort(rng):
 
 
 TRACE = False
+ALLOC = True  # --registered-only: every pinned `async` case registers numpy arrays (the form profiles/r04_q_* is about)
 
 
 def case_async(rng):
@@ -364,6 +365,8 @@ def case_async(rng):
     lap = (int(rng.integers(-10, w)), int(rng.integers(-10, w + 50)))
     pinned = bool(rng.integers(0, 2))
     nb = int(rng.integers(1, 6))
+    # pinned buffers: registered numpy arrays, or (ALLOC, every second pinned case) arrays over vsg_host_alloc memory
+    alloc = pinned and ALLOC and bool(rng.integers(0, 2))
     tickets, bufs = [], []
     ok = True
     if TRACE:
@@ -376,7 +379,13 @@ def case_async(rng):
         big[:, :, :w] = imgs
         view = big[:, :, :w]
         kps, desc = np.zeros((b, cap), orb.KP_DTYPE), np.zeros((b, cap, 32), np.uint8)
-        if pinned:
+        owners = ()
+        if alloc:
+            owners = (orb.PinnedArray(big.shape), orb.PinnedArray(kps.shape, orb.KP_DTYPE), orb.PinnedArray(desc.shape))
+            owners[0].a[...] = big
+            big, kps, desc = owners[0].a, owners[1].a, owners[2].a
+            view = big[:, :, :w]
+        elif pinned:
             big, kps, desc = orb.pin(big), orb.pin(kps), orb.pin(desc)
             view = big[:, :, :w]
         if len(tickets) == ex.slots():
@@ -384,20 +393,24 @@ def case_async(rng):
         if TRACE:
             print("    submit", k, "b", b, "pad", pad, hex(big.ctypes.data), big.nbytes, hex(kps.ctypes.data), kps.nbytes, hex(desc.ctypes.data), desc.nbytes, flush=True)
         tickets.append(ex.submit_batch(view, kps, desc, lap))
-        bufs.append((imgs, big, kps, desc))
+        bufs.append((imgs, big, kps, desc, owners))
     while tickets:
         ok &= _finish(ex, ref, tickets.pop(0), bufs.pop(0), lap, pinned)
     return ok, ("async", w, h, nf, sc_, nl, B, nb, pinned, lap)
 
 
 def _finish(ex, ref, ticket, buf, lap, pinned):
-    imgs, big, kps, desc = buf
+    imgs, big, kps, desc, owners = buf
     n, mono = ex.wait(ticket)
     ok = True
     for i in range(len(imgs)):
         rm, rk, rd = ref(imgs[i], lap)
         ok &= n[i] == len(rk) and mono[i] == rm and kps[i, :n[i]].tobytes() == rk.tobytes() and np.array_equal(desc[i, :n[i]], rd)
-    if pinned:
+    if owners:
+        del big, kps, desc
+        for o in owners:
+            o.free()
+    elif pinned:
         orb.unpin(big), orb.unpin(kps), orb.unpin(desc)
     return bool(ok)
 
@@ -411,10 +424,12 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--only", default="")
     ap.add_argument("--trace", action="store_true", help="print every case's index and name before it runs (a GPU fault kills the process: the last line names the case)")
+    ap.add_argument("--registered-only", action="store_true", help="pinned `async` cases never use vsg_host_alloc memory")
     ap.add_argument("--stop-at", type=int, default=-1, help="run cases up to this index only (the random stream stays the same)")
     args = ap.parse_args()
-    global TRACE
+    global TRACE, ALLOC
     TRACE = args.trace
+    ALLOC = not args.registered_only
     rng = np.random.default_rng(args.seed)
     names = [n for n in CASES if not args.only or n in args.only.split(",")]
     counts = {n: 0 for n in names}

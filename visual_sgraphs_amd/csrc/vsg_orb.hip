@@ -685,6 +685,17 @@ int vsg_host_unregister(void *ptr) {
   HIP_TRY(hipHostUnregister(ptr));
   return VSG_OK;
 }
+int vsg_host_alloc(size_t bytes, void **out) {
+  if (!out || !bytes) return VSG_ERR_INVALID;
+  *out = nullptr;
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocMapped | hipHostMallocPortable));
+  return VSG_OK;
+}
+int vsg_host_free(void *ptr) {
+  if (!ptr) return VSG_ERR_INVALID;
+  HIP_TRY(hipHostFree(ptr));
+  return VSG_OK;
+}
 
 int vsg_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th_fast, int min_th_fast, int device,
                    int max_batch, vsg_orb **out) {

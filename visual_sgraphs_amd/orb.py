@@ -47,7 +47,7 @@ EXPORTS = [
     "vsg_vocab_info", "vsg_bow_transform", "vsg_distinctive_descriptors", "vsg_debug_device_sort",
     "vsg_search_for_triangulation", "vsg_search_by_bow_kf_f_stereo",
     # round 2: threads / staging, async host pipeline, device-resident frames, routine-level searches
-    "vsg_thread_release", "vsg_thread_arena_growths", "vsg_debug_call_profile", "vsg_orb_time_stats", "vsg_host_register", "vsg_host_unregister", "vsg_orb_slots",
+    "vsg_thread_release", "vsg_thread_arena_growths", "vsg_debug_call_profile", "vsg_orb_time_stats", "vsg_host_register", "vsg_host_unregister", "vsg_host_alloc", "vsg_host_free", "vsg_orb_slots",
     "vsg_orb_submit_batch", "vsg_orb_wait", "vsg_orb_copy_pyramid", "vsg_frame_create", "vsg_frame_destroy",
     "vsg_frame_upload", "vsg_frame_from_extractor", "vsg_frame_size", "vsg_frame_copy_grid",
     "vsg_frame_features_in_area", "vsg_frame_search_by_projection", "vsg_frame_search_by_projection_last",
@@ -202,6 +202,8 @@ def load_library():
     L.vsg_orb_time_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), ci]
     L.vsg_host_register.argtypes = [vp, C.c_size_t]
     L.vsg_host_unregister.argtypes = [vp]
+    L.vsg_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.vsg_host_free.argtypes = [vp]
     L.vsg_orb_slots.argtypes = [vp]
     L.vsg_orb_chain_graph_launches.argtypes = [vp]
     L.vsg_orb_chain_graph_launches.restype = C.c_long
@@ -808,6 +810,31 @@ def pin(array):
 
 def unpin(array):
     _check(load_library().vsg_host_unregister(C.c_void_p(array.ctypes.data)), "vsg_host_unregister")
+
+
+class PinnedArray:
+    """A numpy array over hipHostMalloc memory (vsg_host_alloc): pinned without a user-pointer mapping of heap pages underneath.
+    `.a` is the array; free() (or the context manager) releases the memory -- the array must not be used afterwards."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        self._p = C.c_void_p()
+        _check(load_library().vsg_host_alloc(C.c_size_t(max(n, 1)), C.byref(self._p)), "vsg_host_alloc")
+        buf = (C.c_uint8 * max(n, 1)).from_address(self._p.value)
+        self.a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self._p is not None and self._p.value:
+            self.a = None
+            _check(load_library().vsg_host_free(self._p), "vsg_host_free")
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
 
 
 def copy_d2d_async(dst, src, nbytes, stream, device=0):
