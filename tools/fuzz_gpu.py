@@ -351,6 +351,7 @@ def case_undistort(rng):
 
 
 TRACE = False
+ALLOC_ONLY = False  # --alloc-only: every pinned `async` case uses vsg_host_alloc memory
 ALLOC = True  # --registered-only: every pinned `async` case registers numpy arrays (the form profiles/r04_q_* is about)
 
 
@@ -366,7 +367,7 @@ def case_async(rng):
     pinned = bool(rng.integers(0, 2))
     nb = int(rng.integers(1, 6))
     # pinned buffers: registered numpy arrays, or (ALLOC, every second pinned case) arrays over vsg_host_alloc memory
-    alloc = pinned and ALLOC and bool(rng.integers(0, 2))
+    alloc = pinned and ALLOC and (bool(rng.integers(0, 2)) or ALLOC_ONLY)
     tickets, bufs = [], []
     ok = True
     if TRACE:
@@ -425,11 +426,13 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--trace", action="store_true", help="print every case's index and name before it runs (a GPU fault kills the process: the last line names the case)")
     ap.add_argument("--registered-only", action="store_true", help="pinned `async` cases never use vsg_host_alloc memory")
+    ap.add_argument("--alloc-only", action="store_true", help="pinned `async` cases always use vsg_host_alloc memory")
     ap.add_argument("--stop-at", type=int, default=-1, help="run cases up to this index only (the random stream stays the same)")
     args = ap.parse_args()
-    global TRACE, ALLOC
+    global TRACE, ALLOC, ALLOC_ONLY
     TRACE = args.trace
     ALLOC = not args.registered_only
+    ALLOC_ONLY = args.alloc_only
     rng = np.random.default_rng(args.seed)
     names = [n for n in CASES if not args.only or n in args.only.split(",")]
     counts = {n: 0 for n in names}
