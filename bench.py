@@ -53,6 +53,56 @@ def algorithmic_bytes(ex, n_kp):
     return stages, sum(v for k, v in stages.items() if k != "match")
 
 
+class BatchOracle:
+    """The parity gate's checker: the CPU oracle's operator() output for the DISTINCT frames of a workload, computed once
+    on all host threads (or_extract_batch_mt), against which EVERY frame and EVERY match row of a device batch is
+    compared bit for bit (a batch position maps to its distinct frame through `idx`)."""
+
+    def __init__(self, uniq, nfeat, cap):
+        import oracle_lib as ol
+        self.ol, self.cap, self.uniq = ol, cap, uniq
+        self.threads = ol.host_threads()
+        self.counts, self.kps, self.desc = ol.extract_batch(uniq, nfeat, cap, nthreads=self.threads)
+        self._rows = {}
+
+    def frames(self, idx, counts, kps, desc):
+        """device outputs [B, ...] of the frames uniq[idx[f]]: list of differing batch positions"""
+        idx = np.asarray(idx)
+        return self.ol.compare_batch(counts, kps, desc, self.counts[idx], self.kps[idx], self.desc[idx])
+
+    def match_rows(self, idx, pidx, best, second, arg):
+        """row f = brute-force best2 of frame uniq[idx[f]] against uniq[pidx[f]] (pidx[f] < 0: row not checked)"""
+        need = sorted({(int(i), int(j)) for i, j in zip(idx, pidx) if j >= 0} - set(self._rows))
+        if need:
+            a = np.stack([self.desc[i] for i, _ in need])
+            b = np.stack([self.desc[j] for _, j in need])
+            rb, rs, ra = self.ol.block_best2_batch(a, [self.counts[i, 0] for i, _ in need], b,
+                                                   [self.counts[j, 0] for _, j in need], nthreads=self.threads)
+            for k, p in enumerate(need):
+                self._rows[p] = (rb[k], rs[k], ra[k])
+        bad, checked = [], 0
+        for f, (i, j) in enumerate(zip(idx, pidx)):
+            if j < 0:
+                continue
+            checked += 1
+            rb, rs, ra = self._rows[(int(i), int(j))]
+            n = int(self.counts[i, 0])
+            if not (np.array_equal(best[f, :n], rb[:n]) and np.array_equal(second[f, :n], rs[:n])
+                    and np.array_equal(arg[f, :n], ra[:n])):
+                bad.append(f)
+        return bad, checked
+
+
+def gate_report(bad_frames, nframes, bad_rows, nrows, threads):
+    ok = not bad_frames and not bad_rows
+    rep = {"bit_exact_vs_oracle": bool(ok), "checked_frames": "all", "frames_checked": int(nframes),
+           "match_rows_checked": int(nrows), "oracle_threads": int(threads)}
+    if not ok:
+        rep["frames_differing"] = [int(f) for f in bad_frames[:16]]
+        rep["match_rows_differing"] = [int(f) for f in bad_rows[:16]]
+    return rep
+
+
 def effective_cores():
     """Host threads this process may really use: min(affinity, cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -79,20 +129,32 @@ def cpu_baseline(w, h, nfeatures, frames, budget_s, threads):
 
 def host_api_leg(W, H, nfeat, device, batch=64, seconds=1.5):
     """Throughput THROUGH the drop-in boundary: host uint8 frames in, keypoint / descriptor records out
-    (vsg_orb_submit_batch / vsg_orb_wait, three batches in flight), with pinned (vsg_host_register) and with pageable
-    caller memory, and the latency of one blocking single-frame operator().  PCIe-inclusive: never `value`."""
+    (vsg_orb_submit_batch / vsg_orb_wait, three batches in flight), with pinned (vsg_host_alloc = hipHostMalloc) and with
+    pageable caller memory, every frame of every slot's last batch bit-compared with the oracle, and the latency of one
+    blocking single-frame operator().  PCIe-inclusive: never `value`."""
     from visual_sgraphs_amd import orb, synth
     ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, device=device, max_batch=batch)
     cap = ex.capacity(H, W)
     nslot = ex.slots()
     ring_in = [np.stack([synth.sequence_frame(W, H, 2000 + r, t) for t in range(batch)]) for r in range(nslot)]
     out = {"batch": batch, "slots": nslot}
+    chk = BatchOracle(np.concatenate(ring_in), nfeat, cap)
     for mode in ("pinned", "pageable"):
-        ins = [orb.pin(a) for a in ring_in] if mode == "pinned" else ring_in
-        outs = [(np.zeros((batch, cap), orb.KP_DTYPE), np.zeros((batch, cap, 32), np.uint8)) for _ in range(nslot)]
+        # pinned = memory from vsg_host_alloc (hipHostMalloc): the device reads the frames and writes the records in place
+        owners = []
         if mode == "pinned":
-            outs = [(orb.pin(k), orb.pin(d)) for k, d in outs]
+            ins, outs = [], []
+            for a in ring_in:
+                pa = orb.PinnedArray(a.shape)
+                pa.a[...] = a
+                pk, pd = orb.PinnedArray((batch, cap), orb.KP_DTYPE), orb.PinnedArray((batch, cap, 32))
+                owners += [pa, pk, pd]
+                ins.append(pa.a), outs.append((pk.a, pd.a))
+        else:
+            ins = ring_in
+            outs = [(np.zeros((batch, cap), orb.KP_DTYPE), np.zeros((batch, cap, 32), np.uint8)) for _ in range(nslot)]
         tickets, done, k = [], 0, 0
+        last = {}
         t_end = None
         t0 = time.perf_counter()
         warm = 2 * nslot
@@ -100,24 +162,31 @@ def host_api_leg(W, H, nfeat, device, batch=64, seconds=1.5):
             if k == warm:
                 t0 = time.perf_counter()
                 t_end = t0 + seconds
-            tickets.append(ex.submit_batch(ins[k % nslot], *outs[k % nslot]))
+            tickets.append((k % nslot, ex.submit_batch(ins[k % nslot], *outs[k % nslot])))
             k += 1
             if len(tickets) == nslot:
-                n, _ = ex.wait(tickets.pop(0))
+                r, t = tickets.pop(0)
+                last[r] = ex.wait(t)
                 done += 1
             if t_end is not None and time.perf_counter() >= t_end:
                 break
         while tickets:
-            n, _ = ex.wait(tickets.pop(0))
+            r, t = tickets.pop(0)
+            last[r] = ex.wait(t)
             done += 1
         dt = time.perf_counter() - t0
         out[f"{mode}_frames_per_s"] = round((k - warm) * batch / dt, 1)
-        out[f"{mode}_keypoints_last_frame"] = int(n[-1])
-        if mode == "pinned":
-            for a in ins:
-                orb.unpin(a)
-            for kk, dd in outs:
-                orb.unpin(kk), orb.unpin(dd)
+        out[f"{mode}_keypoints_last_frame"] = int(last[(k - 1) % nslot][0][-1])
+        # every frame of the last batch of every slot against the oracle
+        bad = []
+        for r, (n, mono) in last.items():
+            counts = np.stack([n, mono], axis=1)
+            bad += [r * batch + f for f in chk.frames(np.arange(batch) + r * batch, counts, outs[r][0], outs[r][1])]
+        out[f"{mode}_parity"] = {"bit_exact_vs_oracle": not bad, "frames_checked": len(last) * batch,
+                                 **({"frames_differing": bad[:16]} if bad else {})}
+        del ins, outs
+        for o in owners:
+            o.free()
     img = ring_in[0][0]
     for _ in range(20):
         ex(img)
@@ -168,9 +237,9 @@ def config_chain_leg(seconds=2.0, pipelines=4):
 def device_rate(workload, batch, steps, device, cpu_seconds=3.0, uniq=None, label=None, ex=None):
     """Another BASELINE config -- or another CONTENT CLASS of the headline config (`uniq`: the distinct frames the batch
     cycles through) -- on the main bench's terms (frames resident in HBM, one batch per step): extract + brute-force
-    best2 match of every frame against its predecessor, the first and last frame and the last match bit-compared with
-    the CPU oracle, the oracle's own rate on one host thread beside it, the FAST kernel's launch duration by HIP events
-    around its launches inside the timed steps."""
+    best2 match of every frame against its predecessor, EVERY frame and EVERY match row of the last step bit-compared with
+    the CPU oracle (all host threads), the oracle's own rate on one host thread beside it, the FAST kernel's launch
+    duration by HIP events around its launches inside the timed steps."""
     import ctypes as C
     import torch
     import oracle_lib as ol
@@ -213,23 +282,21 @@ def device_rate(workload, batch, steps, device, cpu_seconds=3.0, uniq=None, labe
     fast_ms = ex.timing_ms().get("fast")
     ex.enable_timing(0)
     counts, kps_h, desc_h = d_counts.cpu().numpy(), d_kps.cpu().numpy(), d_desc.cpu().numpy()
-    ref = ol.OracleExtractor(nfeat, 1.2, 8, 20, 7)
-    ok = True
-    for f in (0, batch - 1):
-        mono, rk, rd = ref(frames[f])
-        n = int(counts[f + 1, 0])
-        ok &= n == len(rk) and int(counts[f + 1, 1]) == mono
-        ok &= kps_h[f + 1, :n].tobytes() == rk.tobytes() and np.array_equal(desc_h[f + 1, :n], rd)
-    n = int(counts[batch, 0])
-    rb, rs, ra = ol.block_best2(desc_h[batch, :n], desc_h[batch - 1, :int(counts[batch - 1, 0])])
-    ok &= np.array_equal(d_best[batch - 1, :n].cpu().numpy(), rb) and np.array_equal(d_arg[batch - 1, :n].cpu().numpy(), ra)
-    ok &= np.array_equal(d_second[batch - 1, :n].cpu().numpy(), rs)
+    # the gate: EVERY frame and EVERY match row of the last step's batch against the oracle (all host threads)
+    chk = BatchOracle(uniq, nfeat, cap)
+    idx = np.arange(batch) % nuniq
+    pidx = np.concatenate([[idx[-1]], idx[:-1]])  # row 0: against the previous (identical) step's last frame
+    bad_f = chk.frames(idx, counts[1:], kps_h[1:], desc_h[1:])
+    bad_r, nrows = chk.match_rows(idx, pidx, d_best.cpu().numpy(), d_second.cpu().numpy(), d_arg.cpu().numpy())
+    gate = gate_report(bad_f, batch, bad_r, nrows, chk.threads)
+    ok = gate["bit_exact_vs_oracle"]
     v1, n1 = ol.bench_throughput(uniq, nfeat, 1, cpu_seconds, do_match=True)
     return {"workload": label or f"{workload}: {W}x{H}, nFeatures={nfeat}, extract + brute-force best2 match vs previous "
                                  f"frame, {batch}-frame batches resident in HBM", "unit": "frames/s", "frames_per_step": batch,
             "frames_per_s": round(batch * steps / dt, 1), "keypoints_per_frame": round(float(counts[1:, 0].mean()), 1),
             "fast_ms": round(fast_ms, 4) if fast_ms else None,
-            "parity": bool(ok), "cpu_oracle": {"frames_per_s": round(v1, 2), "threads": 1, "kind": "port", "frames": n1}}
+            "parity": bool(ok), "parity_gate": gate,
+            "cpu_oracle": {"frames_per_s": round(v1, 2), "threads": 1, "kind": "port", "frames": n1}}
 
 
 def content_sweep_leg(device, batch=512, steps=12, nuniq=32, cpu_seconds=1.0):
@@ -247,6 +314,8 @@ def content_sweep_leg(device, batch=512, steps=12, nuniq=32, cpu_seconds=1.0):
         try:
             r = device_rate("C2", batch, steps, device, cpu_seconds, uniq=uniq, label=kind, ex=ex)
             out[kind] = {k: r[k] for k in ("frames_per_s", "fast_ms", "keypoints_per_frame", "parity")}
+            out[kind]["frames_checked"] = r["parity_gate"]["frames_checked"]
+            out[kind]["match_rows_checked"] = r["parity_gate"]["match_rows_checked"]
             out[kind]["cpu_oracle_frames_per_s"] = r["cpu_oracle"]["frames_per_s"]
         except Exception as e:  # noqa: BLE001
             out[kind] = {"error": str(e)}
@@ -260,9 +329,9 @@ def content_sweep_leg(device, batch=512, steps=12, nuniq=32, cpu_seconds=1.0):
 
 
 def visible_gpu_count():
-    """GPUs this process may use, WITHOUT initialising HIP (the launcher below must not touch the GPU before it starts its
-    ranks): the visibility variables if set, else the KFD topology (nodes with SIMDs), else torch's device count (which
-    does not initialise the runtime on this image)."""
+    """GPUs this process may use, WITHOUT importing torch or initialising HIP (the launcher below must not touch the GPU
+    before it starts its ranks): the visibility variables if set, else the KFD topology (nodes with SIMDs); None when
+    neither answers -- the ranks then report a missing device themselves."""
     for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
@@ -277,8 +346,7 @@ def visible_gpu_count():
             return n
     except (OSError, ValueError):
         pass
-    import torch
-    return torch.cuda.device_count()
+    return None
 
 
 def launch_ranks(args, argv):
@@ -291,16 +359,23 @@ def launch_ranks(args, argv):
     n = args.gpus
     if not args.one_device:
         have = visible_gpu_count()
-        if have < n:
+        if have is not None and have < n:
             sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) visible on this node\n")
             return 2
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
-           "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    r = None
+    for attempt in range(3):
+        # a free port is found by bind-then-close, so another process may take it before torchrun binds it: a run
+        # that dies on the rendezvous address is started again on another port
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(r.stderr)
+        if r.returncode == 0 or not any(m in r.stderr for m in ("EADDRINUSE", "Address already in use", "address already in use")):
+            break
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
     for x in r.stdout.splitlines():
         if not x.startswith("{"):
@@ -632,6 +707,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     stage_ms_timed = ex.timing_ms() if not args.no_stage_timing else {}
+    # The parity gate's subject: the outputs of the LAST TIMED STEP (device-side copies, taken after the clock stopped):
+    # the serialized pass below runs other launch forms (k_octree / k_blur apart, k_slots) and overwrites the arrays.
+    steps_done = max(args.ramp_steps, 0) + Wu + K
+    timed_out = {"set": [t.clone() for t in out_sets[cur["last"]]], "match": [t.clone() for t in (d_best, d_second, d_arg)],
+                 "input": in_state["last"], "steps_done": steps_done}
     # Per-kernel durations for the roofline: the same K steps once more with every kernel on ONE stream, so a
     # kernel's HIP-event span is its own duration (in the timed region the blur runs beside FAST/octree and the
     # spans stretch each other).  Not part of `value`.
@@ -647,39 +727,50 @@ def main():
             stage_ms["match"] = sum(a.elapsed_time(b) for a, b in match_events) / len(match_events)
         ex.set_serialize(False)
 
-    # parity gate on this rank: first and last frame of the batch vs the CPU oracle, bit for bit
-    d_kps, d_desc, d_counts = out_sets[cur["last"]]  # the set the last step wrote
-    if in_state["last"] == 1:
-        frames = frames[::-1]  # the last step extracted the reversed batch
-    counts = d_counts.cpu().numpy()
-    kps_h = d_kps.cpu().numpy()
-    desc_h = d_desc.cpu().numpy()
+    # Parity gate on rank 0: EVERY frame and EVERY match row of the last timed step's batch against the CPU oracle, bit for
+    # bit (the oracle runs on all host threads; the reference's contract is per frame, Frame.cc:555-563); then the same for
+    # the last step of the serialized pass (the other launch forms).
+    n_kp = float(timed_out["set"][2][1:, 0].float().mean().item())
     parity = None
-    n_kp = float(counts[1:, 0].mean())
     if rank == 0:
         import oracle_lib as ol
-        ref = ol.OracleExtractor(nfeat, 1.2, 8, 20, 7)
-        ok = True
-        for f in (0, B - 1):
-            mono, rk, rd = ref(frames[f])
-            n = int(counts[f + 1, 0])
-            ok &= n == len(rk) and int(counts[f + 1, 1]) == mono
-            ok &= kps_h[f + 1, :n].tobytes() == rk.tobytes() and np.array_equal(desc_h[f + 1, :n], rd)
-        if not args.no_match:
-            rb, rs, ra = ol.block_best2(desc_h[B, :int(counts[B, 0])], desc_h[B - 1, :int(counts[B - 1, 0])])
-            n = int(counts[B, 0])
-            ok &= np.array_equal(d_best[B - 1, :n].cpu().numpy(), rb) and np.array_equal(d_arg[B - 1, :n].cpu().numpy(), ra)
-            ok &= np.array_equal(d_second[B - 1, :n].cpu().numpy(), rs)
-            if exchange and K + Wu >= 3:
-                # the boundary match: rank 0's first frame against the LAST frame of the last rank, which only the
-                # record exchange delivered -- the oracle extracts that remote frame itself
-                _, _, rd_first = ref(frames[0])
-                _, _, rd_pred = ref(synth.sequence_frame(W, H, 1000, world * B - 1))
-                rb, rs, ra = ol.block_best2(rd_first, rd_pred)
-                n = len(rb)
-                ok &= np.array_equal(d_bbest[0, :n].cpu().numpy(), rb) and np.array_equal(d_barg[0, :n].cpu().numpy(), ra)
-                ok &= np.array_equal(d_bsecond[0, :n].cpu().numpy(), rs)
-        parity = bool(ok)
+        chk = BatchOracle(frames, nfeat, cap)
+
+        def gate(kps_t, desc_t, counts_t, match_t, input_index, nsteps):
+            idx = np.arange(B)[::-1].copy() if input_index == 1 else np.arange(B)
+            if exchange:
+                pidx = np.concatenate([[-1], idx[:-1]])  # row 0 is the boundary match below
+            elif nsteps < 2:
+                pidx = np.concatenate([[-1], idx[:-1]])  # no previous step: slot 0 is empty
+            else:
+                # slot 0 = the previous step's last frame: the other ordering's last frame when the inputs rotate
+                pidx = np.concatenate([[idx[0] if len(d_gray_in) == 2 else idx[-1]], idx[:-1]])
+            counts, kps_h, desc_h = counts_t.cpu().numpy(), kps_t.cpu().numpy(), desc_t.cpu().numpy()
+            bad_f = chk.frames(idx, counts[1:], kps_h[1:], desc_h[1:])
+            bad_r, nrows = [], 0
+            if not args.no_match:
+                bad_r, nrows = chk.match_rows(idx, pidx, *(t.cpu().numpy() for t in match_t))
+            return gate_report(bad_f, B, bad_r, nrows, chk.threads)
+
+        parity = gate(*timed_out["set"], timed_out["match"], timed_out["input"], timed_out["steps_done"])
+        parity["subject"] = "the last step of the timed region (outputs copied on the device after the clock stopped)"
+        if stage_ms:
+            ser = gate(*out_sets[cur["last"]], (d_best, d_second, d_arg), in_state["last"], steps_done + K)
+            parity["serialized_pass"] = {k: ser[k] for k in ("bit_exact_vs_oracle", "frames_checked", "match_rows_checked")}
+            parity["bit_exact_vs_oracle"] = bool(parity["bit_exact_vs_oracle"] and ser["bit_exact_vs_oracle"])
+        if exchange and not args.no_match and K + Wu >= 3:
+            # the boundary match: rank 0's first frame against the LAST frame of the last rank, which only the
+            # record exchange delivered -- the oracle extracts that remote frame itself
+            ref = ol.OracleExtractor(nfeat, 1.2, 8, 20, 7)
+            _, _, rd_first = ref(frames[0])
+            _, _, rd_pred = ref(synth.sequence_frame(W, H, 1000, world * B - 1))
+            rb, rs, ra = ol.block_best2(rd_first, rd_pred)
+            n = len(rb)
+            okb = np.array_equal(d_bbest[0, :n].cpu().numpy(), rb) and np.array_equal(d_barg[0, :n].cpu().numpy(), ra)
+            okb &= np.array_equal(d_bsecond[0, :n].cpu().numpy(), rs)
+            parity["boundary_match_row"] = bool(okb)
+            parity["bit_exact_vs_oracle"] = bool(parity["bit_exact_vs_oracle"] and okb)
+    del timed_out
 
     if rank != 0:
         if distributed:
@@ -852,7 +943,7 @@ def main():
                                  "steady clocks after ~0.1-0.2 s of load)",
                    "inputs": "resident in HBM" + (": two batches (the frames in forward / reverse order) alternate from step to "
                                                   "step" if rotate else "")},
-        "parity": {"bit_exact_vs_oracle": parity, "checked_frames": [0, B - 1]},
+        "parity": parity,
         "roofline": roofline, "cpu_baseline": cpu,
     }
     out.update(extra)

@@ -320,16 +320,31 @@ int vsg_copy_d2d_async(int device, void *dst, const void *src, size_t bytes, voi
  * arena, the launch call, the stream synchronisation (kernel + PCIe), the whole entry point} */
 int vsg_debug_call_profile(float us[4]);
 
-/* Pin (hipHostRegister) caller memory once so that vsg_orb_submit_batch / vsg_orb_wait DMA straight from / into it
- * instead of bouncing through the handle's staging buffers (cv::Mat::data of a reused frame buffer, the keypoint /
- * descriptor arrays of a ring of Frames).  Unpinned memory keeps working everywhere, through a staging memcpy. */
+/* ---- Pinned caller memory (the buffers behind cv::Mat::data of a reused frame, Frame::mvKeys / mDescriptors rings;
+ * the reference hands operator() plain heap memory: ORBextractor.h:59-61, Frame.cc:555-563) ---------------------------
+ * vsg_host_alloc / vsg_host_free: pinned host memory from the runtime's own allocator (hipHostMalloc), what the handle's
+ * staging slots use themselves.  Memory from vsg_host_alloc is the memory the device reads and writes IN PLACE
+ * (vsg_orb_submit_batch / vsg_orb_wait, the blocking entry points): no staging copy on either side.  So is hipHostMalloc
+ * memory the caller obtained elsewhere.
+ * vsg_host_register / vsg_host_unregister: pin ordinary heap memory after the fact (hipHostRegister).  Such memory is a
+ * user-pointer mapping of heap pages; on the round-4 test pool a page of a live, registered, in-use range lost its
+ * device mapping under heap churn (a fatal `Memory access fault by GPU`; profiles/r04_q_open_issue_gpu_fault.txt,
+ * tools/repro_hostregister.cpp).  By DEFAULT the library therefore treats registered memory like pageable memory: it is
+ * staged through the slot's own pinned buffers by the calling thread and the device never touches it.
+ * vsg_orb_set_direct_registered(h, 1) opts a handle in to in-place access of registered memory as well (hosts that
+ * register page-aligned, long-lived, mlock-ed arenas and have qualified their kernel / driver).
+ * vsg_host_kind(ptr, bytes): how the library classifies the WHOLE range [ptr, ptr + bytes) -- both ends must be pinned
+ * the same way under one contiguous device alias, otherwise the range counts as pageable. */
+#define VSG_HOST_PAGEABLE 0      /* staged through the slot's pinned buffers */
+#define VSG_HOST_LIB_ALLOC 1     /* inside one vsg_host_alloc range: in place */
+#define VSG_HOST_HIPHOSTMALLOC 2 /* somebody else's hipHostMalloc memory: in place */
+#define VSG_HOST_REGISTERED 3    /* hipHostRegister-ed heap memory: staged unless vsg_orb_set_direct_registered(h, 1) */
 int vsg_host_register(void *ptr, size_t bytes);
 int vsg_host_unregister(void *ptr);
-/* Pinned host memory from the runtime's own allocator (hipHostMalloc): the same direct paths as registered memory, without
- * the user-pointer mapping of ordinary heap pages underneath (INTEGRATION.md "Pinned host buffers"; what the handle's own
- * staging slots use).  For frame / keypoint / descriptor rings that live as long as the tracker. */
 int vsg_host_alloc(size_t bytes, void **out);
 int vsg_host_free(void *ptr);
+int vsg_host_kind(const void *ptr, size_t bytes);
+int vsg_orb_set_direct_registered(vsg_orb *h, int enable);
 
 /* ---- Asynchronous operator() batches (caller: Frame::ExtractORB, Frame.cc:555-563, in a throughput pipeline) -----
  * vsg_orb_submit_batch enqueues H2D + the stage chain + the output export of one batch into one of the handle's
@@ -337,9 +352,10 @@ int vsg_host_free(void *ptr);
  * holds a batch that has not been waited for, and when the image size differs from the handle's current one while any
  * ticket is still un-waited (a new size rebuilds the slots those tickets live in).  H2D of batch k+1 runs beside the kernels of batch k and the export of
  * batch k-1 (three streams).  kps / desc ([nframes][capacity] records, host memory) must stay valid until the wait
- * returns; if they are pinned (vsg_host_register) the device writes the n[i] records of every frame straight into
- * them, otherwise they are filled from the slot's pinned staging inside vsg_orb_wait -- either way only n[i] records
- * per frame cross PCIe, not `capacity`.  `gray` must stay valid until the wait returns if it is pinned; unpinned
+ * returns; if they are memory the device may touch in place (vsg_host_alloc / hipHostMalloc memory, see "Pinned caller
+ * memory" above) the device writes the n[i] records of every frame straight into them, otherwise they are filled from
+ * the slot's pinned staging inside vsg_orb_wait -- either way only n[i] records per frame cross PCIe, not `capacity`.
+ * `gray` must stay valid until the wait returns if it is such memory; any other
  * input is copied before submit returns (batches of 16 frames and more: by the calling thread and three helper
  * threads the handle keeps asleep between batches).  vsg_orb_wait(ticket) blocks until that batch is complete and delivers n[]
  * and mono_index[] (nframes entries each).  Tickets are waited for in submission order. */

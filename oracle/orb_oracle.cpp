@@ -1055,4 +1055,43 @@ double or_bench_throughput(const uint8_t *frames, int nframes, int rows, int col
   return (double)total.load() / dt;
 }
 
+/* Whole-batch checker input: operator() on every frame of a batch, `nthreads` host threads (one extractor each, frames
+ * dealt round-robin), outputs in fixed-capacity rows.  counts[f] = {n, monoIndex}; a frame whose n exceeds `capacity`
+ * gets counts[f] = {-2, -2}. */
+void or_extract_batch_mt(const uint8_t *frames, int nframes, int rows, int cols, int nfeatures, float scaleFactor,
+                         int nlevels, int iniThFAST, int minThFAST, int lap0, int lap1, int nthreads, int capacity,
+                         int *counts, OrKeyPoint *kps, uint8_t *desc) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > nframes) nthreads = nframes > 0 ? nframes : 1;
+  auto worker = [&](int tid) {
+    OrExtractor *e = or_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
+    for (int f = tid; f < nframes; f += nthreads) {
+      int n = 0;
+      const int mono = or_extract(e, frames + (size_t)f * rows * cols, rows, cols, cols, lap0, lap1,
+                                  kps + (size_t)f * capacity, desc + (size_t)f * capacity * 32, capacity, &n);
+      counts[2 * f] = mono == -2 ? -2 : n;
+      counts[2 * f + 1] = mono;
+    }
+    or_destroy(e);
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+  for (auto &t : th) t.join();
+}
+
+/* Row f of a batch of brute-force searches: descriptors a[f] (na[f] of them) against b[f] (nb[f]); rows of `capacity`
+ * descriptors, `a_stride` / `b_stride` bytes between consecutive frames' descriptor blocks. */
+void or_block_best2_batch_mt(const uint8_t *a, size_t a_stride, const int *na, const uint8_t *b, size_t b_stride,
+                             const int *nb, int nblocks, int capacity, int nthreads, int *best, int *second, int *argbest) {
+  if (nthreads < 1) nthreads = 1;
+  auto worker = [&](int tid) {
+    for (int f = tid; f < nblocks; f += nthreads)
+      or_block_best2(a + (size_t)f * a_stride, na[f], b + (size_t)f * b_stride, nb[f], best + (size_t)f * capacity,
+                     second + (size_t)f * capacity, argbest + (size_t)f * capacity);
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) th.emplace_back(worker, t);
+  for (auto &t : th) t.join();
+}
+
 }  // extern "C"

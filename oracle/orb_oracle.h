@@ -117,6 +117,14 @@ double or_bench_throughput(const uint8_t *frames, int nframes, int rows, int col
                            int nlevels, int iniThFAST, int minThFAST, int nthreads, double seconds, int do_match,
                            long *frames_done);
 
+/* ---- whole-batch checkers (bench.py's parity gate, tests): every frame / every match row of a batch on `nthreads`
+ * host threads, outputs in fixed-capacity rows; counts[f] = {n, monoIndex} ({-2,-2}: capacity too small) ---- */
+void or_extract_batch_mt(const uint8_t *frames, int nframes, int rows, int cols, int nfeatures, float scaleFactor,
+                         int nlevels, int iniThFAST, int minThFAST, int lap0, int lap1, int nthreads, int capacity,
+                         int *counts, OrKeyPoint *kps, uint8_t *desc);
+void or_block_best2_batch_mt(const uint8_t *a, size_t a_stride, const int *na, const uint8_t *b, size_t b_stride,
+                             const int *nb, int nblocks, int capacity, int nthreads, int *best, int *second, int *argbest);
+
 /* ---- ORBmatcher ---- */
 /* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2047-2063) */
 int or_descriptor_distance(const uint8_t *a, const uint8_t *b);

@@ -109,6 +109,12 @@ def lib():
         L.or_bench_throughput.restype = C.c_double
         L.or_bench_throughput.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_long)]
+        L.or_extract_batch_mt.restype = None
+        L.or_extract_batch_mt.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_void_p, _u8p]
+        L.or_block_best2_batch_mt.restype = None
+        L.or_block_best2_batch_mt.argtypes = [_u8p, C.c_size_t, _i32p, _u8p, C.c_size_t, _i32p, C.c_int, C.c_int, C.c_int,
+                                              _i32p, _i32p, _i32p]
         _lib = L
     return _lib
 
@@ -409,6 +415,62 @@ def bench_throughput(frames, nfeatures, nthreads, seconds, do_match=True, scale=
     fps = lib().or_bench_throughput(_ptr(f, _u8p), n, rows, cols, nfeatures, scale, nlevels, ini_th, min_th,
                                     int(nthreads), float(seconds), int(do_match), C.byref(done))
     return fps, done.value
+
+
+def host_threads():
+    """Host threads this process may really use: min(affinity, cgroup CPU quota)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def extract_batch(frames, nfeatures, capacity, scale=1.2, nlevels=8, ini_th=20, min_th=7, lapping=(0, 0), nthreads=None):
+    """operator() on EVERY frame of a batch (frames: [B, rows, cols] uint8) on all host threads.  Returns
+    (counts [B, 2] = n / monoIndex, kps [B, capacity] KP_DTYPE, desc [B, capacity, 32]); rows beyond n are zero."""
+    f = np.ascontiguousarray(frames, dtype=np.uint8)
+    B, rows, cols = f.shape
+    counts = np.zeros((B, 2), np.int32)
+    kps = np.zeros((B, capacity), KP_DTYPE)
+    desc = np.zeros((B, capacity, 32), np.uint8)
+    lib().or_extract_batch_mt(_ptr(f, _u8p), B, rows, cols, nfeatures, scale, nlevels, ini_th, min_th, lapping[0],
+                              lapping[1], nthreads or host_threads(), capacity, _ptr(counts, _i32p),
+                              kps.ctypes.data_as(C.c_void_p), _ptr(desc, _u8p))
+    return counts, kps, desc
+
+
+def block_best2_batch(a_desc, na, b_desc, nb, nthreads=None):
+    """Row f: brute-force best / second / argbest of a_desc[f, :na[f]] against b_desc[f, :nb[f]] (both [B, capacity, 32]),
+    on all host threads.  Returns three [B, capacity] int32 arrays (rows beyond na[f] are zero)."""
+    a, b = _u8c(a_desc), _u8c(b_desc)
+    B, cap = a.shape[0], a.shape[1]
+    assert b.shape[0] == B
+    na, nb = _i32c(na), _i32c(nb)
+    best, second, arg = (np.zeros((B, cap), np.int32) for _ in range(3))
+    lib().or_block_best2_batch_mt(_ptr(a, _u8p), a.strides[0], _ptr(na, _i32p), _ptr(b, _u8p), b.strides[0],
+                                  _ptr(nb, _i32p), B, cap, nthreads or host_threads(), _ptr(best, _i32p),
+                                  _ptr(second, _i32p), _ptr(arg, _i32p))
+    return best, second, arg
+
+
+def compare_batch(counts_gpu, kps_gpu, desc_gpu, counts_ref, kps_ref, desc_ref):
+    """Frames of a batch whose device output differs from the oracle's in any bit: list of frame indices.
+    counts: [B, 2]; kps: [B, cap] records or [B, cap, 28] bytes; desc: [B, cap, 32]."""
+    B = len(counts_ref)
+    kg = np.ascontiguousarray(kps_gpu).view(np.uint8).reshape(B, -1, 28)
+    kr = np.ascontiguousarray(kps_ref).view(np.uint8).reshape(B, -1, 28)
+    bad = []
+    for f in range(B):
+        n = int(counts_ref[f, 0])
+        if (int(counts_gpu[f, 0]) != n or int(counts_gpu[f, 1]) != int(counts_ref[f, 1]) or n < 0
+                or not np.array_equal(kg[f, :n], kr[f, :n]) or not np.array_equal(desc_gpu[f, :n], desc_ref[f, :n])):
+            bad.append(f)
+    return bad
 
 
 def search_window(q_desc, q_blocks, cand_off, cand_idx, t_desc, t_blocked, th_high):

@@ -78,6 +78,73 @@ def test_host_alloc_buffers_take_the_direct_paths():
         assert mono == rm and kps.tobytes() == rk.tobytes() and np.array_equal(desc, rd)
 
 
+def test_host_memory_kinds_are_told_apart_over_the_whole_range():
+    """vsg_host_kind: what decides the route.  hipHostMalloc memory from vsg_host_alloc, registered heap memory, pageable
+    memory; a range that starts inside an allocation and ends outside it is pageable (the whole range counts,
+    not its first byte)."""
+    import ctypes as C
+    L = orb.load_library()
+    heap = np.zeros(1 << 20, np.uint8)
+    assert orb.host_kind(heap) == "pageable"
+    orb.pin(heap)
+    try:
+        assert orb.host_kind(heap) == "registered"
+        assert orb.host_kind(heap[4096:8192]) == "registered"
+        # one byte beyond the registration: the range is not pinned as a whole
+        assert L.vsg_host_kind(C.c_void_p(heap.ctypes.data + 4096), heap.nbytes) in (0, 3)
+    finally:
+        orb.unpin(heap)
+    assert orb.host_kind(heap) == "pageable"
+    pa = orb.PinnedArray((1 << 20,))
+    assert orb.host_kind(pa.a) == "vsg_host_alloc" and orb.host_kind(pa.a[100:5000]) == "vsg_host_alloc"
+    assert L.vsg_host_kind(C.c_void_p(pa.ptr + 4096), 1 << 20) != 1  # runs past the allocation's end
+    import torch
+    t = torch.zeros(1 << 20, dtype=torch.uint8).pin_memory()  # somebody else's pinned allocation
+    assert L.vsg_host_kind(C.c_void_p(t.data_ptr()), t.numel()) in (2, 3)
+
+
+@pytest.mark.parametrize("opt_in", [False, True])
+def test_registered_memory_default_route_is_staged_and_the_opt_in_route_is_direct(opt_in):
+    """Registered (hipHostRegister) caller memory: by default the device never touches it -- the frames are staged through
+    the slot's hipHostMalloc buffers and the records are copied out inside vsg_orb_wait, so rows beyond n[f] ARE untouched
+    and the results are the oracle's; with vsg_orb_set_direct_registered(h, 1) the device reads and writes it in place.
+    Both routes, throughput (submit / wait) and latency (blocking single frame) forms, against the oracle."""
+    B = 3
+    ex = orb.ORBextractor(NF, 1.2, 8, 20, 7, max_batch=B)
+    ex.set_direct_registered(opt_in)
+    cap = ex.capacity(H, W)
+    fr = orb.pin(_frames(91, B))
+    kps, desc = orb.pin(np.zeros((B, cap), orb.KP_DTYPE)), orb.pin(np.full((B, cap, 32), 0xCD, np.uint8))
+    try:
+        for _ in range(3):
+            n, mono = ex.wait(ex.submit_batch(fr, kps, desc))
+            _check(fr, kps, desc, n, mono)
+            for f in range(B):
+                assert np.all(desc[f, n[f]:] == 0xCD)
+        mono, k1, d1 = ex(fr[2])
+        rm, rk, rd = ol.OracleExtractor(NF, 1.2, 8, 20, 7)(fr[2])
+        assert mono == rm and k1.tobytes() == rk.tobytes() and np.array_equal(d1, rd)
+    finally:
+        orb.unpin(fr), orb.unpin(kps), orb.unpin(desc)
+
+
+def test_pinned_array_memory_outlives_its_owner_while_views_exist():
+    """PinnedArray has a finalizer, and the allocation lives as long as any numpy view of it."""
+    import gc
+    pa = orb.PinnedArray((4, 8), np.uint8)
+    v = pa.a[1:3]
+    v[...] = 7
+    pa.free()
+    del pa
+    gc.collect()
+    assert orb.host_kind(v) == "vsg_host_alloc" and int(v.sum()) == 7 * 16  # still mapped, still ours
+    base = v.ctypes.data
+    del v
+    gc.collect()
+    import ctypes as C
+    assert orb.load_library().vsg_host_kind(C.c_void_p(base), 16) != 1       # released with the last view
+
+
 def test_new_image_size_is_refused_while_tickets_are_pending():
     """A different image size rebuilds the handle's buffers and frees the pipeline slots; with un-waited tickets that
     would drop their results silently, so the submit is refused and the pending batch stays intact."""

@@ -462,3 +462,39 @@ def test_search_for_triangulation_last_minimum_and_predicate():
     assert run(0b1000)[1].tolist() == [-1]        # the only passing pair is beyond TH_LOW
     assert run(None, (1, 1, 0, 1))[1].tolist() == [0]  # KF2 feature 2 already has a MapPoint
     assert ol.search_for_triangulation(d1, a1, [0], fv1, d2, a2, [1, 1, 1, 1], fv2, None, None, False)[0] == 0
+
+
+# ----------------------------------------------------------------------------- whole-batch checker (bench.py's gate)
+def test_batch_checker_equals_the_per_frame_calls():
+    """or_extract_batch_mt / or_block_best2_batch_mt (every frame of a batch on all host threads) against the plain
+    per-frame or_extract / or_block_best2 they wrap, with and without a lapping area, incl. a constant frame (n = 0)."""
+    W, H, nf = 320, 240, 300
+    frames = [synth.sequence_frame(W, H, 77, t) for t in range(6)] + [synth.constant_frame(W, H)]
+    frames += [synth.content_frame("value_noise", W, H, 78, t) for t in range(3)]
+    frames = np.stack(frames)
+    cap = nf + 3 * 8 + 64
+    for lap in ((0, 0), (100, 200)):
+        for threads in (1, 3, 16):
+            counts, kps, desc = ol.extract_batch(frames, nf, cap, lapping=lap, nthreads=threads)
+            ref = ol.OracleExtractor(nf, 1.2, 8, 20, 7)
+            for f in range(len(frames)):
+                mono, rk, rd = ref(frames[f], lap)
+                assert counts[f].tolist() == [len(rk), mono]
+                assert kps[f, :len(rk)].tobytes() == rk.tobytes() and np.array_equal(desc[f, :len(rk)], rd)
+                assert not desc[f, len(rk):].any()
+    assert counts[6].tolist() == [0, 0] or counts[6, 0] == 0
+    assert ol.compare_batch(counts, kps, desc, counts, kps, desc) == []
+    d2 = desc.copy()
+    d2[4, 3, 7] ^= 1
+    k2 = kps.copy()
+    k2[8]["angle"][0] = np.nextafter(k2[8]["angle"][0], np.float32(400))
+    assert ol.compare_batch(counts, kps, d2, counts, kps, desc) == [4]
+    assert ol.compare_batch(counts, k2, desc, counts, kps, desc) == [8]
+    # match rows: frame f against frame f - 1 (row 0 against the last frame)
+    prev = np.roll(desc, 1, axis=0)
+    nprev = np.roll(counts[:, 0], 1)
+    best, second, arg = ol.block_best2_batch(desc, counts[:, 0], prev, nprev, nthreads=5)
+    for f in range(len(frames)):
+        n = int(counts[f, 0])
+        rb, rs, ra = ol.block_best2(desc[f, :n], prev[f, :int(nprev[f])])
+        assert np.array_equal(best[f, :n], rb) and np.array_equal(second[f, :n], rs) and np.array_equal(arg[f, :n], ra)

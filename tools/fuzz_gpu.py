@@ -351,6 +351,7 @@ def case_undistort(rng):
 
 
 TRACE = False
+DIRECT_REGISTERED = False  # --direct-registered: registered arrays are read / written in place (opt-in route)
 ALLOC_ONLY = False  # --alloc-only: every pinned `async` case uses vsg_host_alloc memory
 ALLOC = True  # --registered-only: every pinned `async` case registers numpy arrays (the form profiles/r04_q_* is about)
 
@@ -366,8 +367,12 @@ def case_async(rng):
     lap = (int(rng.integers(-10, w)), int(rng.integers(-10, w + 50)))
     pinned = bool(rng.integers(0, 2))
     nb = int(rng.integers(1, 6))
-    # pinned buffers: registered numpy arrays, or (ALLOC, every second pinned case) arrays over vsg_host_alloc memory
+    # pinned buffers: registered numpy arrays, or (ALLOC, every second pinned case) arrays over vsg_host_alloc memory.
+    # Registered arrays take the library's DEFAULT route (staged like pageable memory, the device never touches them)
+    # unless --direct-registered opts the handle in to in-place access (the hunt mode of profiles/r04_q_* / r05_*)
     alloc = pinned and ALLOC and (bool(rng.integers(0, 2)) or ALLOC_ONLY)
+    if DIRECT_REGISTERED:
+        ex.set_direct_registered(True)
     tickets, bufs = [], []
     ok = True
     if TRACE:
@@ -419,6 +424,31 @@ def _finish(ex, ref, ticket, buf, lap, pinned):
 CASES = {"undistort": case_undistort, "resident": case_resident, "async": case_async, "window": case_window, "batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow}
 
 
+def run_child(args, argv):
+    """One run = one FRESH child process (never a re-exec of a process that has touched the GPU): a GPU memory access
+    fault kills the child, and the parent reports it as a failed run with the child's last lines."""
+    import subprocess
+    failed = 0
+    for r in range(args.runs):
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--child"] + [a for a in argv if not a.startswith("--runs")]
+        if "--trace" not in cmd:
+            cmd.append("--trace")  # the last line names the case a fault happened in
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        lines = p.stdout.splitlines()
+        tail = [x for x in lines if not x.startswith(("case ", "  async", "    submit", "REFUSED"))][-5:]
+        if p.returncode == 0:
+            print(f"run {r}: " + (tail[-1] if tail else "ok"), flush=True)
+        else:
+            failed += 1
+            last_case = [x for x in lines if x.startswith("case ")][-1:] or ["(no case printed)"]
+            how = f"signal {-p.returncode}" if p.returncode < 0 else f"exit code {p.returncode}"
+            print(f"run {r}: CHILD DIED ({how}) in / after '{last_case[0]}'", flush=True)
+            for x in lines[-12:]:
+                print("    | " + x, flush=True)
+    print(f"fuzz runs: {args.runs - failed} of {args.runs} clean", flush=True)
+    return 1 if failed else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
@@ -427,12 +457,20 @@ def main():
     ap.add_argument("--trace", action="store_true", help="print every case's index and name before it runs (a GPU fault kills the process: the last line names the case)")
     ap.add_argument("--registered-only", action="store_true", help="pinned `async` cases never use vsg_host_alloc memory")
     ap.add_argument("--alloc-only", action="store_true", help="pinned `async` cases always use vsg_host_alloc memory")
+    ap.add_argument("--direct-registered", action="store_true",
+                    help="hunt mode: handles opt in to in-place device access of registered numpy arrays "
+                         "(vsg_orb_set_direct_registered); default = the library's default route, which stages them")
     ap.add_argument("--stop-at", type=int, default=-1, help="run cases up to this index only (the random stream stays the same)")
+    ap.add_argument("--runs", type=int, default=1, help="repeat the run this many times, each in a fresh child process")
+    ap.add_argument("--child", action="store_true", help="(internal) this process runs the cases itself")
     args = ap.parse_args()
-    global TRACE, ALLOC, ALLOC_ONLY
+    if not args.child:
+        sys.exit(run_child(args, sys.argv[1:]))
+    global TRACE, ALLOC, ALLOC_ONLY, DIRECT_REGISTERED
     TRACE = args.trace
     ALLOC = not args.registered_only
     ALLOC_ONLY = args.alloc_only
+    DIRECT_REGISTERED = args.direct_registered
     rng = np.random.default_rng(args.seed)
     names = [n for n in CASES if not args.only or n in args.only.split(",")]
     counts = {n: 0 for n in names}

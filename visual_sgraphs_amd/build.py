@@ -53,7 +53,9 @@ def build(force=False, verbose=False):
     VSG_EXTRA_FLAGS (experiment builds, tools/build_variant.sh) can never be linked into a later normal build.  A
     build with extra flags always links (the library on disk may come from other flags)."""
     extra = os.environ.get("VSG_EXTRA_FLAGS", "").split()
-    if not force and not extra and not needs_build() and _flag_stamp() == _flag_key([]):
+    # an up-to-date library is taken as it is; only a stamp that is PRESENT and names other flags (an experiment build
+    # was linked last) forces a relink -- a missing stamp (packaged artefact, copied tree: _obj/ is git-ignored) does not
+    if not force and not extra and not needs_build() and _flag_stamp() in ("", _flag_key([])):
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     cflags = [f for f in FLAGS if f != "-shared"]

@@ -701,6 +701,8 @@ int vsg_orb_extract_to_frame(vsg_orb *h, const uint8_t *gray, int rows, int cols
                              vsg_keypoint *keys_un_out) {
   if (n) *n = 0;
   if (frame_check(f) != VSG_OK || !h || !kps || !desc || !n) return VSG_ERR_INVALID;
+  // the hook launches on the extractor's stream with the frame's device pointers: one device for both
+  if (vsg_orb_device_of(h) != f->device) return VSG_ERR_INVALID;
   ToFrameHook H;
   H.f = f, H.un_dev = nullptr;
   H.cam = CamModel();
@@ -718,8 +720,13 @@ int vsg_orb_extract_to_frame(vsg_orb *h, const uint8_t *gray, int rows, int cols
   vsg_orb_set_post_chain(h, to_frame_hook, &H);
   const int mono = vsg_orb_extract(h, gray, rows, cols, stride, lap0, lap1, kps, desc, capacity, n);
   vsg_orb_set_post_chain(h, nullptr, nullptr);  // (a call that failed before its submit leaves the hook unconsumed)
-  if (mono < 0) return mono;
-  if (*n > f->capacity) return VSG_ERR_CAPACITY;
+  if (mono < 0 || *n > f->capacity) {
+    // the bounds are already the new ones and the hook may have rewritten the device arrays: the frame holds nothing
+    // searchable any more, and says so
+    f->n = 0, f->nleft = -1, f->has_uright = false;
+    f->h_kps.clear();
+    return mono < 0 ? mono : VSG_ERR_CAPACITY;
+  }
   f->n = *n, f->nleft = -1, f->has_uright = false;
   if (H.cam.distorted) {
     f->h_kps.assign((const vsg_keypoint *)un_pin, (const vsg_keypoint *)un_pin + *n);

@@ -105,6 +105,7 @@ struct OrbOutputView {
 }  // namespace vsg
 
 int vsg_orb_output_view(vsg_orb *h, int index, vsg::OrbOutputView *v);
+int vsg_orb_device_of(const vsg_orb *h);  // the device the handle lives on
 // Work a blocking extract call enqueues on the handle's stream BEHIND its stage chain and in front of the completion event
 // the call waits for (vsg_orb_extract_to_frame: the resident frame's grid launch rides in operator()'s one wait).  The
 // hook is consumed by the next submit; `v` = frame 0 of that call's outputs.

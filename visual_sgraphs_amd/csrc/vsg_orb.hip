@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -169,6 +170,7 @@ struct vsg_orb {
   // streams exist so that consecutive batches overlap; a call that waits for its own batch has nothing to overlap
   // with, and each cross-stream event wait costs ~15 us of idle GPU (0.175 -> ~0.15 ms per single-frame operator()).
   bool one_stream = false;
+  bool direct_registered = false;  // vsg_orb_set_direct_registered: hipHostRegister-ed caller memory is used in place
   bool capturing = false;  // the calls below are being recorded into a ChainGraph (no timing events, no host waits)
   OutMirror mirror;        // set around an enqueue by the latency path: k_orient_desc also writes pinned host records
   ChainGraph chain[kChainGraphs];
@@ -649,18 +651,69 @@ struct NullStreamBridge {
   }
 };
 
-static bool host_pinned(const void *p, void **dev_alias) {
+// ---- caller host memory the device may touch IN PLACE -------------------------------------------------------------
+// Three kinds of pinned caller memory exist: (1) ranges this library handed out (vsg_host_alloc = hipHostMalloc, kept in
+// the registry below), (2) hipHostMalloc memory of somebody else (torch's pinned tensors, the caller's own ring), (3)
+// ordinary heap pages pinned after the fact (vsg_host_register = hipHostRegister: a user-pointer mapping).  In-place DMA
+// and kernel access to kind (3) is where profiles/r04_q_open_issue_gpu_fault.txt happened (a page of a live registered
+// range lost its device mapping; tools/repro_hostregister.cpp is the library-free reproducer), so kind (3) is staged
+// through the slot's own hipHostMalloc buffers like pageable memory unless the caller opts in per handle
+// (vsg_orb_set_direct_registered).  The WHOLE range [p, p + bytes) is validated, not its first byte.
+static std::mutex g_alloc_mu;
+static std::map<uintptr_t, size_t> g_allocs;  // vsg_host_alloc: base -> bytes
+
+static bool in_lib_alloc(const void *p, size_t bytes) {
+  const uintptr_t a = (uintptr_t)p;
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  auto it = g_allocs.upper_bound(a);
+  if (it == g_allocs.begin()) return false;
+  --it;
+  return a >= it->first && bytes <= it->second && a - it->first <= it->second - bytes;
+}
+
+// what the runtime says about one byte: 0 = pageable / unknown, 2 = hipHostMalloc memory, 3 = hipHostRegister-ed memory
+static int runtime_kind(const void *p, void **dev_alias) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
     (void)hipGetLastError();  // pageable memory: not an error
-    return false;
+    return VSG_HOST_PAGEABLE;
   }
-  if (a.type != hipMemoryTypeHost) return false;
+  if (a.type != hipMemoryTypeHost) return VSG_HOST_PAGEABLE;
   if (dev_alias) *dev_alias = a.devicePointer;
+  // hipHostGetFlags answers for hipHostMalloc allocations only (it refuses registered user memory)
+  unsigned int fl = 0;
+  if (hipHostGetFlags(&fl, const_cast<void *>(p)) == hipSuccess) return VSG_HOST_HIPHOSTMALLOC;
+  (void)hipGetLastError();
+  return VSG_HOST_REGISTERED;
+}
+
+static int host_kind(const void *p, size_t bytes, void **dev_alias) {
+  if (!p || !bytes) return VSG_HOST_PAGEABLE;
+  void *a0 = nullptr, *a1 = nullptr;
+  const int k0 = runtime_kind(p, &a0);
+  if (k0 == VSG_HOST_PAGEABLE) return k0;
+  const int k1 = bytes > 1 ? runtime_kind((const uint8_t *)p + bytes - 1, &a1) : k0;
+  // both ends pinned the same way, one contiguous device alias (two registrations back to back would differ here)
+  if (k1 != k0 || (bytes > 1 && (uintptr_t)a1 - (uintptr_t)a0 != bytes - 1)) return VSG_HOST_PAGEABLE;
+  if (dev_alias) *dev_alias = a0;
+  if (in_lib_alloc(p, bytes)) return VSG_HOST_LIB_ALLOC;
+  return k0;
+}
+
+// may the device read / write [p, p + bytes) in place on behalf of handle h?
+static bool host_direct(const vsg_orb *h, const void *p, size_t bytes, void **dev_alias) {
+  void *alias = nullptr;
+  const int k = host_kind(p, bytes, &alias);
+  if (k == VSG_HOST_PAGEABLE || !alias) return false;
+  if (k == VSG_HOST_REGISTERED && !h->direct_registered) return false;
+  if (dev_alias) *dev_alias = alias;
   return true;
 }
 
-
+// bytes spanned by `nframes` images of rows x cols (row stride `stride`, frame stride `frame_stride`)
+static size_t image_span(int nframes, size_t frame_stride, int rows, int cols, int stride) {
+  return (size_t)(nframes - 1) * frame_stride + (size_t)(rows - 1) * stride + (size_t)cols;
+}
 
 extern "C" {
 
@@ -689,11 +742,32 @@ int vsg_host_alloc(size_t bytes, void **out) {
   if (!out || !bytes) return VSG_ERR_INVALID;
   *out = nullptr;
   HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocMapped | hipHostMallocPortable));
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  g_allocs[(uintptr_t)*out] = bytes;
   return VSG_OK;
 }
 int vsg_host_free(void *ptr) {
   if (!ptr) return VSG_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    auto it = g_allocs.find((uintptr_t)ptr);
+    if (it == g_allocs.end()) {
+      set_err("vsg_host_free: not a pointer vsg_host_alloc returned");
+      return VSG_ERR_INVALID;
+    }
+    g_allocs.erase(it);
+  }
   HIP_TRY(hipHostFree(ptr));
+  return VSG_OK;
+}
+int vsg_host_kind(const void *ptr, size_t bytes) {
+  if (!ptr || !bytes) return VSG_ERR_INVALID;
+  return host_kind(ptr, bytes, nullptr);
+}
+int vsg_orb_set_direct_registered(vsg_orb *h, int enable) {
+  if (!h) return VSG_ERR_INVALID;
+  h->direct_registered = enable != 0;
+  free_chain_graphs(h);  // a recorded chain holds the source / destination route it was recorded with
   return VSG_OK;
 }
 
@@ -911,9 +985,11 @@ struct ExportDst {
   bool direct = false;
   void *dk = nullptr, *dd = nullptr;
 };
-static ExportDst export_dst(vsg_keypoint *kps, uint8_t *desc, int capacity) {
+static ExportDst export_dst(const vsg_orb *h, int nframes, vsg_keypoint *kps, uint8_t *desc, int capacity) {
   ExportDst e;
-  e.direct = kps && desc && capacity > 0 && host_pinned(kps, &e.dk) && host_pinned(desc, &e.dd) && e.dk && e.dd;
+  const size_t recs = (size_t)nframes * (capacity > 0 ? capacity : 0);
+  e.direct = kps && desc && capacity > 0 && host_direct(h, kps, recs * sizeof(vsg_keypoint), &e.dk) &&
+             host_direct(h, desc, recs * 32, &e.dd) && e.dk && e.dd;
   return e;
 }
 
@@ -975,7 +1051,7 @@ static int finish_submit(vsg_orb *h, Slot &S, int nframes, vsg_keypoint *kps, ui
 // kernels of the chain + export for slot S, behind its ev_in
 static int submit_tail(vsg_orb *h, Slot &S, int nframes, int lap0, int lap1, vsg_keypoint *kps, uint8_t *desc,
                        int capacity) {
-  const ExportDst E = export_dst(kps, desc, capacity);
+  const ExportDst E = export_dst(h, nframes, kps, desc, capacity);
   int rc = tail_stream_work(h, S, nframes, lap0, lap1, E, capacity);
   if (rc != VSG_OK) return rc;
   return finish_submit(h, S, nframes, kps, desc, capacity, E.direct);
@@ -1090,7 +1166,7 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
     const uint8_t *src_dev;
     size_t sframe;
     int sstride;
-    if (host_pinned(gray, &alias) && alias) {
+    if (host_direct(h, gray, image_span(nframes, frame_stride, rows, cols, stride), &alias)) {
       src_dev = (const uint8_t *)alias, sframe = frame_stride, sstride = stride;
     } else {
       for (int f = 0; f < nframes; f++) {
@@ -1103,13 +1179,13 @@ int vsg_orb_submit_batch(vsg_orb *h, const uint8_t *gray, int nframes, size_t fr
       }
       src_dev = S.h_in_dev, sframe = fbytes, sstride = ip;
     }
-    const ExportDst E = export_dst(kps, desc, capacity);
+    const ExportDst E = export_dst(h, nframes, kps, desc, capacity);
     rc = run_chain(h, S, (int)(Sp - h->slot), src_dev, sframe, sstride, nframes, lap0, lap1, E, capacity);
     if (rc != VSG_OK) return rc;
     return finish_submit(h, S, nframes, kps, desc, capacity, E.direct);
   }
-  if (host_pinned(gray, nullptr)) {
-    // pinned caller memory: DMA straight from it (one descriptor for a packed batch, one 2-D copy per frame otherwise)
+  if (host_direct(h, gray, image_span(nframes, frame_stride, rows, cols, stride), nullptr)) {
+    // pinned caller memory the device may read in place: DMA straight from it (one descriptor for a packed batch, one 2-D copy per frame otherwise)
     if (packed) {
       HIP_TRY(hipMemcpyAsync(S.d_in, gray, fbytes * nframes, hipMemcpyHostToDevice, s_in));
     } else {
@@ -1419,6 +1495,8 @@ static int pyr_view(vsg_orb *h, int frame, PyrView &v) {
 void vsg_orb_set_post_chain(vsg_orb *h, vsg_post_chain_fn fn, void *ctx) {
   if (h) h->post_fn = fn, h->post_ctx = ctx;
 }
+
+int vsg_orb_device_of(const vsg_orb *h) { return h ? h->device : -1; }
 
 int vsg_orb_output_view(vsg_orb *h, int index, OrbOutputView *v) {
   if (!h || !v || !h->have_last || index < 0 || index >= h->last_frames) return VSG_ERR_INVALID;

@@ -63,6 +63,8 @@ EXPORTS = [
     # round 4
     "vsg_orb_set_pyramid_tiling", "vsg_shard_rank", "vsg_camera_image_bounds", "vsg_frame_from_extractor_undistort",
     "vsg_orb_extract_to_frame",
+    # round 5
+    "vsg_host_kind", "vsg_orb_set_direct_registered",
 ]
 
 
@@ -204,6 +206,8 @@ def load_library():
     L.vsg_host_unregister.argtypes = [vp]
     L.vsg_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.vsg_host_free.argtypes = [vp]
+    L.vsg_host_kind.argtypes = [vp, C.c_size_t]
+    L.vsg_orb_set_direct_registered.argtypes = [vp, ci]
     L.vsg_orb_slots.argtypes = [vp]
     L.vsg_orb_chain_graph_launches.argtypes = [vp]
     L.vsg_orb_chain_graph_launches.restype = C.c_long
@@ -365,6 +369,11 @@ class ORBextractor:
         """ComputePyramid's launch form: -1 automatic (default), 0 / 1 / 2 the fused tilings (32 / 36 / 16 px), 3 one launch
         per level."""
         _check(self._L.vsg_orb_set_pyramid_tiling(self._h, int(which)), "vsg_orb_set_pyramid_tiling")
+
+    def set_direct_registered(self, on=True):
+        """Opt in to in-place device access of hipHostRegister-ed caller memory (`pin()`); by default such memory is staged
+        like pageable memory and only vsg_host_alloc / hipHostMalloc memory (`PinnedArray`) is touched in place."""
+        _check(self._L.vsg_orb_set_direct_registered(self._h, int(on)), "vsg_orb_set_direct_registered")
 
     def capacity(self, rows, cols):
         return _check(self._L.vsg_orb_capacity(self._h, int(rows), int(cols)), "vsg_orb_capacity")
@@ -801,8 +810,18 @@ def ComputeDistinctiveDescriptors(desc, off, device=0):
     return best[:len(o) - 1]
 
 
+HOST_KINDS = {0: "pageable", 1: "vsg_host_alloc", 2: "hipHostMalloc", 3: "registered"}
+
+
+def host_kind(array):
+    """How the library classifies the whole memory range of a (contiguous) numpy array: one of HOST_KINDS' values."""
+    a = np.asarray(array)
+    return HOST_KINDS[_check(load_library().vsg_host_kind(C.c_void_p(a.ctypes.data), max(a.nbytes, 1)), "vsg_host_kind")]
+
+
 def pin(array):
-    """hipHostRegister a numpy array (vsg_host_register): extraction DMAs straight from / into pinned memory."""
+    """hipHostRegister a numpy array (vsg_host_register).  Registered heap memory is only touched in place by handles
+    that opted in (ORBextractor.set_direct_registered); prefer PinnedArray."""
     a = np.ascontiguousarray(array)
     _check(load_library().vsg_host_register(C.c_void_p(a.ctypes.data), a.nbytes), "vsg_host_register")
     return a
@@ -812,23 +831,44 @@ def unpin(array):
     _check(load_library().vsg_host_unregister(C.c_void_p(array.ctypes.data)), "vsg_host_unregister")
 
 
+def _host_free(ptr):
+    lib = _lib
+    if lib is not None and ptr:
+        lib.vsg_host_free(C.c_void_p(ptr))
+
+
 class PinnedArray:
-    """A numpy array over hipHostMalloc memory (vsg_host_alloc): pinned without a user-pointer mapping of heap pages underneath.
-    `.a` is the array; free() (or the context manager) releases the memory -- the array must not be used afterwards."""
+    """A numpy array over hipHostMalloc memory (vsg_host_alloc): pinned without a user-pointer mapping of heap pages
+    underneath; the device reads / writes it in place.  `.a` is the array.  The memory lives as long as this object OR any
+    numpy view derived from `.a` (the views hold the buffer object whose finalizer frees the allocation), so dropping the
+    PinnedArray while a view is still in use -- or in flight -- is safe.  free() releases this object's own references;
+    the allocation itself goes when the last view does."""
+
+    class _Buf:  # owns the allocation; exposes it through the buffer protocol via a ctypes array
+        def __init__(self, nbytes):
+            import weakref
+            p = C.c_void_p()
+            _check(load_library().vsg_host_alloc(C.c_size_t(nbytes), C.byref(p)), "vsg_host_alloc")
+            self.ptr = p.value
+            self.raw = (C.c_uint8 * nbytes).from_address(self.ptr)
+            # the ctypes array is what numpy keeps alive (ndarray.base chain): its death frees the memory
+            self._fin = weakref.finalize(self.raw, _host_free, self.ptr)
 
     def __init__(self, shape, dtype=np.uint8):
         dt = np.dtype(dtype)
-        n = int(np.prod(shape)) * dt.itemsize
-        self._p = C.c_void_p()
-        _check(load_library().vsg_host_alloc(C.c_size_t(max(n, 1)), C.byref(self._p)), "vsg_host_alloc")
-        buf = (C.c_uint8 * max(n, 1)).from_address(self._p.value)
-        self.a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        count = int(np.prod(shape))
+        n = max(count * dt.itemsize, 1)
+        buf = PinnedArray._Buf(n)
+        self._ptr = buf.ptr
+        self.a = np.frombuffer(buf.raw, dtype=dt, count=count).reshape(shape)
+
+    @property
+    def ptr(self):
+        return self._ptr
 
     def free(self):
-        if self._p is not None and self._p.value:
-            self.a = None
-            _check(load_library().vsg_host_free(self._p), "vsg_host_free")
-            self._p = None
+        """Drop this object's array.  The pinned memory is released as soon as no numpy view of it is left."""
+        self.a = None
 
     def __enter__(self):
         return self
