@@ -26,6 +26,26 @@ sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+TRAFFIC_FILE = "traffic_r05.json"   # profiles/: PMC counters per launch (tools/profile_round.sh), tied to a source hash
+ISA_MIX_FILE = "r05_isa_mix.json"
+
+
+def pmc_traffic(key, stage):
+    """HBM bytes per launch of `stage` for workload key (e.g. "C4/128") from the committed counter file -- FETCH_SIZE
+    (doubled for the 16-B-per-lane readers, MI355X_MICROARCH.md HBM section) + WRITE_SIZE -- or None when the file is
+    absent or was measured on other sources."""
+    try:
+        sys.path.insert(0, str(ROOT / "tools"))
+        from source_hash import source_hash
+        doc = json.load(open(ROOT / "profiles" / TRAFFIC_FILE))
+        if doc.get("source_hash") != source_hash():
+            return None
+        tr = doc.get(key, {}).get(stage)
+        if not tr or "fetch_bytes" not in tr:
+            return None
+        return {"fast": 2, "pyramid": 2}.get(stage, 1) * tr["fetch_bytes"] + tr.get("write_bytes", 0)
+    except (OSError, ValueError, KeyError, ImportError):
+        return None
 
 WORKLOADS = {
     # name: (W, H, nfeatures)
@@ -291,11 +311,22 @@ def device_rate(workload, batch, steps, device, cpu_seconds=3.0, uniq=None, labe
     gate = gate_report(bad_f, batch, bad_r, nrows, chk.threads)
     ok = gate["bit_exact_vs_oracle"]
     v1, n1 = ol.bench_throughput(uniq, nfeat, 1, cpu_seconds, do_match=True)
+    # the dominant kernel (FAST) against the HBM roof, as the headline prices it: P bytes per frame x the frames of one
+    # launch / the launch's HIP-event duration inside the timed steps
+    roof = None
+    if fast_ms:
+        stages, bytes_per_frame = algorithmic_bytes(ex, float(counts[1:, 0].mean()))
+        ach = stages["fast"] * batch / (fast_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "fast", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(f"{workload}/{batch}", "fast"),
+                "launch_ms": round(fast_ms, 4), "bytes_per_launch": int(stages["fast"] * batch),
+                "pipeline_achieved_GBs": round(bytes_per_frame * batch * steps / dt / 1e9, 2),
+                "bytes_per_frame": int(bytes_per_frame)}
     return {"workload": label or f"{workload}: {W}x{H}, nFeatures={nfeat}, extract + brute-force best2 match vs previous "
                                  f"frame, {batch}-frame batches resident in HBM", "unit": "frames/s", "frames_per_step": batch,
             "frames_per_s": round(batch * steps / dt, 1), "keypoints_per_frame": round(float(counts[1:, 0].mean()), 1),
             "fast_ms": round(fast_ms, 4) if fast_ms else None,
-            "parity": bool(ok), "parity_gate": gate,
+            "parity": bool(ok), "parity_gate": gate, "roofline": roof,
             "cpu_oracle": {"frames_per_s": round(v1, 2), "threads": 1, "kind": "port", "frames": n1}}
 
 
@@ -347,6 +378,96 @@ def visible_gpu_count():
     except (OSError, ValueError):
         pass
     return None
+
+
+def preflight(n, batch, workload):
+    """`bench.py --gpus N --preflight`: what a first N-GPU run can trip over, checked in a CHILD process (it touches
+    the GPU) before any rank is started -- visible devices; that libvsg_orb.so and torch resolve the SAME libamdhip64
+    (bench.py hands torch streams and device pointers to a library that links the runtime by soname: INTEGRATION.md
+    section 5); that the RCCL the library will dlopen exports what vsg_shard_* binds, ncclCommCount included; the record
+    exchange's receive buffer (world x batch records per rank) against the free memory of every device.  Prints one JSON
+    object; exit code 0 only when every check passed."""
+    import subprocess
+    code = r"""
+import ctypes as C, json, os, sys
+sys.path.insert(0, %r)
+n, batch, workload = %d, %d, %r
+out = {"requested_gpus": n, "checks": {}}
+def check(name, ok, **info):
+    out["checks"][name] = dict(ok=bool(ok), **info)
+class DlInfo(C.Structure):
+    _fields_ = [("fname", C.c_char_p), ("fbase", C.c_void_p), ("sname", C.c_char_p), ("saddr", C.c_void_p)]
+libdl = C.CDLL(None)
+libdl.dladdr.argtypes = [C.c_void_p, C.POINTER(DlInfo)]
+def owner(lib, sym):
+    addr = C.cast(getattr(lib, sym), C.c_void_p).value
+    info = DlInfo()
+    libdl.dladdr(addr, C.byref(info))
+    return addr, (info.fname or b"?").decode()
+import torch
+from visual_sgraphs_amd import orb, sharding
+import bench
+L = orb.load_library()
+tlib = None
+tdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+for cand in ("libtorch_hip.so", "libc10_hip.so"):
+    try:
+        tlib = C.CDLL(os.path.join(tdir, cand)); break
+    except OSError:
+        pass
+try:
+    a_vsg, f_vsg = owner(L, "hipMalloc")
+    a_t, f_t = owner(tlib, "hipMalloc") if tlib is not None else (None, "torch's HIP library not found")
+    check("one_hip_runtime", a_vsg == a_t and os.path.realpath(f_vsg) == os.path.realpath(f_t), libvsg_orb=f_vsg, torch=f_t)
+except Exception as e:
+    check("one_hip_runtime", False, error=repr(e))
+ndev_t = torch.cuda.device_count()
+ndev_v = L.vsg_device_count()
+check("devices", ndev_t >= n and ndev_v >= n, torch_device_count=ndev_t, vsg_device_count=ndev_v,
+      visible_without_runtime=bench.visible_gpu_count())
+rccl = None
+for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+    try:
+        rccl = C.CDLL(name, mode=C.RTLD_GLOBAL); break
+    except OSError:
+        pass
+need = ["ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclSend", "ncclRecv", "ncclGroupStart",
+        "ncclGroupEnd", "ncclGetErrorString", "ncclCommCount", "ncclCommUserRank"]
+if rccl is None:
+    check("rccl", False, error="librccl.so.1 not loadable")
+else:
+    missing = [x for x in need if not hasattr(rccl, x)]
+    _, f_r = owner(rccl, "ncclCommCount") if not missing else (None, "?")
+    uid = (C.c_uint8 * 128)()
+    rc = L.vsg_shard_unique_id(uid)
+    check("rccl", not missing and rc == 0, library=f_r, missing=missing, vsg_shard_unique_id=rc)
+W, H, nfeat = bench.WORKLOADS[workload]
+cap = nfeat + 3 * 8  # >= vsg_orb_capacity for 8 levels; the handle's own figure needs a device allocation
+rec = sharding.record_bytes(cap + 64)
+recv = n * batch * rec
+resident = batch * (W * H * 2 + int(2.6 * 1.38 * W * H) + 2 * (cap + 64) * 60 + 3 * (cap + 64) * 4)
+mem = []
+for d in range(min(n, ndev_t)):
+    free, total = torch.cuda.mem_get_info(d)
+    mem.append({"device": d, "free_bytes": free, "total_bytes": total})
+check("memory", bool(mem) and all(m["free_bytes"] > 2 * (recv + resident) for m in mem), exchange_recv_bytes_per_rank=recv,
+      resident_estimate_bytes_per_rank=resident, devices=mem)
+out["ok"] = all(c["ok"] for c in out["checks"].values())
+print(json.dumps(out))
+sys.exit(0 if out["ok"] else 4)
+""" % (str(ROOT), n, batch, workload)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(ROOT))
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr[-2000:])
+        if lines:
+            bad = [k for k, v in json.loads(lines[-1])["checks"].items() if not v["ok"]]
+            sys.stderr.write(f"bench.py --preflight: FAILED checks: {bad}\n")
+        else:
+            sys.stderr.write(f"bench.py --preflight: the probe died (exit code {r.returncode})\n")
+    return r.returncode
 
 
 def launch_ranks(args, argv):
@@ -426,11 +547,17 @@ def main():
                     help="N > 1: allgather = every rank's whole batch of records into every GPU (what north_star words); "
                          "boundary = only what the chunk partition needs, one ncclSend/ncclRecv of the last frame's record "
                          "to the successor rank")
+    ap.add_argument("--preflight", action="store_true",
+                    help="check what an N-GPU run depends on (devices, one HIP runtime for torch and libvsg_orb.so, RCCL's "
+                         "exports, memory for the exchange buffers) in a child process, print the findings and exit; "
+                         "non-zero exit with the reason when a check fails")
     ap.add_argument("--one-device", action="store_true",
                     help="dry run of the multi-rank path on a single GPU: every rank uses device 0 (needs gloo)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.preflight:
+        sys.exit(preflight(args.gpus, args.batch, args.workload))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args, sys.argv[1:]))  # before torch / HIP are touched in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -797,7 +924,7 @@ def main():
             sys.path.insert(0, str(ROOT / "tools"))
             from source_hash import source_hash
             doc, traffic_source = {}, None
-            for name in ("traffic_r04.json",):
+            for name in (TRAFFIC_FILE,):
                 if (ROOT / "profiles" / name).exists():
                     doc = json.load(open(ROOT / "profiles" / name))
                     traffic_source = f"profiles/{name}"
@@ -808,8 +935,8 @@ def main():
                                 f"{source_hash()}: PMC figures withheld (re-run tools/profile_round.sh)")
                 doc = {}
             isa = {}
-            if (ROOT / "profiles" / "r04_isa_mix.json").exists():
-                isa = json.load(open(ROOT / "profiles" / "r04_isa_mix.json"))
+            if (ROOT / "profiles" / ISA_MIX_FILE).exists():
+                isa = json.load(open(ROOT / "profiles" / ISA_MIX_FILE))
                 if isa.get("source_hash") != source_hash():
                     isa = {}
             per_stage = doc.get(f"{args.workload}/{B}", {})

@@ -666,8 +666,8 @@ class ResidentMatcher {
 };
 
 // Asynchronous operator() batches over the handle's pipeline slots (vsg_orb_submit_batch / vsg_orb_wait): H2D of
-// batch k+1 beside the kernels of batch k beside the export of batch k-1.  Pin the buffers once with
-// vsg_host_register for zero-copy staging.
+// batch k+1 beside the kernels of batch k beside the export of batch k-1.  Buffers from vsg_host_alloc (hipHostMalloc) are
+// read and written by the device in place; any other memory is staged (include/vsg_orb.h, "Pinned caller memory").
 inline int SubmitBatch(const ORBextractor &ex, const uint8_t *gray, int nframes, size_t frameStride, int rows, int cols,
                        int stride, const std::vector<int> &vLappingArea, vsg_keypoint *kps, uint8_t *desc,
                        int capacity) {

@@ -34,3 +34,23 @@ def test_visible_gpu_count_reads_the_visibility_variables(monkeypatch):
     assert bench.visible_gpu_count() == 3
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
     assert bench.visible_gpu_count() == 0
+
+
+def test_preflight_reports_every_check_and_fails_without_devices():
+    """`bench.py --gpus N --preflight` on a box without a GPU: the probe runs in a child, prints its findings, names the
+    failed checks on stderr and exits non-zero; the checks that need no device (one HIP runtime for torch and
+    libvsg_orb.so, RCCL's exports) are answered all the same."""
+    import json
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    r = _run(["--gpus", "8", "--preflight"])
+    assert r.returncode != 0 and "FAILED checks" in r.stderr and "devices" in r.stderr
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["ok"] is False and d["requested_gpus"] == 8
+    assert set(d["checks"]) == {"one_hip_runtime", "devices", "rccl", "memory"}
+    assert d["checks"]["one_hip_runtime"]["ok"] is True
+    assert d["checks"]["one_hip_runtime"]["libvsg_orb"] == d["checks"]["one_hip_runtime"]["torch"]
+    assert d["checks"]["rccl"]["ok"] is True and d["checks"]["rccl"]["missing"] == []
+    assert d["checks"]["memory"]["exchange_recv_bytes_per_rank"] > 200e6  # 8 x 512 records of ~64 KB

@@ -21,7 +21,16 @@ def _pin():
 
 
 def _cases(P):
-    return sorted({k.split("/")[0] for k in P.files if k.endswith("/params")})
+    """every pinned extractor case: (name, frame, nfeatures, nlevels, lapping area)"""
+    out = []
+    for name in sorted({k.split("/")[0] for k in P.files if k.endswith("/params")}):
+        w, h, seed, div, nf, nl, lap0, lap1 = P[name + "/params"].tolist()
+        out.append((name, synth.frame(w, h, seed, amplitude_div=div), nf, nl, (lap0, lap1)))
+    # one frame per content class (pin_dump.cpp "content_<kind>_<width>"): value noise, checkerboards, gratings, ...
+    for name in sorted({k.split("/")[0] for k in P.files if k.endswith("/content_params")}):
+        w, h, seq, t, nf, nl, kind, _ = P[name + "/content_params"].tolist()
+        out.append((name, synth.content_frame(synth.CONTENT_CLASSES[kind], w, h, seq, t), nf, nl, (0, 0)))
+    return out
 
 
 def _taps(P):
@@ -102,11 +111,10 @@ def test_device_undistortion_equals_opencv():
 def test_oracle_equals_reference_extractor(stage):
     P = _pin()
     taps = _taps(P)
-    for name in _cases(P):
-        w, h, seed, div, nf, nl, lap0, lap1 = P[name + "/params"].tolist()
+    for name, frame, nf, nl, lap in _cases(P):
         e = ol.OracleExtractor(nf, 1.2, nl, 20, 7)
         e.set_blur_taps(taps)
-        mono, kps, desc = e(synth.frame(w, h, seed, amplitude_div=div), (lap0, lap1))
+        mono, kps, desc = e(frame, lap)
         if stage == "pyramid":
             for l in range(nl):
                 assert np.array_equal(e.pyramid_level(l, with_border=True), P[f"{name}/pyr{l}"]), (name, l)
@@ -126,14 +134,14 @@ def test_hip_path_equals_reference_extractor():
     from visual_sgraphs_amd import orb
     P = _pin()
     taps = _taps(P)
-    for name in _cases(P):
-        w, h, seed, div, nf, nl, lap0, lap1 = P[name + "/params"].tolist()
+    for name, frame, nf, nl, lap in _cases(P):
         ex = orb.ORBextractor(nf, 1.2, nl, 20, 7)
-        ex.capacity(h, w)
+        ex.capacity(*frame.shape)
         ex.set_blur_taps(taps)
-        mono, kps, desc = ex(synth.frame(w, h, seed, amplitude_div=div), vLappingArea=(lap0, lap1))
+        mono, kps, desc = ex(frame, vLappingArea=lap)
         assert mono == int(P[name + "/mono"][0])
         assert kps.tobytes() == P[name + "/kps"].tobytes() and np.array_equal(desc, P[name + "/desc"].reshape(-1, 32))
         for l in range(nl):
             assert np.array_equal(ex.image_pyramid(l, with_border=True), P[f"{name}/pyr{l}"])
+            # the device blurs every level (the blur rides beside the octree); so does pin_dump
             assert np.array_equal(ex.blurred_level(l), P[f"{name}/blur{l}"])

@@ -220,3 +220,193 @@ def test_cross_rank_boundary_match_equals_single_process_sequence():
     for t in range(1, n_frames):
         want = [a.tolist() for a in ol.block_best2(descs[t], descs[t - 1])]
         assert got[t] == want, t
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# World 4 and 8: what a first 8-GPU run exercises for the first time, rehearsed on gloo with the CPU
+# oracle standing in for the device -- the all-gather at that width, the boundary WRAP (rank 0's predecessor is the last
+# rank's last frame of the PREVIOUS step) over several steps, and C5's two-ranks-per-stream ownership.
+def _spawn(target, world, args, timeout=300):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=timeout) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    return res
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_all_gather_records_gloo_world_4_and_8(world):
+    res = sorted(_spawn(_worker, world, (2, 24)))
+    assert res == [(r, True) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_boundary_exchange_gloo_world_4_and_8(world):
+    res = sorted(_spawn(_boundary_worker, world, (2, 24)))
+    assert res == [(r, True) for r in range(world)]
+
+
+def _steps_worker(rank, world, port, B, n_steps, exchange, q):
+    """bench.py's multi-step protocol on gloo: step s deals frames [(s * world + r) * B, + B) of ONE global sequence to
+    rank r; frames 1 .. B-1 of a chunk are matched locally at once, the chunk's FIRST frame one step later against the
+    record the exchange of its own step delivered -- the predecessor rank's last frame, for rank 0 the LAST rank's last
+    frame of the PREVIOUS step, kept across the step like bench.py's d_tail buffers."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import oracle_lib as ol
+    from visual_sgraphs_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = ol.OracleExtractor(200, 1.2, 4, 20, 7)
+    cap = 200 + 3 * 4 + 16
+    rec = sharding.record_bytes(cap)
+    pred_rank = (rank - 1) % world
+    out, tail, first_prev = {}, None, None
+    for s in range(n_steps):
+        t0 = (s * world + rank) * B
+        counts = torch.zeros((B, 2), dtype=torch.int32)
+        kps = torch.zeros((B, cap, 28), dtype=torch.uint8)
+        desc = torch.zeros((B, cap, 32), dtype=torch.uint8)
+        local = []
+        for i in range(B):
+            mono, k, d = ex(synth.sequence_frame(160, 120, 11, t0 + i))
+            local.append(d)
+            counts[i, 0], counts[i, 1] = len(k), mono
+            kps[i, :len(k)] = torch.from_numpy(k.view(np.uint8).reshape(len(k), 28))
+            desc[i, :len(k)] = torch.from_numpy(d)
+        for i in range(1, B):
+            out[t0 + i] = [a.tolist() for a in ol.block_best2(local[i], local[i - 1])]
+        if exchange == "allgather":
+            send = torch.zeros((B, rec), dtype=torch.uint8)
+            recv = torch.zeros((world * B, rec), dtype=torch.uint8)
+            sharding.pack_records(send, counts, kps, desc)
+            sharding.all_gather_records(recv, send)
+            c, _, d = sharding.unpack_records(recv, cap)
+            row = pred_rank * B + (B - 1)
+            got_pred = d[row, :int(c[row, 0])].numpy().copy()           # the predecessor rank's last frame, THIS step
+            lrow = (world - 1) * B + (B - 1)
+            got_last = d[lrow, :int(c[lrow, 0])].numpy().copy()         # the last rank's last frame, THIS step
+        else:
+            send = torch.zeros((1, rec), dtype=torch.uint8)
+            recv = torch.zeros((1, rec), dtype=torch.uint8)
+            sharding.pack_records(send, counts[B - 1:], kps[B - 1:], desc[B - 1:])
+            sharding.send_recv_boundary(recv, send, (rank + 1) % world, pred_rank)
+            c, _, d = sharding.unpack_records(recv, cap)
+            got_pred = d[0, :int(c[0, 0])].numpy().copy()
+            got_last = got_pred                                          # rank 0 receives from the last rank
+        # the chunk's first frame: rank > 0 against this step's record of rank - 1; rank 0 against the LAST step's tail
+        if rank > 0:
+            out[t0] = [a.tolist() for a in ol.block_best2(local[0], got_pred)]
+        elif tail is not None:
+            out[t0] = [a.tolist() for a in ol.block_best2(local[0], tail)]
+        if rank == 0:
+            tail = got_last  # what the NEXT step's first frame (the next global frame) is matched against
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,exchange", [(4, "allgather"), (8, "allgather"), (8, "boundary")])
+def test_multi_step_sequence_with_the_boundary_wrap(world, exchange):
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import oracle_lib as ol
+    from visual_sgraphs_amd import synth
+    B, n_steps = 2, 3
+    got = {}
+    for _, o in _spawn(_steps_worker, world, (B, n_steps, exchange)):
+        got.update(o)
+    n = n_steps * world * B
+    ex = ol.OracleExtractor(200, 1.2, 4, 20, 7)
+    descs = [ex(synth.sequence_frame(160, 120, 11, t))[2] for t in range(n)]
+    assert sorted(got) == list(range(1, n))  # every frame but the very first has been matched exactly once
+    for t in range(1, n):
+        assert got[t] == [a.tolist() for a in ol.block_best2(descs[t], descs[t - 1])], t
+
+
+def _c5_worker(rank, world, port, n_streams, n_frames, q):
+    """Config C5 on `world` ranks: camera stream s, frame f belongs to rank stream_to_rank(s, n_streams, world, f) (two
+    ranks per stream at world 8, taking its frames alternately).  Every rank extracts what it owns, the records are
+    all-gathered (padded to the per-rank maximum), and a frame is matched against its predecessor of the SAME stream,
+    which the other sharer of the stream extracted."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import oracle_lib as ol
+    from visual_sgraphs_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    owned = [(s, f) for f in range(n_frames) for s in range(n_streams)
+             if sharding.stream_to_rank(s, n_streams, world, f) == rank]
+    per_rank = max(sum(1 for f in range(n_frames) for s in range(n_streams)
+                       if sharding.stream_to_rank(s, n_streams, world, f) == r) for r in range(world))
+    ex = ol.OracleExtractor(200, 1.2, 4, 20, 7)
+    cap = 200 + 3 * 4 + 16
+    counts = torch.full((per_rank, 2), -1, dtype=torch.int32)
+    kps = torch.zeros((per_rank, cap, 28), dtype=torch.uint8)
+    desc = torch.zeros((per_rank, cap, 32), dtype=torch.uint8)
+    for i, (s, f) in enumerate(owned):
+        mono, k, d = ex(synth.sequence_frame(160, 120, 40 + s, f))
+        counts[i, 0], counts[i, 1] = len(k), mono
+        kps[i, :len(k)] = torch.from_numpy(k.view(np.uint8).reshape(len(k), 28))
+        desc[i, :len(k)] = torch.from_numpy(d)
+    rec = sharding.record_bytes(cap)
+    send = torch.zeros((per_rank, rec), dtype=torch.uint8)
+    recv = torch.zeros((world * per_rank, rec), dtype=torch.uint8)
+    sharding.pack_records(send, counts, kps, desc)
+    sharding.all_gather_records(recv, send)
+    c, _, d = sharding.unpack_records(recv, cap)
+
+    def record(s, f):  # where (stream, frame) sits in the gathered buffer: owner rank, position in its owned list
+        r = sharding.stream_to_rank(s, n_streams, world, f)
+        pos = [(ss, ff) for ff in range(n_frames) for ss in range(n_streams)
+               if sharding.stream_to_rank(ss, n_streams, world, ff) == r].index((s, f))
+        row = r * per_rank + pos
+        return d[row, :int(c[row, 0])].numpy()
+
+    out = {}
+    for (s, f) in owned:
+        if f > 0:
+            out[(s, f)] = [a.tolist() for a in ol.block_best2(record(s, f), record(s, f - 1))]
+    q.put((rank, owned, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_c5_stream_ownership_two_ranks_per_stream(world):
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent))
+    import oracle_lib as ol
+    from visual_sgraphs_amd import synth
+    n_streams, n_frames = 4, 4
+    res = _spawn(_c5_worker, world, (n_streams, n_frames))
+    owned_all = sorted(sum((o for _, o, _ in res), []))
+    assert owned_all == sorted((s, f) for s in range(n_streams) for f in range(n_frames))  # each frame exactly once
+    by_rank = {r: o for r, o, _ in res}
+    if world == 8:  # two ranks per stream: s and s + 4, alternating frames
+        for s in range(n_streams):
+            assert [f for ss, f in by_rank[s] if ss == s] == [0, 2] and [f for ss, f in by_rank[s + 4] if ss == s] == [1, 3]
+            assert all(ss == s for ss, _ in by_rank[s] + by_rank[s + 4])
+    got = {}
+    for _, _, o in res:
+        got.update(o)
+    ex = ol.OracleExtractor(200, 1.2, 4, 20, 7)
+    for s in range(n_streams):
+        descs = [ex(synth.sequence_frame(160, 120, 40 + s, f))[2] for f in range(n_frames)]
+        for f in range(1, n_frames):
+            assert got[(s, f)] == [a.tolist() for a in ol.block_best2(descs[f], descs[f - 1])], (s, f)

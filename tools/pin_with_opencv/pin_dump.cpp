@@ -4,6 +4,9 @@
 //   * mvImagePyramid[l] WITH its 19 px border                                   (ORBextractor.cc:1171-1195)
 //   * the blurred level the descriptors are computed on: clone + GaussianBlur   (:1129-1130)
 //   * keypoints (all 7 cv::KeyPoint fields) and descriptors, monoIndex          (:1083-1169)
+//   * the same for one frame of EVERY content class of synth.CONTENT_CLASSES / vsg_synth_content_frame (value noise,
+//     1 / 2 px checkerboards, gratings, defocus, saturation, ramps, salt and pepper): they stress cv::resize, the blur
+//     and the minThFAST retry differently from rectangles + noise; cases "content_<kind>"
 // and the version-sensitive OpenCV pieces as observations:
 //   * cv::getGaussianKernel(7, 2) and the 8-bit GaussianBlur response to a one-column line image (= the 8.8 taps)
 //   * cv::cvtColor(RGB2GRAY / BGR2GRAY) on 4096 seeded colours (= the fixed-point gray coefficients)
@@ -79,6 +82,41 @@ int main(int argc, char **argv) {
       cv::Mat work = roi.clone();  // exactly :1129-1130
       cv::GaussianBlur(work, work, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
       put_mat_u8(p + "blur" + std::to_string(l), work);
+    }
+  }
+
+  // one frame per content class (kinds in the order of synth.CONTENT_CLASSES): 320x240 / 500 / 4 levels, and the two
+  // natural-image stand-ins plus the worst case for FAST once more at the headline geometry (640x480 / 1000 / 8 levels)
+  {
+    struct CCase {
+      int kind, w, h, seq, t, nf, nl;
+    };
+    std::vector<CCase> cc;
+    for (int kind = 0; kind < VSG_CONTENT_COUNT; kind++) cc.push_back({kind, 320, 240, 5000, 1, 500, 4});
+    for (int kind : {VSG_CONTENT_VALUE_NOISE, VSG_CONTENT_DEFOCUS, VSG_CONTENT_GRATING}) cc.push_back({kind, 640, 480, 5000, 3, 1000, 8});
+    for (const CCase &c : cc) {
+      cv::Mat img(c.h, c.w, CV_8UC1);
+      if (vsg_synth_content_frame(c.kind, c.w, c.h, (uint32_t)c.seq, c.t, img.data, img.step)) return 3;
+      VS_GRAPHS::ORBextractor ex(c.nf, 1.2f, c.nl, 20, 7);
+      std::vector<cv::KeyPoint> kps;
+      cv::Mat desc;
+      std::vector<int> lap{0, 0};
+      const int mono = ex(img, cv::Mat(), kps, desc, lap);
+      const std::string p = "content_" + std::to_string(c.kind) + "_" + std::to_string(c.w) + "/";
+      const int32_t params[8] = {c.w, c.h, c.seq, c.t, c.nf, c.nl, c.kind, 0};
+      put(p + "content_params", 1, {8}, params);
+      const int32_t mono32 = mono;
+      put(p + "mono", 1, {1}, &mono32);
+      put(p + "kps", 0, {(uint32_t)kps.size(), 28}, kps.data());
+      if (!desc.empty()) put_mat_u8(p + "desc", desc); else put(p + "desc", 0, {0, 32}, nullptr);
+      for (int l = 0; l < c.nl; l++) {
+        cv::Mat roi = ex.mvImagePyramid[l], full = roi;
+        full.adjustROI(19, 19, 19, 19);
+        put_mat_u8(p + "pyr" + std::to_string(l), full);
+        cv::Mat work = roi.clone();
+        cv::GaussianBlur(work, work, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
+        put_mat_u8(p + "blur" + std::to_string(l), work);
+      }
     }
   }
 

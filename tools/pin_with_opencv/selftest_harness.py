@@ -88,6 +88,21 @@ def main():
                     put(f, f"{name}/pyr{l}", e.pyramid_level(l, with_border=True))
                     b = e.blurred_level(l)
                     put(f, f"{name}/blur{l}", b if b is not None else ol.gaussian_blur7(e.pyramid_level(l)))
+            # pin_dump's content-class cases (kind index = position in synth.CONTENT_CLASSES)
+            ccases = [(k, 320, 240, 5000, 1, 500, 4) for k in range(len(synth.CONTENT_CLASSES))]
+            ccases += [(synth.CONTENT_CLASSES.index(n), 640, 480, 5000, 3, 1000, 8) for n in ("value_noise", "defocus", "grating")]
+            for kind, w, h, seq, t_, nf, nl in ccases:
+                e = ol.OracleExtractor(nf, 1.2, nl, 20, 7)
+                mono, kps, desc = e(synth.content_frame(synth.CONTENT_CLASSES[kind], w, h, seq, t_))
+                name = f"content_{kind}_{w}"
+                put(f, name + "/content_params", np.array([w, h, seq, t_, nf, nl, kind, 0], np.int32))
+                put(f, name + "/mono", np.array([mono], np.int32))
+                put(f, name + "/kps", kps.view(np.uint8).reshape(len(kps), 28))
+                put(f, name + "/desc", desc)
+                for l in range(nl):
+                    put(f, f"{name}/pyr{l}", e.pyramid_level(l, with_border=True))
+                    b = e.blurred_level(l)
+                    put(f, f"{name}/blur{l}", b if b is not None else ol.gaussian_blur7(e.pyramid_level(l)))
             t = [18, 34, 49, 55, 49, 34, 18]
             put(f, "gauss/kernel_f64", np.array(t, np.float64) / 256)
             put(f, "gauss/line_response", np.array([[(257 * k * 255 + 32768) >> 16 for k in t]], np.uint8))

@@ -33,10 +33,40 @@ cp $OUT/stats_timed/*/*kernel_stats.csv $OUT/kernel_stats_timed_region.csv 2>/de
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > $OUT/pmc_sq.txt 2>&1
 python3 tools/make_traffic_json.py C2/512 $OUT/traffic.json $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > /dev/null 2>&1
+# ---- the other configurations a scaling curve / the stereo chain are quoted on: C4 = 1280x720 / 2000 in
+# 128-frame batches (kernel stats of the timed region and of the serialised step, FETCH / WRITE / SQ / wait passes ->
+# traffic.json["C4/128"]), C3 = the stereo pair chain of tools/config_chain.cpp (k_stereo, k_bow_descend, k_search_by_bow)
+B4="python3 bench.py --cpu-seconds 0 --no-stage-timing --no-extras --workload C4 --batch 128"
+VSG_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -- $B4 > $OUT/c4_bench_rocprof.json 2>> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats_timed -- $B4 > $OUT/c4_bench_rocprof_timed.json 2>> $OUT/rocprof.err
+pass4() {
+  local name=$1; shift
+  VSG_NO_OVERLAP=1 timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/c4_pmc_$name -- $B4 $P > /dev/null 2>>$OUT/rocprof.err
+}
+pass4 fetch FETCH_SIZE
+pass4 write WRITE_SIZE
+pass4 sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES
+pass4 wait SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
+cp $OUT/c4_stats/*/*kernel_stats.csv $OUT/c4_kernel_stats.csv 2>/dev/null
+cp $OUT/c4_stats_timed/*/*kernel_stats.csv $OUT/c4_kernel_stats_timed_region.csv 2>/dev/null
+python3 tools/pmc_summary.py $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_sq $OUT/c4_pmc_wait > $OUT/c4_pmc.txt 2>&1
+python3 tools/make_traffic_json.py C4/128 $OUT/traffic.json $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_sq $OUT/c4_pmc_wait > /dev/null 2>&1
+C3="tools/_bin/config_chain 2 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_stats -- $C3 > $OUT/c3_chain_rocprof.json 2>> $OUT/rocprof.err
+cp $OUT/c3_stats/*/*kernel_stats.csv $OUT/c3_chain_kernel_stats.csv 2>/dev/null
+pass3() {
+  local name=$1; shift
+  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/c3_pmc_$name -- $C3 > /dev/null 2>>$OUT/rocprof.err
+}
+pass3 fetch FETCH_SIZE
+pass3 write WRITE_SIZE
+pass3 sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES
+pass3 wait SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
+python3 tools/pmc_summary.py $OUT/c3_pmc_fetch $OUT/c3_pmc_write $OUT/c3_pmc_sq $OUT/c3_pmc_wait > $OUT/c3_chain_pmc.txt 2>&1
 # the un-profiled bench line LAST among the bench runs, with this build's own counters in place (bench.py only quotes a
 # traffic file whose source hash is the hash of the sources it runs on): the copies under profiles/ on this box are scratch
-cp $OUT/traffic.json profiles/traffic_r04.json
-python3 tools/isa_mix.py > $OUT/isa_mix.json 2>> $OUT/rocprof.err && cp $OUT/isa_mix.json profiles/r04_isa_mix.json
+cp $OUT/traffic.json profiles/traffic_r05.json
+python3 tools/isa_mix.py > $OUT/isa_mix.json 2>> $OUT/rocprof.err && cp $OUT/isa_mix.json profiles/r05_isa_mix.json
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_abi -- tools/_bin/abi_latency 300 > $OUT/abi_latency.json 2>> $OUT/rocprof.err
 cp $OUT/stats_abi/*/*kernel_stats.csv $OUT/abi_kernel_stats.csv 2>/dev/null
@@ -44,6 +74,6 @@ tools/_bin/config_chain 2 4 > $OUT/config_chain.json 2>> $OUT/rocprof.err
 rocprofv3 --kernel-trace --output-format csv -d $OUT/lt -- tools/_bin/extract_latency 300 > $OUT/extract_latency.json 2>> $OUT/rocprof.err
 python3 tools/latency_timeline.py $OUT/lt > $OUT/frame_timeline.txt 2>&1
 for e in "" VSG_GRAPH=1; do echo "== ${e:-default}"; env $e tools/_bin/extract_latency 1000; done > $OUT/frame_latency_ab.txt 2>&1
-rm -rf $OUT/stats/*/*kernel_trace.csv $OUT/stats_timed/*/*kernel_trace.csv $OUT/pmc_fused $OUT/stats_abi/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp $OUT/lt
+rm -rf $OUT/c4_stats/*/*kernel_trace.csv $OUT/c4_stats_timed/*/*kernel_trace.csv $OUT/c3_stats/*/*kernel_trace.csv $OUT/c4_pmc_* $OUT/c3_pmc_* $OUT/stats/*/*kernel_trace.csv $OUT/stats_timed/*/*kernel_trace.csv $OUT/pmc_fused $OUT/stats_abi/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp $OUT/lt
 cat $OUT/bench.json | cut -c1-1200
-cat $OUT/pmc_traffic.txt $OUT/pmc_sq.txt
+cat $OUT/pmc_traffic.txt $OUT/pmc_sq.txt $OUT/c4_pmc.txt $OUT/c3_chain_pmc.txt

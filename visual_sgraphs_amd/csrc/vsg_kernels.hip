@@ -304,6 +304,11 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
   return v;
 }
 
+// phase 1b's trigger (see there): the share of a cell's runs that hold a passer, per pass
+#ifndef VSG_FAST_STAGE_B_NUM
+#define VSG_FAST_STAGE_B_NUM(pass) 4
+#define VSG_FAST_STAGE_B_DEN(pass) 3
+#endif
 #ifndef VSG_FAST_NT
 #define VSG_FAST_NT 128  // threads per FAST cell: 2 waves keep more cells resident per CU than 4 (measured: 0.47 ->
                          // 0.38 ms per 256 frames); 1 wave runs out of LDS before it runs out of wave slots
@@ -631,6 +636,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             }
           }
           __syncthreads();
+          // No pixel of the cell passes the necessary test at iniThFAST (every cell of smooth natural content: value noise,
+          // defocus -- the tracking thresholds of ORBextractor.cc:832-851 were chosen so that such cells take the second
+          // threshold): nothing to unpack, score or suppress, and the 6-bit tile is still whole (the queue that aliases it
+          // was never written) -- straight to the minThFAST sweep.  Cell-uniform.
+          if (pass == 0 && s_cnt[4] == 0 && minTh < thr) {
+            thr = minTh;
+            continue;
+          }
 #ifndef VSG_FAST_NO_STAGE_B
           // ---- phase 1b, dense cells only: the same necessary test on the two DIAGONAL ring pairs (ring positions 2 / 10
           // and 6 / 14: offsets (+-2, +-2)), run entry by run entry.  A 9-arc holds one pixel of every opposite pair, so a
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
           // 1.05-2.47 ms instead of 0.39 per 512 frames: profiles/r04_b_bench_content_sweep_before_stage_b.json).  The
           // diagonals see the other phase of a checkerboard and the iso-line of a ramp.  Cell-uniform trigger: more than
           // three quarters of the cell's runs hold a passer.
-          if (4 * s_cnt[4] > 3 * nruns) {
+          if (VSG_FAST_STAGE_B_NUM(pass) * s_cnt[4] > VSG_FAST_STAGE_B_DEN(pass) * nruns) {
             const int nr1 = s_cnt[4];
             const int t6 = thr <= 2 ? 0 : min(64, (thr + 1) >> 2);
             const uint32_t K = (uint32_t)(128 - t6) * 0x01010101u, H = 0x80808080u;
@@ -1563,55 +1576,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   // keypoint with every lane computing the same value; FP64 issues at a fraction of the FP32 rate on this part.
   int k_l[kOdKpPerWave], k_slot[kOdKpPerWave], k_m01[kOdKpPerWave], k_m10[kOdKpPerWave], nk = 0;
   uint32_t k_c[kOdKpPerWave];
-#pragma unroll
-  for (int j = 0; j < kOdKpPerWave; j++) k_l[j] = 0, k_slot[j] = 0, k_m01[j] = 0, k_m10[j] = 0, k_c[j] = 0;
+  // the workgroup's keypoints: wave w takes blk.x * 4 * G + 4 * j + w  (adjacent keypoints run side by side)
+  const int g0 = __builtin_amdgcn_readfirstlane(blk.x * kOdKpPerWave * 4 + (tid >> 6));
+  if (g0 >= n) return;  // nothing for this wave (no barrier follows)
+  nk = min(kOdKpPerWave, (n - g0 + 3) >> 2);  // wave-uniform
+  // (level, candidate, slot) of every keypoint of the wave first -- past the wave's last keypoint: the last one again, so
+  // that every address below is valid and the loads need no branch -- then ALL their patch loads in one block of
+  // back-to-back instructions: one trip to L2 / HBM for the wave's three IC_Angle patches instead of three dependent ones
+  // (load, reduce, next keypoint's load; 59 % of this kernel's wave-cycles were parked at waits, profiles/r04_r_pmc_*)
 #pragma unroll
   for (int j = 0; j < kOdKpPerWave; j++) {
-  // the workgroup's keypoints: wave w takes blk.x * 4 * G + 4 * j + w  (adjacent keypoints run side by side)
-  const int g = __builtin_amdgcn_readfirstlane((blk.x * kOdKpPerWave + j) * 4 + (tid >> 6));
-  if (g >= n) break;
-  int l, slot;
-  uint32_t c;
-  if (kSelf) {
-    l = 0;
-    while (g >= s_hdr[3 + l]) l++;  // wave-uniform (g < n = s_hdr[2 + kMaxLevels])
-    l = __builtin_amdgcn_readfirstlane(l);
-    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)sel[(size_t)frame * fg->sel_frame + fg->lv[l].sel_off + (g - s_hdr[2 + l])]);
-    slot = g;
-  } else {
-    l = __builtin_amdgcn_readfirstlane(rec[j].z);
-    c = (uint32_t)__builtin_amdgcn_readfirstlane(rec[j].x);
-    slot = __builtin_amdgcn_readfirstlane(rec[j].y);
+    const int jj = min(j, nk - 1);
+    const int g = g0 + 4 * jj;
+    int l, slot;
+    uint32_t c;
+    if (kSelf) {
+      l = 0;
+      while (g >= s_hdr[3 + l]) l++;  // wave-uniform (g < n = s_hdr[2 + kMaxLevels])
+      l = __builtin_amdgcn_readfirstlane(l);
+      c = sel[(size_t)frame * fg->sel_frame + fg->lv[l].sel_off + (g - s_hdr[2 + l])];
+      slot = g;
+    } else {
+      int4 r = rec[0];
+#pragma unroll
+      for (int q = 1; q < kOdKpPerWave; q++)
+        if (q == jj) r = rec[q];
+      l = r.z, c = (uint32_t)r.x, slot = r.y;
+    }
+    k_l[j] = l, k_slot[j] = slot, k_c[j] = c;
   }
-  const LevelGeom &L = fg->lv[l];
-  const int cx = VSG_CAND_X(c) + kFastBorder, cy = VSG_CAND_Y(c) + kFastBorder;
-  int upitch;
-  const uint8_t *unblurred = level_ptr(fg, s0, pyr, frame, l, upitch);
+#pragma unroll
+  for (int j = 0; j < kOdKpPerWave; j++) {
+    k_l[j] = __builtin_amdgcn_readfirstlane(k_l[j]);
+    k_c[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)k_c[j]);
+    k_slot[j] = __builtin_amdgcn_readfirstlane(k_slot[j]);
+  }
   // ---- IC_Angle: 16 rows x 4 (unaligned) qwords per load instruction, 2 instructions per patch; the disc mask and
   // the column weights are v_dot4_u32_u8 operands.  The row past v = 15 (it = 1, row = 15) is masked by the weights;
   // those lanes re-read row 30 so the address stays inside the image.
-  int m10 = 0, m01 = 0;
   {
     const int row = lane >> 2, col = lane & 3;
-    const uint8_t *ptr = unblurred + (ptrdiff_t)(cy - kHalfPatch) * upitch + (cx - kHalfPatch) + 8 * col;
-    const u32x2 p0 = *(const u64_global_unaligned *)(ptr + (ptrdiff_t)row * upitch);
-    const u32x2 p1 = *(const u64_global_unaligned *)(ptr + (ptrdiff_t)min(row + 16, 2 * kHalfPatch) * upitch);
+    u32x2 p0[kOdKpPerWave], p1[kOdKpPerWave];
+#pragma unroll
+    for (int j = 0; j < kOdKpPerWave; j++) {
+      const int cx = VSG_CAND_X(k_c[j]) + kFastBorder, cy = VSG_CAND_Y(k_c[j]) + kFastBorder;
+      int upitch;
+      const uint8_t *unblurred = level_ptr(fg, s0, pyr, frame, k_l[j], upitch);
+      const uint8_t *ptr = unblurred + (ptrdiff_t)(cy - kHalfPatch) * upitch + (cx - kHalfPatch) + 8 * col;
+      p0[j] = *(const u64_global_unaligned *)(ptr + (ptrdiff_t)row * upitch);
+      p1[j] = *(const u64_global_unaligned *)(ptr + (ptrdiff_t)min(row + 16, 2 * kHalfPatch) * upitch);
+    }
     const u32x4 w0 = s_ic[lane], w1 = s_ic[64 + lane];
-    // S = sum p, U = sum (u + 15) p over the lane's 2 x 8 pixels;  v = 16 it + row - 15
-    const uint32_t s0p = __builtin_amdgcn_udot4(p0.y, w0.z, __builtin_amdgcn_udot4(p0.x, w0.x, 0u, false), false);
-    const uint32_t s1p = __builtin_amdgcn_udot4(p1.y, w1.z, __builtin_amdgcn_udot4(p1.x, w1.x, 0u, false), false);
-    uint32_t su = __builtin_amdgcn_udot4(p0.x, w0.y, 0u, false);
-    su = __builtin_amdgcn_udot4(p0.y, w0.w, su, false);
-    su = __builtin_amdgcn_udot4(p1.x, w1.y, su, false);
-    su = __builtin_amdgcn_udot4(p1.y, w1.w, su, false);
-    const int S = (int)(s0p + s1p);
-    m10 = (int)su - kHalfPatch * S;
-    m01 = (row - kHalfPatch) * S + 16 * (int)s1p;
-  }
-  k_m10[j] = wave_sum_i32(m10);
-  k_m01[j] = wave_sum_i32(m01);
-  k_l[j] = l, k_slot[j] = slot, k_c[j] = c;
-  nk = j + 1;
+#pragma unroll
+    for (int j = 0; j < kOdKpPerWave; j++) {
+      // S = sum p, U = sum (u + 15) p over the lane's 2 x 8 pixels;  v = 16 it + row - 15
+      const uint32_t s0p = __builtin_amdgcn_udot4(p0[j].y, w0.z, __builtin_amdgcn_udot4(p0[j].x, w0.x, 0u, false), false);
+      const uint32_t s1p = __builtin_amdgcn_udot4(p1[j].y, w1.z, __builtin_amdgcn_udot4(p1[j].x, w1.x, 0u, false), false);
+      uint32_t su = __builtin_amdgcn_udot4(p0[j].x, w0.y, 0u, false);
+      su = __builtin_amdgcn_udot4(p0[j].y, w0.w, su, false);
+      su = __builtin_amdgcn_udot4(p1[j].x, w1.y, su, false);
+      su = __builtin_amdgcn_udot4(p1[j].y, w1.w, su, false);
+      const int S = (int)(s0p + s1p);
+      k_m10[j] = wave_sum_i32((int)su - kHalfPatch * S);
+      k_m01[j] = wave_sum_i32((row - kHalfPatch) * S + 16 * (int)s1p);
+    }
   }
   // ---- descriptor patch.  The rotated pattern stays within +-18 px of the centre (|p| <= 18.38).  The blurred level is TILED
   // (16 x 4 pixels per 64-byte line, LevelGeom::btx): the 37 x 37 patch touches 10 tile rows x 3 or 4 tile columns, and
@@ -1651,9 +1679,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
       if (it * 16 + tg < T.nt) *(u32x4 *)(patch + T.lo[it]) = T.pv[it];
     }
   };
-  // the first keypoint's tiles are requested before the rotations are evaluated (~120 instructions with nothing in flight)
-  TileLoad T0;
-  if (nk > 0) issue_tiles(k_l[0], k_c[0], T0);
+  // the first keypoint's tiles are requested before the rotations are evaluated (~120 instructions with nothing in flight);
+  // keypoint j + 1's are requested right after keypoint j's have been written to LDS, so they travel while the 256 tests
+  // of keypoint j run (two register sets, alternating: the kernel holds 8 waves per SIMD on 36 registers, 16 more are free)
+  TileLoad TA, TB;
+  issue_tiles(k_l[0], k_c[0], TA);
   float ang_v, a_v, b_v;
   {
     float fm01 = 0.0f, fm10 = 0.0f;
@@ -1673,12 +1703,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a_v), j));
   const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b_v), j));
   const int tx0 = (cx - kPatchR) >> 4, ty0 = (cy - kPatchR) >> 2;
-  if (j == 0) {
-    commit_tiles(T0);
+  if ((j & 1) == 0) {
+    commit_tiles(TA);
+    if (j + 1 < kOdKpPerWave && j + 1 < nk) issue_tiles(k_l[j + 1], k_c[j + 1], TB);
   } else {
-    TileLoad T;
-    issue_tiles(l, c, T);
-    commit_tiles(T);
+    commit_tiles(TB);
+    if (j + 1 < kOdKpPerWave && j + 1 < nk) issue_tiles(k_l[j + 1], k_c[j + 1], TA);
   }
   // the patch is private to this wavefront: LDS writes complete in order before the reads below
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
