@@ -304,10 +304,13 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
   return v;
 }
 
-// phase 1b's trigger (see there): the share of a cell's runs that hold a passer, per pass
+// phase 1b's trigger (see there): NUM x (runs with a passer) > DEN x (runs of the cell), per pass: more than half of the
+// runs at iniThFAST, more than a quarter in the minThFAST pass -- there the two-pair test passes 17-50 % of a natural
+// cell's pixels and the four-pair test removes 60 % of them for the price of 4 % of the pass (in-run A/Bs of eight
+// settings: profiles/r05_a_fast_pass_ablation.txt, r05_d_fast_stage_b_trigger_ab.txt)
 #ifndef VSG_FAST_STAGE_B_NUM
-#define VSG_FAST_STAGE_B_NUM(pass) 4
-#define VSG_FAST_STAGE_B_DEN(pass) 3
+#define VSG_FAST_STAGE_B_NUM(pass) ((pass) ? 4 : 2)
+#define VSG_FAST_STAGE_B_DEN(pass) 1
 #endif
 #ifndef VSG_FAST_NT
 #define VSG_FAST_NT 128  // threads per FAST cell: 2 waves keep more cells resident per CU than 4 (measured: 0.47 ->
@@ -652,8 +655,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
           // two pairs); on fine texture -- 1-2 px checkerboards, gratings, steep ramps -- EVERY pixel passes the N / S / W / E
           // test, on ramps on both sides, and the cell scored its whole area two or three times per threshold (FAST launch
           // 1.05-2.47 ms instead of 0.39 per 512 frames: profiles/r04_b_bench_content_sweep_before_stage_b.json).  The
-          // diagonals see the other phase of a checkerboard and the iso-line of a ramp.  Cell-uniform trigger: more than
-          // three quarters of the cell's runs hold a passer.
+          // diagonals see the other phase of a checkerboard and the iso-line of a ramp.  Cell-uniform trigger: the share of
+          // the cell's runs that hold a passer (VSG_FAST_STAGE_B_NUM / _DEN above).
           if (VSG_FAST_STAGE_B_NUM(pass) * s_cnt[4] > VSG_FAST_STAGE_B_DEN(pass) * nruns) {
             const int nr1 = s_cnt[4];
             const int t6 = thr <= 2 ? 0 : min(64, (thr + 1) >> 2);
@@ -1449,8 +1452,17 @@ __global__ __launch_bounds__(256) void k_slots(const FrameGeom *__restrict__ fg,
 // One wavefront per keypoint: intensity-centroid angle on the un-blurred level, steered rBRIEF-256 on
 // the blurred level, keypoint record + 32 descriptor bytes written to the keypoint's output slot.
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-// rBRIEF patch radius / width; the LDS copy holds the 10 x (3 or 4) blurred TILES the patch touches: 40 rows of 64 bytes
-enum { kPatchR = 18, kPatchW = 2 * kPatchR + 1, kPatchP = 64, kPatchRows = 40 };
+// rBRIEF patch radius / width; the LDS copy holds the 10 x (3 or 4) blurred TILES the patch touches: 40 rows of 64 bytes at
+// a row pitch of 80.  The 512 test points of a keypoint are byte reads at rotated pattern offsets clustered around the
+// centre: at a pitch of 64 bytes (16 dwords) every second row lies on the same 16 banks and a 32-lane group of one
+// ds_read_u8 meets 4.6 distinct dwords on its busiest bank on average (the real pattern under random rotations, simulated);
+// at 80 bytes (20 dwords: eight row classes) 3.1 -- what 32 random addresses give.  The test reads are two thirds of the
+// LDS pipe's busy time in this kernel.  80 keeps the tile rows 16-byte aligned for the b128 commits.
+#ifndef VSG_OD_PITCH
+#define VSG_OD_PITCH 80
+#endif
+enum { kPatchR = 18, kPatchW = 2 * kPatchR + 1, kPatchP = VSG_OD_PITCH, kPatchRows = 40 };
+static_assert(kPatchP % 16 == 0 && kPatchP >= 64 && kPatchP < 256, "tile rows are committed as aligned 16-byte stores");
 
 // IC_Angle lane layout: 16 rows x 4 (unaligned) qwords per load instruction (lane = 4 * row + column), 2 instructions
 // cover the 31 x 31 patch (rows 16 * it + row - 15, pixels u = 8 * column + 4 * half + b - 15).  Per (it, lane, half)
@@ -1721,11 +1733,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
   uint64_t word = 0;
   // cvRound (round half to even) of |v| <= 26 as ONE float addition: v + 1.5 * 2^23 has an ulp of 1, so the sum's rounding
   // IS the rounding to the nearest integer, ties to even, and its bit pattern is 0x4B400000 + round(v) =: M + round(v).
-  // Both points at once (v_pk_add_f32), and the constant leaves through the base address: the byte of (dy, dx) sits at
-  // centre + (dy << 6) + dx = (centre - 65 M) + (By << 6) + Bx modulo 2^32 (v_rndne + v_cvt_i32 per coordinate before: 8
-  // instructions per pair of points, now 2).
+  // Both points at once (v_pk_add_f32), and the constant leaves through the base address: with By = M + dy, Bx = M + dx the
+  // byte of (dy, dx) sits at centre + P dy + dx = (centre - P (M & 0xFFFFFF) - M) + P By[23:0] + Bx modulo 2^32 -- the low
+  // 24 bits of By are 0x400000 + dy, a positive 24-bit number, so the row term is ONE v_mad_u32_u24 for any pitch P
+  // (v_rndne + v_cvt_i32 per coordinate before: 8 instructions per pair of points, now 2).
   {
-    const uint32_t cbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)center - 65u * 0x4B400000u;
+    const uint32_t cbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)center -
+                           (uint32_t)kPatchP * 0x400000u - 0x4B400000u;
     const f32x2 kMagic = {12582912.0f, 12582912.0f};
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -1734,8 +1748,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
       const f32x2 ry = (X * b + Y * a) + kMagic, rx = (X * a - Y * b) + kMagic;
       // (the components through named floats: __builtin_bit_cast of `ry.y` itself read component x)
       const float ry0 = ry.x, ry1 = ry.y, rx0 = rx.x, rx1 = rx.y;
-      const uint32_t o0 = cbase + (__builtin_bit_cast(uint32_t, ry0) << 6) + __builtin_bit_cast(uint32_t, rx0);
-      const uint32_t o1 = cbase + (__builtin_bit_cast(uint32_t, ry1) << 6) + __builtin_bit_cast(uint32_t, rx1);
+      const uint32_t o0 = cbase + (__umul24(__builtin_bit_cast(uint32_t, ry0), (uint32_t)kPatchP) + __builtin_bit_cast(uint32_t, rx0));
+      const uint32_t o1 = cbase + (__umul24(__builtin_bit_cast(uint32_t, ry1), (uint32_t)kPatchP) + __builtin_bit_cast(uint32_t, rx1));
       const uint32_t t0 = *(const __attribute__((address_space(3))) uint8_t *)(uintptr_t)o0;
       const uint32_t t1 = *(const __attribute__((address_space(3))) uint8_t *)(uintptr_t)o1;
       const uint64_t m = __ballot(t0 < t1);  // 64 descriptor bits per ballot
