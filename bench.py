@@ -1066,6 +1066,9 @@ def main():
                                         "k + 1 (two alternating output sets); all K matches end inside the timed region"}
                       if overlap_match["on"] else {}),
                    "keypoints_per_frame": round(n_kp, 1),
+                   "content": "rectangles (synth.sequence_frame: rectangles + uniform noise, translated per frame); the other "
+                              "nine content classes: `content_sweep`, the natural-image stand-ins also as `value_value_noise` / "
+                              "`value_defocus`",
                    "clock_ramp": f"{max(args.ramp_steps, 0)} untimed steps before the {Wu} warm-up steps (the GPU reaches its "
                                  "steady clocks after ~0.1-0.2 s of load)",
                    "inputs": "resident in HBM" + (": two batches (the frames in forward / reverse order) alternate from step to "
@@ -1086,17 +1089,39 @@ def main():
         # the other BASELINE.json configurations as stated there, each with its parity flag and the CPU oracle's rate
         other = []
         chain = config_chain_leg()
-        other.append(chain.get("C3", {"workload": "C3", **chain}))
+        c3 = chain.get("C3", {"workload": "C3", **chain})
+        if isinstance(c3.get("stage_ms"), dict) and c3["stage_ms"].get("extract_2_eyes"):
+            # the pair chain is ONE stereo pair per blocking call: dependency-bound, priced against the same HBM roof for
+            # the record (5 630 695 algorithmic bytes per 752x480 / 1200 eye; both eyes extract side by side)
+            ach = 2 * 5630695 / (c3["stage_ms"]["extract_2_eyes"] * 1e-3) / 1e9
+            c3["roofline"] = {"bound": "hbm", "kernel": "operator() of both eyes (one pair per call: latency-bound)",
+                              "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                              "traffic": None, "launch_ms": c3["stage_ms"]["extract_2_eyes"], "bytes_per_launch": 2 * 5630695,
+                              "counters": "profiles/r05_*_c3_chain_pmc.txt (k_stereo, k_bow_descend, k_search_by_bow per call)"}
+        other.append(c3)
         try:
             other.append(device_rate("C4", 128, 10, local_rank))
         except Exception as e:  # noqa: BLE001
             other.append({"workload": "C4", "error": str(e)})
         other.append(chain.get("C5", {"workload": "C5", **chain}))
+        try:  # C3's eyes as a throughput batch (the chain above is the per-pair latency form): its FAST roofline
+            r3 = device_rate("C3", 256, 10, local_rank)
+            r3["workload"] = "C3 eyes as a batch: " + r3["workload"]
+            other.append(r3)
+        except Exception as e:  # noqa: BLE001
+            other.append({"workload": "C3 eyes as a batch", "error": str(e)})
         out["other_configs"] = other
         try:
             out["content_sweep"] = content_sweep_leg(local_rank, cpu_seconds=min(1.0, max(0.3, args.cpu_seconds / 8)))
         except Exception as e:  # noqa: BLE001
             out["content_sweep"] = {"error": str(e)}
+        # `value` is measured on rectangles + noise (config.content), the most favourable but one of the ten classes; the same
+        # workload on the natural-image stand-ins -- every FAST cell empty at iniThFAST, the reference's second pass at
+        # minThFAST on all of them -- beside it, from the sweep above (every frame checked there too)
+        cls = out["content_sweep"].get("classes", {}) if isinstance(out["content_sweep"], dict) else {}
+        for kind in ("value_noise", "defocus"):
+            if isinstance(cls.get(kind), dict) and "frames_per_s" in cls[kind]:
+                out[f"value_{kind}"] = cls[kind]["frames_per_s"]
         # the call pattern the reference has: ONE frame per blocking operator() (System.cc:359, Tracking.cc:1583,
         # Frame.cc:344,555-563), from plain C++ through the C ABI, with the CPU oracle's chain beside each figure
         fl = dict(chain.get("frame_latency") or {"error": chain.get("error", "config_chain gave no frame_latency")})

@@ -430,7 +430,15 @@ def run_child(args, argv):
     import subprocess
     failed = 0
     for r in range(args.runs):
-        cmd = [sys.executable, str(Path(__file__).resolve()), "--child"] + [a for a in argv if not a.startswith("--runs")]
+        child_args, skip = [], False
+        for a in argv:  # everything but --runs N / --runs=N
+            if skip:
+                skip = False
+            elif a == "--runs":
+                skip = True
+            elif not a.startswith("--runs="):
+                child_args.append(a)
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--child"] + child_args
         if "--trace" not in cmd:
             cmd.append("--trace")  # the last line names the case a fault happened in
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the one-frame octree spends its time: a diagnostic build (tools/build_variant.sh octstamp -DVSG_OCT_STAMPS) stamps
+"""Where the one-frame octree spends its time: a diagnostic build (tools/build_oct_stamps.py) stamps
 s_memtime at the phase boundaries of DistributeOctTree (tid 0 of every level's workgroup, frame 0); this script runs
 blocking single-frame operator() calls through that build and prints the deltas per level.  Shares, not lengths: the
 stamps' waits forbid overlaps the real kernel has.
@@ -14,7 +14,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "tests")]
 from visual_sgraphs_amd import orb, synth  # noqa: E402
 
-TAGS = {0: "enter", 1: "prefix scan done", 2: "points loaded", 3: "initial nodes", 10: "main pass", 20: "sort keys built",
+TAGS = {0: "enter", 1: "prefix scan done", 2: "points loaded", 3: "initial nodes", 10: "main pass", 11: "fused main passes",
+        20: "sort keys built",
         21: "partition phase", 22: "stable ranks", 23: "careful pass", 30: "best point per node", 31: "exit"}
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "rectangles"

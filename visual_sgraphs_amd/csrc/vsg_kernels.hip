@@ -914,7 +914,91 @@ struct BlockGroup {
   // A_k < B_k; it returns min(A_K, B_{K-1}) at the first K with A_K >= B_K.  The pairs are disjoint, so ranks from
   // wave ballots, one parallel round of swaps and a popcount reproduce a whole partition step.  Median selection
   // and the (rare) heapsort fallback stay on lane 0.  Other waves fall through; the caller's barrier orders them.
+  // n <= 64 (the careful phase of every level whose list holds at most 64 splittable nodes: all of C2's): the array lives
+  // in the 64 lanes' REGISTERS.  Median selection reads three lanes (v_readlane, scalar compares), the A / B position
+  // lists are ranks of two ballots, lane k learns (A_k, B_k) through two ds_permute, the partners through two more and
+  // the items cross through two ds_bpermute: no LDS array, no fence, no dependent LDS round trips per step (the LDS form
+  // below took 11.2 k cycles for 64 items on the one-frame path, profiles/r05_c_octree_stamps_one_frame.txt).
+  __device__ void sort_partition_phase_regs(introsort::item_t *a, int n) {
+    if (tid >= 64) return;
+    const int lane = tid;
+    introsort::item_t item = lane < n ? a[lane] : ~(introsort::item_t)0;
+    const uint64_t below = (1ull << lane) - 1, above = lane == 63 ? 0ull : ~((2ull << lane) - 1);
+    auto lane_item = [&](int p) {
+      const uint32_t lo32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)item, p);
+      const uint32_t hi32 = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(item >> 32), p);
+      return ((introsort::item_t)hi32 << 32) | lo32;
+    };
+    int sp = 0, lo = 0, hi = n, depth = 2 * introsort::lg_(n > 0 ? n : 1);
+    while (true) {
+      while (hi - lo > 16) {
+        if (depth == 0) {  // heapsort fallback (never seen on real lists): through LDS, on lane 0
+          if (lane < n) a[lane] = item;
+          __threadfence_block();
+          if (lane == 0) introsort::heap_sort_(a + lo, hi - lo);
+          __threadfence_block();
+          item = lane < n ? a[lane] : ~(introsort::item_t)0;
+          break;
+        }
+        --depth;
+        // __move_median_to_first(first, first + 1, mid, last - 1): the median of three goes to position lo
+        const int pa = lo + 1, pb = lo + (hi - lo) / 2, pc = hi - 1;
+        const introsort::item_t ia = lane_item(pa), ib = lane_item(pb), ic = lane_item(pc), i0 = lane_item(lo);
+        const uint32_t ka = (uint32_t)(ia >> 32), kb = (uint32_t)(ib >> 32), kc = (uint32_t)(ic >> 32);
+        int pm;
+        if (ka < kb)
+          pm = kb < kc ? pb : ka < kc ? pc : pa;
+        else
+          pm = ka < kc ? pa : kb < kc ? pc : pb;
+        const introsort::item_t im = pm == pa ? ia : pm == pb ? ib : ic;
+        if (lane == lo) item = im;
+        if (lane == pm) item = i0;
+        const uint32_t P = (uint32_t)(im >> 32);
+        const uint32_t key = (uint32_t)(item >> 32);
+        // __unguarded_partition(first + 1, last, first): A = ascending positions of the elements >= pivot, B = descending
+        // positions of the elements <= pivot, then the pivot slot itself (see the LDS form below)
+        const bool in = lane > lo && lane < hi;
+        const bool fa = in && key >= P, fb = (in && key <= P) || lane == lo;
+        const uint64_t ba = __ballot(fa), bb = __ballot(fb);
+        const int nA = __popcll(ba), nB = __popcll(bb);
+        const int rA = __popcll(ba & below), rB = __popcll(bb & above);
+        // lane k receives A_k and B_k (exactly one sender per k < nA / k < nB; other lanes' values are not used)
+        // (ds_permute is a push and every lane pushes: the lanes outside the list take the slots behind it, in lane order,
+        // so that the destinations are a permutation of the 64 lanes)
+        const int Ak = __builtin_amdgcn_ds_permute((fa ? rA : nA + __popcll(~ba & below)) << 2, lane);
+        const int Bk = __builtin_amdgcn_ds_permute((fb ? rB : nB + __popcll(~bb & below)) << 2, lane);
+        const bool sw = lane < nA && lane < nB && Ak < Bk;
+        const int K = __popcll(__ballot(sw));  // the pairs are monotone: valid exactly for k < K
+        // the swapping lanes PULL their partners from the lane of their own rank, then the partner's item
+        const int partA = __builtin_amdgcn_ds_bpermute(rA << 2, Bk);
+        const int partB = __builtin_amdgcn_ds_bpermute(rB << 2, Ak);
+        const bool isA = fa && rA < K, isB = fb && rB < K;
+        const int partner = isA ? partA : isB ? partB : lane;
+        const uint32_t xlo = (uint32_t)__builtin_amdgcn_ds_bpermute(partner << 2, (int)(uint32_t)item);
+        const uint32_t xhi = (uint32_t)__builtin_amdgcn_ds_bpermute(partner << 2, (int)(uint32_t)(item >> 32));
+        if (isA || isB) item = ((introsort::item_t)xhi << 32) | xlo;
+        const int cutA = K < nA ? __builtin_amdgcn_readlane(Ak, K) : 0x7FFFFFFF;
+        const int cutB = K >= 1 ? __builtin_amdgcn_readlane(Bk, K - 1) : hi;
+        const int cut = cutA < cutB ? cutA : cutB;
+        if (lane == 0) stk[3 * sp] = lo, stk[3 * sp + 1] = cut, stk[3 * sp + 2] = depth;  // uniform values
+        sp++;
+        lo = cut;
+      }
+      if (sp == 0) break;
+      --sp;
+      __threadfence_block();
+      lo = stk[3 * sp], hi = stk[3 * sp + 1], depth = stk[3 * sp + 2];
+    }
+    if (lane < n) a[lane] = item;
+    __threadfence_block();
+  }
   __device__ void sort_partition_phase(introsort::item_t *a, int n, uint16_t *posA, uint16_t *posB) {
+#ifndef VSG_OCT_NO_REGSORT  // A/B builds: the LDS form for every n
+    if (n <= 64) {
+      sort_partition_phase_regs(a, n);
+      return;
+    }
+#endif
     if (tid >= 64) return;
     const int lane = tid;
     const uint64_t lt = (1ull << lane) - 1;
@@ -1052,6 +1136,10 @@ struct SegRegPts {
   }
 };
 
+#ifndef VSG_OCT_FEW
+#define VSG_OCT_FEW 8
+#endif
+constexpr int kOctFewFrames = VSG_OCT_FEW;  // calls of up to this many frames take the 4-waves-per-SIMD octree launch (k_octree_blur_few)
 struct OctArgs {
   const FrameGeom *fg;
   const uint32_t *cand;
@@ -1134,7 +1222,17 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
   if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;
 }
 
-__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_octree(OctArgs a) {
+#ifndef VSG_OCT_WAVES
+#define VSG_OCT_WAVES 5
+#endif
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG_OCT_WAVES, VSG_OCT_WAVES))) void k_octree(OctArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
+  __shared__ int wtot[2 * kMaxWaves];
+  __shared__ int sort_stack[3 * kSortStack];
+  octree_block(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
+}
+// calls of a few frames: registers instead of residency (see k_octree_blur_few)
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree_few(OctArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[3 * kSortStack];
@@ -1364,11 +1462,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 #ifndef VSG_OB_WAVES
 #define VSG_OB_WAVES 5
 #endif
-__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG_OB_WAVES, VSG_OB_WAVES))) void k_octree_blur(
-    OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels, int nframes, int lead) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
-  __shared__ int wtot[2 * kMaxWaves];
-  __shared__ int sort_stack[3 * kSortStack];
+__device__ __forceinline__ void octree_blur_body(const OctArgs &a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                                 const Src0 &s0, int nlevels, int nframes, int lead, uint8_t *oct_lds, int *wtot,
+                                                 int *sort_stack) {
   static_assert(kOctThreads == 256, "the blur body is written for 256-thread workgroups");
   // frame-major over the combined grid: the workgroups that share an XCD (and its L2) work on whole frames
   BlockXY blk = frame_major_block();
@@ -1384,6 +1480,24 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG
     octree_block(a, blk.x, blk.y, oct_lds, wtot, sort_stack);
   else
     blur_block<VSG_BLUR_AHEAD>(pyr, blur, a.fg, s0, BlockXY{blk.x - nlevels, blk.y});
+}
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG_OB_WAVES, VSG_OB_WAVES))) void k_octree_blur(
+    OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels, int nframes, int lead) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
+  __shared__ int wtot[2 * kMaxWaves];
+  __shared__ int sort_stack[3 * kSortStack];
+  octree_blur_body(a, pyr, blur, s0, nlevels, nframes, lead, oct_lds, wtot, sort_stack);
+}
+// The same launch for calls of a few frames (the blocking one-frame operator()): there the octree IS the critical path --
+// eight workgroups per frame on 256 CUs -- and residency buys nothing, so this instantiation takes the 125 registers the
+// octree wants instead of the 96 of five waves per SIMD, where 46 of them live in scratch memory (every spill reload a
+// trip to L2 in the middle of a latency-bound pass).
+__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree_blur_few(
+    OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels, int nframes, int lead) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
+  __shared__ int wtot[2 * kMaxWaves];
+  __shared__ int sort_stack[3 * kSortStack];
+  octree_blur_body(a, pyr, blur, s0, nlevels, nframes, lead, oct_lds, wtot, sort_stack);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2104,12 +2218,23 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
     // (64 rows, a multiple of 8 = whole XCD rounds: 317.5 -> 320.5 k frames/s at 512 C2 frames; 32 and 128 measured the same +-0.3 %)
     constexpr int kLead = 64;
     const int lead = nframes >= 4 * kLead ? kLead : 0;
+    if (nframes <= kOctFewFrames) {
+      lds_limit_ensure(3, dev, (const void *)k_octree_blur_few, lds);
+      hipLaunchKernelGGL(k_octree_blur_few, dim3(fg.nlevels + fg.total_blur_blocks, nframes + lead), dim3(kOctThreads), lds, s,
+                         a, blur_pyr, blur_out, *blur_s0, fg.nlevels, nframes, lead);
+      return;
+    }
     hipLaunchKernelGGL(k_octree_blur, dim3(fg.nlevels + fg.total_blur_blocks, nframes + lead), dim3(kOctThreads), lds, s, a,
                        blur_pyr, blur_out, *blur_s0, fg.nlevels, nframes, lead);
     return;
   }
-  lds_limit_ensure(1, dev, (const void *)k_octree, lds);
   dim3 grid(fg.nlevels, nframes), block(kOctThreads);
+  if (nframes <= kOctFewFrames) {
+    lds_limit_ensure(4, dev, (const void *)k_octree_few, lds);
+    hipLaunchKernelGGL(k_octree_few, grid, block, lds, s, a);
+    return;
+  }
+  lds_limit_ensure(1, dev, (const void *)k_octree, lds);
   hipLaunchKernelGGL(k_octree, grid, block, lds, s, a);
 }
 void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n) {

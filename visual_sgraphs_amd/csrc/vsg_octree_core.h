@@ -165,11 +165,20 @@ struct Work {
   uint8_t *divided;
   int *scanA, *scanB;
   int *ctrl;            // [0]=nL [1]=nV [2]=break index
+  // fused first main passes (fused_main_passes below): point counts of every quadtree cell down to depth kFuseDepth under
+  // each of up to kFuseRoots initial nodes, the cell -> list position table, and each node's (root, depth, path) word
+  int *hist;            // [kFuseRoots][4 + 16 + 64]
+  uint16_t *cellpos;    // [kFuseRoots][64]
+  // node words of the fused passes, root << 8 | depth << 6 | path (2 bits per level), generation b in proc (b = 0) /
+  // keeppos (b = 1): neither is live during the fused passes, and both are written before they are read afterwards
+  VSG_OCT_HD uint16_t *ncode(int b) const { return b ? keeppos : proc; }
 };
+
+enum { kFuseDepth = 3, kFuseRoots = 4, kFuseCells = 4 + 16 + 64 };
 
 VSG_OCT_HD size_t work_bytes(int cap) {
   size_t capa = (size_t)((cap + 3) & ~3);
-  return capa * (2 * 4 * 2 + 2 * 4 + 16 + 8 + 2 + 2 + 2 + 1 + 4 + 4) + 64;
+  return capa * (2 * 4 * 2 + 2 * 4 + 16 + 8 + 2 + 2 + 2 + 1 + 4 + 4) + 64 + kFuseRoots * (kFuseCells * 4 + 64 * 2);
 }
 
 VSG_OCT_HD void carve(Work &W, void *buf, int cap) {
@@ -196,6 +205,10 @@ VSG_OCT_HD void carve(Work &W, void *buf, int cap) {
   p += capa * 2;
   W.V = (uint16_t *)p;
   p += capa * 2;
+  W.cellpos = (uint16_t *)p;
+  p += kFuseRoots * 64 * 2;
+  W.hist = (int *)p;  // 4-byte aligned: everything before it is a multiple of 4 bytes (capa is a multiple of 4)
+  p += kFuseRoots * kFuseCells * 4;
   W.divided = (uint8_t *)p;
 }
 
@@ -208,9 +221,17 @@ VSG_OCT_HD int quadrant(const Work &W, int b, int n, int x, int y) {
 
 // position of a candidate in the reference's candidate order (cells row-major, pixels row-major
 // inside a cell): ORBextractor.cc:811-875 + FAST_t's row-major output.
-VSG_OCT_HD uint32_t cand_rank(const Params &P, int x, int y) {
+// a / b for 0 <= a < 2^15, 0 < b < 2^12 through the float reciprocal (an integer division is ~40 instructions on the device
+// and this runs twice per candidate): the float quotient is off by at most one, two compares make it exact
+VSG_OCT_HD int div_exact(int a, int b, float inv_b) {
+  int q = (int)((float)a * inv_b);
+  q -= q * b > a;
+  q += (q + 1) * b <= a;
+  return q;
+}
+VSG_OCT_HD uint32_t cand_rank(const Params &P, int x, int y, float inv_w, float inv_h) {
   const int cx = x - 3, cy = y - 3;  // valid region of a cell starts 3 px inside it
-  const int j = cx / P.wCell, i = cy / P.hCell;
+  const int j = div_exact(cx, P.wCell, inv_w), i = div_exact(cy, P.hCell, inv_h);
   return (uint32_t)(((i * P.nCols + j) * P.hCell + (cy - i * P.hCell)) * P.wCell + (cx - j * P.wCell));
 }
 
@@ -391,6 +412,140 @@ VSG_OCT_HD int run_main_pass(G &g, const Params &P, Work &W, int &cur, int nL, P
   return newL;
 }
 
+// ---- The first (up to kFuseDepth) MAIN passes without a point sweep per pass.
+// A main pass splits every node that holds more than one point, so which nodes exist after k passes -- and in which list
+// order -- only depends on how many points lie in each quadtree cell of depth <= k: the boxes are pure geometry (a node's
+// box is its root's box halved along its path, :484-527), the points are never moved, and the list surgery of a pass
+// (children in creation order n1..n4, pushed to the front; :617-690) only looks at counts.  So: ONE sweep over the points
+// computes each point's path down to depth kFuseDepth in registers (no LDS gathers) and counts it into its depth-3 cell;
+// the coarser counts are sums of four; the passes then run on the node arrays alone -- the same statements as run_main_pass
+// with the child counts read from the histogram -- with the reference's stop tests (:692, :696) after each; ONE more sweep
+// gives every point the list position of the node its depth-3 cell ended up in.  Two point sweeps and no per-point LDS
+// traffic for the three passes that otherwise cost two sweeps with five LDS gathers and an LDS atomic per point each
+// (the one-frame octree: 29 of 81 k cycles in these passes, profiles/r05_c_octree_stamps_one_frame.txt).
+// Requires nL <= kFuseRoots initial nodes in generation `cur`, labels n = list position.  Returns the new list length;
+// *state: 0 = all fused passes done and the main loop goes on, 1 = finish (:692), 2 = enter the careful phase (:696).
+template <class G, class PT>
+VSG_OCT_HD int fused_main_passes(G &g, const Params &P, Work &W, int &cur, int nL, PT &pts, int npts, int *nV_out,
+                                 int *state) {
+  const int nRoots = nL;
+  for (int i = g.tid; i < nRoots * kFuseCells; i += g.nthreads) W.hist[i] = 0;
+  for (int i = g.tid; i < nL; i += g.nthreads) W.ncode(cur)[i] = (uint16_t)(i << 8);
+  g.sync();
+  // sweep 1: path of every point below its root, counted into its depth-3 cell; the label becomes root * 64 + path
+  {
+    const int b = cur;
+    pts.for_each(g, npts, [&](uint32_t c, int &n) {
+      const int x = VSG_CAND_X(c), y = VSG_CAND_Y(c);
+      int ulx = W.ulx(b)[n], uly = W.uly(b)[n], urx = W.urx(b)[n], bly = W.bly(b)[n], path = 0;
+      for (int d = 0; d < kFuseDepth; d++) {
+        const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
+        const int qx = x >= midX, qy = y >= midY;
+        path = path * 4 + (qx | (qy << 1));
+        if (qx) ulx = midX; else urx = midX;
+        if (qy) uly = midY; else bly = midY;
+      }
+      n = n * 64 + path;
+      g.atomic_add(&W.hist[(n >> 6) * kFuseCells + 20 + path], 1);
+    });
+  }
+  g.sync();
+  for (int i = g.tid; i < nRoots * 16; i += g.nthreads) {  // depth 2 = sums of four depth-3 cells
+    const int r = i >> 4, c2 = i & 15;
+    const int *h3 = &W.hist[r * kFuseCells + 20 + 4 * c2];
+    W.hist[r * kFuseCells + 4 + c2] = h3[0] + h3[1] + h3[2] + h3[3];
+  }
+  g.sync();
+  for (int i = g.tid; i < nRoots * 4; i += g.nthreads) {
+    const int r = i >> 2, c1 = i & 3;
+    const int *h2 = &W.hist[r * kFuseCells + 4 + 4 * c1];
+    W.hist[r * kFuseCells + c1] = h2[0] + h2[1] + h2[2] + h2[3];
+  }
+  g.sync();
+  int nV = 0;
+  *state = 0;
+  for (int pass = 0; pass < kFuseDepth; pass++) {
+    const int b = cur, nb = cur ^ 1, prevSize = nL;
+    // counts of the four children of every node that splits (all of them sit at depth `pass`)
+    for (int i = g.tid; i < nL; i += g.nthreads) {
+      const bool d = W.cnt(b)[i] > 1;
+      W.divided[i] = d;
+      int k = 0, e = 0;
+      if (d) {
+        const int code = W.ncode(b)[i], r = code >> 8, path = code & 63;
+        const int base = r * kFuseCells + (pass == 0 ? 0 : pass == 1 ? 4 : 20) + 4 * path;
+        for (int c = 0; c < 4; c++) {
+          const int cc = W.hist[base + c];
+          W.childcnt[4 * i + c] = cc;
+          k += cc > 0;
+          e += cc > 1;
+        }
+      }
+      W.scanA[i] = k | (e << 16);
+      W.scanB[i] = d ? 0 : 1;
+    }
+    g.sync();
+    int kept = 0;
+    const int total = g.exclusive_scan2(W.scanA, W.scanB, nL, &kept);
+    const int K = total & 0xFFFF, E = total >> 16;
+    const int newL = K + kept;
+    for (int i = g.tid; i < nL; i += g.nthreads) {
+      const int ulx = W.ulx(b)[i], uly = W.uly(b)[i], urx = W.urx(b)[i], bly = W.bly(b)[i];
+      const int code = W.ncode(b)[i];
+      if (W.divided[i]) {
+        const int q0 = W.scanA[i] & 0xFFFF, e0 = W.scanA[i] >> 16;
+        const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
+        int m = 0, ev = 0;
+        for (int c = 0; c < 4; c++) {
+          const int cc = W.childcnt[4 * i + c];
+          if (cc > 0) {
+            const int pos = K - 1 - (q0 + m);  // push_front => reversed creation order
+            W.ulx(nb)[pos] = (int16_t)((c & 1) ? midX : ulx);
+            W.urx(nb)[pos] = (int16_t)((c & 1) ? urx : midX);
+            W.uly(nb)[pos] = (int16_t)((c & 2) ? midY : uly);
+            W.bly(nb)[pos] = (int16_t)((c & 2) ? bly : midY);
+            W.cnt(nb)[pos] = cc;
+            W.ncode(nb)[pos] = (uint16_t)((code & 0xFF00) | ((pass + 1) << 6) | ((code & 63) * 4 + c));
+            if (cc > 1) W.V[e0 + ev++] = (uint16_t)pos;
+            m++;
+          }
+        }
+      } else {
+        const int pos = K + W.scanB[i];
+        W.ulx(nb)[pos] = (int16_t)ulx;
+        W.urx(nb)[pos] = (int16_t)urx;
+        W.uly(nb)[pos] = (int16_t)uly;
+        W.bly(nb)[pos] = (int16_t)bly;
+        W.cnt(nb)[pos] = W.cnt(b)[i];
+        W.ncode(nb)[pos] = (uint16_t)code;
+      }
+    }
+    g.sync();
+    cur = nb;
+    nL = newL;
+    nV = E;
+    if (nL >= P.N || nL == prevSize) {  // (:692)
+      *state = 1;
+      break;
+    }
+    if (nL + nV * 3 > P.N) {  // (:696)
+      *state = 2;
+      break;
+    }
+  }
+  // depth-3 cell -> list position of the node that holds it: a node at depth d covers 4^(3 - d) consecutive paths
+  for (int i = g.tid; i < nL; i += g.nthreads) {
+    const int code = W.ncode(cur)[i], r = code >> 8, d = (code >> 6) & 3, path = code & 63;
+    const int span = 1 << (2 * (kFuseDepth - d)), first = path * span;
+    for (int j = 0; j < span; j++) W.cellpos[r * 64 + first + j] = (uint16_t)i;
+  }
+  g.sync();
+  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.cellpos[n]; });
+  g.sync();
+  *nV_out = nV;
+  return nL;
+}
+
 // DistributeOctTree.  cand[0..npts): packed candidates in ANY order.  node_of: npts uint16 scratch.
 // sel_out: receives the chosen candidate of every final node, in the reference's list order.
 // Returns the number of selected keypoints.  Must be called by every thread of the group.
@@ -399,53 +554,86 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
   int cur = 0;
   pts.load(g, npts);
   // initial nodes (:575-586)
-  for (int i = g.tid; i < P.nIni; i += g.nthreads) {
-    W.ulx(0)[i] = (int16_t)P.iniUL[i];
-    W.urx(0)[i] = (int16_t)P.iniUL[i + 1];
-    W.uly(0)[i] = 0;
-    W.bly(0)[i] = (int16_t)P.height;
-    W.cnt(0)[i] = 0;
-  }
-  g.sync();
-  // vpIniNodes[kp.pt.x / hX] (:589-593)
-  pts.init_each(g, npts, [&](uint32_t c, int &n) {
-    const int x = VSG_CAND_X(c);
-    int idx = 0;
-    for (int i = 1; i < P.nIni; i++) idx += (x >= P.iniThresh[i]);
-    n = idx;
-    g.atomic_add(&W.cnt(0)[idx], 1);
-  });
-  g.sync();
-  // erase empty initial nodes, keep order (:597-608)
-  if (g.tid == 0) {
-    int pos = 0;
-    for (int i = 0; i < P.nIni; i++) {
-      if (W.cnt(0)[i] > 0) {
-        W.ulx(1)[pos] = W.ulx(0)[i];
-        W.urx(1)[pos] = W.urx(0)[i];
-        W.uly(1)[pos] = W.uly(0)[i];
-        W.bly(1)[pos] = W.bly(0)[i];
-        W.cnt(1)[pos] = W.cnt(0)[i];
-        W.keeppos[i] = (uint16_t)pos;
-        pos++;
-      }
+  int nL;
+  if (P.nIni == 1) {
+    // one initial node (width / height rounds to 1: every 4:3 and 16:10 level): it holds every point -- no counting sweep
+    // with npts atomics on ONE LDS word, no compaction, no relabelling (5.7 of the one-frame octree's 81 k cycles)
+    if (g.tid == 0) {
+      W.ulx(1)[0] = (int16_t)P.iniUL[0];
+      W.urx(1)[0] = (int16_t)P.iniUL[1];
+      W.uly(1)[0] = 0;
+      W.bly(1)[0] = (int16_t)P.height;
+      W.cnt(1)[0] = npts;
     }
-    W.ctrl[0] = pos;
+    pts.init_each(g, npts, [&](uint32_t, int &n) { n = 0; });
+    cur = 1;
+    nL = npts > 0 ? 1 : 0;
+    g.sync();
+  } else {
+    for (int i = g.tid; i < P.nIni; i += g.nthreads) {
+      W.ulx(0)[i] = (int16_t)P.iniUL[i];
+      W.urx(0)[i] = (int16_t)P.iniUL[i + 1];
+      W.uly(0)[i] = 0;
+      W.bly(0)[i] = (int16_t)P.height;
+      W.cnt(0)[i] = 0;
+    }
+    g.sync();
+    // vpIniNodes[kp.pt.x / hX] (:589-593); the first four nodes are counted in registers, one atomic per thread and node
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    pts.init_each(g, npts, [&](uint32_t c, int &n) {
+      const int x = VSG_CAND_X(c);
+      int idx = 0;
+      for (int i = 1; i < P.nIni; i++) idx += (x >= P.iniThresh[i]);
+      n = idx;
+      c0 += idx == 0, c1 += idx == 1, c2 += idx == 2, c3 += idx == 3;
+      if (idx > 3) g.atomic_add(&W.cnt(0)[idx], 1);
+    });
+    if (c0) g.atomic_add(&W.cnt(0)[0], c0);
+    if (c1) g.atomic_add(&W.cnt(0)[1], c1);
+    if (c2) g.atomic_add(&W.cnt(0)[2], c2);
+    if (c3) g.atomic_add(&W.cnt(0)[3], c3);
+    g.sync();
+    // erase empty initial nodes, keep order (:597-608)
+    if (g.tid == 0) {
+      int pos = 0;
+      for (int i = 0; i < P.nIni; i++) {
+        if (W.cnt(0)[i] > 0) {
+          W.ulx(1)[pos] = W.ulx(0)[i];
+          W.urx(1)[pos] = W.urx(0)[i];
+          W.uly(1)[pos] = W.uly(0)[i];
+          W.bly(1)[pos] = W.bly(0)[i];
+          W.cnt(1)[pos] = W.cnt(0)[i];
+          W.keeppos[i] = (uint16_t)pos;
+          pos++;
+        }
+      }
+      W.ctrl[0] = pos;
+    }
+    g.sync();
+    pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.keeppos[n]; });
+    cur = 1;
+    nL = W.ctrl[0];
+    g.sync();
   }
-  g.sync();
-  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.keeppos[n]; });
-  cur = 1;
-  int nL = W.ctrl[0];
-  g.sync();
 
   bool finish = false;
+  int fused = nL >= 1 && nL <= kFuseRoots ? 1 : 0;  // the first passes without per-pass point sweeps (fused_main_passes)
+#ifdef VSG_OCT_NO_FUSE
+  fused = 0;  // A/B builds (tools/build_variant.sh): the regular passes from the start
+#endif
   while (!finish) {  // (:617)
     const int prevSize = nL;
-    int nV = 0;
-    nL = run_main_pass(g, P, W, cur, nL, pts, npts, &nV);
-    if (nL >= P.N || nL == prevSize) {  // (:692)
+    int nV = 0, state = -1;
+    if (fused) {
+      fused = 0;
+      nL = fused_main_passes(g, P, W, cur, nL, pts, npts, &nV, &state);
+      if (state == 0) continue;  // every fused pass ran and neither stop test fired: the regular passes go on
+    } else {
+      nL = run_main_pass(g, P, W, cur, nL, pts, npts, &nV);
+    }
+    if (state == 1 || (state < 0 && (nL >= P.N || nL == prevSize))) {  // (:692)
       finish = true;
-    } else if (nL + nV * 3 > P.N) {  // (:696)
+    } else if (state == 2 || (state < 0 && nL + nV * 3 > P.N)) {  // (:696)
       while (!finish) {
         const int prev2 = nL;
         introsort::item_t *sortbuf = (introsort::item_t *)W.childcnt;
@@ -467,11 +655,16 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
           // The partition phase leaves consecutive runs of <= 16 items, every run >= the ones before it (a
           // heap-sorted run is already in order), so only the 15 neighbours on either side can change an item's
           // stable rank: everything further left counts, nothing further right does.
+          // a fixed trip count with clamped indices: the 30 loads are independent and issue back to back (with run-time
+          // bounds every iteration waited for its own load: 5.1 k cycles for 64 items on the one-frame path)
           const int lo = t > 15 ? t - 15 : 0, hi = t + 15 < nV - 1 ? t + 15 : nV - 1;
           int rank = lo;
-          for (int j = lo; j <= hi; j++) {
-            const uint32_t kj = (uint32_t)(sortbuf[j] >> 32);
-            rank += (kj < key) | ((kj == key) & (j < t));
+          VSG_OCT_UNROLL
+          for (int d = -15; d <= 15; d++) {
+            if (d == 0) continue;
+            const int j = t + d, jc = j < lo ? lo : j > hi ? hi : j;
+            const uint32_t kj = (uint32_t)(sortbuf[jc] >> 32);
+            rank += (j >= lo) & (j <= hi) & ((kj < key) | ((kj == key) & (d < 0)));
           }
           W.proc[nV - 1 - rank] = (uint16_t)(uint32_t)it;
         }
@@ -488,13 +681,14 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
   uint32_t *bestkey = (uint32_t *)W.childcnt;
   for (int i = g.tid; i < nL; i += g.nthreads) bestkey[i] = 0;
   g.sync();
+  const float inv_w = 1.0f / (float)P.wCell, inv_h = 1.0f / (float)P.hCell;
   pts.for_each(g, npts, [&](uint32_t c, int &n) {
-    const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c)));
+    const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c), inv_w, inv_h));
     g.atomic_max(&bestkey[n], key);
   });
   g.sync();
   pts.for_each(g, npts, [&](uint32_t c, int &n) {
-    const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c)));
+    const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c), inv_w, inv_h));
     if (bestkey[n] == key) sel_out[n] = c;
   });
   g.sync();
