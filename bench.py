@@ -380,7 +380,7 @@ def visible_gpu_count():
     return None
 
 
-def preflight(n, batch, workload):
+def preflight(n, batch, workload, one_device=False, quiet=False):
     """`bench.py --gpus N --preflight`: what a first N-GPU run can trip over, checked in a CHILD process (it touches
     the GPU) before any rank is started -- visible devices; that libvsg_orb.so and torch resolve the SAME libamdhip64
     (bench.py hands torch streams and device pointers to a library that links the runtime by soname: INTEGRATION.md
@@ -391,7 +391,7 @@ def preflight(n, batch, workload):
     code = r"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, %r)
-n, batch, workload = %d, %d, %r
+n, batch, workload, one_device = %d, %d, %r, %r
 out = {"requested_gpus": n, "checks": {}}
 def check(name, ok, **info):
     out["checks"][name] = dict(ok=bool(ok), **info)
@@ -423,8 +423,9 @@ except Exception as e:
     check("one_hip_runtime", False, error=repr(e))
 ndev_t = torch.cuda.device_count()
 ndev_v = L.vsg_device_count()
-check("devices", ndev_t >= n and ndev_v >= n, torch_device_count=ndev_t, vsg_device_count=ndev_v,
-      visible_without_runtime=bench.visible_gpu_count())
+need_dev = 1 if one_device else n  # --one-device: every rank on device 0 (dry runs of the multi-rank path)
+check("devices", ndev_t >= need_dev and ndev_v >= need_dev, torch_device_count=ndev_t, vsg_device_count=ndev_v,
+      visible_without_runtime=bench.visible_gpu_count(), needed=need_dev)
 rccl = None
 for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
     try:
@@ -447,19 +448,22 @@ rec = sharding.record_bytes(cap + 64)
 recv = n * batch * rec
 resident = batch * (W * H * 2 + int(2.6 * 1.38 * W * H) + 2 * (cap + 64) * 60 + 3 * (cap + 64) * 4)
 mem = []
-for d in range(min(n, ndev_t)):
+for d in range(min(need_dev, ndev_t)):
     free, total = torch.cuda.mem_get_info(d)
     mem.append({"device": d, "free_bytes": free, "total_bytes": total})
-check("memory", bool(mem) and all(m["free_bytes"] > 2 * (recv + resident) for m in mem), exchange_recv_bytes_per_rank=recv,
+ranks_per_dev = n if one_device else 1
+check("memory", bool(mem) and all(m["free_bytes"] > 2 * ranks_per_dev * (recv + resident) for m in mem), exchange_recv_bytes_per_rank=recv,
       resident_estimate_bytes_per_rank=resident, devices=mem)
 out["ok"] = all(c["ok"] for c in out["checks"].values())
 print(json.dumps(out))
 sys.exit(0 if out["ok"] else 4)
-""" % (str(ROOT), n, batch, workload)
+""" % (str(ROOT), n, batch, workload, bool(one_device))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(ROOT))
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
-    if lines:
+    if lines and not quiet:
         print(lines[-1], flush=True)
+    elif lines and r.returncode != 0:
+        sys.stderr.write(lines[-1] + "\n")
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-2000:])
         if lines:
@@ -483,6 +487,14 @@ def launch_ranks(args, argv):
         if have is not None and have < n:
             sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) visible on this node\n")
             return 2
+    if not args.no_preflight:
+        # what an N-GPU run depends on, checked in a child BEFORE any rank starts (stdout stays the one result line): a
+        # torch wheel with another libamdhip64 than libvsg_orb.so resolves, an RCCL without ncclCommCount, too little memory
+        # for the exchange buffers -- each ends here with its reason instead of inside a hung or crashed rank
+        rc = preflight(n, args.batch, args.workload, one_device=args.one_device, quiet=True)
+        if rc != 0:
+            sys.stderr.write(f"bench.py: --gpus {n}: preflight failed (exit code {rc}); no ranks started (--no-preflight skips it)\n")
+            return rc
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     r = None
     for attempt in range(3):
@@ -551,13 +563,14 @@ def main():
                     help="check what an N-GPU run depends on (devices, one HIP runtime for torch and libvsg_orb.so, RCCL's "
                          "exports, memory for the exchange buffers) in a child process, print the findings and exit; "
                          "non-zero exit with the reason when a check fails")
+    ap.add_argument("--no-preflight", action="store_true", help="--gpus N > 1: start the ranks without the preflight checks")
     ap.add_argument("--one-device", action="store_true",
                     help="dry run of the multi-rank path on a single GPU: every rank uses device 0 (needs gloo)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.preflight:
-        sys.exit(preflight(args.gpus, args.batch, args.workload))
+        sys.exit(preflight(args.gpus, args.batch, args.workload, one_device=args.one_device))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args, sys.argv[1:]))  # before torch / HIP are touched in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))

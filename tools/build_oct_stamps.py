@@ -36,6 +36,11 @@ def main():
         s = sub(s, "        g.sort_partition_phase(sortbuf, nV, (uint16_t *)W.scanA, (uint16_t *)W.scanB);\n        g.sync();",
                 "        VSG_OCT_STAMP(20);\n        g.sort_partition_phase(sortbuf, nV, (uint16_t *)W.scanA, (uint16_t *)W.scanB);\n        g.sync();\n        VSG_OCT_STAMP(21);", "sort")
         s = sub(s, "        nL = run_pass(g, P, W, cur, nL, nV, true, pts, npts, &nV2);\n", "        VSG_OCT_STAMP(22);\n        nL = run_pass(g, P, W, cur, nL, nV, true, pts, npts, &nV2);\n        VSG_OCT_STAMP(23);\n", "careful")
+        # inside fused_main_passes: after the counting sweep, the coarser counts, every node-only pass, the table, the relabel
+        s = sub(s, "  for (int i = g.tid; i < nRoots * 16; i += g.nthreads) {  // depth 2", "  VSG_OCT_STAMP(12);\n  for (int i = g.tid; i < nRoots * 16; i += g.nthreads) {  // depth 2", "f12")
+        s = sub(s, "  int nV = 0;\n  *state = 0;\n", "  VSG_OCT_STAMP(13);\n  int nV = 0;\n  *state = 0;\n", "f13")
+        s = sub(s, "    cur = nb;\n    nL = newL;\n    nV = E;\n", "    cur = nb;\n    nL = newL;\n    nV = E;\n    VSG_OCT_STAMP(14);\n", "f14")
+        s = sub(s, "  g.sync();\n  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.cellpos[n]; });", "  g.sync();\n  VSG_OCT_STAMP(15);\n  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.cellpos[n]; });", "f15")
         s = sub(s, "  g.sync();\n  return nL;\n}\n\n// Points in memory", "  g.sync();\n  VSG_OCT_STAMP(30);\n  return nL;\n}\n\n// Points in memory", "final")
         core.write_text(s)
         k = d / "vsg_kernels.hip"
