@@ -40,6 +40,11 @@ def main():
         s = sub(s, "  for (int i = g.tid; i < nRoots * 16; i += g.nthreads) {  // depth 2", "  VSG_OCT_STAMP(12);\n  for (int i = g.tid; i < nRoots * 16; i += g.nthreads) {  // depth 2", "f12")
         s = sub(s, "  int nV = 0;\n  *state = 0;\n", "  VSG_OCT_STAMP(13);\n  int nV = 0;\n  *state = 0;\n", "f13")
         s = sub(s, "    cur = nb;\n    nL = newL;\n    nV = E;\n", "    cur = nb;\n    nL = newL;\n    nV = E;\n    VSG_OCT_STAMP(14);\n", "f14")
+        # inside the one-node-per-thread pass: node read, child counts read, block scan, children written, barrier
+        s = sub(s, "        d = cnt > 1;\n        if (d) {\n          const int base = (code >> 8)", "        d = cnt > 1;\n        asm volatile(\"\" : \"+v\"(ulx), \"+v\"(uly), \"+v\"(urx), \"+v\"(bly), \"+v\"(code), \"+v\"(cnt));\n        VSG_OCT_STAMP(40);\n        if (d) {\n          const int base = (code >> 8)", "f40")
+        s = sub(s, "      int ex = 0, exKept = 0, kept = 0;\n", "      asm volatile(\"\" : \"+v\"(k), \"+v\"(e));\n      VSG_OCT_STAMP(41);\n      int ex = 0, exKept = 0, kept = 0;\n", "f41")
+        s = sub(s, "      const int K = total & 0xFFFF, E = total >> 16;\n      if (have) {\n        if (d) {\n          const int q0 = ex & 0xFFFF", "      const int K = total & 0xFFFF, E = total >> 16;\n      VSG_OCT_STAMP(42);\n      if (have) {\n        if (d) {\n          const int q0 = ex & 0xFFFF", "f42")
+        s = sub(s, "      g.sync();\n      cur = nb;\n      nL = K + kept;\n", "      VSG_OCT_STAMP(43);\n      g.sync();\n      VSG_OCT_STAMP(44);\n      cur = nb;\n      nL = K + kept;\n", "f43")
         s = sub(s, "  g.sync();\n  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.cellpos[n]; });", "  g.sync();\n  VSG_OCT_STAMP(15);\n  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.cellpos[n]; });", "f15")
         s = sub(s, "  g.sync();\n  return nL;\n}\n\n// Points in memory", "  g.sync();\n  VSG_OCT_STAMP(30);\n  return nL;\n}\n\n// Points in memory", "final")
         core.write_text(s)

@@ -854,6 +854,7 @@ struct BlockGroup {
   __device__ void sync() { __syncthreads(); }
   __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
   __device__ void atomic_max(uint32_t *p, uint32_t v) { atomicMax(p, v); }
+  __device__ void atomic_max64(uint64_t *p, uint64_t v) { atomicMax((unsigned long long *)p, (unsigned long long)v); }
   __device__ void atomic_min(int *p, int v) { atomicMin(p, v); }
   static __device__ __forceinline__ int wave_inclusive_scan(int v) { return wave_inclusive_scan_i32(v); }
   __device__ int exclusive_scan(int *a, int n) {
@@ -907,6 +908,23 @@ struct BlockGroup {
     return ta;
   }
 
+  // one value pair per thread: exclusive prefixes over the workgroup, ONE barrier (the caller's next barrier frees wtot)
+  __device__ int exclusive_scan2_one(int a, int b, int *ex_a, int *ex_b, int *total_b) {
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int ia = wave_inclusive_scan(a), ib = wave_inclusive_scan(b);
+    if (lane == 63) wtot[wave] = ia, wtot[kMaxWaves + wave] = ib;
+    __syncthreads();
+    int basea = 0, ta = 0, baseb = 0, tb = 0;
+    for (int w = 0; w < nwaves; w++) {
+      const int x = wtot[w], y = wtot[kMaxWaves + w];
+      if (w < wave) basea += x, baseb += y;
+      ta += x, tb += y;
+    }
+    *ex_a = basea + ia - a, *ex_b = baseb + ib - b;
+    *total_b = tb;
+    return ta;
+  }
+
   // introsort::partition_phase replayed by the 64 lanes of wave 0 with the SAME resulting array (bit for bit).
   // The serial loop `while (*first < pivot) ++first; --last; while (pivot < *last) --last; swap` visits, in the
   // ORIGINAL data of the range, the ascending positions A_0 < A_1 < ... of the elements >= pivot and the descending
@@ -919,7 +937,10 @@ struct BlockGroup {
   // lists are ranks of two ballots, lane k learns (A_k, B_k) through two ds_permute, the partners through two more and
   // the items cross through two ds_bpermute: no LDS array, no fence, no dependent LDS round trips per step (the LDS form
   // below took 11.2 k cycles for 64 items on the one-frame path, profiles/r05_c_octree_stamps_one_frame.txt).
-  __device__ void sort_partition_phase_regs(introsort::item_t *a, int n) {
+  // proc != nullptr: std::sort's final insertion pass as well -- a stable sort of what the partition phase leaves, i.e.
+  // a rank among the 15 neighbours on either side (vsg_octree_core.h) -- on the lanes' registers (30 ds_bpermute of the
+  // keys, all in flight together), written straight into the back-to-front processing order: the items never return to LDS
+  __device__ void sort_partition_phase_regs(introsort::item_t *a, int n, uint16_t *proc = nullptr) {
     if (tid >= 64) return;
     const int lane = tid;
     introsort::item_t item = lane < n ? a[lane] : ~(introsort::item_t)0;
@@ -989,8 +1010,31 @@ struct BlockGroup {
       __threadfence_block();
       lo = stk[3 * sp], hi = stk[3 * sp + 1], depth = stk[3 * sp + 2];
     }
+    if (proc) {
+      const uint32_t key = (uint32_t)(item >> 32);
+      const int lo_t = lane > 15 ? lane - 15 : 0, hi_t = lane + 15 < n - 1 ? lane + 15 : n - 1;
+      int rank = lo_t;
+#pragma unroll
+      for (int d = -15; d <= 15; d++) {
+        if (d == 0) continue;
+        const int j = lane + d;
+        const uint32_t kj = (uint32_t)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)key);
+        rank += (j >= lo_t) & (j <= hi_t) & ((kj < key) | ((kj == key) & (d < 0)));
+      }
+      if (lane < n) proc[n - 1 - rank] = (uint16_t)(uint32_t)item;
+      return;
+    }
     if (lane < n) a[lane] = item;
     __threadfence_block();
+  }
+  __device__ bool sort_to_proc(introsort::item_t *a, int n, uint16_t *proc) {
+#ifndef VSG_OCT_NO_REGSORT
+    if (n <= 64) {
+      sort_partition_phase_regs(a, n, proc);
+      return true;
+    }
+#endif
+    return false;
   }
   __device__ void sort_partition_phase(introsort::item_t *a, int n, uint16_t *posA, uint16_t *posB) {
 #ifndef VSG_OCT_NO_REGSORT  // A/B builds: the LDS form for every n
@@ -1254,6 +1298,18 @@ __global__ __launch_bounds__(256) void k_debug_sort(uint64_t *items, int n) {
   g.stk = sort_stack;
   for (int i = g.tid; i < n; i += g.nthreads) buf[i] = items[i];
   __syncthreads();
+  {
+    // the form the octree takes for <= 64 nodes: partition phase AND stable ranks on wave 0's registers, the processing order
+    // (back to front) as the result.  Run on a copy whose payload is the item's index, then gathered back.
+    introsort::item_t *tmp = (introsort::item_t *)(((uintptr_t)(posB + n + 2) + 7) & ~(uintptr_t)7);
+    for (int i = g.tid; i < n; i += g.nthreads) tmp[i] = (buf[i] & 0xFFFFFFFF00000000ull) | (uint32_t)i;
+    __syncthreads();
+    if (g.sort_to_proc(tmp, n, posA)) {
+      __syncthreads();
+      for (int t = g.tid; t < n; t += g.nthreads) items[n - 1 - t] = buf[posA[t]];
+      return;
+    }
+  }
   g.sort_partition_phase(buf, n, posA, posB);
   __syncthreads();
   for (int t = g.tid; t < n; t += g.nthreads) {
@@ -2238,7 +2294,7 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   hipLaunchKernelGGL(k_octree, grid, block, lds, s, a);
 }
 void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n) {
-  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(256), (size_t)n * 8 + 2 * (n + 2) * 2 + 16, s, d_items, n);
+  hipLaunchKernelGGL(k_debug_sort, dim3(1), dim3(256), (size_t)n * 16 + 2 * (n + 2) * 2 + 32, s, d_items, n);
 }
 void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                  const FrameGeom &fg, int nframes) {

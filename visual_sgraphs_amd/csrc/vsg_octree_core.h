@@ -45,6 +45,9 @@ struct SerialGroup {
   VSG_OCT_HD void atomic_max(uint32_t *p, uint32_t v) {
     if (v > *p) *p = v;
   }
+  VSG_OCT_HD void atomic_max64(uint64_t *p, uint64_t v) {
+    if (v > *p) *p = v;
+  }
   VSG_OCT_HD void atomic_min(int *p, int v) {
     if (v < *p) *p = v;
   }
@@ -62,11 +65,19 @@ struct SerialGroup {
     *total_b = exclusive_scan(b, n);
     return exclusive_scan(a, n);
   }
+  // one value pair per THREAD (tid = element index): exclusive prefixes of a and b over the group, totals returned
+  VSG_OCT_HD int exclusive_scan2_one(int a, int b, int *ex_a, int *ex_b, int *total_b) {
+    *ex_a = 0, *ex_b = 0, *total_b = b;
+    return a;
+  }
   // std::sort's quicksort half on items[0..n) (see vsg_introsort.h); posA/posB: n + 1 uint16 of scratch each.
   // The caller syncs afterwards.
   VSG_OCT_HD void sort_partition_phase(introsort::item_t *items, int n, uint16_t *, uint16_t *) {
     introsort::partition_phase(items, n);
   }
+  // whole std::sort + the back-to-front processing order in one step, where the group has a faster form (false: use the
+  // two-step form: sort_partition_phase, then the stable ranks)
+  VSG_OCT_HD bool sort_to_proc(introsort::item_t *, int, uint16_t *) { return false; }
 };
 
 struct Params {
@@ -466,6 +477,74 @@ VSG_OCT_HD int fused_main_passes(G &g, const Params &P, Work &W, int &cur, int n
   *state = 0;
   for (int pass = 0; pass < kFuseDepth; pass++) {
     const int b = cur, nb = cur ^ 1, prevSize = nL;
+    if (nL <= g.nthreads) {
+      // One node per thread (on the device always: at most 4^2 x kFuseRoots = 64 nodes enter the last fused pass): the
+      // node, its four child counts and its scan values stay in the thread's registers from the first read to the last
+      // write -- one block scan and one barrier per pass instead of three LDS round trips through divided / childcnt /
+      // scanA / scanB and four barriers.
+      const int i = g.tid;
+      const bool have = i < nL;
+      int ulx = 0, uly = 0, urx = 0, bly = 0, code = 0, cnt = 0, k = 0, e = 0, cc[4] = {0, 0, 0, 0};
+      bool d = false;
+      if (have) {
+        cnt = W.cnt(b)[i];
+        ulx = W.ulx(b)[i], uly = W.uly(b)[i], urx = W.urx(b)[i], bly = W.bly(b)[i];
+        code = W.ncode(b)[i];
+        d = cnt > 1;
+        if (d) {
+          const int base = (code >> 8) * kFuseCells + (pass == 0 ? 0 : pass == 1 ? 4 : 20) + 4 * (code & 63);
+          for (int c = 0; c < 4; c++) {
+            cc[c] = W.hist[base + c];
+            k += cc[c] > 0;
+            e += cc[c] > 1;
+          }
+        }
+      }
+      int ex = 0, exKept = 0, kept = 0;
+      const int total = g.exclusive_scan2_one(k | (e << 16), have && !d ? 1 : 0, &ex, &exKept, &kept);
+      const int K = total & 0xFFFF, E = total >> 16;
+      if (have) {
+        if (d) {
+          const int q0 = ex & 0xFFFF, e0 = ex >> 16;
+          const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
+          int m = 0, ev = 0;
+          for (int c = 0; c < 4; c++) {
+            if (cc[c] > 0) {
+              const int pos = K - 1 - (q0 + m);  // push_front => reversed creation order
+              W.ulx(nb)[pos] = (int16_t)((c & 1) ? midX : ulx);
+              W.urx(nb)[pos] = (int16_t)((c & 1) ? urx : midX);
+              W.uly(nb)[pos] = (int16_t)((c & 2) ? midY : uly);
+              W.bly(nb)[pos] = (int16_t)((c & 2) ? bly : midY);
+              W.cnt(nb)[pos] = cc[c];
+              W.ncode(nb)[pos] = (uint16_t)((code & 0xFF00) | ((pass + 1) << 6) | ((code & 63) * 4 + c));
+              if (cc[c] > 1) W.V[e0 + ev++] = (uint16_t)pos;
+              m++;
+            }
+          }
+        } else {
+          const int pos = K + exKept;
+          W.ulx(nb)[pos] = (int16_t)ulx;
+          W.urx(nb)[pos] = (int16_t)urx;
+          W.uly(nb)[pos] = (int16_t)uly;
+          W.bly(nb)[pos] = (int16_t)bly;
+          W.cnt(nb)[pos] = cnt;
+          W.ncode(nb)[pos] = (uint16_t)code;
+        }
+      }
+      g.sync();
+      cur = nb;
+      nL = K + kept;
+      nV = E;
+      if (nL >= P.N || nL == prevSize) {  // (:692)
+        *state = 1;
+        break;
+      }
+      if (nL + nV * 3 > P.N) {  // (:696)
+        *state = 2;
+        break;
+      }
+      continue;
+    }
     // counts of the four children of every node that splits (all of them sit at depth `pass`)
     for (int i = g.tid; i < nL; i += g.nthreads) {
       const bool d = W.cnt(b)[i] > 1;
@@ -647,6 +726,9 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
         // std::sort (:707) = serial quicksort partitioning + a stable sort of what it leaves (vsg_introsort.h);
         // the stable part is a rank computation spread over the group, written straight into the back-to-front
         // processing order of (:708).
+        if (g.sort_to_proc(sortbuf, nV, W.proc)) {
+          g.sync();
+        } else {
         g.sort_partition_phase(sortbuf, nV, (uint16_t *)W.scanA, (uint16_t *)W.scanB);
         g.sync();
         for (int t = g.tid; t < nV; t += g.nthreads) {
@@ -669,6 +751,7 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
           W.proc[nV - 1 - rank] = (uint16_t)(uint32_t)it;
         }
         g.sync();
+        }
         int nV2 = 0;
         nL = run_pass(g, P, W, cur, nL, nV, true, pts, npts, &nV2);
         nV = nV2;
@@ -678,19 +761,18 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
   }
 
   // retain the best point of every node, first maximum wins (:763-782)
-  uint32_t *bestkey = (uint32_t *)W.childcnt;
+  // ONE sweep: the key (response, then the EARLIER candidate) rides above the candidate word in a 64-bit LDS maximum, so the
+  // winner's word is what the maximum leaves behind (two sweeps and a barrier between them before: key, then compare)
+  uint64_t *bestkey = (uint64_t *)W.childcnt;  // 8 of the 16 bytes per node
   for (int i = g.tid; i < nL; i += g.nthreads) bestkey[i] = 0;
   g.sync();
   const float inv_w = 1.0f / (float)P.wCell, inv_h = 1.0f / (float)P.hCell;
   pts.for_each(g, npts, [&](uint32_t c, int &n) {
     const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c), inv_w, inv_h));
-    g.atomic_max(&bestkey[n], key);
+    g.atomic_max64(&bestkey[n], ((uint64_t)key << 32) | c);
   });
   g.sync();
-  pts.for_each(g, npts, [&](uint32_t c, int &n) {
-    const uint32_t key = ((uint32_t)VSG_CAND_R(c) << 24) | (0xFFFFFFu - cand_rank(P, VSG_CAND_X(c), VSG_CAND_Y(c), inv_w, inv_h));
-    if (bestkey[n] == key) sel_out[n] = c;
-  });
+  for (int i = g.tid; i < nL; i += g.nthreads) sel_out[i] = (uint32_t)bestkey[i];
   g.sync();
   return nL;
 }
