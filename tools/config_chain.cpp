@@ -178,14 +178,16 @@ struct C3Gpu {
     PairResult &R = res[t & 1], &P = res[(t + 1) & 1];
     vsg_frame *cur = FL[t & 1], *prev = FL[(t + 1) & 1];
     double t0 = now_ms();
-    // each eye's thread extracts AND makes its features resident (the two eyes are independent until ComputeStereoMatches)
+    // each eye's thread extracts AND makes its features resident in ONE call and one wait (vsg_orb_extract_to_frame: the grid
+    // launch rides behind operator()'s chain; rectified pair: no distortion model, Frame.cc:893-897): the two eyes are
+    // independent until ComputeStereoMatches
     right_eye.run([&] {
-      CHECK(vsg_orb_extract(exR, right, H3, W3, W3, 0, 0, R.kpR.data(), R.dsR.data(), cap, &R.nR) >= 0);
-      CHECK(vsg_frame_from_extractor(FR, exR, 0, R.kpR.data(), R.nR, 0.f, 0.f, (float)W3, (float)H3) == VSG_OK);
+      CHECK(vsg_orb_extract_to_frame(exR, right, H3, W3, W3, 0, 0, R.kpR.data(), R.dsR.data(), cap, &R.nR, FR, nullptr, nullptr, 0,
+                                     0.f, 0.f, (float)W3, (float)H3, nullptr) >= 0);
     });
-    CHECK(vsg_orb_extract(exL, left, H3, W3, W3, 0, 0, R.kpL.data(), R.dsL.data(), cap, &R.nL) >= 0);
+    CHECK(vsg_orb_extract_to_frame(exL, left, H3, W3, W3, 0, 0, R.kpL.data(), R.dsL.data(), cap, &R.nL, cur, nullptr, nullptr, 0, 0.f,
+                                   0.f, (float)W3, (float)H3, nullptr) >= 0);
     double t1 = now_ms();
-    CHECK(vsg_frame_from_extractor(cur, exL, 0, R.kpL.data(), R.nL, 0.f, 0.f, (float)W3, (float)H3) == VSG_OK);
     right_eye.wait();
     double t2 = now_ms();
     R.nstereo = vsg_frame_stereo_matches(exL, 0, exR, 0, cur, FR, MB, MBF, R.uR.data(), R.depth.data());
@@ -331,7 +333,7 @@ static std::string run_c3(double seconds, int npipes) {
   char b[4096];
   snprintf(b, sizeof b,
            "{\"workload\": \"C3: stereo 752x480, nFeatures=1200; per pair 2 x (operator() -> resident frame) on two host threads "
-           "(stage extract_2_eyes = the left eye's operator(), make_resident_2 = until both eyes are resident) "
+           "(stage extract_2_eyes = the left eye's operator() + resident frame in one call, make_resident_2 = until the right eye's thread is done too) "
            "-> ComputeStereoMatches -> ComputeBoW (k=%d, L=%d vocabulary, %d nodes, levelsup 4) -> SearchByBoW(KF = "
            "previous pair, F)\", \"unit\": \"stereo pairs/s\", \"pairs_per_s\": %.1f, \"ms_per_pair\": %.4f, "
            "\"stage_ms\": {\"extract_2_eyes\": %.4f, \"make_resident_2\": %.4f, \"stereo_matches\": %.4f, \"compute_bow\": %.4f, "

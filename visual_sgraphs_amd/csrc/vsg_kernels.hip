@@ -932,6 +932,9 @@ struct BlockGroup {
   // A_k < B_k; it returns min(A_K, B_{K-1}) at the first K with A_K >= B_K.  The pairs are disjoint, so ranks from
   // wave ballots, one parallel round of swaps and a popcount reproduce a whole partition step.  Median selection
   // and the (rare) heapsort fallback stay on lane 0.  Other waves fall through; the caller's barrier orders them.
+#ifndef VSG_OCT_RANK_UNROLL
+#define VSG_OCT_RANK_UNROLL 6  // neighbour keys in flight at a time in the register form's stable ranks
+#endif
   // n <= 64 (the careful phase of every level whose list holds at most 64 splittable nodes: all of C2's): the array lives
   // in the 64 lanes' REGISTERS.  Median selection reads three lanes (v_readlane, scalar compares), the A / B position
   // lists are ranks of two ballots, lane k learns (A_k, B_k) through two ds_permute, the partners through two more and
@@ -1014,9 +1017,10 @@ struct BlockGroup {
       const uint32_t key = (uint32_t)(item >> 32);
       const int lo_t = lane > 15 ? lane - 15 : 0, hi_t = lane + 15 < n - 1 ? lane + 15 : n - 1;
       int rank = lo_t;
-#pragma unroll
-      for (int d = -15; d <= 15; d++) {
-        if (d == 0) continue;
+      // (six neighbours in flight at a time: all thirty at once cost the whole kernel ~ 150 spilled registers)
+#pragma unroll VSG_OCT_RANK_UNROLL
+      for (int i = 0; i < 30; i++) {
+        const int d = i < 15 ? i - 15 : i - 14;
         const int j = lane + d;
         const uint32_t kj = (uint32_t)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)key);
         rank += (j >= lo_t) & (j <= hi_t) & ((kj < key) | ((kj == key) & (d < 0)));
@@ -1269,6 +1273,7 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
 #ifndef VSG_OCT_WAVES
 #define VSG_OCT_WAVES 5
 #endif
+
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG_OCT_WAVES, VSG_OCT_WAVES))) void k_octree(OctArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
