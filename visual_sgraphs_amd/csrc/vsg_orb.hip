@@ -527,7 +527,9 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   const bool fused_blur = !tm && sb != s && (lds_fits || (h->one_stream && nf <= 8));
   // Without a lapping area (every keypoint has x >= 19, so lap1 < 19 -- the {0, 0} of the RGB-D / stereo callers,
   // Frame.cc:108,344 -- selects nothing): k_orient_desc derives slots and level starts itself, k_slots is not launched
-  // (8 us of the one-frame chain; for 512-frame batches + 0.4 % frames/s in the same run, round 4)
+  // (8 us of the one-frame chain; for 512-frame batches + 0.4 % frames/s in the same run, round 4; in the two-stream form of
+  // the geometries whose octree workspace keeps the blur out of its launch -- 1280x720 / 2000 -- k_slots was 51 us of a
+  // 128-frame step, 5 %: profiles/r05_j_c4_kernel_stats_timed_region.csv)
   const bool self_slots = !tm && (lap1 < kEdgeThreshold || lap0 > lap1);
   if (fused_blur) {
     Range r_tail("DistributeOctTree (+ blur workgroups) + slots + IC_Angle / rBRIEF");
@@ -562,7 +564,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
                   sel_count, fg, h->G.maxQuota, h->G.maxCellsPerLevel, nf);
     if (tm) HIP_TRY(hipEventRecord(h->ev[3], s));
   }
-  launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
+  if (!self_slots) launch_slots(s, h->d_fg, sel, sel_count, flags, slots, hdr, lap0, lap1, nf);
   if (tm) HIP_TRY(hipEventRecord(h->ev[4], s));
   HIP_TRY(hipStreamWaitEvent(s, ev_blur, 0));
   if (tm) HIP_TRY(hipEventRecord(h->ev[9], s));
@@ -570,7 +572,7 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   OutMirror mir = h->mirror;
   if (mir.kps) mir.kps += F * mir.capacity, mir.desc += F * mir.capacity * 32, mir.counts += F * 2;
   launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, sel_count, slots, hdr, h->d_pattern, d_kps + F * capacity,
-                     d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf, mir, self_slots && fused_blur);
+                     d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf, mir, self_slots);
   if (tm) HIP_TRY(hipEventRecord(h->ev[5], s));
   return VSG_OK;
 }
