@@ -26,7 +26,7 @@ def main():
         for k in agg:
             stage = next((v for s, v in STAGE.items() if s in k), None)
             if k.strip() == "" or stage is None:
-                stage = "match" if k.strip() == "" else stage  # the MFMA matcher's long name is cut to ''
+                stage = "match" if k.strip() == "" else stage  # (older dumps: the MFMA matcher's long name was cut to '')
             if stage is None:
                 continue
             for c, v in agg[k].items():

@@ -8,9 +8,10 @@ import sys
 
 def kernel_key(name):
     """'void vsg::k_fast_cells<128, 52, 44>(unsigned char const*, ...)' -> 'vsg::k_fast_cells'."""
-    name = name.split('(')[0].strip()
     if name.startswith('void '):
         name = name[5:]
+    name = name.replace('(anonymous namespace)::', 'vsg::')  # the matcher / frame / BoW kernels live in unnamed namespaces
+    name = name.split('(')[0].strip()
     name = name.split('<')[0]
     return name[-26:]
 
