@@ -195,6 +195,37 @@ def test_blur_taps_are_data():
     assert np.array_equal(ex.blurred_level(0), ol.gaussian_blur7(img, ed))
 
 
+@pytest.mark.parametrize("taps", [(18, 34, 49, 55, 49, 34, 18), (18, 34, 48, 56, 48, 34, 18), (1, 0, 0, 0, 0, 0, 255),
+                                  (255, 2, 0, 0, 0, 0, 0), (0, 0, 1, 255, 1, 0, 0), (128, 129, 0, 0, 0, 0, 0), (0, 0, 0, 0, 128, 129, 0),
+                                  (37, 37, 37, 36, 37, 37, 36), (0, 0, 0, 0, 0, 0, 0)])
+def test_blur_saturation_and_extreme_tap_tables(taps):
+    """saturate_cast<uchar> of the 8.8 blur: a tap table that sums to 257 (OpenCV 4.2's plain rounding) takes a 255-valued
+    area to (257 * 65535 + 32768) >> 16 = 257 -> 255.  The kernel forms the vertical sum 256 times too large and lets the
+    clamp bit of v_dot2_u32_u16 saturate it; every level of a frame with white / black blocks, white borders and noise must
+    equal the CPU blur for the shipped tables and for tables that put the whole weight on one end of the window."""
+    w, h = 338, 262  # ragged: the last tile column and the last strip are partial
+    rng = np.random.default_rng(sum(taps) * 7 + taps[0])
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[:40] = 255
+    img[-9:] = 255
+    img[:, :21] = 255
+    img[:, -5:] = 255
+    img[60:140, 100:260] = 255
+    img[150:200, 30:90] = 0
+    img[120:131, 280:291] = 254
+    ex = orb.ORBextractor(400, 1.2, 4, 20, 7)
+    ex.set_blur_taps(taps)
+    ref = ol.OracleExtractor(400, 1.2, 4, 20, 7)
+    ref.set_blur_taps(taps)
+    assert_same_output(ex(img), ref(img), f"taps {taps}")
+    for l in range(4):
+        want = ol.gaussian_blur7(ref.pyramid_level(l), taps)
+        got = ex.blurred_level(l)
+        assert np.array_equal(got, want), (taps, l, int((got != want).sum()))
+    if sum(taps) == 257:
+        assert int(ex.blurred_level(0)[10, 100]) == 255  # the case the clamp exists for
+
+
 def test_unsupported_inputs_return_codes():
     ex = orb.ORBextractor(500, 1.2, 8, 20, 7)
     with pytest.raises(orb.VsgError) as ei:

@@ -1357,12 +1357,14 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 
 // rows whose loads a blur thread keeps in flight ahead of the row it works on: 7 inside the octree's launch (the fused
 // kernel is compiled for the octree's 96 VGPRs: 311-313 k frames/s with 7-12 rows ahead against 306-308 k for the
-// fetch-7 / work-7 form, 14 spills), 14 in the blur's own launch (0.285 against 0.294 ms per 512 C2 frames; 7: 0.298)
+// fetch-7 / work-7 form, 14 spills), 10 in the blur's own launch: with the round-5 arithmetic (shifted tap words, clamp
+// bit, two-offset row addresses) that is 92 VGPRs = 5 waves per SIMD, 0.216 ms per 512 C2 frames against 0.220-0.226 with
+// 14 rows ahead (104 VGPRs, 4 waves) and 0.253 for the round-4 arithmetic (in-run A/B, profiles/r05_p_*)
 #ifndef VSG_BLUR_AHEAD
 #define VSG_BLUR_AHEAD 7
 #endif
 #ifndef VSG_BLUR_AHEAD_ALONE
-#define VSG_BLUR_AHEAD_ALONE 14
+#define VSG_BLUR_AHEAD_ALONE 10
 #endif
 template <int kBlurAhead>
 __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
@@ -1403,11 +1405,19 @@ __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint
   const uint32_t tile_row_bytes = (uint32_t)L.btx * kBlurTileBytes;
   const bool q_odd = q & 1, q_hi = q & 2;
   uint32_t trow[4] = {0, 0, 0, 0};  // the thread's dwords of the four rows of the current tile
-  const uint32_t T0 = fg->taps[0] | (fg->taps[1] << 8) | (fg->taps[2] << 16) | ((uint32_t)fg->taps[3] << 24);
-  const uint32_t T1 = fg->taps[4] | (fg->taps[5] << 8) | (fg->taps[6] << 16);
   uint32_t k[7];
 #pragma unroll
   for (int j = 0; j < 7; j++) k[j] = fg->taps[j];
+  // Horizontal pass without byte alignment: the 12 source bytes stay in their three dwords {e0, e1, e2} and the TAPS are
+  // shifted instead -- pixel j's window is bytes j+1 .. j+7, so its seven taps sit at byte offsets that differ per pixel:
+  // ten v_dot4_u32_u8 against ten scalar tap words (2 + 3 + 3 + 2) instead of eight and six v_alignbyte_b32.
+  auto tw = [&](int a, int b, int c, int d) {  // tap word: tap index per byte, -1 = no tap
+    return (a < 0 ? 0u : k[a]) | (b < 0 ? 0u : k[b] << 8) | (c < 0 ? 0u : k[c] << 16) | (d < 0 ? 0u : k[d] << 24);
+  };
+  const uint32_t TA0 = tw(-1, 0, 1, 2), TA1 = tw(3, 4, 5, 6);                          // pixel 0: e0, e1
+  const uint32_t TB0 = tw(-1, -1, 0, 1), TB1 = tw(2, 3, 4, 5), TB2 = tw(6, -1, -1, -1);  // pixel 1: e0, e1, e2
+  const uint32_t TC0 = tw(-1, -1, -1, 0), TC1 = tw(1, 2, 3, 4), TC2 = tw(5, 6, -1, -1);  // pixel 2
+  const uint32_t TD1 = tw(0, 1, 2, 3), TD2 = tw(4, 5, 6, -1);                          // pixel 3: e1, e2
   const bool interior = x0 >= 4 && x0 + 8 <= w;  // all 12 source bytes exist: aligned dword loads
   // column groups past the image (the padding of the last tile column) compute on clamped addresses and store garbage
   // into bytes nothing reads
@@ -1431,8 +1441,19 @@ __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint
   // P[r] = H[r-1] | H[r] << 16 and an output row is three v_dot2_u32_u16 (taps 0-1, 2-3, 4-5 against P[r-5], P[r-3],
   // P[r-1]) plus one multiply-add for tap 6 on the newest row: 4 + 1 (the pack) operations per pixel instead of 7.
   uint32_t pw[7][4], hprev[4] = {0, 0, 0, 0};
-  const u16x2 K01 = {(unsigned short)k[0], (unsigned short)k[1]}, K23 = {(unsigned short)k[2], (unsigned short)k[3]},
-              K45 = {(unsigned short)k[4], (unsigned short)k[5]};
+  // The vertical sums are formed 256 times too large (taps << 8, rounding constant 32768 << 8): the output byte is byte 3
+  // of the sum, and saturate_cast<uchar> -- a sum >= 2^24, which only a tap table that sums to 257 reaches, on 255-valued
+  // areas -- is the CLAMP bit of the v_dot2_u32_u16 (an unsigned overflow saturates to 0xFFFFFFFF, byte 3 = 255) instead
+  // of a v_min_u32 per pixel.  Taps are <= 255 and sum to <= 257 (vsg_orb_set_blur_taps), so the multiply-add of tap 6
+  // cannot overflow by itself: 65 280 x 65 535 + 2^23 < 2^32.
+  const u16x2 K01 = {(unsigned short)(k[0] << 8), (unsigned short)(k[1] << 8)},
+              K23 = {(unsigned short)(k[2] << 8), (unsigned short)(k[3] << 8)},
+              K45 = {(unsigned short)(k[4] << 8), (unsigned short)(k[5] << 8)};
+  // tap 6 in a vector register and the rounding constant in a scalar one: v_mad_u32_u24 reads one scalar operand, and
+  // left alone the compiler keeps the tap scalar and re-materialises the literal with a v_mov_b32 in every row
+  uint32_t k6s, round_s;
+  asm("v_mov_b32 %0, %1" : "=v"(k6s) : "s"(k[6] << 8));
+  asm("s_mov_b32 %0, 0x800000" : "=s"(round_s));
   // The 36 + 6 source rows of the strip as a software pipeline: the three dwords of row r + kBlurAhead are requested
   // before row r is worked on, so a wave always has kBlurAhead rows' loads in flight under its arithmetic (the first form
   // fetched 7 rows, waited for them, worked through them and only then fetched the next 7: every 7th row paid a full
@@ -1440,13 +1461,20 @@ __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint
   // indices constants.
   constexpr int kRowsIn = kBlurStrip + 6;
   uint32_t d0[kRowsIn], d1[kRowsIn], d2[kRowsIn];
+  // Row addresses: source row y0 - 3 + rr, REFLECT_101 without a loop (rows start at >= -3 and overshoot the bottom by
+  // < h: levels are >= 64 rows, a strip is 36 + 6, so one fold per side is exact; rows past the fold are never stored).
+  // Only the first three rows can fold at the top; from the fourth on the byte offset is min(down, up) of two offsets
+  // that move by one row pitch per row -- an add, a subtract (of a scalar multiple of the pitch) and a minimum.
+  const uint32_t off_dn = (uint32_t)((y0 - 3) * spitch + base), off_up = (uint32_t)((2 * h - 2 - (y0 - 3)) * spitch + base);
   auto fetch_row = [&](int rr) {
-    // REFLECT_101 of the row without a loop: rows start at >= -3 and overshoot the bottom by < h (levels are
-    // >= 64 rows, a strip is 36 + 6), so one fold per side is exact; rows past the fold are never stored
-    int ysrc = y0 - 3 + rr;
-    ysrc = ysrc < 0 ? -ysrc : ysrc;
-    ysrc = ysrc >= h ? 2 * h - 2 - ysrc : ysrc;
-    const uint8_t *row = img + (uint32_t)(ysrc * spitch + base);  // uniform base + 32-bit lane offset
+    uint32_t off;
+    if (rr < 3) {
+      const int ysrc = y0 == 0 ? 3 - rr : y0 - 3 + rr;
+      off = (uint32_t)(ysrc * spitch + base);
+    } else {
+      off = min(off_dn + (uint32_t)(rr * spitch), off_up - (uint32_t)(rr * spitch));
+    }
+    const uint8_t *row = img + off;  // uniform base + 32-bit lane offset
     d0[rr] = *(const u32_unaligned *)(row);
     d1[rr] = *(const u32_unaligned *)(row + 4);
     d2[rr] = *(const u32_unaligned *)(row + 8);
@@ -1459,20 +1487,19 @@ __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint
     const int s = rr % 7;
     uint32_t e0 = d0[rr], e1 = d1[rr], e2 = d2[rr];
     if (!interior) {
-      const uint32_t a0 = e0, a1 = e1, a2 = e2;
-      e0 = __builtin_amdgcn_perm(a1, a0, selLo[0]) | __builtin_amdgcn_perm(0u, a2, selHi[0]);
-      e1 = __builtin_amdgcn_perm(a1, a0, selLo[1]) | __builtin_amdgcn_perm(0u, a2, selHi[1]);
-      e2 = __builtin_amdgcn_perm(a1, a0, selLo[2]) | __builtin_amdgcn_perm(0u, a2, selHi[2]);
+      const uint32_t b0 = __builtin_amdgcn_perm(e1, e0, selLo[0]) | __builtin_amdgcn_perm(0u, e2, selHi[0]);
+      const uint32_t b1 = __builtin_amdgcn_perm(e1, e0, selLo[1]) | __builtin_amdgcn_perm(0u, e2, selHi[1]);
+      const uint32_t b2 = __builtin_amdgcn_perm(e1, e0, selLo[2]) | __builtin_amdgcn_perm(0u, e2, selHi[2]);
+      // written back INTO the registers the loads filled, so that the interior waves (which skip this block) need no
+      // copies to meet the edge waves' values in other registers
+      asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "+v"(e0), "+v"(e1), "+v"(e2) : "v"(b0), "v"(b1), "v"(b2));
     }
     // pixel j: taps over bytes j+1 .. j+7 of {e0,e1,e2}
     uint32_t H[4];
-    H[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e1, e0, 1), T0,
-                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e2, e1, 1), T1, 0u, false), false);
-    H[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e1, e0, 2), T0,
-                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e2, e1, 2), T1, 0u, false), false);
-    H[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e1, e0, 3), T0,
-                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(e2, e1, 3), T1, 0u, false), false);
-    H[3] = __builtin_amdgcn_udot4(e1, T0, __builtin_amdgcn_udot4(e2, T1, 0u, false), false);
+    H[0] = __builtin_amdgcn_udot4(e0, TA0, __builtin_amdgcn_udot4(e1, TA1, 0u, false), false);
+    H[1] = __builtin_amdgcn_udot4(e0, TB0, __builtin_amdgcn_udot4(e1, TB1, __builtin_amdgcn_udot4(e2, TB2, 0u, false), false), false);
+    H[2] = __builtin_amdgcn_udot4(e0, TC0, __builtin_amdgcn_udot4(e1, TC1, __builtin_amdgcn_udot4(e2, TC2, 0u, false), false), false);
+    H[3] = __builtin_amdgcn_udot4(e1, TD1, __builtin_amdgcn_udot4(e2, TD2, 0u, false), false);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       pw[s][j] = hprev[j] | (H[j] << 16);
@@ -1484,20 +1511,19 @@ __device__ __forceinline__ void blur_block(const uint8_t *__restrict__ pyr, uint
         uint32_t cl[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          uint32_t acc = __umul24(k[6], H[j]) + 32768u;
-          acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 2) % 7][j]), K01, acc, false);  // rows r-6, r-5
-          acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 4) % 7][j]), K23, acc, false);  // rows r-4, r-3
-          acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 6) % 7][j]), K45, acc, false);  // rows r-2, r-1
-          cl[j] = min(acc, 0x00FFFFFFu);  // saturate_cast<uchar>(acc >> 16): byte 2 of the clamped sum
+          uint32_t acc = __umul24(k6s, H[j]) + round_s;  // 32768 << 8
+          acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 2) % 7][j]), K01, acc, true);  // rows r-6, r-5
+          acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 4) % 7][j]), K23, acc, true);  // rows r-4, r-3
+          cl[j] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, pw[(s + 6) % 7][j]), K45, acc, true);  // rows r-2, r-1
         }
-        const uint32_t out = __builtin_amdgcn_perm(cl[1], cl[0], 0x0C0C0602u) |
-                             (__builtin_amdgcn_perm(cl[3], cl[2], 0x0C0C0602u) << 16);
+        const uint32_t out = __builtin_amdgcn_perm(cl[1], cl[0], 0x0C0C0703u) |
+                             (__builtin_amdgcn_perm(cl[3], cl[2], 0x0C0C0703u) << 16);
         trow[(rr - 6) & 3] = out;
       }
       const int o = rr - 6;  // output row of the strip: tile row o / 4, line row o % 4
       if ((o & 3) == 3 && y0 + o - 3 < h) {  // the tile row is complete (rows past the level's last one: padding)
-        auto x1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); };  // quad_perm [1,0,3,2]
-        auto x2 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false); };  // quad_perm [2,3,0,1]
+        auto x1 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); };  // quad_perm [1,0,3,2]: every lane has a source
+        auto x2 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); };  // quad_perm [2,3,0,1]
         const uint32_t p01 = x1(trow[1]), p10 = x1(trow[0]), p23 = x1(trow[3]), p32 = x1(trow[2]);
         const uint32_t c0 = q_odd ? p01 : trow[0], c1 = q_odd ? trow[1] : p10;
         const uint32_t c2 = q_odd ? p23 : trow[2], c3 = q_odd ? trow[3] : p32;
