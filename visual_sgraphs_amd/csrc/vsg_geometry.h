@@ -100,7 +100,7 @@ struct PyrTiling {
   int ldsA = 0, ldsB = 0;  // LDS bytes for even / odd levels of the ping-pong
   int tabMax = 0;          // max over tiles of staged table entries
   bool ok = false;         // usable by k_pyramid (16-bit LDS row offsets, column span)
-  int lds_bytes() const { return ((ldsA + 15) & ~15) + ((ldsB + 15) & ~15) + 8 * tabMax; }
+  int lds_bytes() const { return ((ldsA + 15) & ~15) + ((ldsB + 15) & ~15) + 8 * (tabMax + 1); }
 };
 
 struct Geometry {

@@ -229,51 +229,66 @@ __global__ __launch_bounds__(kPyrThreads) void k_pyramid(uint8_t *__restrict__ p
         const uint32_t A = __builtin_amdgcn_alignbyte(w1, w0, sh), B = __builtin_amdgcn_alignbyte(w2, w1, sh);
 #pragma unroll
         for (int k = 0; k < 4; k++)
+        {
           H[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, __builtin_amdgcn_perm(B, A, sel[k])), wgt[k], 0u,
                                         false) >> 4;
+          asm volatile("" : "+v"(H[k]));  // the shifted sum is THE value: otherwise the compiler carries the un-shifted one
+                                          // across rows and shifts it again where it is reused
+        }
       };
       // ownership of this column group: all 4 bytes, some (a seam between tiles), or none
       const int gx = dx0a + 4 * cg;  // level column of byte 0
       const int ox0 = T.own[l][0], oy0 = T.own[l][1], ox1 = T.own[l][2], oy1 = T.own[l][3];
       const bool full = gx >= ox0 && gx + 4 <= ox1, part = !full && gx < ox1 && gx + 4 > ox0;
-      uint32_t Hc[4] = {0, 0, 0, 0};
-      int offc = -1;  // LDS row offset whose horizontal sums are cached in Hc
+      // Two destination rows per trip with the roles of the two horizontal-sum sets swapped (the lower source row of one
+      // destination row is the upper one of the next 5 times out of 6: no register copies), the next row's table entry
+      // requested before the current row is worked on, and the lower row's sums formed unconditionally (where the
+      // reference clamps sy + 1 to sy the same row is summed twice: same value).  Ownership as one unsigned range test
+      // per row, the level's address as a uniform base + a 32-bit lane offset.
+      uint32_t HA[4] = {0, 0, 0, 0}, HB[4];
+      int offc = -1;  // LDS row offset whose horizontal sums are cached (in the set that is "upper" next)
       uint8_t *drow = dst + ya * dpitch + 4 * cg;
-      uint8_t *grow = frame_base + D.img_off + (size_t)(dy0 + ya) * D.pitch + gx;
-      for (int y = ya; y < yb; y++, drow += dpitch, grow += D.pitch) {
-        const Short4 ty = tyv[y];
-        uint32_t H0[4], H1[4];
-        if (ty.a == offc) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) H0[k] = Hc[k];
-        } else {
-          hrow(ty.a, H0);
-        }
-        if (ty.b == ty.a) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) H1[k] = H0[k];
-        } else {
-          hrow(ty.b, H1);
-        }
+      uint8_t *gbase = frame_base + D.img_off;
+      uint32_t goff = (uint32_t)((dy0 + ya) * D.pitch + gx);
+      const uint32_t gpitch = (uint32_t)D.pitch;
+      const int own_lo = oy0 - dy0;
+      const uint32_t own_n = (uint32_t)max(oy1 - oy0, 0);
+      auto emit = [&](int y, const Short4 &ty, const uint32_t (&H0)[4], const uint32_t (&H1)[4]) {
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const uint32_t v = ((__umul24((uint32_t)ty.c, H0[k]) >> 16) + (__umul24((uint32_t)ty.d, H1[k]) >> 16) + 2u) >> 2;
           out |= v << (8 * k);
-          Hc[k] = H1[k];
         }
-        offc = ty.b;
         *(uint32_t *)drow = out;
-        const int gy = dy0 + y;
-        if (gy >= oy0 && gy < oy1) {
+        if ((uint32_t)(y - own_lo) < own_n) {
           if (full) {
-            *(uint32_t *)grow = out;
+            *(uint32_t *)(gbase + goff) = out;
           } else if (part) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
-              if (gx + j >= ox0 && gx + j < ox1) grow[j] = (uint8_t)(out >> (8 * j));
+              if (gx + j >= ox0 && gx + j < ox1) gbase[goff + j] = (uint8_t)(out >> (8 * j));
           }
         }
+        drow += dpitch;
+        goff += gpitch;
+      };
+      // (the entry after a chunk's last row is read and not used: within the table, or the one entry of padding the
+      // launch allocates after it)
+      const Short4 *typ = tyv + ya;
+      Short4 ty = typ[0];
+      for (int y = ya; y < yb; y += 2, typ += 2) {
+        const Short4 ty1 = typ[1];
+        if (ty.a != offc) hrow(ty.a, HA);
+        hrow(ty.b, HB);
+        emit(y, ty, HA, HB);
+        offc = ty.b;
+        if (y + 1 >= yb) break;
+        ty = typ[2];
+        if (ty1.a != offc) hrow(ty1.a, HB);
+        hrow(ty1.b, HA);
+        emit(y + 1, ty1, HB, HA);
+        offc = ty1.b;
       }
     }
     __syncthreads();
@@ -2238,12 +2253,12 @@ void launch_resize(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Sho
 void launch_pyramid(hipStream_t s, uint8_t *pyr, const FrameGeom *d_fg, const Short4 *d_tile_tab, const Src0 &s0,
                     const PyrTile *d_tiles, int ntiles, int ldsA, int ldsB, int tabMax, int nframes, int *cand_count) {
   const int a16 = (ldsA + 15) & ~15, ab16 = a16 + ((ldsB + 15) & ~15);
-  const size_t lds = ab16 + tabMax * sizeof(Short4);
+  const size_t lds = ab16 + (tabMax + 1) * sizeof(Short4);  // + 1: the row loop reads one entry ahead
   // the raised limit is a per-DEVICE attribute of the function (vsg_ctx.h lds_limit_ensure)
   int dev = 0;
   hipGetDevice(&dev);
   lds_limit_ensure(0, dev, (const void *)k_pyramid, lds);
-  hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(kPyrThreads), ab16 + tabMax * sizeof(Short4), s, pyr, d_fg,
+  hipLaunchKernelGGL(k_pyramid, dim3(ntiles, nframes), dim3(kPyrThreads), lds, s, pyr, d_fg,
                      d_tile_tab, s0, d_tiles, a16, ab16, cand_count);
 }
 template <int NT, int TP, int SP, int PRE>
