@@ -27,6 +27,11 @@
 #include <thread>
 #include <vector>
 
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include "../include/vsg_orb.h"
 #include "../include/vsg_synth.h"
 #include "../oracle/orb_oracle.h"
@@ -700,7 +705,40 @@ static std::string run_latency(double seconds) {
   return b;
 }
 
+// VSG_CRASH_MAPS=1: on SIGSEGV write the faulting address, the raw return addresses and /proc/self/maps to stderr (async-
+// signal-safe calls only), then die by the default action -- tells WHICH libraries the frames under a crash belong to
+// (profiles/r05_q_rocprofv3_kernel_trace_c5_segfault.txt: rocprofv3's own handler prints addresses without names).
+static void crash_maps(int sig, siginfo_t *si, void *) {
+  char buf[256];
+  int n = snprintf(buf, sizeof buf, "\n=== config_chain: signal %d at address %p; return addresses:\n", sig, si->si_addr);
+  (void)!write(2, buf, n);
+  void *bt[48];
+  const int nb = backtrace(bt, 48);
+  for (int i = 0; i < nb; i++) {
+    n = snprintf(buf, sizeof buf, "  #%d %p\n", i, bt[i]);
+    (void)!write(2, buf, n);
+  }
+  (void)!write(2, "=== /proc/self/maps\n", 20);
+  const int fd = open("/proc/self/maps", O_RDONLY);
+  if (fd >= 0) {
+    static char big[1 << 16];
+    ssize_t r;
+    while ((r = read(fd, big, sizeof big)) > 0) (void)!write(2, big, r);
+    close(fd);
+  }
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
 int main(int argc, char **argv) {
+  if (getenv("VSG_CRASH_MAPS")) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_sigaction = crash_maps;
+    sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+    sigaction(SIGSEGV, &sa, nullptr);
+    sigaction(SIGBUS, &sa, nullptr);
+  }
   const double seconds = argc > 1 ? atof(argv[1]) : 2.0;
   const int npipes = argc > 2 ? atoi(argv[2]) : 4;
   const std::string only = argc > 3 ? argv[3] : "";  // "c5": that configuration alone (kernel traces of the four streams)

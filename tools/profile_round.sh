@@ -51,8 +51,15 @@ cp $OUT/c4_stats/*/*kernel_stats.csv $OUT/c4_kernel_stats.csv 2>/dev/null
 cp $OUT/c4_stats_timed/*/*kernel_stats.csv $OUT/c4_kernel_stats_timed_region.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_sq $OUT/c4_pmc_wait > $OUT/c4_pmc.txt 2>&1
 python3 tools/make_traffic_json.py C4/128 $OUT/traffic.json $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_sq $OUT/c4_pmc_wait > /dev/null 2>&1
-C3="tools/_bin/config_chain 2 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_stats -- $C3 > $OUT/c3_chain_rocprof.json 2>> $OUT/rocprof.err
+# (the C3 leg alone: with the four host threads of the C5 leg in the same process rocprofv3 --kernel-trace itself
+# segfaults in 2 of 6 runs -- inside hipStreamSynchronize, below the HIP runtime, in the tool's HSA queue interception;
+# un-profiled and --pmc runs of the same binary never do: profiles/r05_q_rocprofv3_kernel_trace_c5_segfault.txt --
+# and up to three attempts)
+C3="tools/_bin/config_chain 2 1 c3"
+for attempt in 1 2 3; do
+  rm -rf $OUT/c3_stats
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3_stats -- $C3 > $OUT/c3_chain_rocprof.json 2>> $OUT/rocprof.err && break
+done
 cp $OUT/c3_stats/*/*kernel_stats.csv $OUT/c3_chain_kernel_stats.csv 2>/dev/null
 pass3() {
   local name=$1; shift

@@ -36,6 +36,12 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
                    int *sel_count, const FrameGeom &fg, int maxQuota, int maxCellsPerLevel, int nframes,
                    const uint8_t *blur_pyr = nullptr, uint8_t *blur_out = nullptr, const Src0 *blur_s0 = nullptr);
 size_t octree_lds_bytes(const FrameGeom &fg, int maxQuota, int maxCellsPerLevel);
+// waves per SIMD the fused octree + blur launch is compiled for = its 256-thread workgroups per CU (the LDS they need decides
+// whether a geometry takes that launch: vsg_orb.hip)
+#ifndef VSG_OB_WAVES
+#define VSG_OB_WAVES 4
+#endif
+constexpr int kOctBlurWaves = VSG_OB_WAVES;
 void launch_debug_sort(hipStream_t s, uint64_t *d_items, int n);
 void launch_blur(hipStream_t s, const uint8_t *pyr, uint8_t *blur, const FrameGeom *d_fg, const Src0 &s0,
                  const FrameGeom &fg, int nframes);

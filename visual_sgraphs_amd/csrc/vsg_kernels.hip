@@ -1370,13 +1370,13 @@ __device__ __forceinline__ int reflect101(int p, int len) {
   return p;
 }
 
-// rows whose loads a blur thread keeps in flight ahead of the row it works on: 7 inside the octree's launch (the fused
-// kernel is compiled for the octree's 96 VGPRs: 311-313 k frames/s with 7-12 rows ahead against 306-308 k for the
-// fetch-7 / work-7 form, 14 spills), 10 in the blur's own launch: with the round-5 arithmetic (shifted tap words, clamp
-// bit, two-offset row addresses) that is 92 VGPRs = 5 waves per SIMD, 0.216 ms per 512 C2 frames against 0.220-0.226 with
-// 14 rows ahead (104 VGPRs, 4 waves) and 0.253 for the round-4 arithmetic (in-run A/B, profiles/r05_p_*)
+// rows whose loads a blur thread keeps in flight ahead of the row it works on: 12 inside the octree's launch (compiled for 4
+// waves per SIMD = 128 VGPRs; rounds 3-4: 7 rows at 5 waves / 96 VGPRs), 10 in the blur's own launch: with the round-5
+// arithmetic (shifted tap words, clamp bit, two-offset row addresses) that is 92 VGPRs = 5 waves per SIMD, 0.216 ms per
+// 512 C2 frames against 0.220-0.226 with 14 rows ahead (104 VGPRs, 4 waves) and 0.253 for the round-4 arithmetic (in-run
+// A/B, profiles/r05_p_*)
 #ifndef VSG_BLUR_AHEAD
-#define VSG_BLUR_AHEAD 7
+#define VSG_BLUR_AHEAD 12
 #endif
 #ifndef VSG_BLUR_AHEAD_ALONE
 #define VSG_BLUR_AHEAD_ALONE 10
@@ -1561,9 +1561,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 // stream whose fork / join events cost the chain as much GPU idle time as the blur itself takes (measured: 5-7 us at
 // each of the two cross-stream waits against 12 us of blur).  Both need only the pyramid.  Throughput batches keep the
 // two kernels apart: there the blur is issue-bound work that wants its own occupancy.
-#ifndef VSG_OB_WAVES
-#define VSG_OB_WAVES 5
-#endif
+// (VSG_OB_WAVES, vsg_kernels.h: 4 waves per SIMD = 128 registers.  With the round-5 blur arithmetic the blur's waves are
+// bound by memory latency more than by issue slots, and 12 rows of loads in flight at 4 waves beat 7 rows at 5 waves and the
+// octree's 59 spilled registers: + 1.0-1.2 % on the 512-frame step, 3 waves - 2.5 %: profiles/r05_p_*)
 __device__ __forceinline__ void octree_blur_body(const OctArgs &a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                                  const Src0 &s0, int nlevels, int nframes, int lead, uint8_t *oct_lds, int *wtot,
                                                  int *sort_stack) {

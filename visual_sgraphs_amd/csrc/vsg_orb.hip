@@ -523,6 +523,8 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   // Throughput batches only take the fused launch while five of its workgroups (the 5 waves per SIMD it is compiled
   // for) still fit a CU's 160 KB of LDS: every blur workgroup is charged the octree's workspace, and at 1280x720 /
   // 2000 features (33 KB) the fifth no longer fits -- 93.1 -> 90.1 k frames/s there, so that geometry keeps two streams.
+  // (re-measured in round 5 with the launch compiled for 4 waves per SIMD, where four 33 KB workgroups WOULD fit: 1280x720 /
+  // 2000 fused 113.2-114.6 k frames/s, two streams 115.4-117.2 k -- the threshold stays at five workgroups' worth of LDS)
   const bool lds_fits = 5 * octree_lds_bytes(fg, h->G.maxQuota, h->G.maxCellsPerLevel) <= 160 * 1024;
   const bool fused_blur = !tm && sb != s && (lds_fits || (h->one_stream && nf <= 8));
   // Without a lapping area (every keypoint has x >= 19, so lap1 < 19 -- the {0, 0} of the RGB-D / stereo callers,
