@@ -2331,7 +2331,12 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
     return;
   }
   dim3 grid(fg.nlevels, nframes), block(kOctThreads);
-  if (nframes <= kOctFewFrames) {
+  // The 4-waves-per-SIMD instantiation (126 VGPRs, no spills, no scratch) for calls of a few frames AND for every geometry
+  // whose workspace lets five workgroups share a CU's LDS (640x480 / 1000: 0.110 ms per 512 frames against 0.137-0.161 for the
+  // 5-waves one with its 59 spilled registers -- its launch time was bimodal from run to run, the only scratch user of the
+  // chain); where the workspace caps a CU at four workgroups anyway (1280x720 / 2000: 33 KB) the 5-waves form measures 0.8 %
+  // more frames/s (115.3-116.8 against 115.1-115.6 k, profiles/r05_p_*) and stays.
+  if (nframes <= kOctFewFrames || 5 * lds <= 160 * 1024) {
     lds_limit_ensure(4, dev, (const void *)k_octree_few, lds);
     hipLaunchKernelGGL(k_octree_few, grid, block, lds, s, a);
     return;
