@@ -226,6 +226,25 @@ def test_blur_saturation_and_extreme_tap_tables(taps):
         assert int(ex.blurred_level(0)[10, 100]) == 255  # the case the clamp exists for
 
 
+@pytest.mark.parametrize("w,h,nl,sc", [(80, 80, 1, 1.2), (97, 83, 1, 1.2), (131, 80, 1, 1.2), (83, 131, 1, 1.2), (283, 167, 3, 1.2),
+                                       (201, 149, 2, 1.5), (1241, 376, 8, 1.2), (644, 116, 2, 1.2), (100, 150, 2, 1.1)])
+def test_blurred_levels_on_small_and_odd_geometries(w, h, nl, sc):
+    """Every pixel of every blurred level (not only the ones a descriptor samples) on geometries at the small end: levels of
+    80-120 rows are two or three 36-row strips whose REFLECT_101 folds at the top and at the bottom fall into the same
+    strip or the next one, widths that leave a partial tile column, one-tile-column levels."""
+    rng = np.random.default_rng(w * 1000 + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[: h // 5] = 255
+    img[-3:] = 0
+    ex = orb.ORBextractor(300, sc, nl, 20, 7)
+    ref = ol.OracleExtractor(300, sc, nl, 20, 7)
+    assert_same_output(ex(img), ref(img), f"{w}x{h}")
+    for l in range(nl):
+        want = ol.gaussian_blur7(ref.pyramid_level(l))
+        got = ex.blurred_level(l)
+        assert got.shape == want.shape and np.array_equal(got, want), (w, h, l, np.argwhere(got != want)[:4].tolist())
+
+
 def test_unsupported_inputs_return_codes():
     ex = orb.ORBextractor(500, 1.2, 8, 20, 7)
     with pytest.raises(orb.VsgError) as ei:
