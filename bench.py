@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of ORB extract+match on MI355X (BASELINE.json metric, config C2).
 
-One STEP = one pass of the hot path over one batch of `--batch` (default 512) synthetic 640x480 gray frames that are
+One STEP = one pass of the hot path over one batch of `--batch` (default 1024) synthetic 640x480 gray frames that are
 already resident in HBM: ORBextractor::operator() for every frame (pyramid, per-cell FAST, octree,
 orientation, 7x7 blur, rBRIEF-256; nFeatures=1000, 8 levels) + the brute-force Hamming best/second-best
 match of every frame against its predecessor (the inner search of ORBmatcher::SearchByBoW with one node).
@@ -533,7 +533,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=512, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024,
+                    help="frames per step per GPU (1024: 383-385 k frames/s where 512 gives 374-375 k in the same run -- six "
+                         "launch tails per step, whatever its size; profiles/r05_v_*)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -614,7 +616,7 @@ def main():
     d_gray = torch.from_numpy(frames).to(dev)
     # N = 1: a second resident batch (the same frames in reverse order: other addresses, other neighbours) alternates
     # with the first from step to step, so no step re-reads what the previous one left in the caches (the 157 MB of a
-    # batch are below the 256 MB of Infinity Cache)
+    # 512-frame batch are below the 256 MB of Infinity Cache)
     rotate = not distributed and not args.no_rotate_inputs
     d_gray_in = [d_gray] + ([torch.flip(d_gray, dims=[0]).contiguous()] if rotate else [])
     in_state = {"k": 0, "last": 0}
@@ -1113,7 +1115,7 @@ def main():
                               "counters": "profiles/r05_*_c3_chain_pmc.txt (k_stereo, k_bow_descend, k_search_by_bow per call)"}
         other.append(c3)
         try:
-            other.append(device_rate("C4", 128, 10, local_rank))
+            other.append(device_rate("C4", 256, 10, local_rank))
         except Exception as e:  # noqa: BLE001
             other.append({"workload": "C4", "error": str(e)})
         other.append(chain.get("C5", {"workload": "C5", **chain}))
@@ -1125,7 +1127,7 @@ def main():
             other.append({"workload": "C3 eyes as a batch", "error": str(e)})
         out["other_configs"] = other
         try:
-            out["content_sweep"] = content_sweep_leg(local_rank, cpu_seconds=min(1.0, max(0.3, args.cpu_seconds / 8)))
+            out["content_sweep"] = content_sweep_leg(local_rank, batch=B, cpu_seconds=min(1.0, max(0.3, args.cpu_seconds / 8)))
         except Exception as e:  # noqa: BLE001
             out["content_sweep"] = {"error": str(e)}
         # `value` is measured on rectangles + noise (config.content), the most favourable but one of the ten classes; the same

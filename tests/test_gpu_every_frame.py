@@ -119,6 +119,20 @@ def test_c4_batch_128_every_frame(kind, nsub, monkeypatch):
     assert lo > 1800
 
 
+@pytest.mark.parametrize("cfg,B,nuniq,floor", [("C2", 1024, 64, 900), ("C4", 256, 32, 1800)])
+@pytest.mark.parametrize("kind", ["rectangles", "value_noise"])
+def test_bench_default_batches_every_frame(cfg, B, nuniq, floor, kind, monkeypatch):
+    """The batch sizes bench.py runs by default since the end of round 5 (C2 / 1024 for `value`, C4 / 256 in other_configs):
+    every frame and every match row of one such batch against the oracle."""
+    monkeypatch.delenv("VSG_SUBBATCH", raising=False)
+    W, H, nfeat = GEOM[cfg]
+    uniq, frames = _frames(kind, W, H, B, nuniq)
+    ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    lo, hi = check_every_frame(*_run_device(ex, frames, cap), uniq, nfeat, cap, f"{cfg}/{B} {kind}")
+    assert lo > floor
+
+
 def test_every_frame_of_a_ragged_tail_batch():
     """509 frames (not a multiple of the 8 XCDs, of 32, or of the cells-per-workgroup factor) of mixed content classes,
     one class per frame."""

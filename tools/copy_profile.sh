@@ -7,13 +7,26 @@ cd "$(dirname "$0")/.."
 c() { [ -f "$O/$1" ] && cp "$O/$1" "${P}_$2"; }
 c bench.json bench.json; c bench_rocprof.json bench_under_rocprof_serialized.json
 c kernel_stats.csv kernel_stats_serialized.csv; c kernel_stats_timed_region.csv kernel_stats_timed_region.csv
-c pmc_traffic.txt pmc_traffic_fetch_write_all_kernels_batch512.txt; c pmc_sq.txt pmc_sq_wait_l1_all_kernels_batch512.txt
+c pmc_traffic.txt pmc_traffic_fetch_write_all_kernels.txt; c pmc_sq.txt pmc_sq_wait_l1_all_kernels.txt
 c pmc_sq_timed_region_fused_octree_blur.txt pmc_sq_timed_region_fused_octree_blur.txt
 c c4_bench_rocprof_timed.json c4_bench_under_rocprof_timed_region.json; c c4_kernel_stats.csv c4_kernel_stats_serialized.csv
-c c4_kernel_stats_timed_region.csv c4_kernel_stats_timed_region.csv; c c4_pmc.txt c4_pmc_fetch_write_sq_wait_batch128.txt
+c c4_kernel_stats_timed_region.csv c4_kernel_stats_timed_region.csv; c c4_pmc.txt c4_pmc_fetch_write_sq_wait.txt
 c c3_chain_kernel_stats.csv c3_chain_kernel_stats.csv; c c3_chain_pmc.txt c3_chain_pmc.txt; c c3_chain_rocprof.json c3_chain_under_rocprof.json
 c config_chain.json config_chain.json; c extract_latency.json extract_latency.json; c frame_latency_ab.txt frame_latency_ab.txt
 c frame_timeline.txt frame_timeline.txt; c abi_latency.json abi_latency.json; c abi_kernel_stats.csv abi_kernel_stats.csv
-cp $O/traffic.json profiles/traffic_r05.json; cp $O/isa_mix.json profiles/r05_isa_mix.json
+# merge: keys of earlier runs of the SAME sources (other batch sizes) stay, this run's keys replace their namesakes
+python3 - $O/traffic.json profiles/traffic_r05.json <<'PY'
+import json, sys
+new = json.load(open(sys.argv[1]))
+try:
+    old = json.load(open(sys.argv[2]))
+except Exception:
+    old = {}
+if old.get('source_hash') == new.get('source_hash'):
+    for k, v in old.items():
+        new.setdefault(k, v)
+json.dump(new, open(sys.argv[2], 'w'), indent=1)
+PY
+cp $O/isa_mix.json profiles/r05_isa_mix.json
 [ -n "$2" ] && grep -E "passed|failed" "$2" > ${P}_gpu_tests.txt
 python3 -c "import json;print('traffic source hash', json.load(open('profiles/traffic_r05.json'))['source_hash'])"; python3 tools/source_hash.py

@@ -32,11 +32,11 @@ cp $OUT/stats/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 cp $OUT/stats_timed/*/*kernel_stats.csv $OUT/kernel_stats_timed_region.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > $OUT/pmc_sq.txt 2>&1
-python3 tools/make_traffic_json.py C2/512 $OUT/traffic.json $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > /dev/null 2>&1
+python3 tools/make_traffic_json.py C2/1024 $OUT/traffic.json $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp > /dev/null 2>&1
 # ---- the other configurations a scaling curve / the stereo chain are quoted on: C4 = 1280x720 / 2000 in
-# 128-frame batches (kernel stats of the timed region and of the serialised step, FETCH / WRITE / SQ / wait passes ->
-# traffic.json["C4/128"]), C3 = the stereo pair chain of tools/config_chain.cpp (k_stereo, k_bow_descend, k_search_by_bow)
-B4="python3 bench.py --cpu-seconds 0 --no-stage-timing --no-extras --workload C4 --batch 128"
+# 256-frame batches (kernel stats of the timed region and of the serialised step, FETCH / WRITE / SQ / wait passes ->
+# traffic.json["C4/256"]), C3 = the stereo pair chain of tools/config_chain.cpp (k_stereo, k_bow_descend, k_search_by_bow)
+B4="python3 bench.py --cpu-seconds 0 --no-stage-timing --no-extras --workload C4 --batch 256"
 VSG_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -- $B4 > $OUT/c4_bench_rocprof.json 2>> $OUT/rocprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats_timed -- $B4 > $OUT/c4_bench_rocprof_timed.json 2>> $OUT/rocprof.err
 pass4() {
@@ -50,7 +50,7 @@ pass4 wait SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 cp $OUT/c4_stats/*/*kernel_stats.csv $OUT/c4_kernel_stats.csv 2>/dev/null
 cp $OUT/c4_stats_timed/*/*kernel_stats.csv $OUT/c4_kernel_stats_timed_region.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_sq $OUT/c4_pmc_wait > $OUT/c4_pmc.txt 2>&1
-python3 tools/make_traffic_json.py C4/128 $OUT/traffic.json $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_sq $OUT/c4_pmc_wait > /dev/null 2>&1
+python3 tools/make_traffic_json.py C4/256 $OUT/traffic.json $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_sq $OUT/c4_pmc_wait > /dev/null 2>&1
 # (the C3 leg alone: with the four host threads of the C5 leg in the same process rocprofv3 --kernel-trace itself
 # segfaults in 2 of 6 runs -- inside hipStreamSynchronize, below the HIP runtime, in the tool's HSA queue interception;
 # un-profiled and --pmc runs of the same binary never do: profiles/r05_q_rocprofv3_kernel_trace_c5_segfault.txt --
