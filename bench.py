@@ -537,6 +537,9 @@ def main():
                     help="frames per step per GPU (1024: 383-385 k frames/s where 512 gives 374-375 k in the same run -- six "
                          "launch tails per step, whatever its size; profiles/r05_v_*)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--content", default="rectangles",
+                    help="content class of the timed frames (visual_sgraphs_amd.synth.CONTENT_CLASSES; the default is what "
+                         "`value` is quoted on; photo_china / photo_hopper / photo_flower are real photographs)")
     ap.add_argument("--no-match", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--ramp-steps", type=int, default=150,
@@ -612,7 +615,9 @@ def main():
     # chunk boundary -- the predecessor of a rank's first frame is the LAST frame of rank r - 1, which only the record
     # exchange can deliver (for rank 0: the last rank's last frame of the previous step)
     t_first = rank * B
-    frames = np.stack([synth.sequence_frame(W, H, 1000, t_first + t) for t in range(B)])
+    def frame_of(t):  # frame t of the global sequence (content_frame("rectangles", ...) is sequence_frame)
+        return synth.content_frame(args.content, W, H, 1000, t)
+    frames = np.stack([frame_of(t_first + t) for t in range(B)])
     d_gray = torch.from_numpy(frames).to(dev)
     # N = 1: a second resident batch (the same frames in reverse order: other addresses, other neighbours) alternates
     # with the first from step to step, so no step re-reads what the previous one left in the caches (the 157 MB of a
@@ -905,7 +910,7 @@ def main():
             # record exchange delivered -- the oracle extracts that remote frame itself
             ref = ol.OracleExtractor(nfeat, 1.2, 8, 20, 7)
             _, _, rd_first = ref(frames[0])
-            _, _, rd_pred = ref(synth.sequence_frame(W, H, 1000, world * B - 1))
+            _, _, rd_pred = ref(frame_of(world * B - 1))
             rb, rs, ra = ol.block_best2(rd_first, rd_pred)
             n = len(rb)
             okb = np.array_equal(d_bbest[0, :n].cpu().numpy(), rb) and np.array_equal(d_barg[0, :n].cpu().numpy(), ra)
@@ -1081,9 +1086,10 @@ def main():
                                         "k + 1 (two alternating output sets); all K matches end inside the timed region"}
                       if overlap_match["on"] else {}),
                    "keypoints_per_frame": round(n_kp, 1),
-                   "content": "rectangles (synth.sequence_frame: rectangles + uniform noise, translated per frame); the other "
-                              "nine content classes: `content_sweep`, the natural-image stand-ins also as `value_value_noise` / "
-                              "`value_defocus`",
+                   "content": (args.content + ": " if args.content != "rectangles" else "") +
+                              "rectangles (synth.sequence_frame: rectangles + uniform noise, translated per frame); the other "
+                              "nine generated classes and three real photographs: `content_sweep`, the natural-image stand-ins "
+                              "also as `value_value_noise` / `value_defocus`, the slowest photograph as `value_photo`",
                    "clock_ramp": f"{max(args.ramp_steps, 0)} untimed steps before the {Wu} warm-up steps (the GPU reaches its "
                                  "steady clocks after ~0.1-0.2 s of load)",
                    "inputs": "resident in HBM" + (": two batches (the frames in forward / reverse order) alternate from step to "
@@ -1137,6 +1143,19 @@ def main():
         for kind in ("value_noise", "defocus"):
             if isinstance(cls.get(kind), dict) and "frames_per_s" in cls[kind]:
                 out[f"value_{kind}"] = cls[kind]["frames_per_s"]
+        # ... and on REAL photographs (round 6: tests/golden/photos_v1.npz, gray planes committed as data): the slowest of the
+        # three, its class, and the parity flag over every frame and match row of its batch
+        from visual_sgraphs_amd import synth as _synth
+        photos = {k: cls[k] for k in _synth.PHOTO_CLASSES if isinstance(cls.get(k), dict) and "frames_per_s" in cls[k]}
+        if photos:
+            worst = min(photos, key=lambda k: photos[k]["frames_per_s"])
+            out["value_photo"] = photos[worst]["frames_per_s"]
+            out["value_photo_detail"] = {"class": worst, "parity": photos[worst]["parity"],
+                                         "frames_checked": photos[worst]["frames_checked"],
+                                         "match_rows_checked": photos[worst]["match_rows_checked"],
+                                         "fast_ms": photos[worst]["fast_ms"],
+                                         "all_photos": {k: v["frames_per_s"] for k, v in photos.items()},
+                                         "all_photos_parity": all(v["parity"] is True for v in photos.values())}
         # the call pattern the reference has: ONE frame per blocking operator() (System.cc:359, Tracking.cc:1583,
         # Frame.cc:344,555-563), from plain C++ through the C ABI, with the CPU oracle's chain beside each figure
         fl = dict(chain.get("frame_latency") or {"error": chain.get("error", "config_chain gave no frame_latency")})

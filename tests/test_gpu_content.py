@@ -67,3 +67,21 @@ def test_the_cold_paths_are_really_reached():
     assert len(k) < 800                                             # the quota is not met: short lists everywhere
     ref(synth.content_frame("sawtooth", 640, 480, 40, 1))
     assert len(ref.candidates(0)[0]) == 0 and len(ref.candidates(1)[0]) > 1500
+
+
+def test_the_photographs_are_the_dense_mixed_regime():
+    """What the photo classes are FOR (VERDICT r5 "missing" #3), stated on the oracle's numbers: several times the
+    candidates of the generated classes at level 0 (the octree's memory-resident form: more than 2048 per level), and
+    iniThFAST cells, minThFAST cells and empty cells inside ONE frame."""
+    ref = ol.OracleExtractor(1000, 1.2, 8, 20, 7)
+    _, k, _ = ref(synth.content_frame("photo_china", 640, 480, 40, 1))
+    n_china = len(ref.candidates(0)[0])
+    r0 = ref.candidates(0)[2]
+    assert n_china > 4000 and (r0 < 20).any() and (r0 >= 20).mean() > 0.5   # both thresholds inside level 0
+    ref(synth.sequence_frame(640, 480, 40, 1))
+    assert n_china > 2.5 * len(ref.candidates(0)[0])
+    _, k, _ = ref(synth.content_frame("photo_hopper", 640, 480, 40, 1))
+    assert 0.1 < (k["response"] < 20).mean() < 0.6                           # a real share of retry keypoints
+    ref4 = ol.OracleExtractor(2000, 1.2, 8, 20, 7)
+    ref4(synth.content_frame("photo_china", 1280, 720, 40, 1))
+    assert len(ref4.candidates(0)[0]) > 15000

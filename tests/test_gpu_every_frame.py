@@ -120,10 +120,12 @@ def test_c4_batch_128_every_frame(kind, nsub, monkeypatch):
 
 
 @pytest.mark.parametrize("cfg,B,nuniq,floor", [("C2", 1024, 64, 900), ("C4", 256, 32, 1800)])
-@pytest.mark.parametrize("kind", ["rectangles", "value_noise"])
+@pytest.mark.parametrize("kind", ["rectangles", "value_noise", "photo_china"])
 def test_bench_default_batches_every_frame(cfg, B, nuniq, floor, kind, monkeypatch):
     """The batch sizes bench.py runs by default since the end of round 5 (C2 / 1024 for `value`, C4 / 256 in other_configs):
-    every frame and every match row of one such batch against the oracle."""
+    every frame and every match row of one such batch against the oracle.  `photo_china` (round 6): a real photograph --
+    5.7 k (C2) / 19.6 k (C4) level-0 candidates per frame, 3.5 - 12 x the rectangles' -- so the octree's memory-resident
+    form (more than 2048 candidates of a level) and the long candidate segments run at the timed batch sizes."""
     monkeypatch.delenv("VSG_SUBBATCH", raising=False)
     W, H, nfeat = GEOM[cfg]
     uniq, frames = _frames(kind, W, H, B, nuniq)
@@ -131,6 +133,20 @@ def test_bench_default_batches_every_frame(cfg, B, nuniq, floor, kind, monkeypat
     cap = ex.capacity(H, W)
     lo, hi = check_every_frame(*_run_device(ex, frames, cap), uniq, nfeat, cap, f"{cfg}/{B} {kind}")
     assert lo > floor
+
+
+@pytest.mark.parametrize("cfg,B,nuniq", [("C2", 510, 48), ("C4", 96, 24)])
+def test_every_frame_of_a_batch_of_photographs(cfg, B, nuniq):
+    """All three photographs interleaved frame by frame (a building: dense corners everywhere but the sky; a portrait:
+    a quarter of the keypoints from the minThFAST retry; a flower: large defocused areas), so neighbouring workgroups of the
+    batch-wide launches see 10 x different candidate counts."""
+    W, H, nfeat = GEOM[cfg]
+    kinds = list(synth.PHOTO_CLASSES)
+    uniq = np.stack([synth.content_frame(kinds[t % 3], W, H, 7000 + t // 3, t) for t in range(nuniq)])
+    frames = np.concatenate([uniq] * ((B + nuniq - 1) // nuniq))[:B]
+    ex = orb.ORBextractor(nfeat, 1.2, 8, 20, 7, max_batch=B)
+    cap = ex.capacity(H, W)
+    check_every_frame(*_run_device(ex, frames, cap), uniq, nfeat, cap, f"{cfg}/{B} photographs")
 
 
 def test_every_frame_of_a_ragged_tail_batch():

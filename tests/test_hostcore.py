@@ -387,9 +387,10 @@ def test_synth_header_matches_python(hc):
 
 
 def test_synth_header_content_classes_match_python(hc):
-    """vsg_synth_content_frame (C) == synth.content_frame (Python) for every content class, byte for byte."""
+    """vsg_synth_content_frame (C) == synth.content_frame (Python) for every GENERATED content class, byte for byte (the
+    photo classes are data read from tests/golden/photos_v1.npz, not generated: no C mirror)."""
     hc.hc_synth_content_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p, C.c_size_t]
-    for kind, name in enumerate(synth.CONTENT_CLASSES):
+    for kind, name in enumerate(synth.SYNTH_CLASSES):
         for (w, h, seq, t) in ((160, 120, 5, 0), (333, 241, 4099, 7)):
             out = np.zeros((h, w + 5), np.uint8)
             assert hc.hc_synth_content_frame(kind, w, h, seq, t, out.ctypes.data, out.strides[0]) == 0

@@ -29,7 +29,11 @@ def _cases(P):
     # one frame per content class (pin_dump.cpp "content_<kind>_<width>"): value noise, checkerboards, gratings, ...
     for name in sorted({k.split("/")[0] for k in P.files if k.endswith("/content_params")}):
         w, h, seq, t, nf, nl, kind, _ = P[name + "/content_params"].tolist()
-        out.append((name, synth.content_frame(synth.CONTENT_CLASSES[kind], w, h, seq, t), nf, nl, (0, 0)))
+        out.append((name, synth.content_frame(synth.SYNTH_CLASSES[kind], w, h, seq, t), nf, nl, (0, 0)))
+    # real photographs (pin_dump.cpp "photo_<index>_<width>", frames from tools/pin_with_opencv/export_photo_frames.py)
+    for name in sorted({k.split("/")[0] for k in P.files if k.endswith("/photo_params")}):
+        w, h, seq, t, nf, nl, idx, _ = P[name + "/photo_params"].tolist()
+        out.append((name, synth.content_frame(synth.PHOTO_CLASSES[idx], w, h, seq, t), nf, nl, (0, 0)))
     return out
 
 

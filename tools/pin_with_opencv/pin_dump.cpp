@@ -7,6 +7,9 @@
 //   * the same for one frame of EVERY content class of synth.CONTENT_CLASSES / vsg_synth_content_frame (value noise,
 //     1 / 2 px checkerboards, gratings, defocus, saturation, ramps, salt and pepper): they stress cv::resize, the blur
 //     and the minThFAST retry differently from rectangles + noise; cases "content_<kind>"
+//   * the same for REAL PHOTOGRAPHS (round 6): frames of synth.PHOTO_CLASSES exported by export_photo_frames.py from the
+//     committed gray planes (tests/golden/photos_v1.npz) into a flat file given as the optional second argument: ~10 k
+//     level-0 corners per frame, iniThFAST / minThFAST / empty cells mixed inside one frame; cases "photo_<index>_<width>"
 // and the version-sensitive OpenCV pieces as observations:
 //   * cv::getGaussianKernel(7, 2) and the 8-bit GaussianBlur response to a one-column line image (= the 8.8 taps)
 //   * cv::cvtColor(RGB2GRAY / BGR2GRAY) on 4096 seeded colours (= the fixed-point gray coefficients)
@@ -53,7 +56,7 @@ static const Case kCases[] = {{"qvga_rgbd", 320, 240, 42, 1, 500, 4, 0, 0},
                               {"vga_c2", 640, 480, 7, 1, 1000, 8, 0, 0}};
 
 int main(int argc, char **argv) {
-  if (argc < 2) return fprintf(stderr, "usage: pin_dump <out.bin>\n"), 2;
+  if (argc < 2) return fprintf(stderr, "usage: pin_dump <out.bin> [photo_frames.bin]\n"), 2;
   g_out = fopen(argv[1], "wb");
   if (!g_out) return 2;
   const std::string ver = CV_VERSION;
@@ -118,6 +121,36 @@ int main(int argc, char **argv) {
         put_mat_u8(p + "blur" + std::to_string(l), work);
       }
     }
+  }
+
+  if (argc > 2) {  // photographs: records of 8 x i32 {w, h, seq, t, nfeatures, nlevels, photo index, 0} + w * h gray bytes
+    FILE *pf = fopen(argv[2], "rb");
+    if (!pf) return fprintf(stderr, "cannot open %s\n", argv[2]), 2;
+    int32_t params[8];
+    while (fread(params, 4, 8, pf) == 8) {
+      const int w = params[0], h = params[1], nf = params[4], nl = params[5];
+      cv::Mat img(h, w, CV_8UC1);
+      if (fread(img.data, 1, (size_t)w * h, pf) != (size_t)w * h) return 3;
+      VS_GRAPHS::ORBextractor ex(nf, 1.2f, nl, 20, 7);
+      std::vector<cv::KeyPoint> kps;
+      cv::Mat desc;
+      std::vector<int> lap{0, 0};
+      const int32_t mono32 = ex(img, cv::Mat(), kps, desc, lap);
+      const std::string p = "photo_" + std::to_string(params[6]) + "_" + std::to_string(w) + "/";
+      put(p + "photo_params", 1, {8}, params);
+      put(p + "mono", 1, {1}, &mono32);
+      put(p + "kps", 0, {(uint32_t)kps.size(), 28}, kps.data());
+      if (!desc.empty()) put_mat_u8(p + "desc", desc); else put(p + "desc", 0, {0, 32}, nullptr);
+      for (int l = 0; l < nl; l++) {
+        cv::Mat roi = ex.mvImagePyramid[l], full = roi;
+        full.adjustROI(19, 19, 19, 19);
+        put_mat_u8(p + "pyr" + std::to_string(l), full);
+        cv::Mat work = roi.clone();
+        cv::GaussianBlur(work, work, cv::Size(7, 7), 2, 2, cv::BORDER_REFLECT_101);
+        put_mat_u8(p + "blur" + std::to_string(l), work);
+      }
+    }
+    fclose(pf);
   }
 
   {  // Gaussian taps: the double kernel, and the 8-bit blur of a line image (every row = 255 at one column)

@@ -14,6 +14,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 import oracle_lib as ol  # noqa: E402
 from visual_sgraphs_amd import synth  # noqa: E402
 
@@ -89,13 +90,27 @@ def main():
                     b = e.blurred_level(l)
                     put(f, f"{name}/blur{l}", b if b is not None else ol.gaussian_blur7(e.pyramid_level(l)))
             # pin_dump's content-class cases (kind index = position in synth.CONTENT_CLASSES)
-            ccases = [(k, 320, 240, 5000, 1, 500, 4) for k in range(len(synth.CONTENT_CLASSES))]
+            ccases = [(k, 320, 240, 5000, 1, 500, 4) for k in range(len(synth.SYNTH_CLASSES))]
             ccases += [(synth.CONTENT_CLASSES.index(n), 640, 480, 5000, 3, 1000, 8) for n in ("value_noise", "defocus", "grating")]
             for kind, w, h, seq, t_, nf, nl in ccases:
                 e = ol.OracleExtractor(nf, 1.2, nl, 20, 7)
                 mono, kps, desc = e(synth.content_frame(synth.CONTENT_CLASSES[kind], w, h, seq, t_))
                 name = f"content_{kind}_{w}"
                 put(f, name + "/content_params", np.array([w, h, seq, t_, nf, nl, kind, 0], np.int32))
+                put(f, name + "/mono", np.array([mono], np.int32))
+                put(f, name + "/kps", kps.view(np.uint8).reshape(len(kps), 28))
+                put(f, name + "/desc", desc)
+                for l in range(nl):
+                    put(f, f"{name}/pyr{l}", e.pyramid_level(l, with_border=True))
+                    b = e.blurred_level(l)
+                    put(f, f"{name}/blur{l}", b if b is not None else ol.gaussian_blur7(e.pyramid_level(l)))
+            # pin_dump's photo cases (export_photo_frames.py; index = position in synth.PHOTO_CLASSES)
+            from export_photo_frames import PHOTO_CASES
+            for idx, w, h, seq, t_, nf, nl in PHOTO_CASES:
+                e = ol.OracleExtractor(nf, 1.2, nl, 20, 7)
+                mono, kps, desc = e(synth.content_frame(synth.PHOTO_CLASSES[idx], w, h, seq, t_))
+                name = f"photo_{idx}_{w}"
+                put(f, name + "/photo_params", np.array([w, h, seq, t_, nf, nl, idx, 0], np.int32))
                 put(f, name + "/mono", np.array([mono], np.int32))
                 put(f, name + "/kps", kps.view(np.uint8).reshape(len(kps), 28))
                 put(f, name + "/desc", desc)
