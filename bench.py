@@ -1086,10 +1086,11 @@ def main():
                                         "k + 1 (two alternating output sets); all K matches end inside the timed region"}
                       if overlap_match["on"] else {}),
                    "keypoints_per_frame": round(n_kp, 1),
-                   "content": (args.content + ": " if args.content != "rectangles" else "") +
-                              "rectangles (synth.sequence_frame: rectangles + uniform noise, translated per frame); the other "
-                              "nine generated classes and three real photographs: `content_sweep`, the natural-image stand-ins "
-                              "also as `value_value_noise` / `value_defocus`, the slowest photograph as `value_photo`",
+                   "content": ("rectangles (synth.sequence_frame: rectangles + uniform noise, translated per frame); the other "
+                               "nine generated classes and three real photographs: `content_sweep`, the natural-image stand-ins "
+                               "also as `value_value_noise` / `value_defocus`, the slowest photograph as `value_photo`")
+                   if args.content == "rectangles" else
+                   f"{args.content} (synth.content_frame, --content: NOT the content `value` is quoted on)",
                    "clock_ramp": f"{max(args.ramp_steps, 0)} untimed steps before the {Wu} warm-up steps (the GPU reaches its "
                                  "steady clocks after ~0.1-0.2 s of load)",
                    "inputs": "resident in HBM" + (": two batches (the frames in forward / reverse order) alternate from step to "
