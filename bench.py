@@ -26,8 +26,8 @@ sys.path.insert(0, str(ROOT / "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-TRAFFIC_FILE = "traffic_r05.json"   # profiles/: PMC counters per launch (tools/profile_round.sh), tied to a source hash
-ISA_MIX_FILE = "r05_isa_mix.json"
+TRAFFIC_FILE = "traffic_r06.json"   # profiles/: PMC counters per launch (tools/profile_round.sh), tied to a source hash
+ISA_MIX_FILE = "r06_isa_mix.json"
 
 
 def pmc_traffic(key, stage):
@@ -359,6 +359,30 @@ def content_sweep_leg(device, batch=512, steps=12, nuniq=32, cpu_seconds=1.0):
             "all_parity": all(v.get("parity") is True for v in out.values())}
 
 
+def wants_library_exchange(backend, one_device, torch_gather):
+    """The record exchange of a real multi-GPU run goes through the library's own RCCL communicator (vsg_shard_*);
+    torch.distributed carries it only in the rehearsals: gloo, --one-device, or an explicit --torch-gather."""
+    return backend == "nccl" and not one_device and not torch_gather
+
+
+def refuse_without_library_exchange(rank, world, why):
+    """--gpus N > 1 on the nccl backend without --torch-gather and vsg_shard_create failed on some rank: exit non-zero with
+    the reason, on every rank, instead of measuring torch's all-gather under this library's name."""
+    msg = (f"[bench] rank {rank}/{world}: vsg_shard_create failed on at least one rank"
+           + (f" (here: {why})" if why else " (not on this one)")
+           + "; refusing to fall back to torch.distributed -- pass --torch-gather to measure that on purpose")
+    print(msg, file=sys.stderr)
+    raise SystemExit(3)
+
+
+def check_rccl_world(seen, world, rank=0):
+    """The multi-GPU line is printed only if the live communicator (ncclCommCount) spans exactly the launched ranks."""
+    if seen != world:
+        print(f"[bench] rank {rank}: RCCL communicator spans {seen} ranks, launched {world}: no line", file=sys.stderr)
+        raise SystemExit(4)
+    return True
+
+
 def visible_gpu_count():
     """GPUs this process may use, WITHOUT importing torch or initialising HIP (the launcher below must not touch the GPU
     before it starts its ranks): the visibility variables if set, else the KFD topology (nodes with SIMDs); None when
@@ -384,8 +408,9 @@ def preflight(n, batch, workload, one_device=False, quiet=False):
     """`bench.py --gpus N --preflight`: what a first N-GPU run can trip over, checked in a CHILD process (it touches
     the GPU) before any rank is started -- visible devices; that libvsg_orb.so and torch resolve the SAME libamdhip64
     (bench.py hands torch streams and device pointers to a library that links the runtime by soname: INTEGRATION.md
-    section 5); that the RCCL the library will dlopen exports what vsg_shard_* binds, ncclCommCount included; the record
-    exchange's receive buffer (world x batch records per rank) against the free memory of every device.  Prints one JSON
+    section 5); that every pair of the N devices is peer-accessible (hipDeviceCanAccessPeer) and over which link
+    (hipExtGetLinkTypeAndHopCount: xgmi / pcie); that the RCCL the library will dlopen exports what vsg_shard_* binds,
+    ncclCommCount included; the record exchange's receive buffer (world x batch records per rank) against the free memory of every device.  Prints one JSON
     object; exit code 0 only when every check passed."""
     import subprocess
     code = r"""
@@ -426,6 +451,32 @@ ndev_v = L.vsg_device_count()
 need_dev = 1 if one_device else n  # --one-device: every rank on device 0 (dry runs of the multi-rank path)
 check("devices", ndev_t >= need_dev and ndev_v >= need_dev, torch_device_count=ndev_t, vsg_device_count=ndev_v,
       visible_without_runtime=bench.visible_gpu_count(), needed=need_dev)
+# every pair of the N devices peer-accessible, and over which link (round 6, VERDICT r5 #5c): RCCL's all-gather and the
+# neighbour send / recv go device to device; a pair without peer access would fall back to staging through the host
+try:
+    hip = C.CDLL(f_vsg)  # the libamdhip64 the process already runs on
+    hip.hipDeviceCanAccessPeer.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int]
+    hip.hipExtGetLinkTypeAndHopCount.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    LINK = {0: "hypertransport", 1: "qpi", 2: "pcie", 3: "infiniband", 4: "xgmi"}
+    pairs, bad = [], []
+    ndev_p = 0 if one_device else min(n, ndev_t)
+    for a in range(ndev_p):
+        for b in range(ndev_p):
+            if a == b:
+                continue
+            can, lt, hops = C.c_int(0), C.c_uint32(99), C.c_uint32(0)
+            rc1 = hip.hipDeviceCanAccessPeer(C.byref(can), a, b)
+            rc2 = hip.hipExtGetLinkTypeAndHopCount(a, b, C.byref(lt), C.byref(hops))
+            pairs.append({"from": a, "to": b, "peer": bool(can.value) and rc1 == 0,
+                          "link": LINK.get(lt.value, str(lt.value)) if rc2 == 0 else None, "hops": hops.value if rc2 == 0 else None})
+            if rc1 != 0 or not can.value:
+                bad.append((a, b))
+    links = sorted({p_["link"] for p_ in pairs if p_["link"]})
+    check("peer_access", not bad, device_pairs_checked=len(pairs), pairs_without_peer_access=bad, link_types=links,
+          all_xgmi_one_hop=bool(pairs) and all(p_["link"] == "xgmi" and p_["hops"] == 1 for p_ in pairs),
+          note="one device per rank; --one-device and N = 1 have no pairs to check")
+except Exception as e:
+    check("peer_access", False, error=repr(e))
 rccl = None
 for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
     try:
@@ -474,6 +525,28 @@ sys.exit(0 if out["ok"] else 4)
     return r.returncode
 
 
+def run_teeing_stderr(cmd, env):
+    """Run `cmd`, relaying its stderr LIVE (a multi-GPU run that hangs in the RCCL rendezvous or in IPC shows its
+    diagnostics while it hangs) and keeping a copy for the caller; stdout is captured (the one JSON line)."""
+    import subprocess
+    import threading
+    import types
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    kept = []
+
+    def pump():
+        for line in p.stderr:
+            sys.stderr.write(line)
+            sys.stderr.flush()
+            kept.append(line)
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    out = p.stdout.read()
+    p.wait()
+    t.join()
+    return types.SimpleNamespace(returncode=p.returncode, stdout=out, stderr="".join(kept[-400:]))
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment): start the N ranks -- one process per GPU,
     `python -m torch.distributed.run` -- as a CHILD process before this one imports torch or touches a GPU, relay rank
@@ -505,9 +578,11 @@ def launch_ranks(args, argv):
             port = so.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
                "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        sys.stderr.write(r.stderr)
-        if r.returncode == 0 or not any(m in r.stderr for m in ("EADDRINUSE", "Address already in use", "address already in use")):
+        r = run_teeing_stderr(cmd, env)
+        # started again only when the RENDEZVOUS lost its port: the address error is there and no rank got as far as
+        # printing anything of its own (a rank-side socket error of gloo / RCCL carries the same words and is a real failure)
+        addr_in_use = any(m in r.stderr for m in ("EADDRINUSE", "Address already in use", "address already in use"))
+        if r.returncode == 0 or not addr_in_use or "[bench]" in r.stderr or r.stdout.strip():
             break
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
     for x in r.stdout.splitlines():
@@ -653,18 +728,23 @@ def main():
         cstream = torch.cuda.Stream(device=dev)
         rec_bytes = sharding.record_bytes(cap)
         od = sharding.desc_offset(cap)
-        if args.dist_backend == "nccl" and not args.one_device and not args.torch_gather:
+        if wants_library_exchange(args.dist_backend, args.one_device, args.torch_gather):
+            why = ""
             try:  # the library's own RCCL communicator (C ABI: vsg_shard_*)
                 comm = sharding.ShardComm(local_rank, rank, world, cap, B)
                 comm_kind = "C ABI vsg_shard_* (ncclAllGather)"
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench] vsg_shard_create failed ({e}); using torch.distributed for the exchange", file=sys.stderr)
-            # every rank must take the same path: one rank falling back alone would leave the others in a collective
+            except Exception as e:  # noqa: BLE001  (the message carries vsg_shard_last_error())
+                why = str(e)
+            # every rank learns whether ALL ranks have their communicator; a multi-GPU line is this library's exchange or it
+            # is not printed at all (the run used to go on over torch.distributed with only `comm_kind` saying so)
             ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and comm is not None:
-                comm.close()
-                comm = None
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                dist.destroy_process_group()
+                refuse_without_library_exchange(rank, world, why)
+            check_rccl_world(comm.world_seen(), world, rank)
         if comm is None:
             comm_kind = f"torch.distributed {args.dist_backend} " + ("all_gather_into_tensor" if args.exchange == "allgather"
                                                                      else "batch_isend_irecv")

@@ -5,6 +5,9 @@ import subprocess
 import sys
 from pathlib import Path
 
+import pytest
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 ROOT = Path(__file__).resolve().parent.parent
 
 
@@ -49,8 +52,44 @@ def test_preflight_reports_every_check_and_fails_without_devices():
     assert r.returncode != 0 and "FAILED checks" in r.stderr and "devices" in r.stderr
     d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert d["ok"] is False and d["requested_gpus"] == 8
-    assert set(d["checks"]) == {"one_hip_runtime", "devices", "rccl", "memory"}
+    assert set(d["checks"]) == {"one_hip_runtime", "devices", "peer_access", "rccl", "memory"}
+    # no device here: no pair to check, the check itself must have run (hipDeviceCanAccessPeer / link type bound)
+    assert d["checks"]["peer_access"].get("device_pairs_checked") == 0 and "error" not in d["checks"]["peer_access"]
     assert d["checks"]["one_hip_runtime"]["ok"] is True
     assert d["checks"]["one_hip_runtime"]["libvsg_orb"] == d["checks"]["one_hip_runtime"]["torch"]
     assert d["checks"]["rccl"]["ok"] is True and d["checks"]["rccl"]["missing"] == []
     assert d["checks"]["memory"]["exchange_recv_bytes_per_rank"] > 200e6  # 8 x 512 records of ~64 KB
+
+
+def test_a_failed_library_communicator_is_a_refusal_not_a_fallback(capsys):
+    """with --gpus N > 1, the nccl backend and no --torch-gather, a failed vsg_shard_create on any rank ends
+    the run non-zero with the reason; torch.distributed carries the exchange only in the rehearsals."""
+    import bench
+    assert bench.wants_library_exchange("nccl", False, False)
+    assert not bench.wants_library_exchange("gloo", False, False)       # CPU rehearsal
+    assert not bench.wants_library_exchange("nccl", True, False)        # --one-device dry run
+    assert not bench.wants_library_exchange("nccl", False, True)        # --torch-gather: measured on purpose
+    with pytest.raises(SystemExit) as e:
+        bench.refuse_without_library_exchange(3, 8, "vsg_shard_create: ncclCommInitRank: unhandled system error")
+    assert e.value.code == 3
+    err = capsys.readouterr().err
+    assert "rank 3/8" in err and "ncclCommInitRank" in err and "--torch-gather" in err
+    with pytest.raises(SystemExit) as e:
+        bench.refuse_without_library_exchange(0, 8, "")                 # a rank whose own create succeeded leaves too
+    assert e.value.code == 3
+
+
+def test_the_line_needs_a_communicator_that_spans_the_launched_ranks(capsys):
+    import bench
+    assert bench.check_rccl_world(8, 8)
+    with pytest.raises(SystemExit) as e:
+        bench.check_rccl_world(4, 8, rank=2)
+    assert e.value.code == 4 and "spans 4 ranks, launched 8" in capsys.readouterr().err
+
+
+def test_the_fallback_is_gone_from_the_source():
+    """No path from a failed ShardComm to torch.distributed on the nccl backend is left in bench.py."""
+    src = (ROOT / "bench.py").read_text()
+    assert "using torch.distributed for the exchange" not in src
+    i = src.index("comm = sharding.ShardComm(")
+    assert "refuse_without_library_exchange(rank, world, why)" in src[i:i + 1500]

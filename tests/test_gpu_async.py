@@ -1,5 +1,7 @@
 """GPU tests of the asynchronous host pipeline (vsg_orb_submit_batch / vsg_orb_wait), pinned caller memory, the
 NULL-stream ordering of the device entry points and the one-copy pyramid read-back."""
+import os
+
 import numpy as np
 import pytest
 
@@ -91,16 +93,30 @@ def test_host_memory_kinds_are_told_apart_over_the_whole_range():
         assert orb.host_kind(heap) == "registered"
         assert orb.host_kind(heap[4096:8192]) == "registered"
         # one byte beyond the registration: the range is not pinned as a whole
-        assert L.vsg_host_kind(C.c_void_p(heap.ctypes.data + 4096), heap.nbytes) in (0, 3)
+        assert L.vsg_host_kind(C.c_void_p(heap.ctypes.data + 4096), heap.nbytes) == 0
     finally:
         orb.unpin(heap)
     assert orb.host_kind(heap) == "pageable"
     pa = orb.PinnedArray((1 << 20,))
     assert orb.host_kind(pa.a) == "vsg_host_alloc" and orb.host_kind(pa.a[100:5000]) == "vsg_host_alloc"
-    assert L.vsg_host_kind(C.c_void_p(pa.ptr + 4096), 1 << 20) != 1  # runs past the allocation's end
+    assert L.vsg_host_kind(C.c_void_p(pa.ptr + 4096), 1 << 20) == 0  # runs past the allocation's end
     import torch
     t = torch.zeros(1 << 20, dtype=torch.uint8).pin_memory()  # somebody else's pinned allocation
-    assert L.vsg_host_kind(C.c_void_p(t.data_ptr()), t.numel()) in (2, 3)
+    # torch's caching host allocator hands out hipHostMalloc blocks: exactly kind 2 (exact kinds, so that a
+    # misclassification cannot hide), unless torch was told to pin by registration
+    expect = 3 if "pinned_use_cuda_host_register:True" in os.environ.get("PYTORCH_CUDA_ALLOC_CONF", "") else 2
+    assert L.vsg_host_kind(C.c_void_p(t.data_ptr()), t.numel()) == expect
+    # memory somebody else registered (hipHostRegister called behind the library's back, as a caller's own code would):
+    # never reported as hipHostMalloc memory
+    other = np.zeros(1 << 20, np.uint8)
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))  # the copy the process already runs on
+    hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    assert hip.hipHostRegister(C.c_void_p(other.ctypes.data), other.nbytes, 2 | 1) == 0  # mapped | portable
+    try:
+        assert L.vsg_host_kind(C.c_void_p(other.ctypes.data), other.nbytes) == 3
+    finally:
+        hip.hipHostUnregister.argtypes = [C.c_void_p]
+        assert hip.hipHostUnregister(C.c_void_p(other.ctypes.data)) == 0
 
 
 @pytest.mark.parametrize("opt_in", [False, True])

@@ -4,7 +4,9 @@
 set -e
 T=$1; O=gpurun_out/$T; P=profiles/$T
 cd "$(dirname "$0")/.."
-c() { [ -f "$O/$1" ] && cp "$O/$1" "${P}_$2"; }
+R=r06  # the round whose traffic / ISA-mix files bench.py reads (bench.py: TRAFFIC_FILE, ISA_MIX_FILE)
+# (an `[ -f x ] && cp` body returns 1 for an absent file and `set -e` then ends the script: ADVICE r5)
+c() { if [ -f "$O/$1" ]; then cp "$O/$1" "${P}_$2"; fi; }
 c bench.json bench.json; c bench_rocprof.json bench_under_rocprof_serialized.json
 c kernel_stats.csv kernel_stats_serialized.csv; c kernel_stats_timed_region.csv kernel_stats_timed_region.csv
 c pmc_traffic.txt pmc_traffic_fetch_write_all_kernels.txt; c pmc_sq.txt pmc_sq_wait_l1_all_kernels.txt
@@ -13,9 +15,11 @@ c c4_bench_rocprof_timed.json c4_bench_under_rocprof_timed_region.json; c c4_ker
 c c4_kernel_stats_timed_region.csv c4_kernel_stats_timed_region.csv; c c4_pmc.txt c4_pmc_fetch_write_sq_wait.txt
 c c3_chain_kernel_stats.csv c3_chain_kernel_stats.csv; c c3_chain_pmc.txt c3_chain_pmc.txt; c c3_chain_rocprof.json c3_chain_under_rocprof.json
 c config_chain.json config_chain.json; c extract_latency.json extract_latency.json; c frame_latency_ab.txt frame_latency_ab.txt
+c photo_kernel_stats_timed_region.csv photo_china_kernel_stats_timed_region.csv; c photo_kernel_stats.csv photo_china_kernel_stats_serialized.csv
+c photo_pmc.txt photo_china_pmc_sq_wait.txt; c photo_bench_rocprof_timed.json photo_china_bench_under_rocprof_timed_region.json
 c frame_timeline.txt frame_timeline.txt; c abi_latency.json abi_latency.json; c abi_kernel_stats.csv abi_kernel_stats.csv
 # merge: keys of earlier runs of the SAME sources (other batch sizes) stay, this run's keys replace their namesakes
-python3 - $O/traffic.json profiles/traffic_r05.json <<'PY'
+python3 - $O/traffic.json profiles/traffic_$R.json <<'PY'
 import json, sys
 new = json.load(open(sys.argv[1]))
 try:
@@ -27,6 +31,6 @@ if old.get('source_hash') == new.get('source_hash'):
         new.setdefault(k, v)
 json.dump(new, open(sys.argv[2], 'w'), indent=1)
 PY
-cp $O/isa_mix.json profiles/r05_isa_mix.json
-[ -n "$2" ] && grep -E "passed|failed" "$2" > ${P}_gpu_tests.txt
-python3 -c "import json;print('traffic source hash', json.load(open('profiles/traffic_r05.json'))['source_hash'])"; python3 tools/source_hash.py
+cp $O/isa_mix.json profiles/${R}_isa_mix.json
+if [ -n "${2:-}" ]; then grep -E "passed|failed" "$2" > ${P}_gpu_tests.txt || true; fi
+python3 -c "import json;print('traffic source hash', json.load(open('profiles/traffic_$R.json'))['source_hash'])"; python3 tools/source_hash.py

@@ -51,6 +51,22 @@ cp $OUT/c4_stats/*/*kernel_stats.csv $OUT/c4_kernel_stats.csv 2>/dev/null
 cp $OUT/c4_stats_timed/*/*kernel_stats.csv $OUT/c4_kernel_stats_timed_region.csv 2>/dev/null
 python3 tools/pmc_summary.py $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_sq $OUT/c4_pmc_wait > $OUT/c4_pmc.txt 2>&1
 python3 tools/make_traffic_json.py C4/256 $OUT/traffic.json $OUT/c4_pmc_fetch $OUT/c4_pmc_write $OUT/c4_pmc_sq $OUT/c4_pmc_wait > /dev/null 2>&1
+# ---- a real photograph at the headline geometry (round 6): the building photo, ~3.5 x the level-0 candidates of the default
+# content, iniThFAST / minThFAST / empty cells inside one frame -> kernel stats of the timed region and of the serialised step,
+# SQ counters for FAST and the octree (traffic.json["C2/1024/photo_china"])
+BP="python3 bench.py --cpu-seconds 0 --no-stage-timing --no-extras --content photo_china"
+VSG_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/photo_stats -- $BP > $OUT/photo_bench_rocprof.json 2>> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/photo_stats_timed -- $BP > $OUT/photo_bench_rocprof_timed.json 2>> $OUT/rocprof.err
+passp() {
+  local name=$1; shift
+  VSG_NO_OVERLAP=1 timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/photo_pmc_$name -- $BP $P > /dev/null 2>>$OUT/rocprof.err
+}
+passp sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES
+passp wait SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
+cp $OUT/photo_stats/*/*kernel_stats.csv $OUT/photo_kernel_stats.csv 2>/dev/null
+cp $OUT/photo_stats_timed/*/*kernel_stats.csv $OUT/photo_kernel_stats_timed_region.csv 2>/dev/null
+python3 tools/pmc_summary.py $OUT/photo_pmc_sq $OUT/photo_pmc_wait > $OUT/photo_pmc.txt 2>&1
+python3 tools/make_traffic_json.py C2/1024/photo_china $OUT/traffic.json $OUT/photo_pmc_sq $OUT/photo_pmc_wait > /dev/null 2>&1
 # (the C3 leg alone: with the four host threads of the C5 leg in the same process rocprofv3 --kernel-trace itself
 # segfaults in 2 of 6 runs -- inside hipStreamSynchronize, below the HIP runtime, in the tool's HSA queue interception;
 # un-profiled and --pmc runs of the same binary never do: profiles/r05_q_rocprofv3_kernel_trace_c5_segfault.txt --
@@ -72,8 +88,8 @@ pass3 wait SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 python3 tools/pmc_summary.py $OUT/c3_pmc_fetch $OUT/c3_pmc_write $OUT/c3_pmc_sq $OUT/c3_pmc_wait > $OUT/c3_chain_pmc.txt 2>&1
 # the un-profiled bench line LAST among the bench runs, with this build's own counters in place (bench.py only quotes a
 # traffic file whose source hash is the hash of the sources it runs on): the copies under profiles/ on this box are scratch
-cp $OUT/traffic.json profiles/traffic_r05.json
-python3 tools/isa_mix.py > $OUT/isa_mix.json 2>> $OUT/rocprof.err && cp $OUT/isa_mix.json profiles/r05_isa_mix.json
+cp $OUT/traffic.json profiles/traffic_r06.json
+python3 tools/isa_mix.py > $OUT/isa_mix.json 2>> $OUT/rocprof.err && cp $OUT/isa_mix.json profiles/r06_isa_mix.json
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_abi -- tools/_bin/abi_latency 300 > $OUT/abi_latency.json 2>> $OUT/rocprof.err
 cp $OUT/stats_abi/*/*kernel_stats.csv $OUT/abi_kernel_stats.csv 2>/dev/null
@@ -81,6 +97,6 @@ tools/_bin/config_chain 2 4 > $OUT/config_chain.json 2>> $OUT/rocprof.err
 rocprofv3 --kernel-trace --output-format csv -d $OUT/lt -- tools/_bin/extract_latency 300 > $OUT/extract_latency.json 2>> $OUT/rocprof.err
 python3 tools/latency_timeline.py $OUT/lt > $OUT/frame_timeline.txt 2>&1
 for e in "" VSG_GRAPH=1; do echo "== ${e:-default}"; env $e tools/_bin/extract_latency 1000; done > $OUT/frame_latency_ab.txt 2>&1
-rm -rf $OUT/c4_stats/*/*kernel_trace.csv $OUT/c4_stats_timed/*/*kernel_trace.csv $OUT/c3_stats/*/*kernel_trace.csv $OUT/c4_pmc_* $OUT/c3_pmc_* $OUT/stats/*/*kernel_trace.csv $OUT/stats_timed/*/*kernel_trace.csv $OUT/pmc_fused $OUT/stats_abi/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp $OUT/lt
+rm -rf $OUT/c4_stats/*/*kernel_trace.csv $OUT/c4_stats_timed/*/*kernel_trace.csv $OUT/c3_stats/*/*kernel_trace.csv $OUT/c4_pmc_* $OUT/c3_pmc_* $OUT/photo_pmc_* $OUT/photo_stats/*/*kernel_trace.csv $OUT/photo_stats_timed/*/*kernel_trace.csv $OUT/stats/*/*kernel_trace.csv $OUT/stats_timed/*/*kernel_trace.csv $OUT/pmc_fused $OUT/stats_abi/*/*kernel_trace.csv $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_wait $OUT/pmc_active $OUT/pmc_tcp $OUT/lt
 cat $OUT/bench.json | cut -c1-1200
-cat $OUT/pmc_traffic.txt $OUT/pmc_sq.txt $OUT/c4_pmc.txt $OUT/c3_chain_pmc.txt
+cat $OUT/pmc_traffic.txt $OUT/pmc_sq.txt $OUT/c4_pmc.txt $OUT/photo_pmc.txt $OUT/c3_chain_pmc.txt

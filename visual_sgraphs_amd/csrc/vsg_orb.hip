@@ -665,17 +665,24 @@ struct NullStreamBridge {
 // (vsg_orb_set_direct_registered).  The WHOLE range [p, p + bytes) is validated, not its first byte.
 static std::mutex g_alloc_mu;
 static std::map<uintptr_t, size_t> g_allocs;  // vsg_host_alloc: base -> bytes
+static std::map<uintptr_t, size_t> g_regs;    // vsg_host_register: base -> bytes
 
-static bool in_lib_alloc(const void *p, size_t bytes) {
+// the registered / allocated range that holds byte a, if any: 0 = none, 1 = holds [a, a + bytes), -1 = holds a but not the end
+static int in_ranges(const std::map<uintptr_t, size_t> &m, const void *p, size_t bytes) {
   const uintptr_t a = (uintptr_t)p;
-  std::lock_guard<std::mutex> lk(g_alloc_mu);
-  auto it = g_allocs.upper_bound(a);
-  if (it == g_allocs.begin()) return false;
+  auto it = m.upper_bound(a);
+  if (it == m.begin()) return 0;
   --it;
-  return a >= it->first && bytes <= it->second && a - it->first <= it->second - bytes;
+  if (a < it->first || a - it->first >= it->second) return 0;
+  return bytes <= it->second && a - it->first <= it->second - bytes ? 1 : -1;
 }
 
-// what the runtime says about one byte: 0 = pageable / unknown, 2 = hipHostMalloc memory, 3 = hipHostRegister-ed memory
+// What the runtime says about one byte this library knows nothing about: 0 = pageable / unknown, 2 = hipHostMalloc memory,
+// 3 = anything else that is pinned.  FAIL CLOSED: "somebody else's hipHostMalloc" is only claimed when the
+// runtime answers hipHostGetFlags for the pointer AND the device sees the byte at the host's own address -- hipHostMalloc
+// memory is one allocation mapped at one address for both, a hipHostRegister mapping (hsa_amd_memory_lock) hands the
+// device an address of its own.  hipHostGetFlags refusing registered memory is undocumented ROCclr behaviour and not
+// relied on; whatever fails either test is REGISTERED: staged unless the handle opted in.
 static int runtime_kind(const void *p, void **dev_alias) {
   hipPointerAttribute_t a;
   if (hipPointerGetAttributes(&a, p) != hipSuccess) {
@@ -684,15 +691,22 @@ static int runtime_kind(const void *p, void **dev_alias) {
   }
   if (a.type != hipMemoryTypeHost) return VSG_HOST_PAGEABLE;
   if (dev_alias) *dev_alias = a.devicePointer;
-  // hipHostGetFlags answers for hipHostMalloc allocations only (it refuses registered user memory)
   unsigned int fl = 0;
-  if (hipHostGetFlags(&fl, const_cast<void *>(p)) == hipSuccess) return VSG_HOST_HIPHOSTMALLOC;
-  (void)hipGetLastError();
-  return VSG_HOST_REGISTERED;
+  const bool flags_ok = hipHostGetFlags(&fl, const_cast<void *>(p)) == hipSuccess;
+  if (!flags_ok) (void)hipGetLastError();
+  return flags_ok && a.devicePointer == p ? VSG_HOST_HIPHOSTMALLOC : VSG_HOST_REGISTERED;
 }
 
 static int host_kind(const void *p, size_t bytes, void **dev_alias) {
   if (!p || !bytes) return VSG_HOST_PAGEABLE;
+  // ranges this library pinned itself are classified by ITS books, whatever the runtime says about them; a span that starts
+  // inside one and ends outside it is not pinned as a whole
+  int lib, reg;
+  {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    lib = in_ranges(g_allocs, p, bytes), reg = in_ranges(g_regs, p, bytes);
+  }
+  if (lib < 0 || reg < 0) return VSG_HOST_PAGEABLE;
   void *a0 = nullptr, *a1 = nullptr;
   const int k0 = runtime_kind(p, &a0);
   if (k0 == VSG_HOST_PAGEABLE) return k0;
@@ -700,7 +714,8 @@ static int host_kind(const void *p, size_t bytes, void **dev_alias) {
   // both ends pinned the same way, one contiguous device alias (two registrations back to back would differ here)
   if (k1 != k0 || (bytes > 1 && (uintptr_t)a1 - (uintptr_t)a0 != bytes - 1)) return VSG_HOST_PAGEABLE;
   if (dev_alias) *dev_alias = a0;
-  if (in_lib_alloc(p, bytes)) return VSG_HOST_LIB_ALLOC;
+  if (reg) return VSG_HOST_REGISTERED;
+  if (lib) return VSG_HOST_LIB_ALLOC;
   return k0;
 }
 
@@ -735,10 +750,16 @@ int vsg_device_count(void) {
 int vsg_host_register(void *ptr, size_t bytes) {
   if (!ptr || !bytes) return VSG_ERR_INVALID;
   HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+  std::lock_guard<std::mutex> lk(g_alloc_mu);
+  g_regs[(uintptr_t)ptr] = bytes;
   return VSG_OK;
 }
 int vsg_host_unregister(void *ptr) {
   if (!ptr) return VSG_ERR_INVALID;
+  {
+    std::lock_guard<std::mutex> lk(g_alloc_mu);
+    g_regs.erase((uintptr_t)ptr);
+  }
   HIP_TRY(hipHostUnregister(ptr));
   return VSG_OK;
 }
