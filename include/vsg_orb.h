@@ -150,11 +150,6 @@ int vsg_orb_enable_timing(vsg_orb *h, int enable);
 int vsg_orb_set_serialize(vsg_orb *h, int serialize);
 int vsg_orb_get_timing(vsg_orb *h, float *ms_out, int cap);
 
-/* Test hook: sorts items[0..n) (n <= 2048) by their upper 32 bits with the device code DistributeOctTree uses for
- * `std::sort(vSizeAndPointerToNode...)` (ORBextractor.cc:707): a replay of libstdc++'s introsort whose result --
- * including the order of equal keys -- must equal std::sort's.  Lets tests compare the two directly. */
-int vsg_debug_device_sort(int device, uint64_t *items, int n);
-
 /* void Frame::ComputeStereoMatches() (Frame.cc:957-1127) for a rectified pair.  hl/hr = the
  * extractors that just processed the left/right image (their mvImagePyramid is read on the device; one handle
  * with a 2-frame batch works too: frame_l/frame_r index the batch).  kps/desc = the operator() outputs (host).
@@ -316,9 +311,6 @@ int vsg_thread_arena_growths(int device);
 /* hipMemcpyAsync(dst, src, bytes, DeviceToDevice, stream) on `device`, for hosts that hold raw device pointers (the
  * records of vsg_shard_record) and should not bind a second copy of the HIP runtime for one copy. */
 int vsg_copy_d2d_async(int device, void *dst, const void *src, size_t bytes, void *stream);
-/* debug: wall time in microseconds of the calling thread's last vsg_frame_* window search -- {filling the pinned
- * arena, the launch call, the stream synchronisation (kernel + PCIe), the whole entry point} */
-int vsg_debug_call_profile(float us[4]);
 
 /* ---- Pinned caller memory (the buffers behind cv::Mat::data of a reused frame, Frame::mvKeys / mDescriptors rings;
  * the reference hands operator() plain heap memory: ORBextractor.h:59-61, Frame.cc:555-563) ---------------------------

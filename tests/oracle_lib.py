@@ -9,6 +9,8 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent.parent
 ORACLE_DIR = ROOT / "oracle"
 LIB_PATH = ORACLE_DIR / "liborb_oracle.so"
+if os.environ.get("VSG_ORACLE_LIB"):  # tests/test_sanitizers.py: the ASan + UBSan build of the same sources
+    LIB_PATH = Path(os.environ["VSG_ORACLE_LIB"])
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
@@ -29,7 +31,8 @@ def build():
                                      "brief_pattern_data.inc")]
     if LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= s.stat().st_mtime for s in srcs):
         return
-    subprocess.check_call(["make", "-C", str(ORACLE_DIR)], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", str(ORACLE_DIR)] + (["asan"] if "asan" in LIB_PATH.name else []),
+                          stdout=subprocess.DEVNULL)
 
 
 _lib = None

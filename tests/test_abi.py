@@ -24,7 +24,14 @@ def test_header_symbols_are_exported(lib):
     assert len(declared) >= 25
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/vsg_orb.h but not exported"
-    assert sorted(orb.EXPORTS) == declared
+    # the test / measurement hooks live in a header of their own, outside the boundary a maintainer binds (VERDICT r5 #8b)
+    assert not [n for n in declared if n.startswith("vsg_debug_")], "debug hooks belong in include/vsg_orb_debug.h"
+    dbg = sorted(set(re.findall(r"\b(vsg_debug_[a-z0-9_]+)\s*\(", (ROOT / "include" / "vsg_orb_debug.h").read_text())))
+    assert dbg == ["vsg_debug_call_profile", "vsg_debug_device_sort"]
+    for name in dbg:
+        assert hasattr(lib, name), f"{name} declared in include/vsg_orb_debug.h but not exported"
+    assert "vsg_orb_debug.h" not in (ROOT / "INTEGRATION.md").read_text()
+    assert sorted(orb.EXPORTS) == sorted(declared + dbg)
 
 
 def test_keypoint_record_is_cv_keypoint_layout():

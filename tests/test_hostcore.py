@@ -2,6 +2,7 @@
 tests/_hostcore): geometry tables, the libstdc++-exact introsort, the array-based octree (run as a
 1-thread group) and the float helpers -- each against the oracle or against libm / std::sort."""
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -17,8 +18,9 @@ _i32p = C.POINTER(C.c_int32)
 
 @pytest.fixture(scope="module")
 def hc():
-    subprocess.check_call(["make", "-C", str(HC_DIR)], stdout=subprocess.DEVNULL)
-    L = C.CDLL(str(HC_DIR / "libvsg_hostcore.so"))
+    asan = bool(os.environ.get("VSG_HOSTCORE_ASAN"))  # tests/test_sanitizers.py: the ASan + UBSan build of the same core
+    subprocess.check_call(["make", "-C", str(HC_DIR)] + (["asan"] if asan else []), stdout=subprocess.DEVNULL)
+    L = C.CDLL(str(HC_DIR / ("libvsg_hostcore_asan.so" if asan else "libvsg_hostcore.so")))
     L.hc_build.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.hc_level.argtypes = [C.c_int, _i32p]
     L.hc_octree.argtypes = [C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int, _i32p]

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../include/vsg_orb.h"
+#include "../include/vsg_orb_debug.h"
 #include "../include/vsg_synth.h"
 #include "../oracle/orb_oracle.h"
 

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/vsg_orb.h"
+#include "../../include/vsg_orb_debug.h"
 #include "vsg_common.h"
 #include "vsg_ctx.h"
 #include "vsg_frame_int.h"
