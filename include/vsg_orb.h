@@ -517,7 +517,10 @@ int vsg_frame_search_for_initialization(vsg_frame *f1, vsg_frame *f2, const floa
                                         int window_size, float nnratio, int check_orientation, int32_t *matches12);
 
 /* SearchByBoW(KeyFrame*, Frame&) / (KeyFrame*, KeyFrame*) (ORBmatcher.cc:226-428, 758-900) on resident descriptors:
- * only the FeatureVectors and the validity flags go up.  Same outputs as vsg_search_by_bow_kf_f_stereo / _kf_kf. */
+ * only the FeatureVectors and the validity flags go up.  Same outputs as vsg_search_by_bow_kf_f_stereo / _kf_kf.
+ * With ALL FeatureVector arrays NULL the FeatureVectors both frames keep resident since their vsg_frame_bow_transform
+ * (Frame::mFeatVec; frames of at most 2048 features) are joined on the device and only the flags go up;
+ * VSG_ERR_INVALID when either frame never had its ComputeBoW since its features were last written. */
 int vsg_frame_search_by_bow_kf_f(vsg_frame *kf, const uint8_t *kf_valid, const int32_t *kf_node_id,
                                  const int32_t *kf_off, const int32_t *kf_idx, int kf_nodes, vsg_frame *f,
                                  const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
@@ -543,6 +546,19 @@ int vsg_frame_bow_transform(vsg_vocab *voc, vsg_frame *f, int levelsup, int32_t 
  * Frame, straight out of the two extractors): nothing but mvuRight / mvDepth crosses PCIe. */
 int vsg_frame_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, vsg_frame *fl, vsg_frame *fr,
                              float mb, float mbf, float *u_right, float *depth);
+
+/* Frame::ComputeStereoMatches (Frame.cc:957-1127) + Frame::ComputeBoW (Frame.cc:882-889) + ORBmatcher::SearchByBoW(KeyFrame*,
+ * Frame&, ...) (ORBmatcher.cc:226-428) of one stereo Frame in ONE enqueue and ONE wait: what depends only on two resident
+ * frames shares a stream round trip instead of paying three.  Arguments as vsg_frame_stereo_matches (fl / fr = the resident
+ * left / right eye; *n_stereo = matches kept by the median cut), vsg_frame_bow_transform (of fl; its FeatureVector also
+ * stays resident in fl) and vsg_frame_search_by_bow_kf_f with NULL FeatureVector arrays (kf = a frame whose own ComputeBoW
+ * ran earlier; kf == NULL: no search, match_f / n_match are not touched).  Results are those of the three blocking calls. */
+int vsg_frame_stereo_bow_search(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, vsg_frame *fl, vsg_frame *fr, float mb,
+                                float mbf, float *u_right, float *depth, int *n_stereo, vsg_vocab *voc, int levelsup,
+                                int32_t *bow_ids, double *bow_vals, int bow_cap, int *n_bow, int32_t *fv_node,
+                                int32_t *fv_off, int32_t *fv_idx, int fv_cap, int *n_fv, vsg_frame *kf,
+                                const uint8_t *kf_valid, float nnratio, int check_orientation, int32_t *match_f,
+                                int *n_match);
 
 /* ---- Frame sharding over the GPUs of one node (one process per GPU) -------------------------------
  * The reference has no distributed layer.  Extraction shards by frame (or camera stream) with no collective; the

@@ -117,10 +117,15 @@ def test_c3_chain_at_reference_vocabulary_scale(reference_scale_vocabulary):
     got = f0.SearchByBoW_KF_F(valid, fv0, f1m, fv1m, 0.7, True)
     want = ol.search_by_bow_kf_f(d0, k0["angle"], valid, fv0, d1m, k0["angle"], ofv1m, 0.7, True)
     assert want[0] > 100 and got[0] == want[0] and np.array_equal(got[1], want[1])
+    # round 6: both FeatureVectors are resident since the ComputeBoW calls above (Frame::mFeatVec) -- joined on the device
+    got_r = f0.SearchByBoW_KF_F(valid, None, f1m, None, 0.7, True)
+    assert got_r[0] == want[0] and np.array_equal(got_r[1], want[1])
     v2 = np.ones(len(k0), np.uint8)
     got = f0.SearchByBoW_KF_KF(valid, fv0, f1m, v2, fv1m, 0.8, True)
     want = ol.search_by_bow_kf_kf(d0, k0["angle"], valid, fv0, d1m, k0["angle"], v2, ofv1m, 0.8, True)
     assert want[0] > 100 and got[0] == want[0] and np.array_equal(got[1], want[1])
+    got_r = f0.SearchByBoW_KF_KF(valid, None, f1m, v2, None, 0.8, True)
+    assert got_r[0] == want[0] and np.array_equal(got_r[1], want[1])
     e1 = (ur0 < 0).astype(np.uint8)      # no map point yet
     got = f0.SearchForTriangulation(e1, fv0, f1m, v2, fv1m, True)
     want = ol.search_for_triangulation(d0, k0["angle"], e1, fv0, d1m, k0["angle"], v2, ofv1m, None, None, True)
@@ -145,3 +150,86 @@ def test_c3_chain_extract_bow_search(frames):
     n_want, want = ol.search_by_bow_kf_f(d0, k0["angle"], valid, rfv_kf, d1, k1["angle"], rfv_f, 0.7, True)
     assert n_got == n_want and np.array_equal(got, want)
     assert n_want > 100
+
+
+def test_resident_feature_vector_needs_its_compute_bow(reference_scale_vocabulary):
+    """SearchByBoW with NULL FeatureVector arrays joins what ComputeBoW left in the frames; a frame whose features were
+    written after its last ComputeBoW (or that never had one) is refused, not searched with a stale FeatureVector."""
+    ref, voc = reference_scale_vocabulary
+    e = ol.OracleExtractor(600, 1.2, 8, 20, 7)
+    _, k0, d0 = e(synth.sequence_frame(640, 480, 21, 0))
+    _, k1, d1 = e(synth.sequence_frame(640, 480, 21, 1))
+    b = (0.0, 0.0, 640.0, 480.0)
+    f0, f1 = orb.Frame(700).upload(k0, d0, b), orb.Frame(700).upload(k1, d1, b)
+    valid = np.ones(len(k0), np.uint8)
+    with pytest.raises(orb.VsgError):
+        f0.SearchByBoW_KF_F(valid, None, f1, None, 0.7, True)
+    fv0, fv1 = f0.ComputeBoW(voc, 4)["fv"], f1.ComputeBoW(voc, 4)["fv"]
+    want = ol.search_by_bow_kf_f(d0, k0["angle"], valid, ref.transform(d0, 4)["fv"], d1, k1["angle"], ref.transform(d1, 4)["fv"],
+                                 0.7, True)
+    got = f0.SearchByBoW_KF_F(valid, None, f1, None, 0.7, True)
+    assert want[0] > 50 and got[0] == want[0] and np.array_equal(got[1], want[1])
+    f1.upload(k0, d0, b)          # new features: the resident FeatureVector is stale
+    with pytest.raises(orb.VsgError):
+        f0.SearchByBoW_KF_F(valid, None, f1, None, 0.7, True)
+
+
+@pytest.mark.parametrize("scoring,weighting", [(0, 0), (1, 1), (5, 0), (2, 2), (0, 3)])
+def test_bow_assembly_on_the_device_and_on_the_host_agree_with_the_oracle(scoring, weighting):
+    """Frames of up to 2048 features are assembled by k_bow_assemble (bitonic sort in LDS, sums in the reference's order);
+    larger ones by the same steps on the host.  Both against the oracle, bit for bit, incl. stopped words (a third of the
+    leaves weigh 0 here) and features that share a word (descriptors repeated)."""
+    blob = synth.synthetic_vocabulary(6, 3, seed=91, scoring=scoring, weighting=weighting, stop_fraction=0.3)
+    ref, voc = ol.OracleVocabulary(blob), orb.ORBVocabulary(blob)
+    for n in (1, 2, 63, 1024, 2047, 2048, 2049, 3000):
+        d = synth.random_descriptors(n, 700 + n)
+        d[1::3] = d[0]                     # many features in one word: the running sum of addWeight
+        want, got = ref.transform(d, 1), voc.transform(d, 1)
+        for key in ("word", "node", "bow_ids"):
+            assert np.array_equal(got[key], want[key]), (n, key)
+        assert np.array_equal(got["bow_vals"].view(np.uint64), want["bow_vals"].view(np.uint64)), n
+        for a, b_ in zip(got["fv"], want["fv"]):
+            assert np.array_equal(a, b_), n
+
+
+def test_stereo_bow_search_in_one_wait_is_the_three_blocking_calls(reference_scale_vocabulary):
+    """vsg_frame_stereo_bow_search (round 6): ComputeStereoMatches + ComputeBoW + SearchByBoW(KF, F) of a stereo Frame as one
+    enqueue and one wait.  Every output against the oracle's chain and against the three blocking calls, over three pairs
+    (the first has no KeyFrame to search)."""
+    from test_gpu_stereo import rectified_pair
+    ref, voc = reference_scale_vocabulary
+    W, H, NF = 752, 480, 1200
+    exl, exr = orb.ORBextractor(NF, 1.2, 8, 20, 7), orb.ORBextractor(NF, 1.2, 8, 20, 7)
+    rl, rr = ol.OracleExtractor(NF, 1.2, 8, 20, 7), ol.OracleExtractor(NF, 1.2, 8, 20, 7)
+    b = (0.0, 0.0, float(W), float(H))
+    cap = exl.capacity(H, W)
+    FL, FR = [orb.Frame(cap), orb.Frame(cap)], orb.Frame(cap)
+    prev = None
+    for t in range(3):
+        L_, R_ = rectified_pair(W, H, 77, 17 + t)
+        (_, kl, dl), (_, kr, dr) = exl(L_), exr(R_)
+        (_, okl, odl), (_, okr, odr) = rl(L_), rr(R_)
+        assert kl.tobytes() == okl.tobytes() and np.array_equal(dl, odl) and np.array_equal(dr, odr)
+        cur = FL[t & 1].from_extractor(exl, 0, kl, b)
+        FR.from_extractor(exr, 0, kr, b)
+        our, odep = ol.stereo_matches(rl, rr, kl, dl, kr, dr, 0.11, 47.9)
+        obow = ref.transform(dl, 4)
+        kf, kf_valid = (prev["frame"], prev["valid"]) if prev else (None, None)
+        got = orb.stereo_bow_search(exl, 0, exr, 0, cur, FR, 0.11, 47.9, voc, 4, kf, kf_valid, 0.7, True)
+        assert got["u_right"].tobytes() == our.tobytes() and got["depth"].tobytes() == odep.tobytes()
+        assert got["n_stereo"] == int((our >= 0).sum()) and got["n_stereo"] > 100
+        assert np.array_equal(got["bow_ids"], obow["bow_ids"])
+        assert np.array_equal(got["bow_vals"].view(np.uint64), obow["bow_vals"].view(np.uint64))
+        assert all(np.array_equal(x, y) for x, y in zip(got["fv"], obow["fv"]))
+        if prev:
+            want = ol.search_by_bow_kf_f(prev["d"], prev["k"]["angle"], prev["valid"], prev["fv"], dl, kl["angle"], obow["fv"],
+                                         0.7, True)
+            assert got["n_match"] == want[0] and np.array_equal(got["match_f"], want[1])
+            # ... and the three blocking calls on the same frames
+            ur3, dep3 = orb.ComputeStereoMatches_resident(exl, 0, exr, 0, cur, FR, 0.11, 47.9)
+            bow3 = cur.ComputeBoW(voc, 4)
+            m3 = prev["frame"].SearchByBoW_KF_F(prev["valid"], prev["fv"], cur, bow3["fv"], 0.7, True)
+            assert ur3.tobytes() == got["u_right"].tobytes() and dep3.tobytes() == got["depth"].tobytes()
+            assert np.array_equal(bow3["bow_vals"].view(np.uint64), got["bow_vals"].view(np.uint64))
+            assert m3[0] == got["n_match"] and np.array_equal(m3[1], got["match_f"])
+        prev = dict(frame=cur, valid=(our >= 0).astype(np.uint8), d=dl, k=kl, fv=obow["fv"])

@@ -109,6 +109,54 @@ def case_bow(rng):
     return ok, ("bow", k, L, n, lv)
 
 
+def case_bow_search(rng):
+    """SearchByBoW(KF, F) / (KF, KF) on two resident frames (ORBmatcher.cc:226-428, 758-900), FeatureVectors host-side and
+    resident: clustered descriptors (many features fight for the same candidates: the ordered walk's fixed point needs several
+    rounds), random validity, nodes from a handful of features to the whole frame (the large-node form), fisheye Nleft."""
+    k, L = int(rng.choice([3, 6, 10])), int(rng.integers(2, 4))
+    blob = synth.synthetic_vocabulary(k=k, L=L, seed=int(rng.integers(0, 1000)))
+    voc, ref = orb.ORBVocabulary(blob), ol.OracleVocabulary(blob)
+    lv = int(rng.integers(0, L + 2))
+    nA, nB = int(rng.integers(1, 420)), int(rng.integers(1, 420))
+    base = synth.random_descriptors(int(rng.integers(1, 40)), int(rng.integers(0, 1 << 16)))
+
+    def cloud(n):
+        d = base[rng.integers(0, len(base), n)].copy()
+        nflip = int(rng.integers(0, 12))
+        for _ in range(nflip):
+            bit = rng.integers(0, 256, n)
+            d[np.arange(n), bit >> 3] ^= (1 << (bit & 7)).astype(np.uint8)
+        return d
+
+    def keys(n):
+        kp = np.zeros(n, orb.KP_DTYPE)
+        kp["x"], kp["y"] = rng.uniform(20, 600, n), rng.uniform(20, 440, n)
+        kp["angle"] = rng.choice([0.0, 15.0, 29.9, 30.0, 45.0, 180.0, 359.0], n) if rng.random() < 0.5 else rng.uniform(0, 360, n)
+        kp["octave"] = rng.integers(0, 8, n)
+        kp["size"] = 31.0
+        return kp
+    dA, dB, kA, kB = cloud(nA), cloud(nB), keys(nA), keys(nB)
+    b = (0.0, 0.0, 640.0, 480.0)
+    nleft = int(rng.integers(0, nB + 1)) if rng.random() < 0.3 else -1
+    fA, fB = orb.Frame(nA + 2).upload(kA, dA, b), orb.Frame(nB + 2).upload(kB, dB, b, nleft=nleft)
+    fvA, fvB = fA.ComputeBoW(voc, lv)["fv"], fB.ComputeBoW(voc, lv)["fv"]
+    ofvA, ofvB = ref.transform(dA, lv)["fv"], ref.transform(dB, lv)["fv"]
+    ok = all(np.array_equal(x, y) for x, y in zip(fvA + fvB, ofvA + ofvB))
+    vA = (rng.random(nA) < 0.8).astype(np.uint8)
+    vB = (rng.random(nB) < 0.8).astype(np.uint8)
+    ratio, ori = float(rng.choice([0.6, 0.7, 0.8, 0.9, 1.0])), bool(rng.integers(0, 2))
+    want = ol.search_by_bow_kf_f(dA, kA["angle"], vA, ofvA, dB, kB["angle"], ofvB, ratio, ori, nleft)
+    for fv in ((None, None), (fvA, fvB)):
+        got = fA.SearchByBoW_KF_F(vA, fv[0], fB, fv[1], ratio, ori)
+        ok = ok and got[0] == want[0] and np.array_equal(got[1], want[1])
+    if nleft < 0:
+        want = ol.search_by_bow_kf_kf(dA, kA["angle"], vA, ofvA, dB, kB["angle"], vB, ofvB, ratio, ori)
+        for fv in ((None, None), (fvA, fvB)):
+            got = fA.SearchByBoW_KF_KF(vA, fv[0], fB, vB, fv[1], ratio, ori)
+            ok = ok and got[0] == want[0] and np.array_equal(got[1], want[1])
+    return ok, ("bow_search", k, L, lv, nA, nB, len(base), nleft, ratio, ori)
+
+
 def _rand_camera(rng, w, h):
     """None (mDistCoef(0) == 0: bounds = the image) a third of the time, otherwise a random pinhole camera with 4 or 5
     distortion coefficients in the range of the reference's settings files (TUM1: k1 0.26, k2 -0.95, k3 1.16; D435i:
@@ -421,7 +469,7 @@ def _finish(ex, ref, ticket, buf, lap, pinned):
     return bool(ok)
 
 
-CASES = {"undistort": case_undistort, "resident": case_resident, "async": case_async, "window": case_window, "batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow}
+CASES = {"undistort": case_undistort, "resident": case_resident, "async": case_async, "window": case_window, "batch": case_batch, "colour": case_colour, "best2": case_best2, "stereo": case_stereo, "bow": case_bow, "bow_search": case_bow_search}
 
 
 def run_child(args, argv):

@@ -52,7 +52,8 @@ template <int G>
 __global__ __launch_bounds__(256) void k_bow_descend(const NodeRec *__restrict__ rec, const double *__restrict__ weight,
                                                      uint32_t root_link, const uint8_t *__restrict__ desc, int n,
                                                      int nid_level, int *__restrict__ word_of, int *__restrict__ node_of,
-                                                     double *__restrict__ weight_of) {
+                                                     double *__restrict__ weight_of, int *__restrict__ m_word,
+                                                     int *__restrict__ m_node, double *__restrict__ m_weight) {
   const int i = (blockIdx.x * 256 + threadIdx.x) / G, j = threadIdx.x & (G - 1);
   if (i >= n) return;  // whole groups leave together
   const uint4 *f = (const uint4 *)(desc + (size_t)i * 32);
@@ -75,13 +76,205 @@ __global__ __launch_bounds__(256) void k_bow_descend(const NodeRec *__restrict__
     const uint32_t best = group_min_u32<G>(key);
     const int jw = (int)(best & 0xFFu);
     link = (uint32_t)__shfl((int)mylink, jw, G);
+    if (level == nid_level) nid = __shfl(myid, jw, G);  // group-uniform: every lane keeps the node id of that level
     if (j == jw) {  // the winner's lane holds everything the outputs need
-      if (level == nid_level) nid = myid, node_of[i] = myid;
       if (!(link >> 24)) {
-        word_of[i] = myword;
-        weight_of[i] = weight[first + jw];
-        if (nid_level > level || nid_level <= 0) node_of[i] = 0;  // levelsup beyond the tree height: nid stays 0
+        if (nid_level > level || nid_level <= 0) nid = 0;  // levelsup beyond the tree height: nid stays 0
+        const double w = weight[first + jw];
+        word_of[i] = myword, node_of[i] = nid, weight_of[i] = w;
+        if (m_word) m_word[i] = myword, m_node[i] = nid, m_weight[i] = w;  // pinned mirror: the per-feature outputs
       }
+    }
+  }
+}
+
+// ---- BowVector / FeatureVector assembly ON THE DEVICE (round 6; TemplatedVocabulary.h:1158-1206, BowVector.cpp:34-84,
+// FeatureVector.cpp:31-45).  The reference inserts feature by feature into two std::maps; the same content falls out of
+// two sorts of (id << 32 | feature) keys -- ascending ids, the features of an id in feature order.  Two launches: the rank
+// of every key among the frame's keys, computed all over the chip (k_bow_rank; stopped words -- weight <= 0 -- take no part),
+// then one workgroup per container (k_bow_assemble): group heads by a block scan, and the floating point exactly as the
+// reference orders it:
+//   * addWeight: every feature of a word carries the word's weight, so the running sum in feature order is the weight
+//     added to itself (count - 1) times, left to right -- the head's thread does just that;
+//   * normalize(): the L1 / L2 norm is ONE sequential sum in ascending word id (thread 0), then a correctly rounded
+//     division (and square root) per entry -- IEEE operations, no contraction (-ffp-contract=off): bit-identical doubles.
+// The host copies the result out of the pinned arena, nothing else; the FeatureVector also stays RESIDENT in the frame
+// (Frame::mFeatVec), where the SearchByBoW kernels join it with another frame's without a host round trip.
+enum { kAsmMax = 2048, kAsmThreads = 1024 };  // features a frame may hold for the device assembly (C4: 2000 + 24)
+// BowVector::normalize (BowVector.cpp:62-84) is ONE dependent chain of n_bow double additions (the reference's loop order IS
+// the result) followed by n_bow divisions: nothing a GPU has to offer -- one lane, ~10 cycles per dependent v_add_f64 at
+// <= 2.4 GHz against 4 cycles at the host's clock.  Measured (profiles/r06_*_bow_norm_ab.txt): the chain on the device
+// lengthens k_bow_assemble by more than the whole host pass takes.  So the kernel leaves the values as addWeight made them
+// and the host normalises what it copies out; -DVSG_BOW_NORM_DEVICE=1 builds the all-device form (same bytes, tested).
+#ifndef VSG_BOW_NORM_DEVICE
+#define VSG_BOW_NORM_DEVICE 0
+#endif
+constexpr bool kNormOnDevice = VSG_BOW_NORM_DEVICE != 0;
+struct BowOut {
+  int *hdr;  // {n_bow, n_fv, features with a non-stopped word, 0}
+  int *bow_ids;
+  double *bow_vals;
+  int *fv_node, *fv_off, *fv_idx;
+  int *r_hdr, *r_fv_node, *r_fv_off, *r_fv_idx;  // the frame's resident copy (nullptr: none)
+};
+
+__device__ __forceinline__ int block_exclusive_scan_2(int v, int *wsum /*[16]*/, int *total) {
+  // exclusive scan of one value per thread over kAsmThreads threads (16 waves): DPP inside the wave (VALU latency per step:
+  // row shifts with zero fill, then the row broadcasts), one LDS word per wave across
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);   // row_shr:1
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);   // row_shr:2
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);   // row_shr:4
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);   // row_shr:8
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < kAsmThreads / 64; k++) {
+    const int t = wsum[k];
+    base += k < wave ? t : 0;
+    tot += t;
+  }
+  *total = tot;
+  __syncthreads();
+  return base + inc - v;
+}
+
+// Step 1, all over the chip: every key's RANK among the frame's keys -- rank(i) = #{j : key_j < key_i}, n^2 comparisons that
+// no one workgroup should make (a bitonic network over 2 x 2048 64-bit keys on ONE compute unit was built first and took
+// 25 us of instruction issue alone) but that ceil(n / 64) workgroups of 16 waves finish in about a microsecond: a workgroup
+// owns 64 keys (one per lane), each of its waves compares them with a sixteenth of all keys (staged in LDS, read at
+// wave-uniform addresses) and the partial counts meet in LDS.  Keys are unique (the feature index is in them), so the ranks
+// are a permutation: the key goes straight to its sorted position.
+enum { kRankChunk = kAsmMax / 16 };
+__global__ __launch_bounds__(kAsmThreads) void k_bow_rank(const int *__restrict__ word_of, const int *__restrict__ node_of,
+                                                          const double *__restrict__ weight_of, int n,
+                                                          uint64_t *__restrict__ sorted_w, uint64_t *__restrict__ sorted_n) {
+  __shared__ uint64_t jw[16][kRankChunk], jn[16][kRankChunk];
+  __shared__ int cw[16][64], cn[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint64_t SENT = ~0ull;
+  const int J = (n + 15) / 16;
+  const int i = blockIdx.x * 64 + lane;
+  const bool on_i = i < n && weight_of[i] > 0;  // w > 0: not a stopped word (TemplatedVocabulary.h:1170)
+  const uint64_t kwi = on_i ? ((uint64_t)(uint32_t)word_of[i] << 32) | (uint32_t)i : SENT;
+  const uint64_t kni = on_i ? ((uint64_t)(uint32_t)node_of[i] << 32) | (uint32_t)i : SENT;
+  for (int q = lane; q < J; q += 64) {
+    const int j = w * J + q;
+    const bool on = j < n && weight_of[j] > 0;
+    jw[w][q] = on ? ((uint64_t)(uint32_t)word_of[j] << 32) | (uint32_t)j : SENT;
+    jn[w][q] = on ? ((uint64_t)(uint32_t)node_of[j] << 32) | (uint32_t)j : SENT;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int c1 = 0, c2 = 0;
+  for (int q = 0; q < J; q++) c1 += jw[w][q] < kwi, c2 += jn[w][q] < kni;  // sentinels are never below a key
+  cw[w][lane] = c1, cn[w][lane] = c2;
+  __syncthreads();
+  if (w == 0 && on_i) {
+    int r1 = 0, r2 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) r1 += cw[k][lane], r2 += cn[k][lane];
+    sorted_w[r1] = kwi, sorted_n[r2] = kni;
+  }
+}
+
+// Step 2, two workgroups side by side: block 0 turns the sorted word keys into the BowVector, block 1 the sorted node keys
+// into the FeatureVector (the BowVector's sequential norm is the long pole; the FeatureVector finishes in its shadow).
+__global__ __launch_bounds__(kAsmThreads) void k_bow_assemble(const uint64_t *__restrict__ sorted_w,
+                                                              const uint64_t *__restrict__ sorted_n,
+                                                              const double *__restrict__ weight_of, int n, int tf,
+                                                              int scoring, int normalize, BowOut o) {
+  __shared__ uint64_t key[kAsmMax];
+  __shared__ double vals[kAsmMax];
+  __shared__ int wsum[kAsmThreads / 64];
+  __shared__ double s_norm;
+  const int tid = threadIdx.x;
+  const bool words = blockIdx.x == 0;
+  // m = features with a non-stopped word = keys in either sorted array; every global load of the prologue is requested
+  // before the first is used (positions >= m of the sorted arrays were never written: masked once m is known)
+  const uint64_t *src = words ? sorted_w : sorted_n;
+  const int i0 = tid, i1 = tid + kAsmThreads;
+  const double w0 = i0 < n ? weight_of[i0] : 0.0, w1 = i1 < n ? weight_of[i1] : 0.0;
+  const uint64_t s0 = i0 < n ? src[i0] : ~0ull, s1 = i1 < n ? src[i1] : ~0ull;
+  int m;
+  (void)block_exclusive_scan_2((int)(w0 > 0) + (int)(w1 > 0), wsum, &m);
+  key[i0] = i0 < m ? s0 : ~0ull, key[i1] = i1 < m ? s1 : ~0ull;
+  __syncthreads();
+  // two consecutive sorted positions per thread
+  const int p0 = 2 * tid;
+  auto head = [&](int p) { return p < m && (p == 0 || (key[p] >> 32) != (key[p - 1] >> 32)); };
+  const int h0 = head(p0), h1 = head(p0 + 1);
+  int n_heads;
+  const int ex = block_exclusive_scan_2(h0 + h1, wsum, &n_heads);
+  if (words) {  // ---- BowVector
+    const int n_bow = n_heads;
+    for (int q = 0; q < 2; q++) {
+      const int p = p0 + q;
+      if (!(q ? h1 : h0)) continue;
+      const int j = ex + (q ? h0 : 0);
+      int e = p + 1;
+      while (e < m && (key[e] >> 32) == (key[p] >> 32)) e++;
+      const double wi = weight_of[(uint32_t)key[p]];
+      double val = wi;
+      if (tf)
+        for (int r = p + 1; r < e; r++) val += wi;  // addWeight, feature by feature (BowVector.cpp:34-47)
+      vals[j] = val;
+      o.bow_ids[j] = (int)(key[p] >> 32);
+    }
+    __syncthreads();
+    if (!normalize) {  // the values as addWeight left them; normalize() runs on the host (see bow_finish)
+      for (int j = tid; j < n_bow; j += kAsmThreads) o.bow_vals[j] = vals[j];
+      if (tid == 0) o.hdr[0] = n_bow, o.hdr[2] = m, o.hdr[3] = 0;
+      return;
+    }
+    const bool must = scoring != 5;  // DotProductScoring: no normalisation (ScoringObject.h:73-89)
+    if (tid == 0) {
+      double norm = 0.0;
+      if (tf && !must) {
+        norm = (double)n_bow;  // TemplatedVocabulary.h:1181-1186: divide by the number of words
+      } else if (must) {       // BowVector::normalize (:62-84): L2 for L2Scoring, L1 otherwise -- ONE sum in id order
+        // sixteen values requested at a time, then added IN ORDER (one dependent chain of n_bow additions is what the
+        // reference's loop is; the LDS round trips need not be part of it)
+        const bool l2 = scoring == 1;
+        int j = 0;
+        for (; j + 16 <= n_bow; j += 16) {
+          double v[16];
+#pragma unroll
+          for (int q = 0; q < 16; q++) v[q] = vals[j + q];
+#pragma unroll
+          for (int q = 0; q < 16; q++) norm += l2 ? v[q] * v[q] : fabs(v[q]);
+        }
+        for (; j < n_bow; j++) norm += l2 ? vals[j] * vals[j] : fabs(vals[j]);
+        if (l2) norm = sqrt(norm);
+      }
+      s_norm = norm;
+      o.hdr[0] = n_bow, o.hdr[2] = m, o.hdr[3] = 0;
+    }
+    __syncthreads();
+    const double norm = s_norm;
+    const bool divide = (tf && !must && n_bow > 0) || (must && norm > 0.0);
+    for (int j = tid; j < n_bow; j += kAsmThreads) o.bow_vals[j] = divide ? vals[j] / norm : vals[j];
+  } else {  // ---- FeatureVector: node id -> the features below it, ascending (FeatureVector.cpp:31-45)
+    const int n_fv = n_heads;
+    for (int q = 0; q < 2; q++) {
+      const int p = p0 + q;
+      if (p < m) {
+        const int f = (int)(uint32_t)key[p];
+        o.fv_idx[p] = f;
+        if (o.r_hdr) o.r_fv_idx[p] = f;
+      }
+      if (!(q ? h1 : h0)) continue;
+      const int j = ex + (q ? h0 : 0), id = (int)(key[p] >> 32);
+      o.fv_node[j] = id, o.fv_off[j] = p;
+      if (o.r_hdr) o.r_fv_node[j] = id, o.r_fv_off[j] = p;
+    }
+    if (tid == 0) {
+      o.fv_off[n_fv] = m, o.hdr[1] = n_fv;
+      if (o.r_hdr) o.r_fv_off[n_fv] = m, o.r_hdr[0] = n_fv, o.r_hdr[1] = m;
     }
   }
 }
@@ -197,52 +390,31 @@ int vsg_vocab_info(const vsg_vocab *v, int *k, int *L, int *scoring, int *weight
 
 }  // extern "C" (vocabulary object)
 
-// tree descent on the calling thread's stream; d_desc = descriptors on the device (resident frame) or nullptr (host
-// descriptors are staged through the arena); per-feature word / node / weight come back through the pinned arena
-static int bow_descend(vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_desc, int n, int levelsup,
-                       const int **word, const int **node, const double **w) {
-  int rc = VSG_OK;
-  vsg::ThreadCtx *c = vsg::thread_ctx(voc->device, &rc);
-  if (!c) return rc;
-  vsg::Stage st;
-  const size_t oD = st.add(d_desc ? 0 : 32 * (size_t)n);
-  const size_t in_bytes = st.total;
-  const size_t oW = st.add(8 * (size_t)n), oWord = st.add(4 * (size_t)n), oNode = st.add(4 * (size_t)n);
-  rc = vsg::ctx_reserve(c, st.total, in_bytes + 64);
-  if (rc != VSG_OK) return rc;
-  if (!d_desc) {
-    memcpy(c->h_pin + oD, desc, 32 * (size_t)n);
-    B_TRY(hipMemcpyAsync(c->d_buf, c->h_pin, in_bytes, hipMemcpyHostToDevice, c->stream));
-    d_desc = c->d_buf + oD;
+// TemplatedVocabulary.h:1181-1190 + BowVector::normalize (BowVector.cpp:62-84) on the n values of a BowVector in id order
+static void bow_normalize_host(const vsg_vocab *voc, double *v, int n) {
+  const bool tf = voc->weighting == 0 || voc->weighting == 1;
+  const bool must = voc->scoring != 5;  // DotProductScoring: no normalisation (ScoringObject.h:73-89)
+  if (tf && n > 0 && !must) {
+    const double nd = (double)n;
+    for (int i = 0; i < n; i++) v[i] /= nd;
   }
-  if (voc->max_children <= 16)
-    hipLaunchKernelGGL(k_bow_descend<16>, dim3((n * 16 + 255) / 256), dim3(256), 0, c->stream, voc->d_rec, voc->d_weight,
-                       voc->root_link, d_desc, n, voc->L - levelsup, (int *)(c->d_pin + oWord), (int *)(c->d_pin + oNode),
-                       (double *)(c->d_pin + oW));
-  else
-    hipLaunchKernelGGL(k_bow_descend<32>, dim3((n * 32 + 255) / 256), dim3(256), 0, c->stream, voc->d_rec, voc->d_weight,
-                       voc->root_link, d_desc, n, voc->L - levelsup, (int *)(c->d_pin + oWord), (int *)(c->d_pin + oNode),
-                       (double *)(c->d_pin + oW));
-  B_TRY(hipGetLastError());
-  B_TRY(hipStreamSynchronize(c->stream));
-  *word = (const int *)(c->h_pin + oWord);
-  *node = (const int *)(c->h_pin + oNode);
-  *w = (const double *)(c->h_pin + oW);
-  return VSG_OK;
+  if (must) {  // L2 for L2Scoring, L1 otherwise
+    double norm = 0.0;
+    if (voc->scoring != 1) {
+      for (int i = 0; i < n; i++) norm += std::fabs(v[i]);
+    } else {
+      for (int i = 0; i < n; i++) norm += v[i] * v[i];
+      norm = std::sqrt(norm);
+    }
+    if (norm > 0.0)
+      for (int i = 0; i < n; i++) v[i] /= norm;
+  }
 }
 
-static int bow_transform(vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_desc, int n, int levelsup,
-                         int32_t *bow_ids, double *bow_vals, int bow_cap, int *n_bow, int32_t *fv_node,
-                         int32_t *fv_off, int32_t *fv_idx, int fv_cap, int *n_fv, int32_t *word_of, int32_t *node_of,
-                         double *weight_of) {
-  if (!voc || n < 0 || !n_bow || !n_fv || !fv_off) return VSG_ERR_INVALID;
-  *n_bow = *n_fv = 0;
-  fv_off[0] = 0;
-  if (n == 0 || voc->nnodes <= 1) return VSG_OK;  // empty() vocabulary: v and fv stay empty (:1147-1150)
-  const int *word = nullptr, *node = nullptr;
-  const double *w = nullptr;
-  int rc = bow_descend(voc, desc, d_desc, n, levelsup, &word, &node, &w);
-  if (rc != VSG_OK) return rc;
+// The same assembly on the host, for frames of more than kAsmMax features (the device form sorts in LDS).
+static int bow_assemble_host(const vsg_vocab *voc, int n, const int *word, const int *node, const double *w,
+                             int32_t *bow_ids, double *bow_vals, int bow_cap, int *n_bow, int32_t *fv_node,
+                             int32_t *fv_off, int32_t *fv_idx, int fv_cap, int *n_fv) {
   // ---- BowVector / FeatureVector assembly (:1158-1206).  The reference inserts feature by feature into two std::maps;
   // the same content falls out of two sorts of (id << 32 | feature) keys: ascending ids, features of an id in feature
   // order.  Every feature of a word carries the word's weight, so addWeight's running sum in feature order is the
@@ -250,9 +422,6 @@ static int bow_transform(vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_d
   static thread_local std::vector<uint64_t> kw, kn;
   kw.clear(), kn.clear();
   for (int i = 0; i < n; i++) {
-    if (word_of) word_of[i] = word[i];
-    if (node_of) node_of[i] = node[i];
-    if (weight_of) weight_of[i] = w[i];
     if (!(w[i] > 0)) continue;  // stopped word
     kw.push_back(((uint64_t)(uint32_t)word[i] << 32) | (uint32_t)i);
     kn.push_back(((uint64_t)(uint32_t)node[i] << 32) | (uint32_t)i);
@@ -310,6 +479,137 @@ static int bow_transform(vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_d
   return (*n_bow > bow_cap || *n_fv > fv_cap) ? VSG_ERR_CAPACITY : VSG_OK;
 }
 
+// ---- one ComputeBoW on the calling thread's stream, in two halves so that other work of the same Frame (stereo matches,
+// SearchByBoW) can be enqueued behind it and share ONE wait (vsg_chain.hip): enqueue() lays its blocks out at the given
+// arena offsets and launches the descent + the assembly; finish() runs after the stream has been waited for and copies
+// the results out of the pinned arena (frames of more than kAsmMax features: the same assembly on the host).
+namespace vsg {
+
+int vocab_device(const vsg_vocab *v) { return v ? v->device : -1; }
+
+void bow_sizes(int n, bool host_desc, size_t *pin_bytes, size_t *dev_bytes) {
+  Stage p, d;
+  const size_t N = (size_t)(n > 0 ? n : 1);
+  p.add(host_desc ? 32 * N : 0);                                     // descriptors going up
+  p.add(8 * N), p.add(4 * N), p.add(4 * N);                          // per-feature weight / word / node mirrors
+  p.add(64), p.add(4 * N), p.add(8 * N), p.add(4 * N), p.add(4 * (N + 1)), p.add(4 * N);  // hdr, bow ids / vals, fv
+  d.add(host_desc ? 32 * N : 0), d.add(8 * N), d.add(4 * N), d.add(4 * N), d.add(8 * N), d.add(8 * N);
+  *pin_bytes = p.total, *dev_bytes = d.total;
+}
+
+int bow_enqueue(BowCall *b, vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_desc, int n, int levelsup,
+                vsg_frame *resident, ThreadCtx *c, size_t pin_base, size_t dev_base) {
+  b->voc = voc, b->n = n, b->c = c, b->pin_base = pin_base, b->active = false, b->device_assembly = false;
+  if (resident) resident->fv_valid = false;
+  if (n == 0 || voc->nnodes <= 1) return VSG_OK;  // empty() vocabulary: v and fv stay empty (:1147-1150)
+  Stage p, d;
+  const size_t N = (size_t)n;
+  const size_t oD = p.add(d_desc ? 0 : 32 * N);
+  b->oW = p.add(8 * N), b->oWord = p.add(4 * N), b->oNode = p.add(4 * N);
+  b->oHdr = p.add(64), b->oBowId = p.add(4 * N), b->oBowVal = p.add(8 * N), b->oFvNode = p.add(4 * N);
+  b->oFvOff = p.add(4 * (N + 1)), b->oFvIdx = p.add(4 * N);
+  const size_t dD = d.add(d_desc ? 0 : 32 * N), dW = d.add(8 * N), dWord = d.add(4 * N), dNode = d.add(4 * N);
+  const size_t dSortW = d.add(8 * N), dSortN = d.add(8 * N);
+  uint8_t *hp = c->h_pin + pin_base, *dp = c->d_pin + pin_base, *dv = c->d_buf + dev_base;
+  if (!d_desc) {
+    memcpy(hp + oD, desc, 32 * N);
+    B_TRY(hipMemcpyAsync(dv + dD, hp + oD, 32 * N, hipMemcpyHostToDevice, c->stream));
+    d_desc = dv + dD;
+  }
+  int *s_word = (int *)(dv + dWord), *s_node = (int *)(dv + dNode);
+  double *s_w = (double *)(dv + dW);
+  if (voc->max_children <= 16)
+    hipLaunchKernelGGL(k_bow_descend<16>, dim3((n * 16 + 255) / 256), dim3(256), 0, c->stream, voc->d_rec, voc->d_weight,
+                       voc->root_link, d_desc, n, voc->L - levelsup, s_word, s_node, s_w, (int *)(dp + b->oWord),
+                       (int *)(dp + b->oNode), (double *)(dp + b->oW));
+  else
+    hipLaunchKernelGGL(k_bow_descend<32>, dim3((n * 32 + 255) / 256), dim3(256), 0, c->stream, voc->d_rec, voc->d_weight,
+                       voc->root_link, d_desc, n, voc->L - levelsup, s_word, s_node, s_w, (int *)(dp + b->oWord),
+                       (int *)(dp + b->oNode), (double *)(dp + b->oW));
+  B_TRY(hipGetLastError());
+  b->active = true;
+  b->device_assembly = n <= kAsmMax;
+  if (b->device_assembly) {
+    BowOut o;
+    o.hdr = (int *)(dp + b->oHdr), o.bow_ids = (int *)(dp + b->oBowId), o.bow_vals = (double *)(dp + b->oBowVal);
+    o.fv_node = (int *)(dp + b->oFvNode), o.fv_off = (int *)(dp + b->oFvOff), o.fv_idx = (int *)(dp + b->oFvIdx);
+    const bool res = resident && resident->capacity >= n;
+    o.r_hdr = res ? resident->d_fv_hdr : nullptr, o.r_fv_node = res ? resident->d_fv_node : nullptr;
+    o.r_fv_off = res ? resident->d_fv_off : nullptr, o.r_fv_idx = res ? resident->d_fv_idx : nullptr;
+    const int tf = voc->weighting == 0 || voc->weighting == 1;  // TF_IDF, TF: addWeight; IDF, BINARY: addIfNotExist
+    uint64_t *s_sw = (uint64_t *)(dv + dSortW), *s_sn = (uint64_t *)(dv + dSortN);
+    hipLaunchKernelGGL(k_bow_rank, dim3((n + 63) / 64), dim3(kAsmThreads), 0, c->stream, s_word, s_node, s_w, n, s_sw, s_sn);
+    B_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_bow_assemble, dim3(2), dim3(kAsmThreads), 0, c->stream, s_sw, s_sn, s_w, n, tf, voc->scoring,
+                       (int)kNormOnDevice, o);
+    B_TRY(hipGetLastError());
+    if (res) {
+      // the joins of the SearchByBoW kernels launch one wavefront per POSSIBLE node of the FeatureVector's level
+      long bound = 1;
+      for (int l = 0; l < voc->L - levelsup && bound < n; l++) bound *= voc->max_children;
+      resident->fv_bound = (int)(bound < n ? bound : n);
+      resident->fv_valid = true;
+    }
+  }
+  return VSG_OK;
+}
+
+int bow_finish(BowCall *b, int32_t *bow_ids, double *bow_vals, int bow_cap, int *n_bow, int32_t *fv_node,
+               int32_t *fv_off, int32_t *fv_idx, int fv_cap, int *n_fv, int32_t *word_of, int32_t *node_of,
+               double *weight_of) {
+  *n_bow = *n_fv = 0;
+  fv_off[0] = 0;
+  if (!b->active) return VSG_OK;
+  const int n = b->n;
+  const uint8_t *hp = b->c->h_pin + b->pin_base;
+  const int *word = (const int *)(hp + b->oWord), *node = (const int *)(hp + b->oNode);
+  const double *w = (const double *)(hp + b->oW);
+  if (word_of) memcpy(word_of, word, 4 * (size_t)n);
+  if (node_of) memcpy(node_of, node, 4 * (size_t)n);
+  if (weight_of) memcpy(weight_of, w, 8 * (size_t)n);
+  if (b->device_assembly) {  // the kernel left everything in final form: copy, nothing else
+    const int *hdr = (const int *)(hp + b->oHdr);
+    const int nb = hdr[0], nf = hdr[1], m = hdr[2];
+    *n_bow = nb, *n_fv = nf;
+    if (bow_ids && bow_vals && nb <= bow_cap) {
+      memcpy(bow_ids, hp + b->oBowId, 4 * (size_t)nb);
+      memcpy(bow_vals, hp + b->oBowVal, 8 * (size_t)nb);
+      if (!kNormOnDevice) bow_normalize_host(b->voc, bow_vals, nb);
+    }
+    if (fv_node && fv_idx && nf <= fv_cap) {
+      memcpy(fv_node, hp + b->oFvNode, 4 * (size_t)nf);
+      memcpy(fv_off, hp + b->oFvOff, 4 * (size_t)(nf + 1));
+      memcpy(fv_idx, hp + b->oFvIdx, 4 * (size_t)m);
+    }
+    return (nb > bow_cap || nf > fv_cap) ? VSG_ERR_CAPACITY : VSG_OK;
+  }
+  return bow_assemble_host(b->voc, n, word, node, w, bow_ids, bow_vals, bow_cap, n_bow, fv_node, fv_off, fv_idx, fv_cap, n_fv);
+}
+
+}  // namespace vsg
+
+static int bow_transform(vsg_vocab *voc, const uint8_t *desc, vsg_frame *f, int n, int levelsup,
+                         int32_t *bow_ids, double *bow_vals, int bow_cap, int *n_bow, int32_t *fv_node,
+                         int32_t *fv_off, int32_t *fv_idx, int fv_cap, int *n_fv, int32_t *word_of, int32_t *node_of,
+                         double *weight_of) {
+  if (!voc || n < 0 || !n_bow || !n_fv || !fv_off) return VSG_ERR_INVALID;
+  *n_bow = *n_fv = 0;
+  fv_off[0] = 0;
+  int rc = VSG_OK;
+  vsg::ThreadCtx *c = vsg::thread_ctx(voc->device, &rc);
+  if (!c) return rc;
+  size_t pin = 0, dev = 0;
+  vsg::bow_sizes(n, f == nullptr, &pin, &dev);
+  rc = vsg::ctx_reserve(c, pin, dev);
+  if (rc != VSG_OK) return rc;
+  vsg::BowCall b;
+  rc = vsg::bow_enqueue(&b, voc, desc, f ? f->d_desc : nullptr, n, levelsup, f, c, 0, 0);
+  if (rc != VSG_OK) return rc;
+  if (b.active) B_TRY(hipStreamSynchronize(c->stream));
+  return vsg::bow_finish(&b, bow_ids, bow_vals, bow_cap, n_bow, fv_node, fv_off, fv_idx, fv_cap, n_fv, word_of, node_of,
+                         weight_of);
+}
+
 
 extern "C" {
 
@@ -326,7 +626,7 @@ int vsg_frame_bow_transform(vsg_vocab *voc, vsg_frame *f, int levelsup, int32_t 
                             int bow_cap, int *n_bow, int32_t *fv_node, int32_t *fv_off, int32_t *fv_idx, int fv_cap,
                             int *n_fv, int32_t *word_of, int32_t *node_of, double *weight_of) {
   if (!voc || !f || f->device != voc->device) return VSG_ERR_INVALID;
-  return bow_transform(voc, nullptr, f->d_desc, f->n, levelsup, bow_ids, bow_vals, bow_cap, n_bow, fv_node, fv_off,
+  return bow_transform(voc, nullptr, f, f->n, levelsup, bow_ids, bow_vals, bow_cap, n_bow, fv_node, fv_off,
                        fv_idx, fv_cap, n_fv, word_of, node_of, weight_of);
 }
 

@@ -472,7 +472,7 @@ namespace {
 
 // device layout of a frame for `cap` features
 struct FrameLayout {
-  size_t oK, oD, oU, oCS0, oE0, oCS1, oE1, total;
+  size_t oK, oD, oU, oCS0, oE0, oCS1, oE1, oFvH, oFvN, oFvO, oFvI, total;
   explicit FrameLayout(int cap) {
     Stage st;
     const size_t C = (size_t)cap + 1;
@@ -483,6 +483,7 @@ struct FrameLayout {
     oE0 = st.add(C * sizeof(GridEnt));
     oCS1 = st.add((kGridCells + 1) * 4);
     oE1 = st.add(C * sizeof(GridEnt));
+    oFvH = st.add(64), oFvN = st.add(C * 4), oFvO = st.add((C + 1) * 4), oFvI = st.add(C * 4);  // Frame::mFeatVec
     total = st.total;
   }
 };
@@ -586,6 +587,8 @@ int vsg_frame_create(int device, int capacity, vsg_frame **out) {
   f->d_ent[0] = (GridEnt *)(f->d_block + L.oE0);
   f->d_cell_start[1] = (int *)(f->d_block + L.oCS1);
   f->d_ent[1] = (GridEnt *)(f->d_block + L.oE1);
+  f->d_fv_hdr = (int *)(f->d_block + L.oFvH), f->d_fv_node = (int *)(f->d_block + L.oFvN);
+  f->d_fv_off = (int *)(f->d_block + L.oFvO), f->d_fv_idx = (int *)(f->d_block + L.oFvI);
   *out = f;
   return VSG_OK;
 }
@@ -613,7 +616,7 @@ int vsg_frame_upload(vsg_frame *f, const vsg_keypoint *keys, const uint8_t *desc
   rc = ctx_reserve(c, L.total, 0);
   if (rc != VSG_OK) return rc;
   set_bounds(f, min_x, min_y, max_x, max_y);
-  f->n = n, f->nleft = nleft, f->has_uright = u_right != nullptr;
+  f->n = n, f->nleft = nleft, f->has_uright = u_right != nullptr, f->fv_valid = false;
   f->h_kps.assign(keys, keys + n);
   // the whole device image of the frame is assembled in the pinned arena and goes up in ONE DMA
   uint8_t *h = c->h_pin;
@@ -651,7 +654,7 @@ static int frame_from_extractor(vsg_frame *f, vsg_orb *h, int index, const vsg_k
     un_pin = (KeyPointPOD *)c->h_pin, un_dev = (KeyPointPOD *)c->d_pin;
   }
   set_bounds(f, min_x, min_y, max_x, max_y);
-  f->n = n, f->nleft = -1, f->has_uright = false;
+  f->n = n, f->nleft = -1, f->has_uright = false, f->fv_valid = false;
   if (v.done) F_TRY(hipStreamWaitEvent(c->stream, v.done, 0));
   hipLaunchKernelGGL(k_frame_grid_build, dim3(1), dim3(1024), 0, c->stream, v.d_kps, 0, n, f->minX, f->minY, f->invW,
                      f->invH, f->d_cell_start[0], f->d_ent[0], f->d_kps, v.d_desc, f->d_desc, f->d_cell_start[1], cam,
@@ -723,11 +726,11 @@ int vsg_orb_extract_to_frame(vsg_orb *h, const uint8_t *gray, int rows, int cols
   if (mono < 0 || *n > f->capacity) {
     // the bounds are already the new ones and the hook may have rewritten the device arrays: the frame holds nothing
     // searchable any more, and says so
-    f->n = 0, f->nleft = -1, f->has_uright = false;
+    f->n = 0, f->nleft = -1, f->has_uright = false, f->fv_valid = false;
     f->h_kps.clear();
     return mono < 0 ? mono : VSG_ERR_CAPACITY;
   }
-  f->n = *n, f->nleft = -1, f->has_uright = false;
+  f->n = *n, f->nleft = -1, f->has_uright = false, f->fv_valid = false;
   if (H.cam.distorted) {
     f->h_kps.assign((const vsg_keypoint *)un_pin, (const vsg_keypoint *)un_pin + *n);
     if (keys_un_out && *n) memcpy(keys_un_out, un_pin, (size_t)*n * sizeof(vsg_keypoint));

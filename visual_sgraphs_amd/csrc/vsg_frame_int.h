@@ -36,6 +36,11 @@ struct vsg_frame {
   int *d_cell_start[2] = {nullptr, nullptr};  // [0] mGrid, [1] mGridRight: CSR over cells ix * 48 + iy
   vsg::GridEnt *d_ent[2] = {nullptr, nullptr};
   std::vector<vsg_keypoint> h_kps;  // host mirror (angle / octave for the ordered host passes)
+  // Frame::mFeatVec (Frame.h:196), resident since round 6: written by the assembly kernel of ComputeBoW (vsg_bow.hip), joined
+  // with another frame's by the SearchByBoW kernels without a host round trip.  hdr = {nodes, features listed}
+  int *d_fv_hdr = nullptr, *d_fv_node = nullptr, *d_fv_off = nullptr, *d_fv_idx = nullptr;
+  bool fv_valid = false;  // a ComputeBoW of the CURRENT features has been enqueued on the owning thread's stream
+  int fv_bound = 0;       // upper bound of the FeatureVector's node count (what the join kernels launch for)
 };
 
 namespace vsg {
@@ -92,6 +97,34 @@ struct WindowCall {
   walk::CandView lists() const;
   const int32_t *best() const { return (const int32_t *)(c->h_pin + base + oOut); }  // pairs {idx, dist}
 };
+
+// One ComputeBoW in flight on a thread's arena (vsg_bow.hip): enqueue -> [other work of the same Frame] -> ONE wait -> finish
+struct BowCall {
+  vsg_vocab *voc = nullptr;
+  ThreadCtx *c = nullptr;
+  int n = 0;
+  bool active = false, device_assembly = false;
+  size_t pin_base = 0, oW = 0, oWord = 0, oNode = 0, oHdr = 0, oBowId = 0, oBowVal = 0, oFvNode = 0, oFvOff = 0, oFvIdx = 0;
+};
+void bow_sizes(int n, bool host_desc, size_t *pin_bytes, size_t *dev_bytes);
+int bow_enqueue(BowCall *b, vsg_vocab *voc, const uint8_t *desc, const uint8_t *d_desc, int n, int levelsup,
+                vsg_frame *resident, ThreadCtx *c, size_t pin_base, size_t dev_base);
+int bow_finish(BowCall *b, int32_t *bow_ids, double *bow_vals, int bow_cap, int *n_bow, int32_t *fv_node, int32_t *fv_off,
+               int32_t *fv_idx, int fv_cap, int *n_fv, int32_t *word_of, int32_t *node_of, double *weight_of);
+int vocab_device(const vsg_vocab *v);
+
+// One SearchByBoW on two frames with resident FeatureVectors (vsg_match.hip), in the same two halves
+struct BowSearchCall {
+  ThreadCtx *c = nullptr;
+  vsg_frame *A = nullptr, *B = nullptr;
+  int mode = 0, nOut = 0;
+  bool active = false;
+  size_t pin_base = 0, oOut = 0;
+};
+void bow_search_sizes(int nA, int nB, int mode, size_t *pin_bytes, size_t *dev_bytes);
+int bow_search_enqueue(BowSearchCall *s, int mode, vsg_frame *A, const uint8_t *validA, vsg_frame *B, const uint8_t *validB,
+                       float nnratio, ThreadCtx *c, size_t pin_base, size_t dev_base);
+int bow_search_finish(BowSearchCall *s, int check_orientation, int32_t *out);
 
 // view of the handle's outputs of the last extract call (vsg_orb.hip)
 struct OrbOutputView {

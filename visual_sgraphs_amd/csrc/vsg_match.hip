@@ -60,6 +60,18 @@ __device__ __forceinline__ void wave_best2(uint32_t &k1, uint32_t &k2) {
     merge2(k1, k2, o1, o2);
   }
 }
+// the same minimum over the DPP path (row shifts, then the row broadcasts; lanes without a source keep the identity): VALU
+// latency per step instead of an LDS round trip per __shfl_xor -- what the ordered walk of k_search_by_bow is made of
+__device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) {
+  const int I = -1;
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+  v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(I, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint32_t wave_min(uint32_t k) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) k = min(k, __shfl_xor(k, d));
@@ -248,16 +260,145 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
 struct NodePair {
   int a_begin, a_end, b_begin, b_end;
 };
+enum { kBowNodeSide = 128 };  // nodes up to this many features a side are matched on a distance matrix in LDS
 
-__global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, int npairs, const uint8_t *descA,
+// A FeatureVector resident on the device (vsg_frame: Frame::mFeatVec written by k_bow_assemble): hdr = {nodes, features}
+struct FvDev {
+  const int *hdr, *node, *off, *idx;
+};
+
+// One WORKGROUP per shared vocabulary node (round 6; rounds 1-5: one wavefront, whose ordered walk chained three dependent
+// global loads and a fence per KeyFrame feature -- 37 us per call, all of it the largest node's walk).
+//   * pairs == nullptr: BOTH FeatureVectors are resident and the join of ORBmatcher.cc:247-405 happens here -- block b takes
+//     node b of A and finds the same id in B's ascending node list by bisection (a node is shared or it is not: the
+//     merge-join's lower_bound jumps and this lookup name the same pairs; nodes are independent, their order is irrelevant).
+//   * The node's descriptors go to LDS once (na + nb rows, not na x nb row pairs), every distance of the node is computed
+//     from there in one sweep of all 256 lanes.
+//   * The ordered, greedy walk (a KeyFrame feature sees the claims of the ones BEFORE it) as a fixed point, one lane per
+//     KeyFrame feature: in round t every feature decides on the claims that the features before it made in round t - 1.
+//     By induction feature i is final from round i + 1 on, and a round that changes no decision is the walk's result
+//     (feature 0 never depended on anyone, feature 1 is consistent with feature 0's final claim, ...).  Conflicts between
+//     neighbours are rare, so a node settles in 2-4 rounds of ~nb LDS reads per lane instead of na dependent reductions.
+// matchA / matchB are WRITE-ONLY (pre-filled with -1 by whoever owns them: they may be pinned host memory); every feature
+// belongs to exactly one node, so a node's block is the only writer and the only reader of its claims.
+__global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, int npairs, FvDev fa, FvDev fb,
+                                                       const uint8_t *descA,
                                                        const uint8_t *validA, const int *idxA, const uint8_t *descB,
                                                        const uint8_t *validB, const int *idxB, float nnratio, int mode,
                                                        int nleftB /*mode0: F.Nleft or -1*/,
-                                                       int *matchA /*mode1: matches12*/, int *matchB /*mode0: match_f; mode1: matched2 flags*/) {
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (wave >= npairs) return;
-  const NodePair np = pairs[wave];
-  const int nb = np.b_end - np.b_begin;
+                                                       int *matchA /*mode1: matches12*/, int *matchB /*mode0: match_f*/,
+                                                       int *claimB /*device scratch [nB]: large nodes only*/) {
+  const int node = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  NodePair np;
+  if (pairs) {
+    if (node >= npairs) return;
+    np = pairs[node];
+  } else {
+    // everything the join needs is requested at once (B's node list 256 entries at a time, whatever the headers say: the
+    // arrays hold capacity + 1 entries): ONE memory round trip in front of the offsets instead of a bisection's eight
+    __shared__ int s_pos;
+    const int nA_nodes = fa.hdr[0], nB_nodes = fb.hdr[0];
+    const int id = node < nA_nodes ? fa.node[node] : -1;
+    if (tid == 0) s_pos = -1;
+    __syncthreads();
+    for (int base = 0; base < nB_nodes; base += 256)  // block-uniform; one pass for the reference's ~100 nodes
+      if (base + tid < nB_nodes && fb.node[base + tid] == id) s_pos = base + tid;  // ids are unique: at most one writer
+    __syncthreads();
+    const int lo = s_pos;
+    if (node >= nA_nodes || lo < 0) return;
+    np.a_begin = fa.off[node], np.a_end = fa.off[node + 1], np.b_begin = fb.off[lo], np.b_end = fb.off[lo + 1];
+    idxA = fa.idx, idxB = fb.idx;
+  }
+  const int nb = np.b_end - np.b_begin, na = np.a_end - np.a_begin;
+  __shared__ uint4 s_da[kBowNodeSide][2], s_db[kBowNodeSide][2];
+  __shared__ uint16_t s_dist[kBowNodeSide * kBowNodeSide];
+  __shared__ int s_rb[kBowNodeSide], s_ra[kBowNodeSide], s_by0[kBowNodeSide], s_by[kBowNodeSide];
+  __shared__ int s_changed[2];  // by round parity: a flag is cleared a whole round before it is written again
+  if (na <= kBowNodeSide && nb <= kBowNodeSide) {
+    const int kFree = 0x7FFFFFFF;
+    {  // rows of both sides: thread = (row, half)
+      const int r = tid >> 1, h = tid & 1;
+      if (r < na) {
+        const int ra = idxA[np.a_begin + r];
+        s_da[r][h] = ((const uint4 *)(descA + (size_t)ra * 32))[h];
+        if (h == 0) s_ra[r] = validA[ra] ? ra : -1;  // !pMP || pMP->isBad()
+      }
+      if (tid < 2) s_changed[tid] = 0;
+      if (r < nb) {
+        const int rb = idxB[np.b_begin + r];
+        s_db[r][h] = ((const uint4 *)(descB + (size_t)rb * 32))[h];
+        if (h == 0) s_rb[r] = rb, s_by0[r] = s_by[r] = (mode == 1 && !validB[rb]) ? -1 : kFree;  // -1: never a candidate
+      }
+    }
+    __syncthreads();
+    const float inv_nb = 1.0f / (float)nb;
+    for (int p = tid; p < na * nb; p += 256) {
+      const int i = min((int)(((float)p + 0.5f) * inv_nb), na - 1), j = p - i * nb;
+      s_dist[p] = (uint16_t)hamming256(s_da[i][0], s_da[i][1], s_db[j][0], s_db[j][1]);
+    }
+    __syncthreads();
+    const int i = tid;
+    const int ra = i < na ? s_ra[i] : -1;
+    const bool active = ra >= 0;
+    int decL = -1, decR = -1;
+    for (int round = 0; round <= na; round++) {  // block-uniform
+      int newL = -1, newR = -1;
+      if (active) {
+        uint32_t k1 = KEY_NONE, k2 = KEY_NONE, r1 = KEY_NONE;
+        const uint16_t *row = s_dist + i * nb;
+        // branch-free, so that the LDS reads of several candidates are in flight together (a taken candidate -- by a feature
+        // before this one, or not a candidate at all -- contributes the neutral key)
+        if (nleftB < 0) {
+#pragma unroll 4
+          for (int j = 0; j < nb; j++) {
+            const uint32_t key = s_by[j] < i ? KEY_NONE : ((uint32_t)row[j] << 20) | (uint32_t)j;
+            k2 = umed3(k1, k2, key), k1 = min(k1, key);
+          }
+        } else {
+#pragma unroll 4
+          for (int j = 0; j < nb; j++) {
+            const uint32_t key = s_by[j] < i ? KEY_NONE : ((uint32_t)row[j] << 20) | (uint32_t)j;
+            const bool isleft = s_rb[j] < nleftB;
+            const uint32_t kl = isleft ? key : KEY_NONE, kr = isleft ? KEY_NONE : key;
+            k2 = umed3(k1, k2, kl), k1 = min(k1, kl);
+            r1 = min(r1, kr);
+          }
+        }
+        const int bestDist1 = (int)(k1 >> 20), bestDist2 = (int)(k2 >> 20);
+        // right block, nested in the left test, no ratio test (:362-389)
+        if (nleftB >= 0 && bestDist1 <= TH_LOW && (int)(r1 >> 20) <= TH_LOW) newR = (int)(r1 & 0xFFFFF);
+        const bool pass = mode == 0 ? bestDist1 <= TH_LOW : bestDist1 < TH_LOW;
+        if (pass && (float)bestDist1 < nnratio * (float)bestDist2) newL = (int)(k1 & 0xFFFFF);  // :335-337 / :843-845
+      }
+      const bool changed = newL != decL || newR != decR;
+      decL = newL, decR = newR;
+      __syncthreads();  // every lane has read the claims of the previous round (and that round's flag)
+      if (tid < nb) s_by[tid] = s_by0[tid];
+      if (tid == 0) s_changed[(round + 1) & 1] = 0;
+      __syncthreads();
+      if (newL >= 0) atomicMin(&s_by[newL], i);
+      if (newR >= 0) atomicMin(&s_by[newR], i);
+      if (changed) s_changed[round & 1] = 1;
+      __syncthreads();
+      if (!s_changed[round & 1]) break;
+    }
+    if (active) {
+      if (mode == 0) {
+        if (decL >= 0) matchB[s_rb[decL]] = ra;  // vpMapPointMatches[bestIdxF] = pMP
+        if (decR >= 0) matchB[s_rb[decR]] = ra;
+      } else if (decL >= 0) {
+        matchA[ra] = s_rb[decL];                 // vpMatches12[idx1] = vpMapPoints2[bestIdx2]
+      }
+    }
+    return;
+  }
+  if (tid >= 64) return;
+  // ---- large nodes: one scan of the node's Frame features per KeyFrame feature; the claims in device scratch, set up here
+  for (int j = lane; j < nb; j += 64) {
+    const int rb = idxB[np.b_begin + j];
+    claimB[rb] = mode == 1 ? (int)(!validB[rb]) : 0;
+  }
+  __threadfence_block();
   for (int ia = np.a_begin; ia < np.a_end; ia++) {
     const int ra = idxA[ia];
     if (!validA[ra]) continue;  // !pMP || pMP->isBad()
@@ -266,8 +407,7 @@ __global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, in
     uint32_t k1 = KEY_NONE, k2 = KEY_NONE, r1 = KEY_NONE, r2 = KEY_NONE;  // left / right-camera (fisheye) candidates
     for (int j = lane; j < nb; j += 64) {
       const int rb = idxB[np.b_begin + j];
-      const bool skip = mode == 0 ? (matchB[rb] >= 0) : (matchB[rb] != 0 || !validB[rb]);
-      if (skip) continue;
+      if (__hip_atomic_load(&claimB[rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) continue;
       uint4 b0, b1;
       load_desc(descB, rb, b0, b1);
       const uint32_t key = ((uint32_t)hamming256(a0, a1, b0, b1) << 20) | (uint32_t)j;
@@ -281,7 +421,8 @@ __global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, in
     if (nleftB >= 0 && bestDist1 <= TH_LOW) {  // right block, nested in the left test, no ratio test (:362-389)
       r1 = wave_min(r1);
       if ((int)(r1 >> 20) <= TH_LOW) {
-        if (lane == 0) matchB[idxB[np.b_begin + (int)(r1 & 0xFFFFF)]] = ra;
+        const int rb = idxB[np.b_begin + (int)(r1 & 0xFFFFF)];
+        if (lane == 0) matchB[rb] = ra, claimB[rb] = 1;
         __threadfence_block();  // later KF features of this node must see the claim
       }
     }
@@ -289,12 +430,11 @@ __global__ __launch_bounds__(256) void k_search_by_bow(const NodePair *pairs, in
     if (pass && (float)bestDist1 < nnratio * (float)bestDist2) {  // :335-337 / :843-845
       const int rb = idxB[np.b_begin + (int)(k1 & 0xFFFFF)];
       if (lane == 0) {
-        if (mode == 0) {
+        if (mode == 0)
           matchB[rb] = ra;  // vpMapPointMatches[bestIdxF] = pMP
-        } else {
+        else
           matchA[ra] = rb;  // vpMatches12[idx1] = vpMapPoints2[bestIdx2]
-          matchB[rb] = 1;   // vbMatched2[bestIdx2] = true
-        }
+        claimB[rb] = 1;     // (mode 1: vbMatched2[bestIdx2] = true)
       }
       __threadfence_block();
     }
@@ -534,7 +674,8 @@ static int search_by_bow(int device, int mode, int nleftB, const uint8_t *descA,
   const size_t in_bytes = st.total;
   Stage dv;  // device-only scratch behind the inputs
   dv.total = in_bytes;
-  const size_t oMA = dv.add((size_t)nA * 4), oMB = dv.add((size_t)nB * 4);
+  const size_t nAB = (size_t)(nA > nB ? nA : nB);
+  const size_t oMA = dv.add(nAB * 4), oMB = dv.add(nAB * 4);
   rc = vsg::ctx_reserve(c, in_bytes + (size_t)nOut * 4 + 64, dv.total);
   if (rc != VSG_OK) return rc;
   uint8_t *h = c->h_pin;
@@ -547,16 +688,12 @@ static int search_by_bow(int device, int mode, int nleftB, const uint8_t *descA,
   if (!dDescB) memcpy(h + oDB, descB, (size_t)nB * 32);
   M_TRY(hipMemcpyAsync(c->d_buf, h, in_bytes, hipMemcpyHostToDevice, c->stream));
   uint8_t *d = c->d_buf;
-  int *dMA = (int *)(d + oMA), *dMB = (int *)(d + oMB);
-  if (mode == 0) {
-    M_TRY(hipMemsetAsync(dMB, 0xFF, (size_t)nB * 4, c->stream));  // -1
-  } else {
-    M_TRY(hipMemsetAsync(dMA, 0xFF, (size_t)nA * 4, c->stream));
-    M_TRY(hipMemsetAsync(dMB, 0, (size_t)nB * 4, c->stream));
-  }
-  hipLaunchKernelGGL(k_search_by_bow, dim3((npairs + 3) / 4), dim3(256), 0, c->stream, (const NodePair *)(d + oP), npairs,
-                     dDescA ? dDescA : d + oDA, d + oVA, (const int *)(d + oIA), dDescB ? dDescB : d + oDB, d + oVB,
-                     (const int *)(d + oIB), nnratio, mode, nleftB, dMA, dMB);
+  int *dMA = (int *)(d + oMA), *dMB = (int *)(d + oMB);  // mode 0: dMB = match_f, dMA = the claim scratch; mode 1: the reverse
+  M_TRY(hipMemsetAsync(mode == 0 ? dMB : dMA, 0xFF, (size_t)(mode == 0 ? nB : nA) * 4, c->stream));  // -1
+  hipLaunchKernelGGL(k_search_by_bow, dim3(npairs), dim3(256), 0, c->stream, (const NodePair *)(d + oP), npairs,
+                     FvDev{}, FvDev{}, dDescA ? dDescA : d + oDA, d + oVA, (const int *)(d + oIA), dDescB ? dDescB : d + oDB, d + oVB,
+                     (const int *)(d + oIB), nnratio, mode, nleftB, dMA, mode == 0 ? dMB : (int *)nullptr,
+                     mode == 0 ? dMA : dMB);
   M_TRY(hipGetLastError());
   int *hOut = (int *)(h + in_bytes);
   M_TRY(hipMemcpyAsync(hOut, mode == 0 ? dMB : dMA, (size_t)nOut * 4, hipMemcpyDeviceToHost, c->stream));
@@ -564,6 +701,77 @@ static int search_by_bow(int device, int mode, int nleftB, const uint8_t *descA,
   memcpy(out, hOut, (size_t)nOut * 4);
   // rotation consistency (:407-425 / :879-897)
   return bow_rotation_filter(out, nOut, mode, angleA, angleB, checkOri != 0);
+}
+
+// ---- SearchByBoW on two frames whose descriptors AND FeatureVectors are resident (round 6): nothing but the KeyFrame's
+// "has a map point" flags goes up, the join runs in the kernel, and the call comes in two halves so that it can share one
+// wait with the ComputeStereoMatches / ComputeBoW of the same Frame (vsg_chain.hip).
+}  // namespace (reopened below: the two halves are called from vsg_chain.hip)
+namespace vsg {
+
+void bow_search_sizes(int nA, int nB, int mode, size_t *pin_bytes, size_t *dev_bytes) {
+  Stage p, d;
+  p.add((size_t)nA), p.add(mode == 1 ? (size_t)nB : 0), p.add(4 * (size_t)(mode == 0 ? nB : nA) + 64);
+  d.add(4 * (size_t)nB + 64);
+  *pin_bytes = p.total, *dev_bytes = d.total;
+}
+
+// ONE launch and nothing else on the stream: the flags are read and the matches written where they lie in the pinned arena
+// (a few hundred scattered bytes each way over PCIe, in parallel over the node waves) -- the DMA of the flags, the fill of the
+// match array and its copy back cost 4.4 us of stream time EACH (rocprofv3: __amd_rocclr_copyBuffer / fillBufferAligned).
+int bow_search_enqueue(BowSearchCall *s, int mode, vsg_frame *A, const uint8_t *validA, vsg_frame *B, const uint8_t *validB,
+                       float nnratio, ThreadCtx *c, size_t pin_base, size_t dev_base) {
+  s->c = c, s->mode = mode, s->A = A, s->B = B, s->active = false, s->pin_base = pin_base;
+  s->nOut = mode == 0 ? B->n : A->n;
+  if (!A->fv_valid || !B->fv_valid) return VSG_ERR_INVALID;  // ComputeBoW first (Frame.cc:882-889)
+  if (A->n == 0 || B->n == 0) return VSG_OK;
+  const int nA = A->n, nB = B->n;
+  Stage p;
+  const size_t oVA = p.add((size_t)nA), oVB = p.add(mode == 1 ? (size_t)nB : 0);
+  s->oOut = p.add(4 * (size_t)s->nOut + 64);
+  uint8_t *hp = c->h_pin + pin_base, *dp = c->d_pin + pin_base;
+  memcpy(hp + oVA, validA, (size_t)nA);
+  if (mode == 1) memcpy(hp + oVB, validB, (size_t)nB);
+  memset(hp + s->oOut, 0xFF, 4 * (size_t)s->nOut);  // -1: the kernel only writes matches
+  const FvDev fa{A->d_fv_hdr, A->d_fv_node, A->d_fv_off, A->d_fv_idx}, fb{B->d_fv_hdr, B->d_fv_node, B->d_fv_off, B->d_fv_idx};
+  const int waves = A->fv_bound > 0 ? A->fv_bound : 1;
+  int *out = (int *)(dp + s->oOut);
+  hipLaunchKernelGGL(k_search_by_bow, dim3(waves), dim3(256), 0, c->stream, (const NodePair *)nullptr, 0, fa, fb,
+                     A->d_desc, dp + oVA, (const int *)nullptr, B->d_desc, dp + oVB, (const int *)nullptr, nnratio, mode,
+                     mode == 0 ? B->nleft : -1, mode == 1 ? out : (int *)nullptr, mode == 0 ? out : (int *)nullptr,
+                     (int *)(c->d_buf + dev_base));
+  M_TRY(hipGetLastError());
+  s->active = true;
+  return VSG_OK;
+}
+
+// after the stream has been waited for: the matches + the rotation-consistency filter (:407-425 / :879-897)
+int bow_search_finish(BowSearchCall *s, int check_orientation, int32_t *out) {
+  for (int i = 0; i < s->nOut; i++) out[i] = -1;
+  if (!s->active) return 0;
+  memcpy(out, s->c->h_pin + s->pin_base + s->oOut, 4 * (size_t)s->nOut);
+  const vsg_keypoint *ka = s->A->h_kps.data(), *kb = s->B->h_kps.data();
+  return bow_rotation_filter(out, s->nOut, s->mode, [&](int i) { return ka[i].angle; }, [&](int i) { return kb[i].angle; },
+                             check_orientation != 0);
+}
+
+}  // namespace vsg
+namespace {
+
+static int search_by_bow_resident(int mode, vsg_frame *A, const uint8_t *validA, vsg_frame *B, const uint8_t *validB,
+                                  float nnratio, int check_orientation, int32_t *out) {
+  int rc = VSG_OK;
+  ThreadCtx *c = vsg::thread_ctx(A->device, &rc);
+  if (!c) return rc;
+  size_t pin = 0, dev = 0;
+  vsg::bow_search_sizes(A->n, B->n, mode, &pin, &dev);
+  rc = vsg::ctx_reserve(c, pin, dev);
+  if (rc != VSG_OK) return rc;
+  vsg::BowSearchCall s;
+  rc = vsg::bow_search_enqueue(&s, mode, A, validA, B, validB, nnratio, c, 0, 0);
+  if (rc != VSG_OK) return rc;
+  if (s.active) M_TRY(hipStreamSynchronize(c->stream));
+  return vsg::bow_search_finish(&s, check_orientation, out);
 }
 
 // SearchForTriangulation on descriptors that are host arrays (desc1/desc2, staged) or already resident (dDesc1/dDesc2)
@@ -764,6 +972,9 @@ int vsg_frame_search_by_bow_kf_f(vsg_frame *kf, const uint8_t *kf_valid, const i
                                  const int32_t *f_node_id, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
                                  float nnratio, int check_orientation, int32_t *match_f) {
   if (!kf || !f || !match_f || kf->device != f->device || !kf_valid) return VSG_ERR_INVALID;
+  if (!kf_node_id && !f_node_id)  // both FeatureVectors resident (ComputeBoW ran on both frames): nothing goes up but the flags
+    return search_by_bow_resident(0, kf, kf_valid, f, nullptr, nnratio, check_orientation, match_f);
+  if (!kf_node_id || !f_node_id || !kf_off || !f_off || !kf_idx || !f_idx) return VSG_ERR_INVALID;
   const vsg_keypoint *ka = kf->h_kps.data(), *kb = f->h_kps.data();
   return search_by_bow(kf->device, 0, f->nleft, nullptr, kf->d_desc, [&](int i) { return ka[i].angle; }, kf_valid, kf->n,
                        kf_node_id, kf_off, kf_idx, kf_nodes, nullptr, f->d_desc, [&](int i) { return kb[i].angle; },
@@ -775,6 +986,8 @@ int vsg_frame_search_by_bow_kf_kf(vsg_frame *kf1, const uint8_t *valid1, const i
                                   const int32_t *node_id2, const int32_t *off2, const int32_t *idx2, int nodes2,
                                   float nnratio, int check_orientation, int32_t *matches12) {
   if (!kf1 || !kf2 || !matches12 || kf1->device != kf2->device || !valid1 || !valid2) return VSG_ERR_INVALID;
+  if (!node_id1 && !node_id2) return search_by_bow_resident(1, kf1, valid1, kf2, valid2, nnratio, check_orientation, matches12);
+  if (!node_id1 || !node_id2 || !off1 || !off2 || !idx1 || !idx2) return VSG_ERR_INVALID;
   const vsg_keypoint *ka = kf1->h_kps.data(), *kb = kf2->h_kps.data();
   return search_by_bow(kf1->device, 1, -1, nullptr, kf1->d_desc, [&](int i) { return ka[i].angle; }, valid1, kf1->n,
                        node_id1, off1, idx1, nodes1, nullptr, kf2->d_desc, [&](int i) { return kb[i].angle; }, valid2,

@@ -1554,10 +1554,11 @@ static int stereo_median_cut(const int *sad, int n_l, float *u_right, float *dep
 }
 
 // Frame::ComputeStereoMatches on device-resident keypoints / descriptors: one launch on the calling thread's stream,
-// results through its pinned arena.  d_kps* / d_desc* are device pointers.
-static int stereo_run(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const KeyPointPOD *dkl, const uint8_t *ddl,
-                      int n_l, const KeyPointPOD *dkr, const uint8_t *ddr, int n_r, float mb, float mbf, ThreadCtx *c,
-                      size_t out_off, float *u_right, float *depth) {
+// results through its pinned arena.  d_kps* / d_desc* are device pointers.  Two halves (round 6): enqueue, and -- after the
+// stream has been waited for, possibly together with other work of the same Frame -- the copy-out and the median cut.
+static int stereo_enqueue(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const KeyPointPOD *dkl, const uint8_t *ddl,
+                          int n_l, const KeyPointPOD *dkr, const uint8_t *ddr, int n_r, float mb, float mbf, ThreadCtx *c,
+                          size_t out_off) {
   PyrView pl, pr;
   int rc = pyr_view(hl, frame_l, pl);
   if (rc == VSG_OK) rc = pyr_view(hr, frame_r, pr);
@@ -1571,12 +1572,23 @@ static int stereo_run(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const 
   launch_stereo(c->stream, pl, pr, mb, mbf, hl->T.scale.data(), hl->T.invScale.data(), hl->T.nlevels, dkl, ddl, n_l, dkr,
                 ddr, n_r, du, dd, ds);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  return VSG_OK;
+}
+static int stereo_finish(ThreadCtx *c, size_t out_off, int n_l, float *u_right, float *depth) {
+  const size_t N = (size_t)n_l;
   const float *hu = (const float *)(c->h_pin + out_off), *hd = hu + N;
   const int *hs = (const int *)(hd + N);
   memcpy(u_right, hu, N * 4);
   memcpy(depth, hd, N * 4);
   return stereo_median_cut(hs, n_l, u_right, depth);
+}
+static int stereo_run(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, const KeyPointPOD *dkl, const uint8_t *ddl,
+                      int n_l, const KeyPointPOD *dkr, const uint8_t *ddr, int n_r, float mb, float mbf, ThreadCtx *c,
+                      size_t out_off, float *u_right, float *depth) {
+  const int rc = stereo_enqueue(hl, frame_l, hr, frame_r, dkl, ddl, n_l, dkr, ddr, n_r, mb, mbf, c, out_off);
+  if (rc != VSG_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return stereo_finish(c, out_off, n_l, u_right, depth);
 }
 
 extern "C" {
@@ -1622,6 +1634,61 @@ int vsg_frame_stereo_matches(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r,
   if (rc != VSG_OK) return rc;
   return stereo_run(hl, frame_l, hr, frame_r, fl->d_kps, fl->d_desc, n_l, fr->d_kps, fr->d_desc, n_r, mb, mbf, c, 0,
                     u_right, depth);
+}
+
+// The part of a stereo Frame's construction and first tracking step that depends only on two resident frames, in ONE enqueue
+// and ONE wait (round 6, VERDICT r5 #3b): ComputeStereoMatches (Frame.cc:957-1127) -> ComputeBoW (Frame.cc:882-889, the
+// BowVector / FeatureVector assembled on the device) -> SearchByBoW(KF, F) (ORBmatcher.cc:226-428) against a KeyFrame whose
+// FeatureVector is resident from ITS ComputeBoW.  Three blocking calls cost three stream round trips (~20 us each) for
+// kernels of 16 + 6 + 37 us; here the kernels queue up behind each other and the host parts (median cut, rotation histogram)
+// run after the one wait, each on the bytes its blocking form would have seen.
+int vsg_frame_stereo_bow_search(vsg_orb *hl, int frame_l, vsg_orb *hr, int frame_r, vsg_frame *fl, vsg_frame *fr, float mb,
+                                float mbf, float *u_right, float *depth, int *n_stereo, vsg_vocab *voc, int levelsup,
+                                int32_t *bow_ids, double *bow_vals, int bow_cap, int *n_bow, int32_t *fv_node,
+                                int32_t *fv_off, int32_t *fv_idx, int fv_cap, int *n_fv, vsg_frame *kf,
+                                const uint8_t *kf_valid, float nnratio, int check_orientation, int32_t *match_f,
+                                int *n_match) {
+  if (!hl || !hr || !fl || !fr || !u_right || !depth || !n_stereo || !voc || !n_bow || !n_fv || !fv_off ||
+      hl->device != hr->device || fl->device != hl->device || fr->device != hl->device || vsg::vocab_device(voc) != hl->device)
+    return VSG_ERR_INVALID;
+  if (kf && (!kf_valid || !match_f || !n_match || kf->device != hl->device || kf == fl)) return VSG_ERR_INVALID;
+  const int n_l = fl->n, n_r = fr->n;
+  for (int i = 0; i < n_l; i++) u_right[i] = -1.0f, depth[i] = -1.0f;
+  *n_stereo = 0;
+  if (n_match) *n_match = 0;
+  int rc = VSG_OK;
+  ThreadCtx *c = thread_ctx(hl->device, &rc);
+  if (!c) return rc;
+  // one arena layout for the three calls, reserved BEFORE anything is enqueued (growing an arena frees the old one)
+  size_t pinB = 0, devB = 0, pinS = 0, devS = 0;
+  vsg::bow_sizes(n_l, false, &pinB, &devB);
+  if (kf) vsg::bow_search_sizes(kf->n, n_l, 0, &pinS, &devS);
+  const size_t pin_stereo = (12 * (size_t)n_l + 127) & ~(size_t)63;
+  rc = ctx_reserve(c, pin_stereo + pinB + pinS, devB + devS);
+  if (rc != VSG_OK) return rc;
+  const bool do_stereo = n_l > 0 && n_r > 0;
+  if (do_stereo) {
+    rc = stereo_enqueue(hl, frame_l, hr, frame_r, fl->d_kps, fl->d_desc, n_l, fr->d_kps, fr->d_desc, n_r, mb, mbf, c, 0);
+    if (rc != VSG_OK) return rc;
+  }
+  vsg::BowCall b;
+  rc = vsg::bow_enqueue(&b, voc, nullptr, fl->d_desc, n_l, levelsup, fl, c, pin_stereo, 0);
+  if (rc != VSG_OK) return rc;
+  vsg::BowSearchCall sc;
+  const bool do_search = kf != nullptr && kf->fv_valid && fl->fv_valid;
+  if (kf && !do_search && kf->n > 0 && n_l > 0 && b.active) return VSG_ERR_INVALID;  // the KeyFrame never had its ComputeBoW
+  if (do_search) {
+    rc = vsg::bow_search_enqueue(&sc, 0, kf, kf_valid, fl, nullptr, nnratio, c, pin_stereo + pinB, devB);
+    if (rc != VSG_OK) return rc;
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the ONE wait
+  if (do_stereo) *n_stereo = stereo_finish(c, 0, n_l, u_right, depth);
+  rc = vsg::bow_finish(&b, bow_ids, bow_vals, bow_cap, n_bow, fv_node, fv_off, fv_idx, fv_cap, n_fv, nullptr, nullptr, nullptr);
+  if (kf) {
+    for (int i = 0; i < n_l; i++) match_f[i] = -1;
+    if (do_search) *n_match = vsg::bow_search_finish(&sc, check_orientation, match_f);
+  }
+  return rc;
 }
 
 int vsg_orb_set_serialize(vsg_orb *h, int serialize) {

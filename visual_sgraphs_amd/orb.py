@@ -53,7 +53,7 @@ EXPORTS = [
     "vsg_frame_features_in_area", "vsg_frame_search_by_projection", "vsg_frame_search_by_projection_last",
     "vsg_frame_search_by_projection_sim3", "vsg_frame_search_by_projection_kf", "vsg_frame_search_by_sim3",
     "vsg_frame_fuse", "vsg_frame_fuse_sim3", "vsg_fuse_decide", "vsg_frame_search_for_initialization",
-    "vsg_frame_search_by_bow_kf_f", "vsg_frame_search_by_bow_kf_kf", "vsg_frame_bow_transform",
+    "vsg_frame_search_by_bow_kf_f", "vsg_frame_search_by_bow_kf_kf", "vsg_frame_bow_transform", "vsg_frame_stereo_bow_search",
     "vsg_frame_search_for_triangulation",
     "vsg_frame_stereo_matches",
     "vsg_shard_last_error", "vsg_shard_record_bytes", "vsg_shard_record_desc_offset", "vsg_shard_frame_owner",
@@ -249,6 +249,8 @@ def load_library():
     L.vsg_frame_bow_transform.argtypes = [vp, vp, ci, _i32p, _f64p, ci, _i32p, _i32p, _i32p, _i32p, ci, _i32p, _i32p,
                                           _i32p, _f64p]
     L.vsg_frame_stereo_matches.argtypes = [vp, ci, vp, ci, vp, vp, cf, cf, _f32p, _f32p]
+    L.vsg_frame_stereo_bow_search.argtypes = [vp, ci, vp, ci, vp, vp, cf, cf, _f32p, _f32p, _i32p, vp, ci, _i32p, _f64p, ci,
+                                              _i32p, _i32p, _i32p, _i32p, ci, _i32p, vp, _u8p, cf, ci, _i32p, _i32p]
     L.vsg_shard_last_error.restype = C.c_char_p
     L.vsg_shard_record_bytes.restype = C.c_size_t
     L.vsg_shard_record_bytes.argtypes = [ci]
@@ -1091,11 +1093,17 @@ class Frame:
         return nm, out[:self.N]
 
     def SearchByBoW_KF_F(self, kf_valid, kf_fv, f, f_fv, nnratio, check_orientation):
-        """self = KeyFrame, f = Frame (both resident).  Returns (nmatches, matchF)."""
+        """self = KeyFrame, f = Frame (both resident).  kf_fv = f_fv = None: the FeatureVectors both frames keep resident
+        since their ComputeBoW are joined on the device.  Returns (nmatches, matchF)."""
         kv = _u8(kf_valid)
+        out = np.full(max(f.N, 1), -1, np.int32)
+        if kf_fv is None and f_fv is None:
+            nm = _check(self._L.vsg_frame_search_by_bow_kf_f(
+                self._h, _p(kv, _u8p), None, None, None, 0, f.handle, None, None, None, 0, float(np.float32(nnratio)),
+                int(check_orientation), _p(out, _i32p)), "vsg_frame_search_by_bow_kf_f")
+            return nm, out[:f.N]
         kn, ko, ki = (_i32(x) for x in kf_fv)
         fn, fo, fi = (_i32(x) for x in f_fv)
-        out = np.full(max(f.N, 1), -1, np.int32)
         nm = _check(self._L.vsg_frame_search_by_bow_kf_f(
             self._h, _p(kv, _u8p), _p(kn, _i32p), _p(ko, _i32p), _p(ki, _i32p), len(kf_fv[0]), f.handle, _p(fn, _i32p),
             _p(fo, _i32p), _p(fi, _i32p), len(f_fv[0]), float(np.float32(nnratio)), int(check_orientation),
@@ -1104,9 +1112,14 @@ class Frame:
 
     def SearchByBoW_KF_KF(self, valid1, fv1, kf2, valid2, fv2, nnratio, check_orientation):
         v1, v2 = _u8(valid1), _u8(valid2)
+        out = np.full(max(self.N, 1), -1, np.int32)
+        if fv1 is None and fv2 is None:  # both FeatureVectors resident
+            nm = _check(self._L.vsg_frame_search_by_bow_kf_kf(
+                self._h, _p(v1, _u8p), None, None, None, 0, kf2.handle, _p(v2, _u8p), None, None, None, 0,
+                float(np.float32(nnratio)), int(check_orientation), _p(out, _i32p)), "vsg_frame_search_by_bow_kf_kf")
+            return nm, out[:self.N]
         n1, o1, i1 = (_i32(x) for x in fv1)
         n2, o2, i2 = (_i32(x) for x in fv2)
-        out = np.full(max(self.N, 1), -1, np.int32)
         nm = _check(self._L.vsg_frame_search_by_bow_kf_kf(
             self._h, _p(v1, _u8p), _p(n1, _i32p), _p(o1, _i32p), _p(i1, _i32p), len(fv1[0]), kf2.handle, _p(v2, _u8p),
             _p(n2, _i32p), _p(o2, _i32p), _p(i2, _i32p), len(fv2[0]), float(np.float32(nnratio)),
@@ -1175,6 +1188,31 @@ def fuse_decide(query_mp, best_idx, best_dist, sim3_form, slot_mp, mp_obs, mp_ba
                                                _p(bad, _u8p), len(mp_obs), _p(act, _i32p), _p(oth, _i32p)),
                 "vsg_fuse_decide")
     return nf, act[:len(query_mp)], oth[:len(query_mp)], sm, ob, bad
+
+
+def stereo_bow_search(ex_left, frame_l, ex_right, frame_r, fl, fr, mb, mbf, voc, levelsup=4, kf=None, kf_valid=None,
+                      nnratio=0.7, check_orientation=True):
+    """vsg_frame_stereo_bow_search: ComputeStereoMatches + ComputeBoW (+ SearchByBoW(kf, fl) when kf is given) of one stereo
+    Frame in one enqueue and one wait.  Returns dict(u_right, depth, n_stereo, bow_ids, bow_vals, fv, n_match, match_f)."""
+    L = load_library()
+    n = fl.N
+    cap = n + 1
+    ur, dep = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    bi, bv = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+    fn, fo, fi = np.zeros(cap, np.int32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+    match = np.full(cap, -1, np.int32)
+    ns, nb, nf, nm = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    f64p = C.POINTER(C.c_double)
+    kv = _u8(kf_valid) if kf is not None else None
+    _check(L.vsg_frame_stereo_bow_search(
+        ex_left.handle, int(frame_l), ex_right.handle, int(frame_r), fl.handle, fr.handle, float(mb), float(mbf), _p(ur, _f32p),
+        _p(dep, _f32p), C.byref(ns), voc._h, int(levelsup), _p(bi, _i32p), _p(bv, f64p), cap, C.byref(nb), _p(fn, _i32p),
+        _p(fo, _i32p), _p(fi, _i32p), cap, C.byref(nf), kf.handle if kf is not None else None,
+        _p(kv, _u8p) if kf is not None else None, float(np.float32(nnratio)), int(check_orientation), _p(match, _i32p),
+        C.byref(nm)), "vsg_frame_stereo_bow_search")
+    return dict(u_right=ur[:n], depth=dep[:n], n_stereo=ns.value, bow_ids=bi[:nb.value].copy(), bow_vals=bv[:nb.value].copy(),
+                fv=(fn[:nf.value].copy(), fo[:nf.value + 1].copy(), fi[:fo[nf.value]].copy()), n_match=nm.value,
+                match_f=match[:n])
 
 
 def ComputeStereoMatches_resident(ex_left, frame_l, ex_right, frame_r, fl, fr, mb, mbf):
