@@ -236,6 +236,26 @@ class ORBVocabulary {
     featVec.off.resize(nf + 1);
     featVec.idx.resize(featVec.off[nf]);
   }
+  // Frame::ComputeBoW / KeyFrame::ComputeBoW (Frame.cc:882-889, KeyFrame.cc:100-110) on a resident frame's descriptors
+  // (`frame` = vsg::ResidentFrame::handle()): nothing goes up, mBowVec / mFeatVec come back in final form, and the
+  // FeatureVector also STAYS on the device inside the frame (Frame::mFeatVec) for the ResidentMatcher::SearchByBoW
+  // overloads that take no FeatureVector.
+  void ComputeBoW(vsg_frame *frame, std::map<unsigned, double> &bowVec, FeatureVectorCSR &featVec, int levelsup = 4) const {
+    const int n = vsg_frame_size(frame);
+    check(n, "vsg_frame_size");
+    const int cap = n > 0 ? n : 1;
+    std::vector<int32_t> ids(cap);
+    std::vector<double> vals(cap);
+    featVec.node.assign(cap, 0), featVec.off.assign(cap + 1, 0), featVec.idx.assign(cap, 0);
+    int nb = 0, nf = 0;
+    check(vsg_frame_bow_transform(v_, frame, levelsup, ids.data(), vals.data(), cap, &nb, featVec.node.data(), featVec.off.data(),
+                                  featVec.idx.data(), cap, &nf, nullptr, nullptr, nullptr),
+          "vsg_frame_bow_transform");
+    bowVec.clear();
+    for (int i = 0; i < nb; ++i) bowVec.emplace_hint(bowVec.end(), (unsigned)ids[i], vals[i]);
+    featVec.node.resize(nf), featVec.off.resize(nf + 1), featVec.idx.resize(featVec.off[nf]);
+  }
+  vsg_vocab *handle() const { return v_; }
 
  private:
   vsg_vocab *v_ = nullptr;
@@ -489,6 +509,38 @@ class ResidentFrame {
   vsg_frame *f_ = nullptr;
 };
 
+// The stereo Frame constructor's tail and the first tracking step in ONE call and one wait (vsg_frame_stereo_bow_search):
+// ComputeStereoMatches (Frame.cc:957-1127) -> ComputeBoW (Frame.cc:882-889) -> SearchByBoW(pKF, F) (ORBmatcher.cc:226-428;
+// Tracking::TrackReferenceKeyFrame, Tracking.cc:2766-2777).  left / right = the extractors that just processed the two eyes,
+// fl / fr = their resident features; pKF = nullptr: no search (the first Frame).  Returns the number of BoW matches.
+struct StereoBowResult {
+  std::vector<float> mvuRight, mvDepth;
+  int nStereo = 0;
+  std::map<unsigned, double> mBowVec;
+  FeatureVectorCSR mFeatVec;
+  std::vector<int32_t> matchF;  // per feature of F: index of the KeyFrame feature whose map point it takes, or -1
+};
+inline int StereoBowSearch(const ORBextractor &left, const ORBextractor &right, ResidentFrame &fl, ResidentFrame &fr, float mb,
+                           float mbf, const ORBVocabulary &voc, ResidentFrame *pKF, const uint8_t *kfValid, float nnratio,
+                           bool checkOri, StereoBowResult &out, int levelsup = 4) {
+  const int n = fl.N(), cap = n > 0 ? n : 1;
+  out.mvuRight.assign(cap, -1.f), out.mvDepth.assign(cap, -1.f), out.matchF.assign(cap, -1);
+  std::vector<int32_t> ids(cap);
+  std::vector<double> vals(cap);
+  out.mFeatVec.node.assign(cap, 0), out.mFeatVec.off.assign(cap + 1, 0), out.mFeatVec.idx.assign(cap, 0);
+  int nb = 0, nf = 0, nm = 0;
+  check(vsg_frame_stereo_bow_search(left.handle(), 0, right.handle(), 0, fl.handle(), fr.handle(), mb, mbf, out.mvuRight.data(),
+                                    out.mvDepth.data(), &out.nStereo, voc.handle(), levelsup, ids.data(), vals.data(), cap, &nb,
+                                    out.mFeatVec.node.data(), out.mFeatVec.off.data(), out.mFeatVec.idx.data(), cap, &nf,
+                                    pKF ? pKF->handle() : nullptr, kfValid, nnratio, checkOri ? 1 : 0, out.matchF.data(), &nm),
+        "vsg_frame_stereo_bow_search");
+  out.mBowVec.clear();
+  for (int i = 0; i < nb; ++i) out.mBowVec.emplace_hint(out.mBowVec.end(), (unsigned)ids[i], vals[i]);
+  out.mFeatVec.node.resize(nf), out.mFeatVec.off.resize(nf + 1), out.mFeatVec.idx.resize(out.mFeatVec.off[nf]);
+  out.mvuRight.resize(n), out.mvDepth.resize(n), out.matchF.resize(n);
+  return nm;
+}
+
 // Projected map points as the routines' geometry code leaves them (one entry per point that passed the routine's
 // visibility / distance tests); see include/vsg_orb.h for which members each search reads.
 struct ProjectedPoints {
@@ -606,6 +658,23 @@ class ResidentMatcher {
                                           fFeatVec.off.data(), fFeatVec.idx.data(), fFeatVec.nodes(), mfNNratio,
                                           mbCheckOrientation, matchF.data());
     check(rc, "vsg_frame_search_by_bow_kf_f");
+    return rc;
+  }
+  // The same two with the FeatureVectors both frames keep resident since their ComputeBoW (ORBVocabulary::ComputeBoW):
+  // the join runs on the device, only the "has a map point" flags go up
+  int SearchByBoW(ResidentFrame &pKF, const uint8_t *kfValid, ResidentFrame &F, std::vector<int32_t> &matchF) const {
+    matchF.assign(F.N(), -1);
+    int rc = vsg_frame_search_by_bow_kf_f(pKF.handle(), kfValid, nullptr, nullptr, nullptr, 0, F.handle(), nullptr, nullptr,
+                                          nullptr, 0, mfNNratio, mbCheckOrientation, matchF.data());
+    check(rc, "vsg_frame_search_by_bow_kf_f");
+    return rc;
+  }
+  int SearchByBoW(ResidentFrame &pKF1, const uint8_t *valid1, ResidentFrame &pKF2, const uint8_t *valid2,
+                  std::vector<int32_t> &vMatches12) const {
+    vMatches12.assign(pKF1.N(), -1);
+    int rc = vsg_frame_search_by_bow_kf_kf(pKF1.handle(), valid1, nullptr, nullptr, nullptr, 0, pKF2.handle(), valid2, nullptr,
+                                           nullptr, nullptr, 0, mfNNratio, mbCheckOrientation, vMatches12.data());
+    check(rc, "vsg_frame_search_by_bow_kf_kf");
     return rc;
   }
   int SearchByBoW(ResidentFrame &pKF1, const uint8_t *valid1, const FeatureVectorCSR &fv1, ResidentFrame &pKF2,

@@ -115,6 +115,22 @@ int main(int argc, char **argv) {
       return 4;
     }
 
+    // ComputeBoW on the resident frames (BowVector / FeatureVector assembled on the device, the FeatureVector staying in the
+    // frame) and SearchByBoW on the resident FeatureVectors: the host-array forms' results expected, to the byte
+    {
+      std::map<unsigned, double> rbow[2];
+      vsg::FeatureVectorCSR rfv[2];
+      voc.ComputeBoW(R0.handle(), rbow[0], rfv[0], 2);
+      voc.ComputeBoW(R1.handle(), rbow[1], rfv[1], 2);
+      std::vector<int32_t> rmatchF;
+      const int nrbow = rm.SearchByBoW(R0, kfValid.data(), R1, rmatchF);
+      if (rbow[1] != bow[1] || rfv[1].node != fv[1].node || rfv[1].off != fv[1].off || rfv[1].idx != fv[1].idx ||
+          nrbow != nbow || rmatchF != matchF) {
+        printf("resident ComputeBoW / SearchByBoW differs from the host-array form (%d vs %d)\n", nrbow, nbow);
+        return 4;
+      }
+    }
+
     std::ofstream f(argv[2], std::ios::binary);
     std::vector<int32_t> head{mono[0], mono[1], nwin, nbow, ninit, d01, ntri, nlast, nsim3, nfuse, nrinit};
     dump(f, head);

@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 for rep in $(seq 1 $reps); do
   for v in "$@"; do
     if [ "$v" = cur ]; then unset VSG_LIB; else export VSG_LIB="$PWD/tools/_bin/libvsg_$v.so"; fi
-    python tools/content_sweep.py 512 12 "$classes" 2>>gpurun_out/ab_content.err | python -c "
+    python tools/content_sweep.py ${AB_BATCH:-1024} 12 "$classes" 2>>gpurun_out/ab_content.err | python -c "
 import json,sys
 for line in sys.stdin:
     line=line.strip()

@@ -365,7 +365,9 @@ inline int build_geometry(Geometry &G, const ExtractorTables &T, int rows, int c
   }
   fg.pyr_frame_bytes = (img_off + 255) & ~255;
   // FastCellRec per cell (layout: vsg_common.h); the run / mask arithmetic is the kernel's, done here once
-  G.fastRecs.assign(G.cells.size(), FastCellRec());
+  // + one empty record past the end: k_fast_cells loads the record of cell ci + 1 unconditionally
+  G.fastRecs.assign(G.cells.size() + 1, FastCellRec());
+  memset(&G.fastRecs.back(), 0, sizeof(FastCellRec));
   for (size_t i = 0; i < G.cells.size(); i++) {
     const CellDesc &c = G.cells[i];
     const LevelGeom &L = fg.lv[c.level];

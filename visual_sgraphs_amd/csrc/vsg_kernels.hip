@@ -450,10 +450,10 @@ struct FastCell {
   __device__ __forceinline__ int th() const { return vh() + 6; }
   __device__ __forceinline__ bool live() const { return w3 != 0; }
 };
-__device__ __forceinline__ FastCell load_fast_cell(const FastCellRec *__restrict__ recs, int idx, const Src0 &s0,
-                                                   const uint8_t *pyr, int pyr_frame_bytes, int frame) {
+__device__ __forceinline__ FastCell load_fast_cell(const FastCellRec *__restrict__ rec, const Src0 &s0, const uint8_t *pyr,
+                                                   int pyr_frame_bytes, int frame) {
   typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-  const u32x8 r = *reinterpret_cast<const u32x8 *>(recs + idx);
+  const u32x8 r = *reinterpret_cast<const u32x8 *>(rec);
   FastCell c;
   c.w3 = r[3], c.first_mask = r[4], c.last_mask = r[5], c.cand_off = r[6], c.xy = r[7];
   c.level = (int)(r[2] >> 20);
@@ -467,6 +467,42 @@ __device__ __forceinline__ FastCell load_fast_cell(const FastCellRec *__restrict
   }
   c.tsrc = img + (size_t)((r[0] >> 16) * (uint32_t)c.pitch + (r[0] & 0xFFFFu));
   return c;
+}
+
+// The kernel's parameter list as it lies in the kernarg segment.  Launch-invariant scalars that the cell loop needs once per
+// cell or per pass (pointers, per-frame strides, thresholds) are RE-LOADED from there at their point of use -- scalar loads
+// out of the constant cache on the scalar unit's own issue port -- instead of being kept alive across the loop: under the
+// 80-SGPR cap that keeps 8 waves per SIMD they did not fit, the compiler parked 31 of them in the lanes of a VGPR and the
+// loop read them back with ~45 v_readlane_b32 per cell, each a slot of the VALU issue port this kernel is bound by
+// (VERDICT r5 #2a).  The pointer passes through an empty asm so that every use site loads afresh (nothing to hoist or merge).
+// A comparison on a value that passed through an empty asm is not loop-invariant to the compiler: it is made where it is
+// used (one v_cmp) instead of once in front of the cell loop, parked as a 64-bit lane mask in two VGPR lanes and read back
+// with two v_readlane_b32 at every use (the SGPR cap again)
+#ifndef VSG_FAST_OPQ
+#define VSG_FAST_OPQ 1
+#endif
+#if VSG_FAST_OPQ
+#define VSG_OPQ(x) ([&] { int t_ = (x); asm volatile("" : "+v"(t_)); return t_; }())
+#else
+#define VSG_OPQ(x) (x)
+#endif
+#ifndef VSG_FAST_KA
+#define VSG_FAST_KA 3   // bit 0: the next cell's image bases, 1: the cell counter, 2: the candidate segment, 3: the record array
+#endif
+struct FastKArgs {
+  const uint8_t *pyr;
+  const FrameGeom *fg;
+  const FastCellRec *recs;
+  Src0 s0;
+  uint32_t *cand;
+  int *cand_count, *cell_count;
+  int tile_bytes, score_bytes, queue_cap, cells_per_wg, pyr_frame_bytes, total_cells, cand_frame, th_pack;
+};
+typedef const FastKArgs __attribute__((address_space(4))) *FastKArgsPtr;
+__device__ __forceinline__ FastKArgsPtr fast_kargs() {
+  FastKArgsPtr p = (FastKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
 }
 
 // A workgroup works through `cells_per_wg` consecutive cells of one frame.  The tile of the NEXT cell is fetched into
@@ -483,8 +519,11 @@ template <int NT, int kTileP, int kScoreP, int kPre>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS), amdgpu_waves_per_eu(VSG_FAST_WAVES_MIN, VSG_FAST_WAVES_MAX))) void k_fast_cells(
     const uint8_t *__restrict__ pyr, const FrameGeom *__restrict__ fg, const FastCellRec *__restrict__ recs, Src0 s0,
     uint32_t *__restrict__ cand, int *__restrict__ cand_count, int *__restrict__ cell_count, int tile_bytes,
-    int score_bytes, int queue_cap, int cells_per_wg) {
+    int score_bytes, int queue_cap, int cells_per_wg, int pyr_frame_bytes, int total_cells, int cand_frame, int th_pack) {
   static_assert(kScoreP == kTileP, "a pixel's score offset is its tile offset minus a constant");
+  static_assert(offsetof(FastKArgs, s0) == 24 && offsetof(FastKArgs, cand) == 48 && offsetof(FastKArgs, cell_count) == 64 &&
+                    offsetof(FastKArgs, tile_bytes) == 72 && offsetof(FastKArgs, th_pack) == 100,
+                "FastKArgs mirrors this parameter list");
   extern __shared__ __attribute__((aligned(16))) uint8_t fast_lds[];
   uint8_t *tile = fast_lds, *score = fast_lds + tile_bytes;
   uint16_t *queue = (uint16_t *)(fast_lds + tile_bytes + score_bytes);  // queue_cap entries = the largest cell's pixels
@@ -493,13 +532,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
   uint8_t *qtile = (uint8_t *)queue;
   // flag word + index of every run with a passer; both lists are consumed before the score rows they alias are cleared
   uint32_t *runF = (uint32_t *)score;
-  __shared__ int s_cnt[5];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base [4]=run entries
+  __shared__ int s_cnt[8];  // [0]=NMS survivors [1]=queue length [2]=emit cursor [3]=global base [4]=run entries
   const BlockXY blk = frame_major_block();
   const int frame = blk.y;
   const int tid = threadIdx.x, lane = tid & 63;
-  const bool seg = fg->cand_segmented != 0;
-  const int total_cells = fg->total_cells, pyr_frame_bytes = fg->pyr_frame_bytes, cand_frame = fg->cand_frame;
-  const int iniTh = fg->iniTh, minTh = fg->minTh;
+  // th_pack = iniThFAST | minThFAST << 8 | cand_segmented << 16 (launch-invariant, ONE register for the whole loop)
   const int c_begin = blk.x * cells_per_wg, c_end = min(c_begin + cells_per_wg, total_cells);
   typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
   u32x4u pre[kPre];
@@ -553,11 +590,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
     }
     return true;
   };
-  FastCell C = load_fast_cell(recs, c_begin, s0, pyr, pyr_frame_bytes, frame);
+  FastCell C = load_fast_cell(recs + c_begin, s0, pyr, pyr_frame_bytes, frame);
   bool have_pre = fetch(C);  // the first cell of the workgroup waits for its tile
   for (int ci = c_begin; ci < c_end; ci++) {
-    // the record of the next cell: its scalar load runs beside the LDS writes below
-    const FastCell N = load_fast_cell(recs, min(ci + 1, c_end - 1), s0, pyr, pyr_frame_bytes, frame);
+    // the record of the next cell: its scalar load runs beside the LDS writes below.  Its inputs come from the kernarg
+    // segment again (see FastKArgs); the record array carries one empty record past its end, so no clamp of the index
+    FastCell N;
+#if VSG_FAST_KA & 1
+    {
+      const FastKArgsPtr ka = fast_kargs();
+      const Src0 ks0 = {ka->s0.base, ka->s0.frame_stride, ka->s0.pitch};
+#if VSG_FAST_KA & 8
+      N = load_fast_cell(ka->recs + (ci + 1), ks0, ka->pyr, ka->pyr_frame_bytes, frame);
+#else
+      N = load_fast_cell(recs + (ci + 1), ks0, ka->pyr, ka->pyr_frame_bytes, frame);
+#endif
+    }
+#else
+    N = load_fast_cell(recs + (ci + 1), s0, pyr, pyr_frame_bytes, frame);
+#endif
     const bool live = C.live();
     if (live) {
       if (C.tdw() < 4) {  // a sliver of a cell at the right edge of a level (cell-uniform)
@@ -585,14 +636,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
     }
     // the next cell's tile is on its way while this one is worked on
     have_pre = ci + 1 < c_end && fetch(N);
-    int *my_count = cell_count + (size_t)frame * total_cells + ci;
+    const bool seg = (th_pack >> 16) != 0;
+    auto my_count = [&]() -> int * {  // the cell's counter, from the kernarg segment at the moment it is written
+#if VSG_FAST_KA & 2
+      const FastKArgsPtr ka = fast_kargs();
+      return ka->cell_count + ((size_t)frame * ka->total_cells + ci);
+#else
+      return cell_count + ((size_t)frame * total_cells + ci);
+#endif
+    };
     if (!live) {  // empty cell
-      if (seg && tid == 0) *my_count = 0;
+      if (seg && VSG_OPQ(tid) == 0) *my_count() = 0;
       C = N;
       continue;
     }
     {
-      uint32_t *seg_out = cand + (size_t)frame * cand_frame + C.cand_off;
+      const int iniTh = th_pack & 0xFF, minTh = (th_pack >> 8) & 0xFF;
       const int vw = C.vw(), vh = C.vh(), ox = C.ox(), th = C.th();
       const int cell_x0 = (int)(C.xy & 0xFFFFu), cell_y0 = (int)(C.xy >> 16), cell_level = C.level;
         // centre pixels live in tile columns [3 + ox, 3 + ox + vw): dword groups g0 .. g1-1, runs of 2 dwords per row
@@ -611,7 +670,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
         uint32_t keep = 0;
         int nq = 0, thr = iniTh;
         for (int pass = 0; pass < 2; pass++) {
-          if (tid < 5) s_cnt[tid] = 0;
+          if (VSG_OPQ(tid) < 5) s_cnt[tid] = 0;
           __syncthreads();  // the tile is staged / the previous pass is done with the score rows
           // ---- phase 1: 6-bit necessary test, 8 pixels (2 dwords) per thread; runs with a passer are appended (flag word
           // + run index) to the run list: one ballot and one LDS atomic per wave and iteration
@@ -751,7 +810,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
           const bool single = s_cnt[1] > queue_cap;  // cell-uniform; only cells where most pixels pass on both sides
           if (single) {
             __syncthreads();
-            if (tid == 0) s_cnt[1] = 0;
+            if (VSG_OPQ(tid) == 0) s_cnt[1] = 0;
             __syncthreads();
             unpack(true);
             __syncthreads();
@@ -799,6 +858,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             __syncthreads();
           }
           // ---- phase 3: non-max suppression inside the cell
+          uint32_t *seg_out;
+#if VSG_FAST_KA & 4
+          {
+            const FastKArgsPtr ka = fast_kargs();
+            seg_out = ka->cand + ((size_t)frame * ka->cand_frame + C.cand_off);
+          }
+#else
+          seg_out = cand + ((size_t)frame * cand_frame + C.cand_off);
+#endif
           keep = 0;  // bit per loop iteration: queued pixel survives NMS
           int it = 0;
           int nbias = kScoreP + 1;  // the 3 x 3 neighbourhood at non-negative offsets from one register (see kBias)
@@ -835,13 +903,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
 
       const int nEmit = s_cnt[0];
       if (seg) {
-        if (tid == 0) *my_count = nEmit;
-      } else if (nEmit) {
-        const LevelGeom &L = fg->lv[cell_level];
-        if (tid == 0) s_cnt[3] = atomicAdd(&cand_count[frame * kMaxLevels + cell_level], nEmit);
+        if (VSG_OPQ(tid) == 0) *my_count() = nEmit;
+      } else if (nEmit) {  // levels of more than 4096 cells: one unordered list per level (rare geometries)
+        const FastKArgsPtr ka = fast_kargs();
+        const LevelGeom &L = ka->fg->lv[cell_level];
+        if (tid == 0) s_cnt[3] = atomicAdd(&ka->cand_count[frame * kMaxLevels + cell_level], nEmit);
         __syncthreads();
         const int base = s_cnt[3];
-        uint32_t *out = cand + (size_t)frame * cand_frame + L.cand_off;
+        uint32_t *out = ka->cand + (size_t)frame * ka->cand_frame + L.cand_off;
         int it = 0;
         for (int q = tid; q < nq; q += NT, it++) {
           if (!(keep & (1u << it))) continue;
@@ -2280,8 +2349,10 @@ static void launch_fast_t(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_
   // the pixel queue's region also holds the 6-bit copy of the tile during the necessary test
   const size_t queue_bytes = std::max<size_t>(((size_t)maxArea * 2 + 15) & ~(size_t)15, (size_t)tile_bytes);
   const size_t lds = (size_t)tile_bytes + score_bytes + queue_bytes;
+  const int th_pack = (fg.iniTh & 0xFF) | ((fg.minTh & 0xFF) << 8) | ((fg.cand_segmented ? 1 : 0) << 16);
   hipLaunchKernelGGL((k_fast_cells<NT, TP, SP, PRE>), grid, block, lds, s, pyr, d_fg, d_recs, s0, cand, cand_count,
-                     cell_count, tile_bytes, score_bytes, maxArea, cells_per_wg);
+                     cell_count, tile_bytes, score_bytes, maxArea, cells_per_wg, fg.pyr_frame_bytes, fg.total_cells,
+                     fg.cand_frame, th_pack);
 }
 void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const FastCellRec *d_recs, const Src0 &s0,
                  uint32_t *cand, int *cand_count, int *cell_count, const FrameGeom &fg, int maxVh, int maxVw, int maxArea,
