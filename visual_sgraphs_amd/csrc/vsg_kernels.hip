@@ -327,6 +327,9 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
 #define VSG_FAST_STAGE_B_NUM(pass) ((pass) ? 4 : 2)
 #define VSG_FAST_STAGE_B_DEN(pass) 1
 #endif
+#ifndef VSG_FAST_STAGE_C
+#define VSG_FAST_STAGE_C 0  // phase 1c: 0 = off (default), 1 = with phase 1b in both passes, 2 = minThFAST pass only, 3 = iniThFAST pass only
+#endif
 #ifndef VSG_FAST_NT
 #define VSG_FAST_NT 128  // threads per FAST cell: 2 waves keep more cells resident per CU than 4 (measured: 0.47 ->
                          // 0.38 ms per 256 frames); 1 wave runs out of LDS before it runs out of wave slots
@@ -762,6 +765,48 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
               runF[e] = F0 & VSG_BITOP3(g[1], g[0] >> 2, 0xC0C0C0C0u, (A & C) | (B & ~C));
             }
             __syncthreads();
+#if VSG_FAST_STAGE_C
+            // ---- phase 1c (round 6 experiment, VERDICT r5 #2b; OFF by default -- measured: profiles/r06_d_fast_stage_c_ab.txt):
+            // the same necessary test on the remaining FOUR ring pairs (1 / 9, 3 / 11, 5 / 13, 7 / 15: rows +-3 at columns -+1,
+            // rows +-1 at columns -+3), run entry by run entry, for cells that took phase 1b.  ~95 vector instructions per run
+            // entry against 62 per queued pixel it removes.
+            if (VSG_FAST_STAGE_C == 1 || (VSG_FAST_STAGE_C == 2 && pass == 1) || (VSG_FAST_STAGE_C == 3 && pass == 0)) {
+              for (int e = tid; e < nr1; e += NT) {
+                const uint32_t F0 = runF[e];
+                if (!F0) continue;
+                const int runB = runI[e];
+                const uint32_t *pc = (const uint32_t *)&qtile[runB];
+                const uint32_t *p3u = pc - 3 * (kTileP / 4), *p3d = pc + 3 * (kTileP / 4), *p1u = pc - (kTileP / 4),
+                               *p1d = pc + (kTileP / 4);
+                uint32_t u3[4] = {p3u[-1], p3u[0], p3u[1], p3u[2]}, d3[4] = {p3d[-1], p3d[0], p3d[1], p3d[2]};
+                uint32_t u1[4] = {p1u[-1], p1u[0], p1u[1], p1u[2]}, d1[4] = {p1d[-1], p1d[0], p1d[1], p1d[2]};
+                const uint32_t qc[2] = {pc[0], pc[1]};
+                const int col = runB - kTileP * div_small(runB, 1.0f / kTileP);
+                const uint32_t left = (g0 == 0 && col == 0) ? 0u : ~0u;  // the dword left of tile column 0 (see phase 1)
+                u3[0] &= left, d3[0] &= left, u1[0] &= left, d1[0] &= left;
+                uint32_t g[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                  const uint32_t n9 = __builtin_amdgcn_alignbyte(u3[k + 1], u3[k], 3);       // row -3, columns -1
+                  const uint32_t n7 = __builtin_amdgcn_alignbyte(u3[k + 2], u3[k + 1], 1);   // row -3, columns +1
+                  const uint32_t n15 = __builtin_amdgcn_alignbyte(d3[k + 1], d3[k], 3);      // row +3, columns -1
+                  const uint32_t n1 = __builtin_amdgcn_alignbyte(d3[k + 2], d3[k + 1], 1);   // row +3, columns +1
+                  const uint32_t n11 = __builtin_amdgcn_alignbyte(u1[k + 1], u1[k], 1);      // row -1, columns -3
+                  const uint32_t n5 = __builtin_amdgcn_alignbyte(u1[k + 2], u1[k + 1], 3);   // row -1, columns +3
+                  const uint32_t n13 = __builtin_amdgcn_alignbyte(d1[k + 1], d1[k], 1);      // row +1, columns -3
+                  const uint32_t n3 = __builtin_amdgcn_alignbyte(d1[k + 2], d1[k + 1], 3);   // row +1, columns +3
+                  const uint32_t A = qc[k] + K, B = K - qc[k];
+                  const uint32_t dA = VSG_BITOP3((A - n1) | (A - n9), (A - n7) | (A - n15), (A - n3) | (A - n11), A & B & C);
+                  const uint32_t dark = dA & ((A - n5) | (A - n13));
+                  const uint32_t bA = VSG_BITOP3((B + n1) | (B + n9), (B + n7) | (B + n15), (B + n3) | (B + n11), A & B & C);
+                  const uint32_t bright = bA & ((B + n5) | (B + n13));
+                  g[k] = VSG_BITOP3(dark, bright >> 1, H, (A & C) | (B & ~C));
+                }
+                runF[e] = F0 & VSG_BITOP3(g[1], g[0] >> 2, 0xC0C0C0C0u, (A & C) | (B & ~C));
+              }
+              __syncthreads();
+            }
+#endif
           }
 #endif
           // ---- run list -> pixel queue.  Entry = the run's dword index in the tile << 5 | bit position of the flag in the
