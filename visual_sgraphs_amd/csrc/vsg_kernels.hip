@@ -484,10 +484,22 @@ __device__ __forceinline__ FastCell load_fast_cell(const FastCellRec *__restrict
 #ifndef VSG_FAST_OPQ
 #define VSG_FAST_OPQ 1
 #endif
+#ifndef VSG_FAST_HINTS
+#define VSG_FAST_HINTS 1
+#endif
 #if VSG_FAST_OPQ
 #define VSG_OPQ(x) ([&] { int t_ = (x); asm volatile("" : "+v"(t_)); return t_; }())
 #else
 #define VSG_OPQ(x) (x)
+#endif
+// block-frequency hints for the paths that almost never run (slivers, tiles that were not prefetched, the one-entry-per-pixel
+// re-unpack, levels of more than 4096 cells): the register allocator weighs spills by block frequency
+#if VSG_FAST_HINTS
+#define VSG_COLD(x) __builtin_expect(!!(x), 0)
+#define VSG_HOT(x) __builtin_expect(!!(x), 1)
+#else
+#define VSG_COLD(x) (x)
+#define VSG_HOT(x) (x)
 #endif
 #ifndef VSG_FAST_KA
 #define VSG_FAST_KA 3   // bit 0: the next cell's image bases, 1: the cell counter, 2: the candidate segment, 3: the record array
@@ -614,7 +626,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
 #endif
     const bool live = C.live();
     if (live) {
-      if (C.tdw() < 4) {  // a sliver of a cell at the right edge of a level (cell-uniform)
+      if (VSG_COLD(C.tdw() < 4)) {  // a sliver of a cell at the right edge of a level (cell-uniform)
         const float inv_tdw = __builtin_amdgcn_rcpf((float)C.tdw());
         for (int i = tid; i < C.tdw() * C.th(); i += NT) {
           const int r = div_small(i, inv_tdw), c = i - r * C.tdw();
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
       } else {
         const int n = C.nq4() * C.th();
         const float inv_nq4 = __builtin_amdgcn_rcpf((float)C.nq4());
-        if (have_pre) {
+        if (VSG_HOT(have_pre)) {
 #pragma unroll
           for (int k = 0; k < kPre; k++)
             if (tid + k * NT < n) put(pre_off[k], pre[k]);
@@ -853,7 +865,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
           unpack(false);
           __syncthreads();
           const bool single = s_cnt[1] > queue_cap;  // cell-uniform; only cells where most pixels pass on both sides
-          if (single) {
+          if (VSG_COLD(single)) {
             __syncthreads();
             if (VSG_OPQ(tid) == 0) s_cnt[1] = 0;
             __syncthreads();
@@ -889,7 +901,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             }
           }
           __syncthreads();
-          if (single) {
+          if (VSG_COLD(single)) {
             for (int q = tid; q < nq; q += NT) {
               const uint32_t ent = queue[q];
               if ((ent >> 14) != 1u) continue;  // bright side, retry flag: the dark side did not score
@@ -927,7 +939,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
             asm volatile("" : "+v"(s), "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7));
             const int mx = max(max(max(n0, n1), max(n2, n3)), max(max(n4, n5), max(n6, n7)));
             if (s > mx) {
-              if (seg) {
+              if (VSG_HOT(seg)) {
                 const int r1 = div_small((int)ent, 1.0f / kScoreP), c1 = (int)ent - r1 * kScoreP;  // row + 1, column + 1
                 seg_out[atomicAdd(&s_cnt[0], 1)] = pack_cand(cell_x0 + c1 - 1 - kFastBorder, cell_y0 + r1 - 1 - kFastBorder, s);
               } else {
@@ -947,7 +959,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
 
 
       const int nEmit = s_cnt[0];
-      if (seg) {
+      if (VSG_HOT(seg)) {
         if (VSG_OPQ(tid) == 0) *my_count() = nEmit;
       } else if (nEmit) {  // levels of more than 4096 cells: one unordered list per level (rare geometries)
         const FastKArgsPtr ka = fast_kargs();
