@@ -327,6 +327,9 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
 #define VSG_FAST_STAGE_B_NUM(pass) ((pass) ? 4 : 2)
 #define VSG_FAST_STAGE_B_DEN(pass) 1
 #endif
+#ifndef VSG_OD_SPATIAL
+#define VSG_OD_SPATIAL 0  // k_orient_desc processes a level's keypoints in Morton order of their cells (experiment)
+#endif
 #ifndef VSG_FAST_STAGE_C
 #define VSG_FAST_STAGE_C 0  // phase 1c: 0 = off (default), 1 = with phase 1b in both passes, 2 = minThFAST pass only, 3 = iniThFAST pass only
 #endif
@@ -1409,6 +1412,29 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
                                          : octree::distribute(g, P, cand + coff, npts, node_of + coff, W, out);
   }
   if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;
+#if VSG_OD_SPATIAL
+  // Experiment (OFF by default: profiles/r06_e_orient_desc_order_ab.txt): the PROCESSING order of the level's
+  // keypoints for k_orient_desc -- Morton order of their 32 x 32 px cells, so that the twelve keypoints of one of its workgroups
+  // are spatial neighbours -- as a permutation in the level's slice of the (by now idle) node_of scratch; the OUTPUT slot of a
+  // keypoint stays its position in the octree's list.  Rank by counting: n <= sel_cap keys, n^2 / 256 comparisons per thread.
+  {
+    __syncthreads();  // out[0..n) is written (same workgroup: the barrier orders it)
+    auto key_of = [&](int i) -> uint32_t {
+      const uint32_t c = out[i];
+      uint32_t x = VSG_CAND_X(c) >> 5, y = VSG_CAND_Y(c) >> 5, m = 0;
+#pragma unroll
+      for (int b = 0; b < 6; b++) m |= ((x >> b) & 1u) << (2 * b) | ((y >> b) & 1u) << (2 * b + 1);
+      return (m << 16) | (uint32_t)i;  // unique: ties by list position
+    };
+    uint16_t *ord = node_of + coff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint32_t ki = key_of(i);
+      int r = 0;
+      for (int j = 0; j < n; j++) r += key_of(j) < ki;
+      ord[r] = (uint16_t)i;
+    }
+  }
+#endif
 }
 
 #ifndef VSG_OCT_WAVES
@@ -1948,8 +1974,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(VSG_OD_SGPRS)))
       l = 0;
       while (g >= s_hdr[3 + l]) l++;  // wave-uniform (g < n = s_hdr[2 + kMaxLevels])
       l = __builtin_amdgcn_readfirstlane(l);
+#if VSG_OD_SPATIAL
+      // processing position g - level start -> the keypoint's position in the octree's list (the octree's epilogue wrote
+      // the permutation into node_of, which travels in the unused `slots` argument of this launch form)
+      const int i = ((const uint16_t *)slots)[(size_t)frame * fg->cand_frame + fg->lv[l].cand_off + (g - s_hdr[2 + l])];
+      c = sel[(size_t)frame * fg->sel_frame + fg->lv[l].sel_off + i];
+      slot = s_hdr[2 + l] + i;
+#else
       c = sel[(size_t)frame * fg->sel_frame + fg->lv[l].sel_off + (g - s_hdr[2 + l])];
       slot = g;
+#endif
     } else {
       int4 r = rec[0];
 #pragma unroll

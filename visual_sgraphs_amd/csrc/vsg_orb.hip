@@ -574,6 +574,9 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   }
   OutMirror mir = h->mirror;
   if (mir.kps) mir.kps += F * mir.capacity, mir.desc += F * mir.capacity * 32, mir.counts += F * 2;
+#ifdef VSG_OD_SPATIAL_ON
+  if (self_slots) slots = (int4 *)nodeof;  // experiment: the processing order of k_orient_desc (vsg_kernels.hip VSG_OD_SPATIAL)
+#endif
   launch_orient_desc(s, pyr, blur, h->d_fg, s0, sel, sel_count, slots, hdr, h->d_pattern, d_kps + F * capacity,
                      d_desc + F * capacity * 32, d_counts + F * 2, capacity, fg, nf, mir, self_slots);
   if (tm) HIP_TRY(hipEventRecord(h->ev[5], s));
