@@ -317,7 +317,9 @@ int vsg_copy_d2d_async(int device, void *dst, const void *src, size_t bytes, voi
  * vsg_host_alloc / vsg_host_free: pinned host memory from the runtime's own allocator (hipHostMalloc), what the handle's
  * staging slots use themselves.  Memory from vsg_host_alloc is the memory the device reads and writes IN PLACE
  * (vsg_orb_submit_batch / vsg_orb_wait, the blocking entry points): no staging copy on either side.  So is hipHostMalloc
- * memory the caller obtained elsewhere.
+ * memory the caller obtained elsewhere.  vsg_host_free releases ONLY pointers vsg_host_alloc returned (VSG_ERR_INVALID for
+ * anything else, also for hipHostMalloc memory of another owner: since round 5 the library keeps a registry of its own blocks and
+ * does not forward foreign pointers to hipHostFree).
  * vsg_host_register / vsg_host_unregister: pin ordinary heap memory after the fact (hipHostRegister).  Such memory is a
  * user-pointer mapping of heap pages; on the round-4 test pool a page of a live, registered, in-use range lost its
  * device mapping under heap churn (a fatal `Memory access fault by GPU`; profiles/r04_q_open_issue_gpu_fault.txt,

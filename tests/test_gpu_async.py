@@ -159,6 +159,16 @@ def test_pinned_array_memory_outlives_its_owner_while_views_exist():
     gc.collect()
     import ctypes as C
     assert orb.load_library().vsg_host_kind(C.c_void_p(base), 16) != 1       # released with the last view
+    # release(): the explicit form -- raises while a view is still referenced, frees once it is gone
+    pb = orb.PinnedArray((64,), np.uint8)
+    view = pb.a[8:16]
+    assert pb.alive
+    with pytest.raises(RuntimeError):
+        pb.release()
+    assert pb.alive and orb.host_kind(view) == "vsg_host_alloc"
+    del view
+    pb.release()
+    assert not pb.alive
 
 
 def test_new_image_size_is_refused_while_tickets_are_pending():

@@ -1331,7 +1331,7 @@ struct SegRegPts {
 #ifndef VSG_OCT_FEW
 #define VSG_OCT_FEW 8
 #endif
-constexpr int kOctFewFrames = VSG_OCT_FEW;  // calls of up to this many frames take the 4-waves-per-SIMD octree launch (k_octree_blur_few)
+constexpr int kOctFewFrames = VSG_OCT_FEW;  // calls of up to this many frames take the 4-waves-per-SIMD octree launch (k_octree_few; the fused launch is compiled for 4 waves anyway)
 struct OctArgs {
   const FrameGeom *fg;
   const uint32_t *cand;
@@ -1447,7 +1447,7 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG
   __shared__ int sort_stack[3 * kSortStack];
   octree_block(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
 }
-// calls of a few frames: registers instead of residency (see k_octree_blur_few)
+// calls of a few frames: registers instead of residency
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree_few(OctArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
@@ -1742,17 +1742,9 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG
   __shared__ int sort_stack[3 * kSortStack];
   octree_blur_body(a, pyr, blur, s0, nlevels, nframes, lead, oct_lds, wtot, sort_stack);
 }
-// The same launch for calls of a few frames (the blocking one-frame operator()): there the octree IS the critical path --
-// eight workgroups per frame on 256 CUs -- and residency buys nothing, so this instantiation takes the 125 registers the
-// octree wants instead of the 96 of five waves per SIMD, where 46 of them live in scratch memory (every spill reload a
-// trip to L2 in the middle of a latency-bound pass).
-__global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree_blur_few(
-    OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels, int nframes, int lead) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
-  __shared__ int wtot[2 * kMaxWaves];
-  __shared__ int sort_stack[3 * kSortStack];
-  octree_blur_body(a, pyr, blur, s0, nlevels, nframes, lead, oct_lds, wtot, sort_stack);
-}
+// (Rounds 3-5 had a second instantiation of this launch for calls of a few frames, compiled for 4 waves per SIMD; since round 5
+// k_octree_blur itself is compiled for VSG_OB_WAVES = 4 waves -- 125 registers, nothing in scratch -- the two were the same code
+// object twice; one-frame calls take k_octree_blur.)
 
 // ------------------------------------------------------------------------------------------------
 // Output slots: keypoints are visited level by level in octree order; those inside the lapping area
@@ -2482,12 +2474,6 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
     // (64 rows, a multiple of 8 = whole XCD rounds: 317.5 -> 320.5 k frames/s at 512 C2 frames; 32 and 128 measured the same +-0.3 %)
     constexpr int kLead = 64;
     const int lead = nframes >= 4 * kLead ? kLead : 0;
-    if (nframes <= kOctFewFrames) {
-      lds_limit_ensure(3, dev, (const void *)k_octree_blur_few, lds);
-      hipLaunchKernelGGL(k_octree_blur_few, dim3(fg.nlevels + fg.total_blur_blocks, nframes + lead), dim3(kOctThreads), lds, s,
-                         a, blur_pyr, blur_out, *blur_s0, fg.nlevels, nframes, lead);
-      return;
-    }
     hipLaunchKernelGGL(k_octree_blur, dim3(fg.nlevels + fg.total_blur_blocks, nframes + lead), dim3(kOctThreads), lds, s, a,
                        blur_pyr, blur_out, *blur_s0, fg.nlevels, nframes, lead);
     return;

@@ -526,13 +526,19 @@ static int enqueue_range(vsg_orb *h, const Src0 &src, int f0, int nf, int lap0, 
   // 2000 features (33 KB) the fifth no longer fits -- 93.1 -> 90.1 k frames/s there, so that geometry keeps two streams.
   // (re-measured in round 5 with the launch compiled for 4 waves per SIMD, where four 33 KB workgroups WOULD fit: 1280x720 /
   // 2000 fused 113.2-114.6 k frames/s, two streams 115.4-117.2 k -- the threshold stays at five workgroups' worth of LDS)
-  const bool lds_fits = 5 * octree_lds_bytes(fg, h->G.maxQuota, h->G.maxCellsPerLevel) <= 160 * 1024;
+  // (kFusedLdsWorkgroups is a MEASURED threshold, not the launch's residency: the fused launch is compiled for kOctBlurWaves = 4
+  // workgroups per CU.  Geometries whose octree workspace -- vsg_octree_core.h work_bytes, + 1.8 KB per workgroup since round 5's
+  // histogram / cell-position tables -- lies between 160 / 5 = 32 KB and 160 / 4 = 40 KB take the two-stream form: 1280x720 / 2000
+  // at 33 KB is the measured case above; nothing between 29 and 33 KB occurs among the reference's configurations
+  // (tests/golden/reference_configs.json: 640x480 / 1000-1500 = 17-23 KB, 752x480 / 1200 = 20 KB, 1241x376 / 2000 = 33 KB).)
+  constexpr int kFusedLdsWorkgroups = 5;
+  const bool lds_fits = kFusedLdsWorkgroups * octree_lds_bytes(fg, h->G.maxQuota, h->G.maxCellsPerLevel) <= 160 * 1024;
   const bool fused_blur = !tm && sb != s && (lds_fits || (h->one_stream && nf <= 8));
   // Without a lapping area (every keypoint has x >= 19, so lap1 < 19 -- the {0, 0} of the RGB-D / stereo callers,
   // Frame.cc:108,344 -- selects nothing): k_orient_desc derives slots and level starts itself, k_slots is not launched
   // (8 us of the one-frame chain; for 512-frame batches + 0.4 % frames/s in the same run, round 4; in the two-stream form of
   // the geometries whose octree workspace keeps the blur out of its launch -- 1280x720 / 2000 -- k_slots was 51 us of a
-  // 128-frame step, 5 %: profiles/r05_j_c4_kernel_stats_timed_region.csv)
+  // 128-frame step, 5 %: profiles/r05_v_c4_kernel_stats_timed_region.csv)
   const bool self_slots = !tm && (lap1 < kEdgeThreshold || lap0 > lap1);
   if (fused_blur) {
     Range r_tail("DistributeOctTree (+ blur workgroups) + slots + IC_Angle / rBRIEF");

@@ -862,6 +862,7 @@ class PinnedArray:
         n = max(count * dt.itemsize, 1)
         buf = PinnedArray._Buf(n)
         self._ptr = buf.ptr
+        self._fin = buf._fin
         self.a = np.frombuffer(buf.raw, dtype=dt, count=count).reshape(shape)
 
     @property
@@ -869,8 +870,26 @@ class PinnedArray:
         return self._ptr
 
     def free(self):
-        """Drop this object's array.  The pinned memory is released as soon as no numpy view of it is left."""
+        """Drop this object's array.  The pinned memory is released as soon as no numpy view of it is left -- it is NOT
+        returned to the runtime here if a slice, a reshape or an exception traceback still holds one: use
+        release() where the pinned footprint has to be bounded."""
         self.a = None
+
+    @property
+    def alive(self):
+        """True while the hipHostMalloc block behind this object is still allocated (this object or a view holds it)."""
+        return self._fin.alive
+
+    def release(self):
+        """free() + a check that the allocation really went: raises if a view of the array is still referenced
+        somewhere (the memory then stays pinned until that view dies)."""
+        self.a = None
+        import gc
+        if self._fin.alive:
+            gc.collect()
+        if self._fin.alive:
+            raise RuntimeError("PinnedArray.release(): a numpy view of the array is still alive; the block stays pinned until "
+                               "it is dropped")
 
     def __enter__(self):
         return self
