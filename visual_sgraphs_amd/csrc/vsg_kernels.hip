@@ -687,6 +687,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
         const int p1_off = (p1_row + 3) * kTileP + 4 * (g0 + 2 * p1_rr);
         uint32_t keep = 0;
         int nq = 0, thr = iniTh;
+#ifdef VSG_FAST_PASS_UNROLL
+#pragma unroll VSG_FAST_PASS_UNROLL
+#endif
         for (int pass = 0; pass < 2; pass++) {
           if (VSG_OPQ(tid) < 5) s_cnt[tid] = 0;
           __syncthreads();  // the tile is staged / the previous pass is done with the score rows
