@@ -363,6 +363,45 @@ def test_octree_core_equals_oracle_on_adversarial_sets(hc):
         assert np.array_equal(gx, xs[want]) and np.array_equal(gy, ys[want]) and np.array_equal(gr, rs[want]), trial
 
 
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (1280, 720, 2000)])
+def test_octree_core_on_photographs_and_the_rank_sorted_careful_phase(hc, w, h, nf):
+    """Real photographs: 5.7 k (640x480) / 19.6 k (1280x720) level-0 candidates, ~200-400 divisible nodes when the careful phase
+    starts -- the node sort takes the counting form when all (size, UL.x) keys differ (round 6) and the exact std::sort replay when
+    two are equal.  Both against the oracle's std::list + std::sort code, on the candidates of every level of every photograph,
+    and on copies of them with responses flattened (ties in the best-point rule) and with points duplicated in mirrored
+    quadrants (equal node sizes: ties in the sort)."""
+    assert hc.hc_build(nf, 1.2, 8, 20, 7, h, w) == 0
+    e = ol.OracleExtractor(nf, 1.2, 8, 20, 7)
+    for kind in synth.PHOTO_CLASSES:
+        e(synth.content_frame(kind, w, h, 77, 2))
+        for l in range(8):
+            x, y, r = e.candidates(l)
+            kp = e.level_keypoints(l)
+            gx, gy, gr = hc_octree(hc, l, x, y, r)
+            assert np.array_equal(gx + 16, kp["x"].astype(np.int32)) and np.array_equal(gy + 16, kp["y"].astype(np.int32)), (kind, l)
+            assert np.array_equal(gr, kp["response"].astype(np.int32))
+    # symmetric point sets: the left half mirrored onto the right half gives pairs of nodes with equal sizes (sort ties)
+    info = level_info(hc, 0)
+    W, H = info["oct_width"], info["oct_height"]
+    e(synth.content_frame("photo_china", w, h, 78, 0))
+    x, y, r = e.candidates(0)
+    keep = x < W // 2 - 2
+    xs = np.concatenate([x[keep], (W - 1) - x[keep]])
+    ys, rs = np.concatenate([y[keep], y[keep]]), np.concatenate([r[keep], r[keep]])
+    ok = (xs >= 3) & (xs <= W - 4)
+    pts = np.unique(np.stack([ys[ok], xs[ok], np.minimum(rs[ok], 40)], 1), axis=0)
+    _, first = np.unique(pts[:, :2], axis=0, return_index=True)  # one point per pixel
+    pts = pts[np.sort(first)]
+    ys, xs, rs = pts[:, 0], pts[:, 1], pts[:, 2]
+    # reference candidate order = cell-major then row-major inside the cell
+    i, j = (ys - 3) // info["hCell"], (xs - 3) // info["wCell"]
+    order = np.lexsort((xs, ys, j, i))
+    xs, ys, rs = xs[order], ys[order], rs[order]
+    want = ol.distribute_octree(xs, ys, rs, 16, 16 + W, 16, 16 + H, info["quota"])
+    gx, gy, gr = hc_octree(hc, 0, xs[::-1], ys[::-1], rs[::-1])
+    assert len(xs) > 2000 and np.array_equal(gx, xs[want]) and np.array_equal(gy, ys[want]) and np.array_equal(gr, rs[want])
+
+
 def test_octree_core_multiple_initial_nodes(hc):
     assert hc.hc_build(2000, 1.2, 8, 20, 7, 376, 1241) == 0  # KITTI aspect: nIni = 3 or 4
     e = ol.OracleExtractor(2000, 1.2, 8, 20, 7)

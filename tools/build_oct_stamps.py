@@ -25,7 +25,8 @@ def main():
         d = Path(td) / "csrc"
         shutil.copytree(CSRC, d, ignore=shutil.ignore_patterns("_obj"))
         for f in list(d.glob("*.hip")) + list(d.glob("*.h")):
-            f.write_text(f.read_text().replace('"../../include/vsg_orb.h"', f'"{ROOT}/include/vsg_orb.h"'))
+            f.write_text(f.read_text().replace('"../../include/vsg_orb.h"', f'"{ROOT}/include/vsg_orb.h"')
+                                        .replace('"../../include/vsg_orb_debug.h"', f'"{ROOT}/include/vsg_orb_debug.h"'))
         core = d / "vsg_octree_core.h"
         s = core.read_text()
         s = sub(s, "namespace vsg {\nnamespace octree {\n", "#ifndef VSG_OCT_STAMP\n#define VSG_OCT_STAMP(tag)\n#endif\n\nnamespace vsg {\nnamespace octree {\n", "namespace")
@@ -69,7 +70,7 @@ __device__ __forceinline__ void vsg_oct_stamp(int tag) {
 '''
         s = sub(s, '#include "vsg_octree_core.h"', stamp + '#include "vsg_octree_core.h"', "include")
         s = sub(s, "  octree::Work W;\n  octree::carve(W, oct_lds, cap);\n  BlockGroup g;", "  VSG_OCT_STAMP(0);\n  octree::Work W;\n  octree::carve(W, oct_lds, cap);\n  BlockGroup g;", "enter")
-        s = sub(s, "  if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;\n}", "  if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;\n  VSG_OCT_STAMP(31);\n}", "exit")
+        s = sub(s, "  if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;\n", "  if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;\n  VSG_OCT_STAMP(31);\n", "exit")
         export = '''extern "C" int vsg_debug_oct_stamps(unsigned long long *out, int reset) {
   hipDeviceSynchronize();
   if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_oct_stamps), sizeof(unsigned long long) * 8 * 32 * 2);

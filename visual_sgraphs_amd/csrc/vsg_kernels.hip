@@ -1346,6 +1346,7 @@ struct OctArgs {
   uint32_t *sel;
   int *sel_count;
   int cap, prefix_off;
+  int lab_off, lab_cap;  // node labels of levels that overflow the registers: u16[lab_cap] behind the workspace (0: none)
 };
 
 __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int frame, uint8_t *oct_lds, int *wtot,
@@ -1399,12 +1400,31 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
       pts.src = src;
       n = octree::distribute_pts(g, P, pts, npts, W, out);
     } else {
-      // too many for the registers: compact once into the scratch list, then the memory-resident form
+      // too many for the registers (a real photograph's level 0 holds 3-6 k candidates at 640x480): compact once into the
+      // scratch list, then the memory-resident form -- with the node labels in LDS when they fit behind the workspace
+      // (round 6: the launch pads a workgroup's LDS up to the share four workgroups per CU leave it anyway; the labels are
+      // what every pass reads AND rewrites, the candidate words are read-only and stream through L2)
       uint32_t *list = cand2 + coff;
-      for (int p = g.tid; p < npts; p += g.nthreads) list[p] = src(p);
+      {
+        // a thread copies a CONTIGUOUS run of the concatenated list: one bisection for its first point, then it walks along
+        // the cell boundaries (a bisection per point -- eight dependent LDS reads each -- was 36 k of the 165 k cycles a
+        // photograph's level 0 took)
+        const int chunk = (npts + g.nthreads - 1) / g.nthreads;
+        const int p0 = g.tid * chunk, p1 = min(p0 + chunk, npts);
+        if (p0 < p1) {
+          int ci = src.cell_of(p0);
+          for (int p = p0; p < p1; p++) {
+            while (p >= src.prefix[ci + 1]) ci++;
+            list[p] = src.level_cand[src.segoff[ci] + (p - src.prefix[ci])];
+          }
+        }
+      }
       __threadfence_block();
       __syncthreads();
-      n = octree::distribute(g, P, list, npts, node_of + coff, W, out);
+      if (npts <= a.lab_cap)  // (two call sites: the compiler has to SEE that the labels are LDS to emit ds_ instead of flat_ accesses)
+        n = octree::distribute(g, P, list, npts, (uint16_t *)(oct_lds + a.lab_off), W, out);
+      else
+        n = octree::distribute(g, P, list, npts, node_of + coff, W, out);
     }
   } else {
     int npts = cand_count[frame * kMaxLevels + level];
@@ -2465,12 +2485,23 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
                    const uint8_t *blur_pyr, uint8_t *blur_out, const Src0 *blur_s0) {
   const int cap = octree::node_capacity(maxQuota);
   const int prefix_off = (int)((octree::work_bytes(cap) + 15) & ~(size_t)15);
-  const size_t lds = (size_t)prefix_off + (fg.cand_segmented ? (2 * (size_t)maxCellsPerLevel + 1) * 4 : 0);
+  const size_t work_lds = (size_t)prefix_off + (fg.cand_segmented ? (2 * (size_t)maxCellsPerLevel + 1) * 4 : 0);
+  // Node labels of levels whose candidates overflow the registers (octree_block): every octree launch form runs four
+  // workgroups per CU at best (4 waves per SIMD, or the workspace's own size), so a workgroup may as well own a quarter of
+  // the CU's 160 KB (less the static part and a margin) -- 6 k labels at 640x480 / 1000, a photograph's level 0.  Geometries
+  // whose workspace already takes that share get none (1280x720 / 2000: 33 KB) and keep the labels in global memory.
+  // (measured, photo_china / rectangles at C2 / 1024: no labels 336.6 / 387.5 k frames/s, a 28 KB share 340.6 / 385.6, 32 KB
+  // 346.6 / 386.9, 36 KB 346.4 / 386.4, 39 KB 346.3 / 387.2 -- profiles/r06_h_octree_large_levels.txt)
+  const size_t share = 36 * 1024;
+  const size_t lab_off = (work_lds + 15) & ~(size_t)15;
+  const size_t lab_bytes = work_lds <= 64 * 1024 && lab_off + 4096 <= share ? share - lab_off : 0;
+  const size_t lds = lab_bytes ? lab_off + lab_bytes : work_lds;
   // beyond 64 KB of dynamic LDS the launch needs the limit raised (quotas above ~1000 per level, e.g. a single
   // level holding every feature); gfx950 has 160 KB per workgroup
   int dev = 0;
   hipGetDevice(&dev);
-  const OctArgs a = {d_fg, cand, cand_count, d_cells, cell_count, cand2, node_of, sel, sel_count, cap, prefix_off};
+  const OctArgs a = {d_fg, cand, cand_count, d_cells, cell_count, cand2, node_of, sel, sel_count, cap, prefix_off,
+                     (int)lab_off, (int)(lab_bytes / 2)};
   if (blur_out) {  // the blur of the same frames as extra workgroups of this launch (latency path)
     lds_limit_ensure(2, dev, (const void *)k_octree_blur, lds);
     // octree workgroups `lead` frames ahead of the blur's (see the kernel); only for launches long enough to have a tail
@@ -2487,7 +2518,7 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   // 5-waves one with its 59 spilled registers -- its launch time was bimodal from run to run, the only scratch user of the
   // chain); where the workspace caps a CU at four workgroups anyway (1280x720 / 2000: 33 KB) the 5-waves form measures 0.8 %
   // more frames/s (115.3-116.8 against 115.1-115.6 k, profiles/r05_p_*) and stays.
-  if (nframes <= kOctFewFrames || 5 * lds <= 160 * 1024) {
+  if (nframes <= kOctFewFrames || 5 * work_lds <= 160 * 1024) {
     lds_limit_ensure(4, dev, (const void *)k_octree_few, lds);
     hipLaunchKernelGGL(k_octree_few, grid, block, lds, s, a);
     return;

@@ -723,6 +723,9 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
           sortbuf[t] = ((introsort::item_t)key << 32) | (uint32_t)n;
         }
         g.sync();
+        // (Round 6 tried a counting sort for the case that all keys differ -- the sorted order is then unique, whatever std::sort
+        // does with ties: on a photograph's level 0 two of the ~200 (size, UL.x) keys are equal almost always, the attempt cost
+        // 22 k cycles and the replay below ran anyway; removed.  profiles/r06_h_octree_large_levels.txt)
         // std::sort (:707) = serial quicksort partitioning + a stable sort of what it leaves (vsg_introsort.h);
         // the stable part is a rank computation spread over the group, written straight into the back-to-front
         // processing order of (:708).
