@@ -227,7 +227,7 @@ def launch_ranks(args, argv):
             so.bind(("127.0.0.1", 0))
             port = so.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
-               "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+               "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py")] + list(argv)
         r = run_teeing_stderr(cmd, env)
         # started again only when the RENDEZVOUS lost its port: the address error is there and no rank got as far as
         # printing anything of its own (a rank-side socket error of gloo / RCCL carries the same words and is a real failure)

@@ -1347,6 +1347,7 @@ struct OctArgs {
   int *sel_count;
   int cap, prefix_off;
   int lab_off, lab_cap;  // node labels of levels that overflow the registers: u16[lab_cap] behind the workspace (0: none)
+  int hist_big;          // the workspace class (vsg_octree_core.h work_bytes)
 };
 
 __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int frame, uint8_t *oct_lds, int *wtot,
@@ -1372,7 +1373,7 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
   P.wCell = L.wCell;
   P.hCell = L.hCell;
   octree::Work W;
-  octree::carve(W, oct_lds, cap);
+  octree::carve(W, oct_lds, cap, a.hist_big != 0);
   BlockGroup g;
   g.tid = threadIdx.x;
   g.nthreads = blockDim.x;
@@ -2475,7 +2476,9 @@ void launch_fast(hipStream_t s, const uint8_t *pyr, const FrameGeom *d_fg, const
 // dynamic LDS of one octree workgroup (also what every blur workgroup of the fused launch is charged)
 size_t octree_lds_bytes(const FrameGeom &fg, int maxQuota, int maxCellsPerLevel) {
   const int cap = octree::node_capacity(maxQuota);
-  const size_t prefix_off = (octree::work_bytes(cap) + 15) & ~(size_t)15;
+  // the workspace with the SMALL histogram: what the fused-launch gate of vsg_orb.hip was measured on (the launch itself
+  // takes the big one where a workgroup's share of the CU has the room: launch_octree)
+  const size_t prefix_off = (octree::work_bytes(cap, false) + 15) & ~(size_t)15;
   return prefix_off + (fg.cand_segmented ? (2 * (size_t)maxCellsPerLevel + 1) * 4 : 0);
 }
 
@@ -2484,15 +2487,18 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
                    int *sel_count, const FrameGeom &fg, int maxQuota, int maxCellsPerLevel, int nframes,
                    const uint8_t *blur_pyr, uint8_t *blur_out, const Src0 *blur_s0) {
   const int cap = octree::node_capacity(maxQuota);
-  const int prefix_off = (int)((octree::work_bytes(cap) + 15) & ~(size_t)15);
-  const size_t work_lds = (size_t)prefix_off + (fg.cand_segmented ? (2 * (size_t)maxCellsPerLevel + 1) * 4 : 0);
-  // Node labels of levels whose candidates overflow the registers (octree_block): every octree launch form runs four
-  // workgroups per CU at best (4 waves per SIMD, or the workspace's own size), so a workgroup may as well own a quarter of
-  // the CU's 160 KB (less the static part and a margin) -- 6 k labels at 640x480 / 1000, a photograph's level 0.  Geometries
-  // whose workspace already takes that share get none (1280x720 / 2000: 33 KB) and keep the labels in global memory.
+  const size_t prefix_bytes = fg.cand_segmented ? (2 * (size_t)maxCellsPerLevel + 1) * 4 : 0;
+  // Node labels of levels whose candidates overflow the registers (octree_block), and the workspace class: every octree
+  // launch form runs four workgroups per CU at best (4 waves per SIMD, or the workspace's own size), so a workgroup may as
+  // well own a quarter of the CU's 160 KB (less the static part and a margin): the big histogram where it fits that share
+  // (640x480 / 1000: 29 KB), and ~3 k labels behind it; geometries whose node arrays fill the share (1280x720 / 2000) take the
+  // small histogram and keep overflowing levels' labels in global memory.
   // (measured, photo_china / rectangles at C2 / 1024: no labels 336.6 / 387.5 k frames/s, a 28 KB share 340.6 / 385.6, 32 KB
   // 346.6 / 386.9, 36 KB 346.4 / 386.4, 39 KB 346.3 / 387.2 -- profiles/r06_h_octree_large_levels.txt)
   const size_t share = 36 * 1024;
+  const bool hist_big = ((octree::work_bytes(cap, true) + 15) & ~(size_t)15) + prefix_bytes <= share;
+  const int prefix_off = (int)((octree::work_bytes(cap, hist_big) + 15) & ~(size_t)15);
+  const size_t work_lds = (size_t)prefix_off + prefix_bytes;
   const size_t lab_off = (work_lds + 15) & ~(size_t)15;
   const size_t lab_bytes = work_lds <= 64 * 1024 && lab_off + 4096 <= share ? share - lab_off : 0;
   const size_t lds = lab_bytes ? lab_off + lab_bytes : work_lds;
@@ -2501,7 +2507,7 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   int dev = 0;
   hipGetDevice(&dev);
   const OctArgs a = {d_fg, cand, cand_count, d_cells, cell_count, cand2, node_of, sel, sel_count, cap, prefix_off,
-                     (int)lab_off, (int)(lab_bytes / 2)};
+                     (int)lab_off, (int)(lab_bytes / 2), hist_big ? 1 : 0};
   if (blur_out) {  // the blur of the same frames as extra workgroups of this launch (latency path)
     lds_limit_ensure(2, dev, (const void *)k_octree_blur, lds);
     // octree workgroups `lead` frames ahead of the blur's (see the kernel); only for launches long enough to have a tail

@@ -176,23 +176,41 @@ struct Work {
   uint8_t *divided;
   int *scanA, *scanB;
   int *ctrl;            // [0]=nL [1]=nV [2]=break index
-  // fused first main passes (fused_main_passes below): point counts of every quadtree cell down to depth kFuseDepth under
-  // each of up to kFuseRoots initial nodes, the cell -> list position table, and each node's (root, depth, path) word
-  int *hist;            // [kFuseRoots][4 + 16 + 64]
-  uint16_t *cellpos;    // [kFuseRoots][64]
-  // node words of the fused passes, root << 8 | depth << 6 | path (2 bits per level), generation b in proc (b = 0) /
-  // keeppos (b = 1): neither is live during the fused passes, and both are written before they are read afterwards
-  VSG_OCT_HD uint16_t *ncode(int b) const { return b ? keeppos : proc; }
+  // histogram mode (hist_* below): point counts of every quadtree cell down to depth D under each of up to kFuseRoots
+  // initial nodes (D = 5 under one root, 4 under two to four: kHistInts either way), the depth-D cell -> list position table,
+  // and each node's (root, depth, path) word in two generations
+  int *hist;            // [roots][4 + 16 + ... + 4^D]
+  uint16_t *cellpos;    // [roots][4^D]
+  int histInts, cellCap;  // capacity of hist / cellpos (two workspace classes, see work_bytes)
+  // node words root << 13 | depth << 10 | path (2 bits per level), generation b in the first two quarters of childpos: the
+  // child positions are what the LABEL-based passes relabel the points through -- not live in histogram mode, and written
+  // before they are read once it has been left
+  VSG_OCT_HD uint16_t *ncode(int b) const { return childpos + (size_t)b * capa; }
 };
 
-enum { kFuseDepth = 3, kFuseRoots = 4, kFuseCells = 4 + 16 + 64 };
-
-VSG_OCT_HD size_t work_bytes(int cap) {
-  size_t capa = (size_t)((cap + 3) & ~3);
-  return capa * (2 * 4 * 2 + 2 * 4 + 16 + 8 + 2 + 2 + 2 + 1 + 4 + 4) + 64 + kFuseRoots * (kFuseCells * 4 + 64 * 2);
+// Two workspace classes: the BIG histogram (depth 5 under one root, 4 under up to four: 5.5 + 2 KB) where a workgroup's LDS
+// share has the room, the SMALL one (depth 4 under one root, 3 under up to four: 1.4 + 0.5 KB, the size rounds 5's depth-3
+// tables had) where the node arrays already fill it (1280x720 / 2000).
+enum { kFuseRoots = 4, kHistIntsBig = 4 + 16 + 64 + 256 + 1024, kHistCellsBig = 1024, kHistIntsSmall = 4 + 16 + 64 + 256,
+       kHistCellsSmall = 256 };
+// cells of levels 1 .. d - 1 = where level d starts inside a root's histogram; a root's histogram holds levels 1 .. D
+VSG_OCT_HD int hist_off(int d) { return ((1 << (2 * d)) - 4) / 3; }
+// the deepest histogram the workspace holds for nRoots initial nodes (0: none)
+VSG_OCT_HD int hist_depth(const Work &W, int nRoots) {
+  int D = 5;
+  while (D > 0 && (nRoots * hist_off(D + 1) > W.histInts || nRoots * (1 << (2 * D)) > W.cellCap)) D--;
+  return D;
 }
 
-VSG_OCT_HD void carve(Work &W, void *buf, int cap) {
+VSG_OCT_HD size_t work_bytes(int cap, bool big = true) {
+  size_t capa = (size_t)((cap + 3) & ~3);
+  return capa * (2 * 4 * 2 + 2 * 4 + 16 + 8 + 2 + 2 + 2 + 1 + 4 + 4) + 64 +
+         (big ? kHistIntsBig * 4 + kHistCellsBig * 2 : kHistIntsSmall * 4 + kHistCellsSmall * 2);
+}
+
+VSG_OCT_HD void carve(Work &W, void *buf, int cap, bool big = true) {
+  W.histInts = big ? kHistIntsBig : kHistIntsSmall;
+  W.cellCap = big ? kHistCellsBig : kHistCellsSmall;
   size_t capa = (size_t)((cap + 3) & ~3);
   uint8_t *p = (uint8_t *)buf;
   W.childcnt = (int *)p;
@@ -217,9 +235,9 @@ VSG_OCT_HD void carve(Work &W, void *buf, int cap) {
   W.V = (uint16_t *)p;
   p += capa * 2;
   W.cellpos = (uint16_t *)p;
-  p += kFuseRoots * 64 * 2;
+  p += (size_t)W.cellCap * 2;
   W.hist = (int *)p;  // 4-byte aligned: everything before it is a multiple of 4 bytes (capa is a multiple of 4)
-  p += kFuseRoots * kFuseCells * 4;
+  p += (size_t)W.histInts * 4;
   W.divided = (uint8_t *)p;
 }
 
@@ -423,206 +441,280 @@ VSG_OCT_HD int run_main_pass(G &g, const Params &P, Work &W, int &cur, int nL, P
   return newL;
 }
 
-// ---- The first (up to kFuseDepth) MAIN passes without a point sweep per pass.
-// A main pass splits every node that holds more than one point, so which nodes exist after k passes -- and in which list
-// order -- only depends on how many points lie in each quadtree cell of depth <= k: the boxes are pure geometry (a node's
-// box is its root's box halved along its path, :484-527), the points are never moved, and the list surgery of a pass
-// (children in creation order n1..n4, pushed to the front; :617-690) only looks at counts.  So: ONE sweep over the points
-// computes each point's path down to depth kFuseDepth in registers (no LDS gathers) and counts it into its depth-3 cell;
-// the coarser counts are sums of four; the passes then run on the node arrays alone -- the same statements as run_main_pass
-// with the child counts read from the histogram -- with the reference's stop tests (:692, :696) after each; ONE more sweep
-// gives every point the list position of the node its depth-3 cell ended up in.  Two point sweeps and no per-point LDS
-// traffic for the three passes that otherwise cost two sweeps with five LDS gathers and an LDS atomic per point each
-// (the one-frame octree: 29 of 81 k cycles in these passes, profiles/r05_c_octree_stamps_one_frame.txt).
-// Requires nL <= kFuseRoots initial nodes in generation `cur`, labels n = list position.  Returns the new list length;
-// *state: 0 = all fused passes done and the main loop goes on, 1 = finish (:692), 2 = enter the careful phase (:696).
+// ---- Histogram mode: passes without point sweeps.
+// A pass splits nodes into four, so which nodes exist after k passes -- and in which list order -- only depends on how many
+// points lie in each quadtree cell of depth <= k: the boxes are pure geometry (a node's box is its root's box halved along
+// its path, :484-527), the points are never moved, and the list surgery of a pass (children in creation order n1..n4, pushed
+// to the front, :617-690; the careful phase's sorted order and its stop test, :696-757) only looks at counts.  So: ONE sweep
+// over the points computes each point's path down to depth D in registers (no LDS gathers) and counts it into its depth-D
+// cell; the coarser counts are sums of four; every pass -- main or careful -- whose nodes sit above depth D then runs on the
+// node arrays alone, the same statements as run_main_pass / run_pass with the child counts read from the histogram; ONE more
+// sweep (hist_leave) gives every point the list position of the node its depth-D cell ended up in.  A node's depth is at
+// most the number of passes so far, so the first D passes qualify whatever they are; a level that needs more leaves the
+// mode and goes on with the label-based passes.
+// Rounds 5-6: depth 3 and main passes only (the one-frame octree: 29 of 81 k cycles in those passes) -> depth 5 under one
+// root / 4 under up to four, careful passes included: a photograph's level 0 (5.7 k points, 165 k cycles in the memory form)
+// ran its fourth main pass and its careful pass with two point sweeps each; the default content's careful pass took its
+// child counts from a sweep.
+// Requires nL <= kFuseRoots initial nodes in generation `cur`, labels n = list position.  Labels become root * 4^D + path.
 template <class G, class PT>
-VSG_OCT_HD int fused_main_passes(G &g, const Params &P, Work &W, int &cur, int nL, PT &pts, int npts, int *nV_out,
-                                 int *state) {
-  const int nRoots = nL;
-  for (int i = g.tid; i < nRoots * kFuseCells; i += g.nthreads) W.hist[i] = 0;
-  for (int i = g.tid; i < nL; i += g.nthreads) W.ncode(cur)[i] = (uint16_t)(i << 8);
+VSG_OCT_HD void hist_setup(G &g, Work &W, int cur, int nL, PT &pts, int npts, int D) {
+  const int nRoots = nL, S = hist_off(D + 1), cellsD = 1 << (2 * D);
+  for (int i = g.tid; i < nRoots * S; i += g.nthreads) W.hist[i] = 0;
+  for (int i = g.tid; i < nL; i += g.nthreads) W.ncode(cur)[i] = (uint16_t)(i << 13);
   g.sync();
-  // sweep 1: path of every point below its root, counted into its depth-3 cell; the label becomes root * 64 + path
   {
-    const int b = cur;
+    const int b = cur, offD = hist_off(D);
     pts.for_each(g, npts, [&](uint32_t c, int &n) {
       const int x = VSG_CAND_X(c), y = VSG_CAND_Y(c);
       int ulx = W.ulx(b)[n], uly = W.uly(b)[n], urx = W.urx(b)[n], bly = W.bly(b)[n], path = 0;
-      for (int d = 0; d < kFuseDepth; d++) {
+      for (int d = 0; d < D; d++) {
         const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
         const int qx = x >= midX, qy = y >= midY;
         path = path * 4 + (qx | (qy << 1));
         if (qx) ulx = midX; else urx = midX;
         if (qy) uly = midY; else bly = midY;
       }
-      n = n * 64 + path;
-      g.atomic_add(&W.hist[(n >> 6) * kFuseCells + 20 + path], 1);
+      g.atomic_add(&W.hist[n * S + offD + path], 1);
+      n = n * cellsD + path;
     });
   }
   g.sync();
-  for (int i = g.tid; i < nRoots * 16; i += g.nthreads) {  // depth 2 = sums of four depth-3 cells
-    const int r = i >> 4, c2 = i & 15;
-    const int *h3 = &W.hist[r * kFuseCells + 20 + 4 * c2];
-    W.hist[r * kFuseCells + 4 + c2] = h3[0] + h3[1] + h3[2] + h3[3];
-  }
-  g.sync();
-  for (int i = g.tid; i < nRoots * 4; i += g.nthreads) {
-    const int r = i >> 2, c1 = i & 3;
-    const int *h2 = &W.hist[r * kFuseCells + 4 + 4 * c1];
-    W.hist[r * kFuseCells + c1] = h2[0] + h2[1] + h2[2] + h2[3];
-  }
-  g.sync();
-  int nV = 0;
-  *state = 0;
-  for (int pass = 0; pass < kFuseDepth; pass++) {
-    const int b = cur, nb = cur ^ 1, prevSize = nL;
-    if (nL <= g.nthreads) {
-      // One node per thread (on the device always: at most 4^2 x kFuseRoots = 64 nodes enter the last fused pass): the
-      // node, its four child counts and its scan values stay in the thread's registers from the first read to the last
-      // write -- one block scan and one barrier per pass instead of three LDS round trips through divided / childcnt /
-      // scanA / scanB and four barriers.
-      const int i = g.tid;
-      const bool have = i < nL;
-      int ulx = 0, uly = 0, urx = 0, bly = 0, code = 0, cnt = 0, k = 0, e = 0, cc[4] = {0, 0, 0, 0};
-      bool d = false;
-      if (have) {
-        cnt = W.cnt(b)[i];
-        ulx = W.ulx(b)[i], uly = W.uly(b)[i], urx = W.urx(b)[i], bly = W.bly(b)[i];
-        code = W.ncode(b)[i];
-        d = cnt > 1;
-        if (d) {
-          const int base = (code >> 8) * kFuseCells + (pass == 0 ? 0 : pass == 1 ? 4 : 20) + 4 * (code & 63);
-          for (int c = 0; c < 4; c++) {
-            cc[c] = W.hist[base + c];
-            k += cc[c] > 0;
-            e += cc[c] > 1;
-          }
-        }
-      }
-      int ex = 0, exKept = 0, kept = 0;
-      const int total = g.exclusive_scan2_one(k | (e << 16), have && !d ? 1 : 0, &ex, &exKept, &kept);
-      const int K = total & 0xFFFF, E = total >> 16;
-      if (have) {
-        if (d) {
-          const int q0 = ex & 0xFFFF, e0 = ex >> 16;
-          const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
-          int m = 0, ev = 0;
-          for (int c = 0; c < 4; c++) {
-            if (cc[c] > 0) {
-              const int pos = K - 1 - (q0 + m);  // push_front => reversed creation order
-              W.ulx(nb)[pos] = (int16_t)((c & 1) ? midX : ulx);
-              W.urx(nb)[pos] = (int16_t)((c & 1) ? urx : midX);
-              W.uly(nb)[pos] = (int16_t)((c & 2) ? midY : uly);
-              W.bly(nb)[pos] = (int16_t)((c & 2) ? bly : midY);
-              W.cnt(nb)[pos] = cc[c];
-              W.ncode(nb)[pos] = (uint16_t)((code & 0xFF00) | ((pass + 1) << 6) | ((code & 63) * 4 + c));
-              if (cc[c] > 1) W.V[e0 + ev++] = (uint16_t)pos;
-              m++;
-            }
-          }
-        } else {
-          const int pos = K + exKept;
-          W.ulx(nb)[pos] = (int16_t)ulx;
-          W.urx(nb)[pos] = (int16_t)urx;
-          W.uly(nb)[pos] = (int16_t)uly;
-          W.bly(nb)[pos] = (int16_t)bly;
-          W.cnt(nb)[pos] = cnt;
-          W.ncode(nb)[pos] = (uint16_t)code;
-        }
-      }
-      g.sync();
-      cur = nb;
-      nL = K + kept;
-      nV = E;
-      if (nL >= P.N || nL == prevSize) {  // (:692)
-        *state = 1;
-        break;
-      }
-      if (nL + nV * 3 > P.N) {  // (:696)
-        *state = 2;
-        break;
-      }
-      continue;
-    }
-    // counts of the four children of every node that splits (all of them sit at depth `pass`)
-    for (int i = g.tid; i < nL; i += g.nthreads) {
-      const bool d = W.cnt(b)[i] > 1;
-      W.divided[i] = d;
-      int k = 0, e = 0;
-      if (d) {
-        const int code = W.ncode(b)[i], r = code >> 8, path = code & 63;
-        const int base = r * kFuseCells + (pass == 0 ? 0 : pass == 1 ? 4 : 20) + 4 * path;
-        for (int c = 0; c < 4; c++) {
-          const int cc = W.hist[base + c];
-          W.childcnt[4 * i + c] = cc;
-          k += cc > 0;
-          e += cc > 1;
-        }
-      }
-      W.scanA[i] = k | (e << 16);
-      W.scanB[i] = d ? 0 : 1;
+  for (int d = D - 1; d >= 1; d--) {  // level d = sums of four level d + 1 cells
+    const int cells = 1 << (2 * d), od = hist_off(d), oc = hist_off(d + 1);
+    for (int i = g.tid; i < nRoots * cells; i += g.nthreads) {
+      const int r = i >> (2 * d), c = i & (cells - 1);
+      const int *h = &W.hist[r * S + oc + 4 * c];
+      W.hist[r * S + od + c] = h[0] + h[1] + h[2] + h[3];
     }
     g.sync();
-    int kept = 0;
-    const int total = g.exclusive_scan2(W.scanA, W.scanB, nL, &kept);
+  }
+}
+
+// child counts of the node with word `code` (its depth < D)
+VSG_OCT_HD const int *hist_children(const Work &W, int code, int S) {
+  const int r = code >> 13, d = (code >> 10) & 7, path = code & 1023;
+  return &W.hist[r * S + hist_off(d + 1) + 4 * path];
+}
+VSG_OCT_HD uint16_t hist_child_code(int code, int c) {
+  return (uint16_t)((code & 0xE000) | ((((code >> 10) & 7) + 1) << 10) | ((code & 1023) * 4 + c));
+}
+
+// leave the mode: depth-D cell -> list position of the node that holds it (a node at depth d covers 4^(D - d) consecutive
+// paths), then every point's label through that table
+template <class G, class PT>
+VSG_OCT_HD void hist_leave(G &g, Work &W, int cur, int nL, PT &pts, int npts, int D) {
+  const int cellsD = 1 << (2 * D);
+  for (int i = g.tid; i < nL; i += g.nthreads) {
+    const int code = W.ncode(cur)[i], r = code >> 13, d = (code >> 10) & 7, path = code & 1023;
+    const int span = 1 << (2 * (D - d)), first = path * span;
+    for (int j = 0; j < span; j++) W.cellpos[r * cellsD + first + j] = (uint16_t)i;
+  }
+  g.sync();
+  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.cellpos[n]; });
+  g.sync();
+}
+
+// A MAIN pass (:617-690) in histogram mode.  Returns the new list length; *nV_out = |V|.
+template <class G>
+VSG_OCT_HD int hist_main_pass(G &g, Work &W, int &cur, int nL, int D, int *nV_out) {
+  const int b = cur, nb = cur ^ 1, S = hist_off(D + 1);
+  if (nL <= g.nthreads) {
+    // One node per thread (on the device the common case: <= 256 nodes enter a pass): the node, its four child counts and
+    // its scan values stay in the thread's registers from the first read to the last write -- one block scan and one
+    // barrier per pass instead of three LDS round trips through divided / childcnt / scanA / scanB and four barriers.
+    const int i = g.tid;
+    const bool have = i < nL;
+    int ulx = 0, uly = 0, urx = 0, bly = 0, code = 0, cnt = 0, k = 0, e = 0, cc[4] = {0, 0, 0, 0};
+    bool d = false;
+    if (have) {
+      cnt = W.cnt(b)[i];
+      ulx = W.ulx(b)[i], uly = W.uly(b)[i], urx = W.urx(b)[i], bly = W.bly(b)[i];
+      code = W.ncode(b)[i];
+      d = cnt > 1;
+      if (d) {
+        const int *h = hist_children(W, code, S);
+        for (int c = 0; c < 4; c++) {
+          cc[c] = h[c];
+          k += cc[c] > 0;
+          e += cc[c] > 1;
+        }
+      }
+    }
+    int ex = 0, exKept = 0, kept = 0;
+    const int total = g.exclusive_scan2_one(k | (e << 16), have && !d ? 1 : 0, &ex, &exKept, &kept);
     const int K = total & 0xFFFF, E = total >> 16;
-    const int newL = K + kept;
-    for (int i = g.tid; i < nL; i += g.nthreads) {
-      const int ulx = W.ulx(b)[i], uly = W.uly(b)[i], urx = W.urx(b)[i], bly = W.bly(b)[i];
-      const int code = W.ncode(b)[i];
-      if (W.divided[i]) {
-        const int q0 = W.scanA[i] & 0xFFFF, e0 = W.scanA[i] >> 16;
+    if (have) {
+      if (d) {
+        const int q0 = ex & 0xFFFF, e0 = ex >> 16;
         const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
         int m = 0, ev = 0;
         for (int c = 0; c < 4; c++) {
-          const int cc = W.childcnt[4 * i + c];
-          if (cc > 0) {
+          if (cc[c] > 0) {
             const int pos = K - 1 - (q0 + m);  // push_front => reversed creation order
             W.ulx(nb)[pos] = (int16_t)((c & 1) ? midX : ulx);
             W.urx(nb)[pos] = (int16_t)((c & 1) ? urx : midX);
             W.uly(nb)[pos] = (int16_t)((c & 2) ? midY : uly);
             W.bly(nb)[pos] = (int16_t)((c & 2) ? bly : midY);
-            W.cnt(nb)[pos] = cc;
-            W.ncode(nb)[pos] = (uint16_t)((code & 0xFF00) | ((pass + 1) << 6) | ((code & 63) * 4 + c));
-            if (cc > 1) W.V[e0 + ev++] = (uint16_t)pos;
+            W.cnt(nb)[pos] = cc[c];
+            W.ncode(nb)[pos] = hist_child_code(code, c);
+            if (cc[c] > 1) W.V[e0 + ev++] = (uint16_t)pos;
             m++;
           }
         }
       } else {
-        const int pos = K + W.scanB[i];
+        const int pos = K + exKept;
         W.ulx(nb)[pos] = (int16_t)ulx;
         W.urx(nb)[pos] = (int16_t)urx;
         W.uly(nb)[pos] = (int16_t)uly;
         W.bly(nb)[pos] = (int16_t)bly;
-        W.cnt(nb)[pos] = W.cnt(b)[i];
+        W.cnt(nb)[pos] = cnt;
         W.ncode(nb)[pos] = (uint16_t)code;
       }
     }
     g.sync();
     cur = nb;
-    nL = newL;
-    nV = E;
-    if (nL >= P.N || nL == prevSize) {  // (:692)
-      *state = 1;
-      break;
-    }
-    if (nL + nV * 3 > P.N) {  // (:696)
-      *state = 2;
-      break;
-    }
+    *nV_out = E;
+    return K + kept;
   }
-  // depth-3 cell -> list position of the node that holds it: a node at depth d covers 4^(3 - d) consecutive paths
+  // counts of the four children of every node that splits
   for (int i = g.tid; i < nL; i += g.nthreads) {
-    const int code = W.ncode(cur)[i], r = code >> 8, d = (code >> 6) & 3, path = code & 63;
-    const int span = 1 << (2 * (kFuseDepth - d)), first = path * span;
-    for (int j = 0; j < span; j++) W.cellpos[r * 64 + first + j] = (uint16_t)i;
+    const bool d = W.cnt(b)[i] > 1;
+    W.divided[i] = d;
+    int k = 0, e = 0;
+    if (d) {
+      const int *h = hist_children(W, W.ncode(b)[i], S);
+      for (int c = 0; c < 4; c++) {
+        const int cc = h[c];
+        W.childcnt[4 * i + c] = cc;
+        k += cc > 0;
+        e += cc > 1;
+      }
+    }
+    W.scanA[i] = k | (e << 16);
+    W.scanB[i] = d ? 0 : 1;
   }
   g.sync();
-  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.cellpos[n]; });
+  int kept = 0;
+  const int total = g.exclusive_scan2(W.scanA, W.scanB, nL, &kept);
+  const int K = total & 0xFFFF, E = total >> 16;
+  const int newL = K + kept;
+  for (int i = g.tid; i < nL; i += g.nthreads) {
+    const int ulx = W.ulx(b)[i], uly = W.uly(b)[i], urx = W.urx(b)[i], bly = W.bly(b)[i];
+    const int code = W.ncode(b)[i];
+    if (W.divided[i]) {
+      const int q0 = W.scanA[i] & 0xFFFF, e0 = W.scanA[i] >> 16;
+      const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
+      int m = 0, ev = 0;
+      for (int c = 0; c < 4; c++) {
+        const int cc = W.childcnt[4 * i + c];
+        if (cc > 0) {
+          const int pos = K - 1 - (q0 + m);  // push_front => reversed creation order
+          W.ulx(nb)[pos] = (int16_t)((c & 1) ? midX : ulx);
+          W.urx(nb)[pos] = (int16_t)((c & 1) ? urx : midX);
+          W.uly(nb)[pos] = (int16_t)((c & 2) ? midY : uly);
+          W.bly(nb)[pos] = (int16_t)((c & 2) ? bly : midY);
+          W.cnt(nb)[pos] = cc;
+          W.ncode(nb)[pos] = hist_child_code(code, c);
+          if (cc > 1) W.V[e0 + ev++] = (uint16_t)pos;
+          m++;
+        }
+      }
+    } else {
+      const int pos = K + W.scanB[i];
+      W.ulx(nb)[pos] = (int16_t)ulx;
+      W.urx(nb)[pos] = (int16_t)urx;
+      W.uly(nb)[pos] = (int16_t)uly;
+      W.bly(nb)[pos] = (int16_t)bly;
+      W.cnt(nb)[pos] = W.cnt(b)[i];
+      W.ncode(nb)[pos] = (uint16_t)code;
+    }
+  }
   g.sync();
-  *nV_out = nV;
-  return nL;
+  cur = nb;
+  *nV_out = E;
+  return newL;
+}
+
+// One CAREFUL pass over proc[0..nProc) (:696-757: the nodes in sorted order, `break` at the first size >= N) in histogram
+// mode: run_pass with the child counts read from the histogram and without its two point sweeps.
+template <class G>
+VSG_OCT_HD int hist_careful_pass(G &g, const Params &P, Work &W, int &cur, int nL, int nProc, int D, int *nV_out) {
+  const int b = cur, nb = cur ^ 1, S = hist_off(D + 1);
+  for (int i = g.tid; i < nL; i += g.nthreads) W.divided[i] = 0;
+  if (g.tid == 0) W.ctrl[2] = nProc;
+  g.sync();
+  for (int t = g.tid; t < nProc; t += g.nthreads) {
+    const int n = W.proc[t];
+    W.divided[n] = 1;
+    const int *h = hist_children(W, W.ncode(b)[n], S);
+    int k = 0, e = 0;
+    for (int c = 0; c < 4; c++) {
+      const int cc = h[c];
+      W.childcnt[4 * n + c] = cc;
+      k += cc > 0;
+      e += cc > 1;
+    }
+    W.scanA[t] = k | (e << 16);
+  }
+  g.sync();
+  const int total = g.exclusive_scan(W.scanA, nProc);
+  // `if ((int)lNodes.size() >= N) break;` after each split (:753)
+  for (int t = g.tid; t < nProc; t += g.nthreads) {
+    const int n = W.proc[t];
+    int k = 0;
+    for (int c = 0; c < 4; c++) k += W.childcnt[4 * n + c] > 0;
+    const int sizeAfter = nL + (W.scanA[t] & 0xFFFF) + k - (t + 1);
+    if (sizeAfter >= P.N) g.atomic_min(&W.ctrl[2], t + 1);
+  }
+  g.sync();
+  const int nEff = W.ctrl[2];
+  g.sync();
+  for (int t = nEff + g.tid; t < nProc; t += g.nthreads) W.divided[W.proc[t]] = 0;
+  const int packed = nEff < nProc ? W.scanA[nEff] : total;
+  const int K = packed & 0xFFFF, E = packed >> 16;
+  g.sync();
+  for (int i = g.tid; i < nL; i += g.nthreads) W.scanB[i] = W.divided[i] ? 0 : 1;
+  g.sync();
+  const int kept = g.exclusive_scan(W.scanB, nL);
+  const int newL = K + kept;
+  for (int t = g.tid; t < nEff; t += g.nthreads) {
+    const int n = W.proc[t];
+    const int q0 = W.scanA[t] & 0xFFFF, e0 = W.scanA[t] >> 16;
+    const int ulx = W.ulx(b)[n], uly = W.uly(b)[n], urx = W.urx(b)[n], bly = W.bly(b)[n];
+    const int midX = ulx + ((urx - ulx + 1) >> 1), midY = uly + ((bly - uly + 1) >> 1);
+    const int code = W.ncode(b)[n];
+    int m = 0, ev = 0;
+    for (int c = 0; c < 4; c++) {
+      const int cc = W.childcnt[4 * n + c];
+      if (cc > 0) {
+        const int pos = K - 1 - (q0 + m);  // push_front => reversed creation order
+        W.ulx(nb)[pos] = (int16_t)((c & 1) ? midX : ulx);
+        W.urx(nb)[pos] = (int16_t)((c & 1) ? urx : midX);
+        W.uly(nb)[pos] = (int16_t)((c & 2) ? midY : uly);
+        W.bly(nb)[pos] = (int16_t)((c & 2) ? bly : midY);
+        W.cnt(nb)[pos] = cc;
+        W.ncode(nb)[pos] = hist_child_code(code, c);
+        if (cc > 1) W.V[e0 + ev++] = (uint16_t)pos;
+        m++;
+      }
+    }
+  }
+  for (int i = g.tid; i < nL; i += g.nthreads) {
+    if (!W.divided[i]) {
+      const int pos = K + W.scanB[i];
+      W.ulx(nb)[pos] = W.ulx(b)[i];
+      W.urx(nb)[pos] = W.urx(b)[i];
+      W.uly(nb)[pos] = W.uly(b)[i];
+      W.bly(nb)[pos] = W.bly(b)[i];
+      W.cnt(nb)[pos] = W.cnt(b)[i];
+      W.ncode(nb)[pos] = W.ncode(b)[i];
+    }
+  }
+  g.sync();
+  cur = nb;
+  *nV_out = E;
+  return newL;
 }
 
 // DistributeOctTree.  cand[0..npts): packed candidates in ANY order.  node_of: npts uint16 scratch.
@@ -696,23 +788,28 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
   }
 
   bool finish = false;
-  int fused = nL >= 1 && nL <= kFuseRoots ? 1 : 0;  // the first passes without per-pass point sweeps (fused_main_passes)
+  // histogram mode for the first hist_D passes (hist_* above); hist_D = 0: the label-based passes
+  int hist_D = nL >= 1 && nL <= kFuseRoots ? hist_depth(W, nL) : 0, hist_pass = 0;
 #ifdef VSG_OCT_NO_FUSE
-  fused = 0;  // A/B builds (tools/build_variant.sh): the regular passes from the start
+  hist_D = 0;  // A/B builds (tools/build_variant.sh): the regular passes from the start
 #endif
+  if (hist_D) hist_setup(g, W, cur, nL, pts, npts, hist_D);
   while (!finish) {  // (:617)
     const int prevSize = nL;
-    int nV = 0, state = -1;
-    if (fused) {
-      fused = 0;
-      nL = fused_main_passes(g, P, W, cur, nL, pts, npts, &nV, &state);
-      if (state == 0) continue;  // every fused pass ran and neither stop test fired: the regular passes go on
+    int nV = 0;
+    if (hist_D && hist_pass >= hist_D) {
+      hist_leave(g, W, cur, nL, pts, npts, hist_D);
+      hist_D = 0;
+    }
+    if (hist_D) {
+      nL = hist_main_pass(g, W, cur, nL, hist_D, &nV);
+      hist_pass++;
     } else {
       nL = run_main_pass(g, P, W, cur, nL, pts, npts, &nV);
     }
-    if (state == 1 || (state < 0 && (nL >= P.N || nL == prevSize))) {  // (:692)
+    if (nL >= P.N || nL == prevSize) {  // (:692)
       finish = true;
-    } else if (state == 2 || (state < 0 && nL + nV * 3 > P.N)) {  // (:696)
+    } else if (nL + nV * 3 > P.N) {  // (:696)
       while (!finish) {
         const int prev2 = nL;
         introsort::item_t *sortbuf = (introsort::item_t *)W.childcnt;
@@ -756,12 +853,22 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
         g.sync();
         }
         int nV2 = 0;
-        nL = run_pass(g, P, W, cur, nL, nV, true, pts, npts, &nV2);
+        if (hist_D && hist_pass >= hist_D) {
+          hist_leave(g, W, cur, nL, pts, npts, hist_D);
+          hist_D = 0;
+        }
+        if (hist_D) {
+          nL = hist_careful_pass(g, P, W, cur, nL, nV, hist_D, &nV2);
+          hist_pass++;
+        } else {
+          nL = run_pass(g, P, W, cur, nL, nV, true, pts, npts, &nV2);
+        }
         nV = nV2;
         if (nL >= P.N || nL == prev2) finish = true;  // (:757)
       }
     }
   }
+  if (hist_D) hist_leave(g, W, cur, nL, pts, npts, hist_D);  // the points' labels: list positions of the final nodes
 
   // retain the best point of every node, first maximum wins (:763-782)
   // ONE sweep: the key (response, then the EARLIER candidate) rides above the candidate word in a 64-bit LDS maximum, so the
