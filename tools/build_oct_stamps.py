@@ -32,20 +32,16 @@ def main():
         s = sub(s, "namespace vsg {\nnamespace octree {\n", "#ifndef VSG_OCT_STAMP\n#define VSG_OCT_STAMP(tag)\n#endif\n\nnamespace vsg {\nnamespace octree {\n", "namespace")
         s = sub(s, "  int cur = 0;\n  pts.load(g, npts);", "  int cur = 0;\n  VSG_OCT_STAMP(1);\n  pts.load(g, npts);\n  VSG_OCT_STAMP(2);", "load")
         s = sub(s, "  bool finish = false;\n", "  VSG_OCT_STAMP(3);\n  bool finish = false;\n", "initial nodes")
-        s = sub(s, "      nL = fused_main_passes(g, P, W, cur, nL, pts, npts, &nV, &state);\n", "      nL = fused_main_passes(g, P, W, cur, nL, pts, npts, &nV, &state);\n      VSG_OCT_STAMP(11);\n", "fused")
+        s = sub(s, "      nL = hist_main_pass(g, W, cur, nL, hist_D, &nV);\n", "      nL = hist_main_pass(g, W, cur, nL, hist_D, &nV);\n      VSG_OCT_STAMP(14);\n", "hist main pass")
+        s = sub(s, "  if (hist_D) hist_setup(g, W, cur, nL, pts, npts, hist_D);\n", "  if (hist_D) hist_setup(g, W, cur, nL, pts, npts, hist_D);\n  VSG_OCT_STAMP(13);\n", "hist setup")
         s = sub(s, "      nL = run_main_pass(g, P, W, cur, nL, pts, npts, &nV);\n", "      nL = run_main_pass(g, P, W, cur, nL, pts, npts, &nV);\n      VSG_OCT_STAMP(10);\n", "main pass")
         s = sub(s, "        g.sort_partition_phase(sortbuf, nV, (uint16_t *)W.scanA, (uint16_t *)W.scanB);\n        g.sync();",
                 "        VSG_OCT_STAMP(20);\n        g.sort_partition_phase(sortbuf, nV, (uint16_t *)W.scanA, (uint16_t *)W.scanB);\n        g.sync();\n        VSG_OCT_STAMP(21);", "sort")
-        s = sub(s, "        nL = run_pass(g, P, W, cur, nL, nV, true, pts, npts, &nV2);\n", "        VSG_OCT_STAMP(22);\n        nL = run_pass(g, P, W, cur, nL, nV, true, pts, npts, &nV2);\n        VSG_OCT_STAMP(23);\n", "careful")
+        s = sub(s, "        int nV2 = 0;\n", "        VSG_OCT_STAMP(22);\n        int nV2 = 0;\n", "careful in")
+        s = sub(s, "        nV = nV2;\n", "        VSG_OCT_STAMP(23);\n        nV = nV2;\n", "careful out")
         # inside fused_main_passes: after the counting sweep, the coarser counts, every node-only pass, the table, the relabel
-        s = sub(s, "  for (int i = g.tid; i < nRoots * 16; i += g.nthreads) {  // depth 2", "  VSG_OCT_STAMP(12);\n  for (int i = g.tid; i < nRoots * 16; i += g.nthreads) {  // depth 2", "f12")
-        s = sub(s, "  int nV = 0;\n  *state = 0;\n", "  VSG_OCT_STAMP(13);\n  int nV = 0;\n  *state = 0;\n", "f13")
-        s = sub(s, "    cur = nb;\n    nL = newL;\n    nV = E;\n", "    cur = nb;\n    nL = newL;\n    nV = E;\n    VSG_OCT_STAMP(14);\n", "f14")
+        s = sub(s, "  for (int d = D - 1; d >= 1; d--) {  // level d = sums of four level d + 1 cells", "  VSG_OCT_STAMP(12);\n  for (int d = D - 1; d >= 1; d--) {  // level d = sums of four level d + 1 cells", "f12")
         # inside the one-node-per-thread pass: node read, child counts read, block scan, children written, barrier
-        s = sub(s, "        d = cnt > 1;\n        if (d) {\n          const int base = (code >> 8)", "        d = cnt > 1;\n        asm volatile(\"\" : \"+v\"(ulx), \"+v\"(uly), \"+v\"(urx), \"+v\"(bly), \"+v\"(code), \"+v\"(cnt));\n        VSG_OCT_STAMP(40);\n        if (d) {\n          const int base = (code >> 8)", "f40")
-        s = sub(s, "      int ex = 0, exKept = 0, kept = 0;\n", "      asm volatile(\"\" : \"+v\"(k), \"+v\"(e));\n      VSG_OCT_STAMP(41);\n      int ex = 0, exKept = 0, kept = 0;\n", "f41")
-        s = sub(s, "      const int K = total & 0xFFFF, E = total >> 16;\n      if (have) {\n        if (d) {\n          const int q0 = ex & 0xFFFF", "      const int K = total & 0xFFFF, E = total >> 16;\n      VSG_OCT_STAMP(42);\n      if (have) {\n        if (d) {\n          const int q0 = ex & 0xFFFF", "f42")
-        s = sub(s, "      g.sync();\n      cur = nb;\n      nL = K + kept;\n", "      VSG_OCT_STAMP(43);\n      g.sync();\n      VSG_OCT_STAMP(44);\n      cur = nb;\n      nL = K + kept;\n", "f43")
         s = sub(s, "  g.sync();\n  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.cellpos[n]; });", "  g.sync();\n  VSG_OCT_STAMP(15);\n  pts.for_each(g, npts, [&](uint32_t, int &n) { n = W.cellpos[n]; });", "f15")
         s = sub(s, "  g.sync();\n  return nL;\n}\n\n// Points in memory", "  g.sync();\n  VSG_OCT_STAMP(30);\n  return nL;\n}\n\n// Points in memory", "final")
         core.write_text(s)
@@ -69,7 +65,7 @@ __device__ __forceinline__ void vsg_oct_stamp(int tag) {
 #define VSG_OCT_STAMP(tag) vsg_oct_stamp(tag)
 '''
         s = sub(s, '#include "vsg_octree_core.h"', stamp + '#include "vsg_octree_core.h"', "include")
-        s = sub(s, "  octree::Work W;\n  octree::carve(W, oct_lds, cap);\n  BlockGroup g;", "  VSG_OCT_STAMP(0);\n  octree::Work W;\n  octree::carve(W, oct_lds, cap);\n  BlockGroup g;", "enter")
+        s = sub(s, "  octree::Work W;\n  octree::carve(W, oct_lds, cap, a.hist_big != 0);\n  BlockGroup g;", "  VSG_OCT_STAMP(0);\n  octree::Work W;\n  octree::carve(W, oct_lds, cap, a.hist_big != 0);\n  BlockGroup g;", "enter")
         s = sub(s, "  if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;\n", "  if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;\n  VSG_OCT_STAMP(31);\n", "exit")
         export = '''extern "C" int vsg_debug_oct_stamps(unsigned long long *out, int reset) {
   hipDeviceSynchronize();
