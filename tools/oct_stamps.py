@@ -3,7 +3,7 @@
 s_memtime at the phase boundaries of DistributeOctTree (tid 0 of every level's workgroup, frame 0); this script runs
 blocking single-frame operator() calls through that build and prints the deltas per level.  Shares, not lengths: the
 stamps' waits forbid overlaps the real kernel has.
-    VSG_LIB=tools/_bin/libvsg_octstamp.so python tools/oct_stamps.py [content class]"""
+    VSG_LIB=tools/_bin/libvsg_octstamp.so python tools/oct_stamps.py [content class [width height nFeatures]]"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -21,8 +21,10 @@ TAGS = {0: "enter", 1: "prefix scan + compaction", 2: "points loaded", 3: "initi
         21: "partition phase", 22: "stable ranks", 23: "careful pass", 30: "best point per node", 31: "exit"}
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "rectangles"
-img = synth.content_frame(kind, 640, 480, 1000, 3)
-ex = orb.ORBextractor(1000, 1.2, 8, 20, 7)
+GW, GH, NF = (int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (640, 480, 1000)
+img = synth.content_frame(kind, GW, GH, NF, 3)
+ex = orb.ORBextractor(NF, 1.2, 8, 20, 7)
+print(f"{kind} {GW}x{GH} / {NF}")
 L = orb.load_library()
 L.vsg_debug_oct_stamps.argtypes = [C.c_void_p, C.c_int]
 for _ in range(30):
@@ -37,6 +39,9 @@ for rep in range(REPS):
     st = buf.reshape(8, 32, 2)
     for lv in range(8):
         rows = [(int(t), int(tag)) for t, tag in st[lv] if t]
+        ends = [i for i, (_, tag) in enumerate(rows) if tag == 31]
+        if ends:
+            rows = rows[:ends[0] + 1]  # the slots behind a call's last stamp hold an earlier call's
         seq = []
         for (t0, _), (t1, tag) in zip(rows, rows[1:]):
             seq.append((tag, t1 - t0))
