@@ -139,6 +139,26 @@ def test_empty_constant_and_lapping_slots():
         assert_same_output(ex(img, None, lap), ref(img, lap), f"lapping {lap}")
 
 
+@pytest.mark.parametrize("w,h,nf", [(752, 480, 1200), (1241, 376, 2000), (1280, 720, 2000)])
+def test_wide_frames_with_empty_initial_nodes(w, h, nf):
+    """Two to four initial nodes (`round(width / height)`, ORBextractor.cc:566-586) of which some hold no candidate and are
+    erased (`:597-608`): frames whose texture is confined to some of the vertical strips, every subset of strips; the
+    whole frame textured is the case the other tests cover.  (Round 6: the two-to-four-node case has its own code path.)"""
+    ex, ref = orb.ORBextractor(nf, 1.2, 8, 20, 7), ol.OracleExtractor(nf, 1.2, 8, 20, 7)
+    nI = int(round(w / h))
+    assert 2 <= nI <= 4
+    img0 = synth.frame(w, h, 21)
+    for mask in range(1, (1 << nI) - 1):
+        img = np.full_like(img0, 97)
+        for i in range(nI):
+            if (mask >> i) & 1:
+                a, b = i * w // nI, (i + 1) * w // nI
+                img[:, a:b] = img0[:, a:b]
+        got, want = ex(img), ref(img)
+        assert len(want[1]) > 50
+        assert_same_output(got, want, f"{w}x{h} strips {mask:0{nI}b}")
+
+
 def test_same_handle_different_sizes_and_reuse():
     ex = orb.ORBextractor(800, 1.2, 6, 20, 7)
     ref = ol.OracleExtractor(800, 1.2, 6, 20, 7)

@@ -412,6 +412,31 @@ def test_octree_core_multiple_initial_nodes(hc):
         kp = e.level_keypoints(l)
         gx, gy, gr = hc_octree(hc, l, x[::-1], y[::-1], r[::-1])
         assert np.array_equal(gx + 16, kp["x"].astype(np.int32)) and np.array_equal(gy + 16, kp["y"].astype(np.int32))
+    # EMPTY initial nodes among two to four (:597-608: erased, the others keep their order): points confined to some of
+    # the vertical strips of the level, every subset of strips
+    rng = np.random.default_rng(5)
+    for l in (0, 3):
+        info = level_info(hc, l)
+        W, H, nI = info["oct_width"], info["oct_height"], info["nIni"]
+        hX = np.float32(W) / np.float32(nI)
+        for mask in range(1, 1 << nI):
+            n = int(rng.integers(40, 900))
+            xs, ys = rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)
+            strip = np.minimum((xs.astype(np.float32) / hX).astype(np.int64), nI - 1)
+            keep = ((mask >> strip) & 1) == 1
+            pts = np.unique(np.stack([ys[keep], xs[keep]], 1), axis=0)
+            if len(pts) == 0:
+                continue
+            ys, xs = pts[:, 0], pts[:, 1]
+            rs = rng.integers(7, 60, len(xs))
+            i, j = (ys - 3) // info["hCell"], (xs - 3) // info["wCell"]
+            order = np.lexsort((xs, ys, j, i))
+            xs, ys, rs = xs[order], ys[order], rs[order]
+            for N in (3, 40, 300):
+                want = ol.distribute_octree(xs, ys, rs, 16, 16 + W, 16, 16 + H, N)
+                perm = rng.permutation(len(xs))
+                gx, gy, gr = hc_octree(hc, l, xs[perm], ys[perm], rs[perm], N)
+                assert np.array_equal(gx, xs[want]) and np.array_equal(gy, ys[want]) and np.array_equal(gr, rs[want]), (l, mask, N)
 
 
 def test_synth_header_matches_python(hc):

@@ -17,7 +17,7 @@ from visual_sgraphs_amd import orb, synth  # noqa: E402
 TAGS = {0: "enter", 1: "prefix scan + compaction", 2: "points loaded", 3: "initial nodes", 10: "main pass (labels)", 12: "hist: counting sweep", 13: "hist: coarser counts",
         14: "hist: main pass (counts)", 15: "hist: cell table", 11: "hist: relabel sweep", 40: "  pass: node read", 41: "  pass: child counts read",
         42: "  pass: block scan", 43: "  pass: children written", 44: "  pass: barrier",
-        20: "sort keys built",
+        20: "sort keys built", 50: "  sort: one round of ranges",
         21: "partition phase", 22: "stable ranks", 23: "careful pass", 30: "best point per node", 31: "exit"}
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "rectangles"

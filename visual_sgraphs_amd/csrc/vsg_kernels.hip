@@ -992,18 +992,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_sgpr(VSG_FAST_SGPRS),
 
 // ------------------------------------------------------------------------------------------------
 // Workgroup implementation of the octree Group concept.
-enum { kSortStack = 24, kMaxWaves = 16 };  // kMaxWaves: wavefronts per workgroup the block scans support  // >= 2 * lg(n) + 1 pending ranges for n < 2048
+enum { kSortStack = 24, kMaxWaves = 16, kSortFrontier = 128, kSortStackInts = 4 + 2 * kSortFrontier };  // kMaxWaves: wavefronts per workgroup the block scans support  // >= 2 * lg(n) + 1 pending ranges for n < 2048
 
 struct BlockGroup {
   int tid, nthreads;
   int *wtot;  // LDS, one int per wave
-  int *stk;   // LDS, 3 * kSortStack ints: the quicksort range stack of sort_partition_phase
+  int *stk;   // LDS, kSortStackInts ints: the quicksort range stack (3 * kSortStack) / the range frontiers of sort_partition_phase
   __device__ void sync() { __syncthreads(); }
   __device__ int atomic_add(int *p, int v) { return atomicAdd(p, v); }
   __device__ void atomic_max(uint32_t *p, uint32_t v) { atomicMax(p, v); }
   __device__ void atomic_max64(uint64_t *p, uint64_t v) { atomicMax((unsigned long long *)p, (unsigned long long)v); }
   __device__ void atomic_min(int *p, int v) { atomicMin(p, v); }
   static __device__ __forceinline__ int wave_inclusive_scan(int v) { return wave_inclusive_scan_i32(v); }
+  // p[0..4) += the workgroup's sums of four per-thread counts: wave sums, then at most four atomics per wave
+  __device__ void add4(int *p, int c0, int c1, int c2, int c3) {
+    const int s0 = __builtin_amdgcn_readlane(wave_inclusive_scan_i32(c0), 63);
+    const int s1 = __builtin_amdgcn_readlane(wave_inclusive_scan_i32(c1), 63);
+    const int s2 = __builtin_amdgcn_readlane(wave_inclusive_scan_i32(c2), 63);
+    const int s3 = __builtin_amdgcn_readlane(wave_inclusive_scan_i32(c3), 63);
+    if ((tid & 63) == 0) {
+      if (s0) atomicAdd(&p[0], s0);
+      if (s1) atomicAdd(&p[1], s1);
+      if (s2) atomicAdd(&p[2], s2);
+      if (s3) atomicAdd(&p[3], s3);
+    }
+  }
   __device__ int exclusive_scan(int *a, int n) {
     const int per = (n + nthreads - 1) / nthreads;
     const int lo = min(tid * per, n), hi = min(lo + per, n);
@@ -1191,6 +1204,83 @@ struct BlockGroup {
 #ifndef VSG_OCT_NO_REGSORT  // A/B builds: the LDS form for every n
     if (n <= 64) {
       sort_partition_phase_regs(a, n);
+      return;
+    }
+#endif
+#ifndef VSG_OCT_SERIAL_SORT
+    // More than 64 items (1200+ features per frame, photographs, 1280x720): the ranges the quicksort loop leaves behind are
+    // disjoint and each is partitioned from its own data alone, so the ORDER in which introsort works them off does not
+    // change the result -- all ranges of one recursion depth are partitioned at once, one range per wave: as many rounds as
+    // the recursion is deep (4-6) instead of one step per range (n / 12: 47 k cycles for the ~150 nodes of a 1250-feature
+    // frame's level 0, profiles/r06_i_*).  A round's ranges lie in a frontier list (lo | hi << 12 | depth << 24), the children
+    // go to the other list; three counters rotate (read / filled / zeroed) so that a round needs ONE barrier.
+    if (n < 4096 && n <= 17 * (kSortFrontier - 1) && nthreads >= 128) {
+      const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+      const uint64_t lt = (1ull << lane) - 1;
+      uint32_t *F0 = (uint32_t *)(stk + 4), *F1 = F0 + kSortFrontier;
+      if (tid == 0) {
+        F0[0] = 0u | ((uint32_t)n << 12) | ((uint32_t)(2 * introsort::lg_(n)) << 24);
+        stk[0] = 1, stk[1] = 0, stk[2] = 0;
+      }
+      __syncthreads();
+      for (int round = 0;; round++) {
+        const int ic = round % 3, in = (round + 1) % 3, iz = (round + 2) % 3;
+        const int R = stk[ic];
+        if (R == 0) break;  // workgroup-uniform
+        const uint32_t *Fc = (round & 1) ? F1 : F0;
+        uint32_t *Fn = (round & 1) ? F0 : F1;
+        if (tid == 0) stk[iz] = 0;  // the counter the round after this one fills (last read a round ago)
+        for (int r = wave; r < R; r += nwaves) {
+          const uint32_t w = Fc[r];
+          const int lo = (int)(w & 0xFFFu), hi = (int)((w >> 12) & 0xFFFu);
+          int depth = (int)(w >> 24);
+          if (depth == 0) {
+            if (lane == 0) introsort::heap_sort_(a + lo, hi - lo);
+            continue;
+          }
+          --depth;
+          if (lane == 0) introsort::move_median_to_first_(a + lo, a + lo + 1, a + lo + (hi - lo) / 2, a + hi - 1);
+          __threadfence_block();
+          const uint32_t P = (uint32_t)(a[lo] >> 32);
+          const int s = lo + 1, e = hi;
+          uint16_t *pA = posA + lo, *pB = posB + lo;  // <= hi - lo - 1 / hi - lo entries: inside the range's own slots
+          int nA = 0, nB = 0;
+          for (int c = 0; s + c < e; c += 64) {
+            const int ia = s + c + lane, ib = e - 1 - c - lane;
+            const bool fa = ia < e && (uint32_t)(a[ia] >> 32) >= P;
+            const bool fb = ib >= s && (uint32_t)(a[ib] >> 32) <= P;
+            const uint64_t ba = __ballot(fa), bb = __ballot(fb);
+            if (fa) pA[nA + __popcll(ba & lt)] = (uint16_t)ia;
+            if (fb) pB[nB + __popcll(bb & lt)] = (uint16_t)ib;
+            nA += __popcll(ba);
+            nB += __popcll(bb);
+          }
+          if (lane == 0) pB[nB] = (uint16_t)lo;  // the pivot slot stops the downward scan
+          nB++;
+          __threadfence_block();
+          const int np = nA < nB ? nA : nB;
+          int K = 0;
+          for (int c = 0; c < np; c += 64) {
+            const int j = c + lane;
+            const bool sw = j < np && pA[j] < pB[j];
+            const uint64_t bs = __ballot(sw);
+            if (sw) {
+              const int ia = pA[j], ib = pB[j];
+              const introsort::item_t t = a[ia];
+              a[ia] = a[ib];
+              a[ib] = t;
+            }
+            K += __popcll(bs);
+          }
+          const int cutA = K < nA ? (int)pA[K] : 0x7FFFFFFF, cutB = K >= 1 ? (int)pB[K - 1] : e;
+          const int cut = cutA < cutB ? cutA : cutB;
+          if (lane == 0) {
+            if (cut - lo > 16) Fn[atomicAdd(&stk[in], 1)] = (uint32_t)lo | ((uint32_t)cut << 12) | ((uint32_t)depth << 24);
+            if (hi - cut > 16) Fn[atomicAdd(&stk[in], 1)] = (uint32_t)cut | ((uint32_t)hi << 12) | ((uint32_t)depth << 24);
+          }
+        }
+        __syncthreads();
+      }
       return;
     }
 #endif
@@ -1468,14 +1558,14 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG_OCT_WAVES, VSG_OCT_WAVES))) void k_octree(OctArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
-  __shared__ int sort_stack[3 * kSortStack];
+  __shared__ int sort_stack[kSortStackInts];
   octree_block(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
 }
 // calls of a few frames: registers instead of residency
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree_few(OctArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
-  __shared__ int sort_stack[3 * kSortStack];
+  __shared__ int sort_stack[kSortStackInts];
   octree_block(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
 }
 
@@ -1484,7 +1574,7 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 
 __global__ __launch_bounds__(256) void k_debug_sort(uint64_t *items, int n) {
   extern __shared__ __attribute__((aligned(16))) uint8_t dbg_lds[];
   __shared__ int wtot[2 * kMaxWaves];
-  __shared__ int sort_stack[3 * kSortStack];
+  __shared__ int sort_stack[kSortStackInts];
   introsort::item_t *buf = (introsort::item_t *)dbg_lds;
   uint16_t *posA = (uint16_t *)(buf + n), *posB = posA + n + 2;
   BlockGroup g;
@@ -1763,7 +1853,7 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG
     OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels, int nframes, int lead) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
-  __shared__ int sort_stack[3 * kSortStack];
+  __shared__ int sort_stack[kSortStackInts];
   octree_blur_body(a, pyr, blur, s0, nlevels, nframes, lead, oct_lds, wtot, sort_stack);
 }
 // (Rounds 3-5 had a second instantiation of this launch for calls of a few frames, compiled for 4 waves per SIMD; since round 5

@@ -51,6 +51,8 @@ struct SerialGroup {
   VSG_OCT_HD void atomic_min(int *p, int v) {
     if (v < *p) *p = v;
   }
+  // p[0..4) += the group's sums of four per-thread counts
+  VSG_OCT_HD void add4(int *p, int c0, int c1, int c2, int c3) { p[0] += c0, p[1] += c1, p[2] += c2, p[3] += c3; }
   // in-place exclusive prefix sum of a[0..n); returns the total
   VSG_OCT_HD int exclusive_scan(int *a, int n) {
     int s = 0;
@@ -740,6 +742,44 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
     cur = 1;
     nL = npts > 0 ? 1 : 0;
     g.sync();
+  } else if (P.nIni <= 4) {
+    // two to four initial nodes (16:9, 752x480, ...): thresholds and corners in registers up front -- read inside the sweep they
+    // were re-loaded from the level's table for every point (its stores may alias them) --, the counts summed per wave
+    // (256 same-word LDS atomics before), every thread places the nodes from the four counts, and the relabelling sweep only
+    // runs when an initial node is empty (one-frame 752x480: 13.1 k -> ... cycles, profiles/r06_i_*)
+    const int nI = P.nIni;
+    const int t1 = P.iniThresh[1], t2 = nI > 2 ? P.iniThresh[2] : 0x7FFFFFFF, t3 = nI > 3 ? P.iniThresh[3] : 0x7FFFFFFF;
+    const int u0 = P.iniUL[0], u1 = P.iniUL[1], u2 = P.iniUL[2], u3 = nI > 2 ? P.iniUL[3] : 0, u4 = nI > 3 ? P.iniUL[4] : 0;
+    for (int i = g.tid; i < 4; i += g.nthreads) W.cnt(0)[i] = 0;
+    g.sync();
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    pts.init_each(g, npts, [&](uint32_t c, int &n) {
+      const int x = VSG_CAND_X(c);
+      const int idx = (x >= t1) + (x >= t2) + (x >= t3);
+      n = idx;
+      c0 += idx == 0, c1 += idx == 1, c2 += idx == 2, c3 += idx == 3;
+    });
+    g.add4(&W.cnt(0)[0], c0, c1, c2, c3);
+    g.sync();
+    // erase empty initial nodes, keep order (:597-608)
+    const int k0 = W.cnt(0)[0], k1 = W.cnt(0)[1], k2 = W.cnt(0)[2], k3 = W.cnt(0)[3];
+    const int p1 = k0 > 0, p2 = p1 + (k1 > 0), p3 = p2 + (k2 > 0);
+    nL = p3 + (k3 > 0);
+    for (int i = g.tid; i < nI; i += g.nthreads) {
+      const int ki = i == 0 ? k0 : i == 1 ? k1 : i == 2 ? k2 : k3;
+      if (ki > 0) {
+        const int pos = i == 0 ? 0 : i == 1 ? p1 : i == 2 ? p2 : p3;
+        W.ulx(1)[pos] = (int16_t)(i == 0 ? u0 : i == 1 ? u1 : i == 2 ? u2 : u3);
+        W.urx(1)[pos] = (int16_t)(i == 0 ? u1 : i == 1 ? u2 : i == 2 ? u3 : u4);
+        W.uly(1)[pos] = 0;
+        W.bly(1)[pos] = (int16_t)P.height;
+        W.cnt(1)[pos] = ki;
+      }
+    }
+    if (nL != nI)  // group-uniform
+      pts.for_each(g, npts, [&](uint32_t, int &n) { n = n == 0 ? 0 : n == 1 ? p1 : n == 2 ? p2 : p3; });
+    cur = 1;
+    g.sync();
   } else {
     for (int i = g.tid; i < P.nIni; i += g.nthreads) {
       W.ulx(0)[i] = (int16_t)P.iniUL[i];
@@ -749,20 +789,14 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
       W.cnt(0)[i] = 0;
     }
     g.sync();
-    // vpIniNodes[kp.pt.x / hX] (:589-593); the first four nodes are counted in registers, one atomic per thread and node
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    // vpIniNodes[kp.pt.x / hX] (:589-593), five and more initial nodes (no such geometry among the reference's settings)
     pts.init_each(g, npts, [&](uint32_t c, int &n) {
       const int x = VSG_CAND_X(c);
       int idx = 0;
       for (int i = 1; i < P.nIni; i++) idx += (x >= P.iniThresh[i]);
       n = idx;
-      c0 += idx == 0, c1 += idx == 1, c2 += idx == 2, c3 += idx == 3;
-      if (idx > 3) g.atomic_add(&W.cnt(0)[idx], 1);
+      g.atomic_add(&W.cnt(0)[idx], 1);
     });
-    if (c0) g.atomic_add(&W.cnt(0)[0], c0);
-    if (c1) g.atomic_add(&W.cnt(0)[1], c1);
-    if (c2) g.atomic_add(&W.cnt(0)[2], c2);
-    if (c3) g.atomic_add(&W.cnt(0)[3], c3);
     g.sync();
     // erase empty initial nodes, keep order (:597-608)
     if (g.tid == 0) {
