@@ -66,7 +66,8 @@ __device__ __forceinline__ void vsg_oct_stamp(int tag) {
 '''
         s = sub(s, '#include "vsg_octree_core.h"', stamp + '#include "vsg_octree_core.h"', "include")
         s = sub(s, "  octree::Work W;\n  octree::carve(W, oct_lds, cap, a.hist_big != 0);\n  BlockGroup g;", "  VSG_OCT_STAMP(0);\n  octree::Work W;\n  octree::carve(W, oct_lds, cap, a.hist_big != 0);\n  BlockGroup g;", "enter")
-        s = sub(s, "          }\n        }\n        __syncthreads();\n      }\n      return;\n    }\n#endif", "          }\n        }\n        __syncthreads();\n        VSG_OCT_STAMP(50);\n      }\n      return;\n    }\n#endif", "sort round")
+        if "--sort-rounds" in sys.argv:  # one stamp per round of the introsort replay (each stamp costs the wave ~1 k cycles)
+            s = sub(s, "          }\n        }\n        __syncthreads();\n      }\n      return;\n    }\n#endif", "          }\n        }\n        __syncthreads();\n        VSG_OCT_STAMP(50);\n      }\n      return;\n    }\n#endif", "sort round")
         s = sub(s, "  if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;\n", "  if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;\n  VSG_OCT_STAMP(31);\n", "exit")
         export = '''extern "C" int vsg_debug_oct_stamps(unsigned long long *out, int reset) {
   hipDeviceSynchronize();

@@ -1239,16 +1239,33 @@ struct BlockGroup {
             continue;
           }
           --depth;
-          if (lane == 0) introsort::move_median_to_first_(a + lo, a + lo + 1, a + lo + (hi - lo) / 2, a + hi - 1);
+          // A step is a chain of dependent LDS round trips (~300 cycles each for one wave of a nearly idle CU), so it is written
+          // to need few: ONE round of reads brings the four items the median rule looks at and the lane's items of the first
+          // chunk from either end; every lane evaluates __move_median_to_first (stl_algo.h) itself and patches what it holds,
+          // lane 0 writes the swap; cut and children come out of registers where the lists fit one chunk.
+          const int s = lo + 1, e = hi, pmid = lo + (hi - lo) / 2;
+          const introsort::item_t i0 = a[lo], iA = a[lo + 1], iB = a[pmid], iC = a[hi - 1];
+          const int qa0 = s + lane, qb0 = e - 1 - lane;
+          introsort::item_t xa = a[qa0 < e ? qa0 : e - 1], xb = a[qb0 >= s ? qb0 : s];
+          const uint32_t ka = (uint32_t)(iA >> 32), kb = (uint32_t)(iB >> 32), kc = (uint32_t)(iC >> 32);
+          int pm;
+          if (ka < kb)
+            pm = kb < kc ? pmid : ka < kc ? hi - 1 : lo + 1;
+          else
+            pm = ka < kc ? lo + 1 : kb < kc ? hi - 1 : pmid;
+          const introsort::item_t im = pm == lo + 1 ? iA : pm == pmid ? iB : iC;
+          if (lane == 0) a[lo] = im, a[pm] = i0;
           __threadfence_block();
-          const uint32_t P = (uint32_t)(a[lo] >> 32);
-          const int s = lo + 1, e = hi;
+          const uint32_t P = (uint32_t)(im >> 32);
           uint16_t *pA = posA + lo, *pB = posB + lo;  // <= hi - lo - 1 / hi - lo entries: inside the range's own slots
           int nA = 0, nB = 0;
           for (int c = 0; s + c < e; c += 64) {
             const int ia = s + c + lane, ib = e - 1 - c - lane;
-            const bool fa = ia < e && (uint32_t)(a[ia] >> 32) >= P;
-            const bool fb = ib >= s && (uint32_t)(a[ib] >> 32) <= P;
+            if (c) xa = a[ia < e ? ia : e - 1], xb = a[ib >= s ? ib : s];  // (behind lane 0's swap: LDS keeps a wave's order)
+            if (ia == pm) xa = i0;
+            if (ib == pm) xb = i0;
+            const bool fa = ia < e && (uint32_t)(xa >> 32) >= P;
+            const bool fb = ib >= s && (uint32_t)(xb >> 32) <= P;
             const uint64_t ba = __ballot(fa), bb = __ballot(fb);
             if (fa) pA[nA + __popcll(ba & lt)] = (uint16_t)ia;
             if (fb) pB[nB + __popcll(bb & lt)] = (uint16_t)ib;
@@ -1259,24 +1276,42 @@ struct BlockGroup {
           nB++;
           __threadfence_block();
           const int np = nA < nB ? nA : nB;
-          int K = 0;
-          for (int c = 0; c < np; c += 64) {
-            const int j = c + lane;
-            const bool sw = j < np && pA[j] < pB[j];
-            const uint64_t bs = __ballot(sw);
+          int K = 0, cut;
+          if (nA < 64 && nB <= 64) {  // both lists in one chunk: the cut comes out of the lanes' registers
+            const int vA = lane < nA ? (int)pA[lane] : 0x7FFFFFFF, vB = lane < nB ? (int)pB[lane] : -1;
+            const bool sw = lane < np && vA < vB;
+            K = __popcll(__ballot(sw));
             if (sw) {
-              const int ia = pA[j], ib = pB[j];
-              const introsort::item_t t = a[ia];
-              a[ia] = a[ib];
-              a[ib] = t;
+              const introsort::item_t t = a[vA];
+              a[vA] = a[vB];
+              a[vB] = t;
             }
-            K += __popcll(bs);
+            const int cutA = __builtin_amdgcn_readlane(vA, K);  // K <= np <= nA < 64; lanes >= nA hold "none"
+            const int cutB = K >= 1 ? __builtin_amdgcn_readlane(vB, K - 1) : e;
+            cut = cutA < cutB ? cutA : cutB;
+          } else {
+            for (int c = 0; c < np; c += 64) {
+              const int j = c + lane;
+              const bool sw = j < np && pA[j] < pB[j];
+              const uint64_t bs = __ballot(sw);
+              if (sw) {
+                const int ia = pA[j], ib = pB[j];
+                const introsort::item_t t = a[ia];
+                a[ia] = a[ib];
+                a[ib] = t;
+              }
+              K += __popcll(bs);
+            }
+            const int cutA = K < nA ? (int)pA[K] : 0x7FFFFFFF, cutB = K >= 1 ? (int)pB[K - 1] : e;
+            cut = cutA < cutB ? cutA : cutB;
           }
-          const int cutA = K < nA ? (int)pA[K] : 0x7FFFFFFF, cutB = K >= 1 ? (int)pB[K - 1] : e;
-          const int cut = cutA < cutB ? cutA : cutB;
           if (lane == 0) {
-            if (cut - lo > 16) Fn[atomicAdd(&stk[in], 1)] = (uint32_t)lo | ((uint32_t)cut << 12) | ((uint32_t)depth << 24);
-            if (hi - cut > 16) Fn[atomicAdd(&stk[in], 1)] = (uint32_t)cut | ((uint32_t)hi << 12) | ((uint32_t)depth << 24);
+            const int cl = cut - lo > 16, cr = hi - cut > 16;
+            if (cl + cr) {
+              const int at = atomicAdd(&stk[in], cl + cr);
+              if (cl) Fn[at] = (uint32_t)lo | ((uint32_t)cut << 12) | ((uint32_t)depth << 24);
+              if (cr) Fn[at + cl] = (uint32_t)cut | ((uint32_t)hi << 12) | ((uint32_t)depth << 24);
+            }
           }
         }
         __syncthreads();
