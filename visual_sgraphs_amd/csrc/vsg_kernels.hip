@@ -1211,7 +1211,7 @@ struct BlockGroup {
     // More than 64 items (1200+ features per frame, photographs, 1280x720): the ranges the quicksort loop leaves behind are
     // disjoint and each is partitioned from its own data alone, so the ORDER in which introsort works them off does not
     // change the result -- all ranges of one recursion depth are partitioned at once, one range per wave: as many rounds as
-    // the recursion is deep (4-6) instead of one step per range (n / 12: 47 k cycles for the ~150 nodes of a 1250-feature
+    // the recursion is deep (5-9 on real node lists) instead of one step per range (n / 12: 47 k cycles for the ~150 nodes of a 1250-feature
     // frame's level 0, profiles/r06_i_*).  A round's ranges lie in a frontier list (lo | hi << 12 | depth << 24), the children
     // go to the other list; three counters rotate (read / filled / zeroed) so that a round needs ONE barrier.
     if (n < 4096 && n <= 17 * (kSortFrontier - 1) && nthreads >= 128) {

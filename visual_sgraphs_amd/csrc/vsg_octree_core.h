@@ -746,7 +746,7 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
     // two to four initial nodes (16:9, 752x480, ...): thresholds and corners in registers up front -- read inside the sweep they
     // were re-loaded from the level's table for every point (its stores may alias them) --, the counts summed per wave
     // (256 same-word LDS atomics before), every thread places the nodes from the four counts, and the relabelling sweep only
-    // runs when an initial node is empty (one-frame 752x480: 13.1 k -> ... cycles, profiles/r06_i_*)
+    // runs when an initial node is empty (one-frame 752x480: 13.1 k -> 4.0 k cycles, profiles/r06_i_*)
     const int nI = P.nIni;
     const int t1 = P.iniThresh[1], t2 = nI > 2 ? P.iniThresh[2] : 0x7FFFFFFF, t3 = nI > 3 ? P.iniThresh[3] : 0x7FFFFFFF;
     const int u0 = P.iniUL[0], u1 = P.iniUL[1], u2 = P.iniUL[2], u3 = nI > 2 ? P.iniUL[3] : 0, u4 = nI > 3 ? P.iniUL[4] : 0;
