@@ -94,7 +94,10 @@ __global__ void k_hamming_pairs(const uint8_t *a, const uint8_t *b, const int *i
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
   return min(max(a, b), max(min(a, b), c));  // folded to v_med3_u32
 }
-enum { kBest2Rows = 128 };  // A rows per workgroup
+#ifndef VSG_MATCH_QW
+#define VSG_MATCH_QW 2
+#endif
+enum { kMatchQW = VSG_MATCH_QW, kBest2Rows = 128 * kMatchQW };  // query sets of 32 per wave; A rows per workgroup
 
 // ---- the best / second-best scan on the matrix cores.  A Hamming distance matrix is a GEMM over +-1 vectors:
 // with s(x) = 2*bit - 1, sum_k s(a_k) * s(b_k) = 256 - 2 * dist.  The train rows are expanded with their bits
@@ -138,16 +141,25 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
   const uint8_t *A = a_base + (size_t)blk * block_stride, *B = b_base + (size_t)blk * block_stride;
   if (blockIdx.x * kBest2Rows >= na) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int q = blockIdx.x * kBest2Rows + wave * 32 + r;  // this lane's query (column)
-  const bool wave_active = blockIdx.x * kBest2Rows + wave * 32 < na;
+  // A wave owns QW sets of 32 queries (round 6: two): the train operand read from LDS feeds QW matrix instructions, whose
+  // accumulator chains are independent, and the workgroup's tile expansion serves twice the queries.  Per 1024 x 1006^2 pairs:
+  // QW 1 / 2 / 3 / 4 = 0.204 / 0.186 / 0.199 / 0.221 ms at 78 / 114 / 154 / 186 VGPRs (6 / 4 / 3 / 2 waves per SIMD); two sets forced
+  // into 96 registers spill and take 0.50 ms (profiles/r06_f_*)
+  constexpr int QW = kMatchQW;
+  const int q0 = blockIdx.x * kBest2Rows + wave * 32 * QW + r;  // this lane's query (column) of set 0; set u: + 32 u
+  const bool wave_active = blockIdx.x * kBest2Rows + wave * 32 * QW < na;
   // queries: dword 2 s + h of the descriptor is the lane's 32 K-values of k-step s (expanded below, once the table is there)
-  uint32_t qraw[4];
-  {
+  uint32_t qraw[QW][4];
+#pragma unroll
+  for (int u = 0; u < QW; u++) {
+    const int q = q0 + 32 * u;
     const uint32_t *qd = (const uint32_t *)(A + (size_t)(q < na ? q : 0) * 32);
 #pragma unroll
-    for (int s = 0; s < 4; s++) qraw[s] = qd[2 * s + h];
+    for (int s = 0; s < 4; s++) qraw[u][s] = qd[2 * s + h];
   }
-  uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+  uint32_t k1[QW], k2[QW];
+#pragma unroll
+  for (int u = 0; u < QW; u++) k1[u] = KEY_NONE, k2[u] = KEY_NONE;
   // tile expansion: thread = (train row, dword); the row runs along the lanes so that a wave's 16-byte LDS stores
   // are contiguous (the dword-fastest mapping put 8 lanes on the same banks: an 8-way conflict on every store)
   const int erow = tid & 31, es = tid >> 5;
@@ -157,7 +169,10 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
   };
   // The train dwords are prefetched a GROUP of kPf tiles ahead (register double bank; 4 keeps the kernel at 5 waves per SIMD): an iteration is ~600 cycles,
   // a global round trip several thousand, so a one-iteration prefetch left every iteration waiting on memory.
-  constexpr int kPf = 4;
+#ifndef VSG_MATCH_PF
+#define VSG_MATCH_PF 4
+#endif
+  constexpr int kPf = VSG_MATCH_PF;
   uint32_t wa[kPf], wn[kPf];
 #pragma unroll
   for (int j = 0; j < kPf; j++) wa[j] = fetch(32 * j), wn[j] = 0u;
@@ -166,9 +181,11 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
   auto expand4 = [&](uint32_t w) {
     return (i32x8){(int)lut[w & 255], (int)lut[(w >> 8) & 255], (int)lut[(w >> 16) & 255], (int)lut[w >> 24], 0, 0, 0, 0};
   };
-  i32x8 Q[4];
+  i32x8 Q[QW][4];
 #pragma unroll
-  for (int s = 0; s < 4; s++) Q[s] = expand4(qraw[s]);
+  for (int u = 0; u < QW; u++)
+#pragma unroll
+    for (int s = 0; s < 4; s++) Q[u][s] = expand4(qraw[u][s]);
   const int kScale = 0x7F7F7F7F;  // e8m0 block scales: 2^0
   int buf = 0;
   for (int tg = 0; tg < nb; tg += 32 * kPf) {
@@ -191,49 +208,54 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
       __syncthreads();
       if (wave_active) {
         // acc = sum of negated products = 2 * dist - 256 (C operand: inline 0)
-        f32x16 acc[TR];
+        f32x16 acc[QW][TR];
         auto opA = [&](int t, int s) {
           const i32x4 v = tiles[buf][t][(s * 2 + h) * 32 + r];
           return (i32x8){v.x, v.y, v.z, v.w, 0, 0, 0, 0};
         };
 #pragma unroll
-        for (int t = 0; t < TR; t++)
-          acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(opA(t, 0), Q[0], zerof, 4, 4, 0, kScale, 0, kScale);
+        for (int s = 0; s < 4; s++)
 #pragma unroll
-        for (int s = 1; s < 4; s++)
+          for (int t = 0; t < TR; t++) {
+            const i32x8 a = opA(t, s);  // ONE operand read for the QW instructions of this k-step
 #pragma unroll
-          for (int t = 0; t < TR; t++)
-            acc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(opA(t, s), Q[s], acc[t], 4, 4, 0, kScale, 0, kScale);
+            for (int u = 0; u < QW; u++)
+              acc[u][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, Q[u][s], s == 0 ? zerof : acc[u][t], 4, 4, 0, kScale, 0,
+                                                                          kScale);
+          }
 #pragma unroll
         for (int t = 0; t < TR; t++) {
           const int tb = t0 + 32 * t + 4 * h;  // row of register 0 of this lane
           if (tb - 4 * h + 32 <= nb) {
-            // full tile: best two of the lane's 16 rows on keys local to the tile -- (acc << 19) + (256 << 19 | row
-            // offset), the constant living in an SGPR: one v_lshl_add_u32 -- then move them to absolute rows
-            // the same fold on FLOAT keys 32 * acc + row offset (exact: |32 acc + 27| < 2^14; the offset < 32 keeps (acc, row)
-            // in lexicographic order): one v_fma_f32, one v_min_f32, one v_med3_f32 per pair; the two survivors become the
-            // integer keys (dist << 20 | row) the rest of the kernel works on
-            float f1 = __builtin_inff(), f2 = __builtin_inff();
+            // full tile: the best two of the lane's 16 rows on FLOAT keys 32 * acc + row offset (exact: |32 acc + 27| < 2^14;
+            // the offset < 32 keeps (acc, row) in lexicographic order): one v_fma_f32, one v_min_f32, one v_med3_f32 per
+            // pair; the two survivors become the integer keys (dist << 20 | row) the rest of the kernel works on
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-              const float kf = __builtin_fmaf(acc[t][g], 32.0f, (float)((g & 3) + 8 * (g >> 2)));
-              f2 = __builtin_amdgcn_fmed3f(f1, f2, kf);
-              f1 = __builtin_fminf(f1, kf);
+            for (int u = 0; u < QW; u++) {
+              float f1 = __builtin_inff(), f2 = __builtin_inff();
+#pragma unroll
+              for (int g = 0; g < 16; g++) {
+                const float kf = __builtin_fmaf(acc[u][t][g], 32.0f, (float)((g & 3) + 8 * (g >> 2)));
+                f2 = __builtin_amdgcn_fmed3f(f1, f2, kf);
+                f1 = __builtin_fminf(f1, kf);
+              }
+              const int i1 = (int)f1, i2 = (int)f2;  // 32 acc + offset: acc = i >> 5 (floor), offset = i & 31
+              const uint32_t l1 = ((uint32_t)((i1 >> 5) + 256) << 19) + (uint32_t)((i1 & 31) + tb);
+              const uint32_t l2 = ((uint32_t)((i2 >> 5) + 256) << 19) + (uint32_t)((i2 & 31) + tb);
+              k2[u] = min(max(k1[u], l1), min(k2[u], l2));
+              k1[u] = min(k1[u], l1);
             }
-            const int i1 = (int)f1, i2 = (int)f2;  // 32 acc + offset: acc = i >> 5 (floor), offset = i & 31
-            const uint32_t l1 = ((uint32_t)((i1 >> 5) + 256) << 19) + (uint32_t)((i1 & 31) + tb);
-            const uint32_t l2 = ((uint32_t)((i2 >> 5) + 256) << 19) + (uint32_t)((i2 & 31) + tb);
-            k2 = min(max(k1, l1), min(k2, l2));
-            k1 = min(k1, l1);
           } else {
 #pragma unroll
-            for (int g = 0; g < 16; g++) {
-              const int row = tb + (g & 3) + 8 * (g >> 2);
-              uint32_t key = ((uint32_t)((int)acc[t][g] + 256) << 19) | (uint32_t)row;
-              if (row >= nb) key = KEY_NONE;
-              k2 = umed3(k1, k2, key);
-              k1 = min(k1, key);
-            }
+            for (int u = 0; u < QW; u++)
+#pragma unroll
+              for (int g = 0; g < 16; g++) {
+                const int row = tb + (g & 3) + 8 * (g >> 2);
+                uint32_t key = ((uint32_t)((int)acc[u][t][g] + 256) << 19) | (uint32_t)row;
+                if (row >= nb) key = KEY_NONE;
+                k2[u] = umed3(k1[u], k2[u], key);
+                k1[u] = min(k1[u], key);
+              }
           }
         }
       }
@@ -242,15 +264,17 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
 #pragma unroll
     for (int j = 0; j < kPf; j++) wa[j] = wn[j];
   }
-  {
-    const uint32_t o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32);
-    merge2(k1, k2, o1, o2);
-  }
-  if (h == 0 && q < na) {
-    const size_t o = (size_t)blk * max_rows + q;
-    best[o] = (int)(k1 >> 20);
-    second[o] = (int)(k2 >> 20);
-    argbest[o] = key_is_none(k1) ? -1 : (int)(k1 & 0xFFFFF);
+#pragma unroll
+  for (int u = 0; u < QW; u++) {
+    const uint32_t o1 = __shfl_xor(k1[u], 32), o2 = __shfl_xor(k2[u], 32);
+    merge2(k1[u], k2[u], o1, o2);
+    const int q = q0 + 32 * u;
+    if (h == 0 && q < na) {
+      const size_t o = (size_t)blk * max_rows + q;
+      best[o] = (int)(k1[u] >> 20);
+      second[o] = (int)(k2[u] >> 20);
+      argbest[o] = key_is_none(k1[u]) ? -1 : (int)(k1[u] & 0xFFFFF);
+    }
   }
 }
 
