@@ -167,10 +167,12 @@ __global__ __launch_bounds__(256) void k_block_best2_mfma(const uint8_t *a_base,
     const int tr = row0 + erow;
     return ~((const uint32_t *)(B + (size_t)(tr < nb ? tr : 0) * 32))[es];
   };
-  // The train dwords are prefetched a GROUP of kPf tiles ahead (register double bank; 4 keeps the kernel at 5 waves per SIMD): an iteration is ~600 cycles,
-  // a global round trip several thousand, so a one-iteration prefetch left every iteration waiting on memory.
+  // The train dwords are prefetched a GROUP of kPf tiles ahead (register double bank): an iteration is ~600 cycles, a global
+  // round trip several thousand, so a one-iteration prefetch left every iteration waiting on memory.  With two query sets per
+  // wave: groups of 4 / 6 / 8 / 10 tiles = 0.185 / 0.200 / 0.181 / 0.188 ms per 1024 x 1006^2 pairs (122 VGPRs at 8: still 4 waves
+  // per SIMD; profiles/r06_f_*)
 #ifndef VSG_MATCH_PF
-#define VSG_MATCH_PF 4
+#define VSG_MATCH_PF 8
 #endif
   constexpr int kPf = VSG_MATCH_PF;
   uint32_t wa[kPf], wn[kPf];
