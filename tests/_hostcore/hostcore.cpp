@@ -98,6 +98,17 @@ int hc_octree(int l, const int *x, const int *y, const int *resp, int n, int N_o
     for (int i = 0; i < m; i++)
       if (sel2[i] != sel[i]) return -1001;
   }
+  {  // the memory form with its sweeps taken 8 points at a time (what the stand-alone k_octree launches)
+    std::vector<uint64_t> buf3(buf.size());
+    octree::Work W3;
+    octree::carve(W3, buf3.data(), cap);
+    std::vector<uint32_t> sel3(cap);
+    std::vector<uint16_t> node3(n > 0 ? n : 1);
+    const int m3 = octree::distribute<8>(g, P, cand.data(), n, node3.data(), W3, sel3.data());
+    if (m3 != m) return -1002;
+    for (int i = 0; i < m; i++)
+      if (sel3[i] != sel[i]) return -1003;
+  }
   return m;
 }
 

@@ -1475,6 +1475,8 @@ struct OctArgs {
   int hist_big;          // the workspace class (vsg_octree_core.h work_bytes)
 };
 
+// kMemU: points per batch of the memory-form sweeps (octree::MemPtsT)
+template <int kMemU>
 __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int frame, uint8_t *oct_lds, int *wtot,
                                              int *sort_stack) {
   const FrameGeom *__restrict__ fg = a.fg;
@@ -1538,8 +1540,25 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
         const int chunk = (npts + g.nthreads - 1) / g.nthreads;
         const int p0 = g.tid * chunk, p1 = min(p0 + chunk, npts);
         if (p0 < p1) {
+          // U points at a time: their source positions from the LDS walk, then U loads in flight, then U stores (one point per
+          // trip waited ~1.5 k cycles for its own load: 116 k cycles for a 1280x720 photograph's level 0, profiles/r06_u_*)
+          constexpr int U = 8;
           int ci = src.cell_of(p0);
-          for (int p = p0; p < p1; p++) {
+          int p = p0;
+          for (; p + U <= p1; p += U) {
+            int so[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+              while (p + u >= src.prefix[ci + 1]) ci++;
+              so[u] = src.segoff[ci] + (p + u - src.prefix[ci]);
+            }
+            uint32_t v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = src.level_cand[so[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) list[p + u] = v[u];
+          }
+          for (; p < p1; p++) {
             while (p >= src.prefix[ci + 1]) ci++;
             list[p] = src.level_cand[src.segoff[ci] + (p - src.prefix[ci])];
           }
@@ -1548,9 +1567,9 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
       __threadfence_block();
       __syncthreads();
       if (npts <= a.lab_cap)  // (two call sites: the compiler has to SEE that the labels are LDS to emit ds_ instead of flat_ accesses)
-        n = octree::distribute(g, P, list, npts, (uint16_t *)(oct_lds + a.lab_off), W, out);
+        n = octree::distribute<kMemU>(g, P, list, npts, (uint16_t *)(oct_lds + a.lab_off), W, out);
       else
-        n = octree::distribute(g, P, list, npts, node_of + coff, W, out);
+        n = octree::distribute<kMemU>(g, P, list, npts, node_of + coff, W, out);
     }
   } else {
     int npts = cand_count[frame * kMaxLevels + level];
@@ -1558,7 +1577,7 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
     // candidates stay in registers across the passes when they fit (the common case); node_of[] is only touched by
     // the fallback
     n = npts <= kOctRegPts * kOctThreads ? octree::distribute_reg<kOctRegPts>(g, P, cand + coff, npts, W, out)
-                                         : octree::distribute(g, P, cand + coff, npts, node_of + coff, W, out);
+                                         : octree::distribute<kMemU>(g, P, cand + coff, npts, node_of + coff, W, out);
   }
   if (threadIdx.x == 0) sel_count[frame * kMaxLevels + level] = n;
 #if VSG_OD_SPATIAL
@@ -1589,19 +1608,29 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
 #ifndef VSG_OCT_WAVES
 #define VSG_OCT_WAVES 5
 #endif
+// Points per batch of the memory-form sweeps (octree::MemPtsT), per kernel: the stand-alone launch (1280x720 and wider: every
+// level 0 is memory-resident) takes 8; the launch that also carries the blur and the one-frame launch keep 1 -- their register
+// allocation is what the default content's register-form levels run on (C2 / 1024, rectangles: octree stage 0.2037 -> 0.2105 ms with
+// 4, unchanged with 1; C4 / 256: 0.318 -> 0.252 with 1, 0.205 with 8; profiles/r06_u_*)
+#ifndef VSG_OCT_MEM_BATCH
+#define VSG_OCT_MEM_BATCH 8
+#endif
+#ifndef VSG_OCT_MEM_BATCH_FUSED
+#define VSG_OCT_MEM_BATCH_FUSED 1
+#endif
 
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG_OCT_WAVES, VSG_OCT_WAVES))) void k_octree(OctArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[kSortStackInts];
-  octree_block(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
+  octree_block<VSG_OCT_MEM_BATCH>(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
 }
 // calls of a few frames: registers instead of residency
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree_few(OctArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[kSortStackInts];
-  octree_block(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
+  octree_block<VSG_OCT_MEM_BATCH_FUSED>(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
 }
 
 // Test hook (vsg_debug_device_sort): the octree's std::sort replay -- wave-parallel partition phase + stable rank --
@@ -1880,7 +1909,7 @@ __device__ __forceinline__ void octree_blur_body(const OctArgs &a, const uint8_t
     if (blk.y < 0 || blk.y >= nframes) return;
   }
   if (blk.x < nlevels)
-    octree_block(a, blk.x, blk.y, oct_lds, wtot, sort_stack);
+    octree_block<VSG_OCT_MEM_BATCH_FUSED>(a, blk.x, blk.y, oct_lds, wtot, sort_stack);
   else
     blur_block<VSG_BLUR_AHEAD>(pyr, blur, a.fg, s0, BlockXY{blk.x - nlevels, blk.y});
 }

@@ -101,14 +101,36 @@ VSG_OCT_HD int node_capacity(int N) { return (N + 3 > 4 * kMaxIniNodes ? N + 3 :
 // MemPts: candidate words and node labels live in memory (cand[] read-only, node_of[] scratch) -- any npts.
 // RegPts<K>: both live in the thread's registers (npts <= K * nthreads): the per-pass sweeps then touch only the
 // node arrays in LDS, which takes the global-memory round trips out of the (latency-bound) pass loop.
-struct MemPts {
+template <int U>
+struct MemPtsT {
   const uint32_t *cand;
   uint16_t *node_of;
   template <class G>
   VSG_OCT_HD void load(G &, int) {}
+  // The sweeps take their points U at a time -- U candidate words and U labels requested, then U bodies, then the changed
+  // labels stored: written one point per trip every trip waited for its own loads (the label store of one trip may alias the
+  // loads of the next, so the compiler keeps them in order), ~700 cycles x 78 trips per sweep over the 20 k candidates of a
+  // photograph's level 0 at 1280x720 (profiles/r06_u_*).  The points of a sweep are independent of each other (shared state
+  // is only touched through the group's atomics), so the order inside a batch does not matter.  U is the kernel's choice: the
+  // batched bodies cost registers, and the launch that also carries the blur and the register form of every 640x480 level
+  // (k_octree_blur) measured 1.2 % slower on the default content with U = 4 where the stand-alone k_octree gains
+  // (vsg_kernels.hip: kOctMemBatch*).
   template <class G, class F>
   VSG_OCT_HD void for_each(G &g, int npts, F f) {
-    for (int p = g.tid; p < npts; p += g.nthreads) {
+    const int step = g.nthreads;
+    int p = g.tid;
+    for (; p + (U - 1) * step < npts; p += U * step) {
+      uint32_t c[U];
+      int n[U], n0[U];
+      VSG_OCT_UNROLL
+      for (int u = 0; u < U; u++) c[u] = cand[p + u * step], n0[u] = n[u] = node_of[p + u * step];
+      VSG_OCT_UNROLL
+      for (int u = 0; u < U; u++) f(c[u], n[u]);
+      VSG_OCT_UNROLL
+      for (int u = 0; u < U; u++)
+        if (n[u] != n0[u]) node_of[p + u * step] = (uint16_t)n[u];
+    }
+    for (; p < npts; p += step) {
       int n = node_of[p];
       const int n0 = n;
       f(cand[p], n);
@@ -117,13 +139,26 @@ struct MemPts {
   }
   template <class G, class F>
   VSG_OCT_HD void init_each(G &g, int npts, F f) {  // first sweep: labels are written, not read
-    for (int p = g.tid; p < npts; p += g.nthreads) {
+    const int step = g.nthreads;
+    int p = g.tid;
+    for (; p + (U - 1) * step < npts; p += U * step) {
+      uint32_t c[U];
+      int n[U];
+      VSG_OCT_UNROLL
+      for (int u = 0; u < U; u++) c[u] = cand[p + u * step], n[u] = 0;
+      VSG_OCT_UNROLL
+      for (int u = 0; u < U; u++) f(c[u], n[u]);
+      VSG_OCT_UNROLL
+      for (int u = 0; u < U; u++) node_of[p + u * step] = (uint16_t)n[u];
+    }
+    for (; p < npts; p += step) {
       int n = 0;
       f(cand[p], n);
       node_of[p] = (uint16_t)n;
     }
   }
 };
+using MemPts = MemPtsT<1>;
 
 // where candidate p comes from: a contiguous array, or (device) the per-cell segments k_fast_cells writes
 struct PtrSrc {
@@ -922,10 +957,10 @@ VSG_OCT_HD int distribute_pts(G &g, const Params &P, PT &pts, int npts, Work &W,
 }
 
 // Points in memory: works for any npts (the host tests and the device fallback).
-template <class G>
+template <int U = 1, class G>
 VSG_OCT_HD int distribute(G &g, const Params &P, const uint32_t *cand, int npts, uint16_t *node_of, Work &W,
                           uint32_t *sel_out) {
-  MemPts pts{cand, node_of};
+  MemPtsT<U> pts{cand, node_of};
   return distribute_pts(g, P, pts, npts, W, sel_out);
 }
 
