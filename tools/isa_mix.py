@@ -42,6 +42,8 @@ def main():
                                  and "octree_blur" not in m.group(1)), None)
                     if name == "orient_desc" and "ILb1E" in m.group(1):
                         name = None  # the mirroring variant of the latency path
+                    if name == "octree" and "k_octree_fewILi1E" not in m.group(1):
+                        name = None  # the instantiation the serialised C2 step launches (k_octree_few<1>)
                     if name == "fast" and "Li128ELi52ELi52E" not in m.group(1):
                         name = None  # the tile-pitch class of 640x480
                     counts = {"full": 0, "half": 0, "dpp_sdwa": 0} if name else None

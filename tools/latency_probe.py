@@ -10,8 +10,10 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from visual_sgraphs_amd import orb, synth  # noqa: E402
 
-ex = orb.ORBextractor(1000, 1.2, 8, 20, 7)
-img = synth.frame(640, 480, 1)
+GW, GH, NF = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (640, 480, 1000)
+KIND = sys.argv[4] if len(sys.argv) > 4 else "rectangles"
+ex = orb.ORBextractor(NF, 1.2, 8, 20, 7)
+img = synth.content_frame(KIND, GW, GH, NF, 1)
 for _ in range(20):
     ex(img)
 n = 300

@@ -1609,7 +1609,8 @@ __device__ __forceinline__ void octree_block(const OctArgs &a, int level, int fr
 #define VSG_OCT_WAVES 5
 #endif
 // Points per batch of the memory-form sweeps (octree::MemPtsT), per kernel: the stand-alone launch (1280x720 and wider: every
-// level 0 is memory-resident) takes 8; the launch that also carries the blur and the one-frame launch keep 1 -- their register
+// level 0 is memory-resident) and the few-frame launch of geometries too large for the fused one take 8; the launch that also
+// carries the blur keeps 1 -- their register
 // allocation is what the default content's register-form levels run on (C2 / 1024, rectangles: octree stage 0.2037 -> 0.2105 ms with
 // 4, unchanged with 1; C4 / 256: 0.318 -> 0.252 with 1, 0.205 with 8; profiles/r06_u_*)
 #ifndef VSG_OCT_MEM_BATCH
@@ -1626,11 +1627,12 @@ __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG
   octree_block<VSG_OCT_MEM_BATCH>(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
 }
 // calls of a few frames: registers instead of residency
+template <int kMemU>
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree_few(OctArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[kSortStackInts];
-  octree_block<VSG_OCT_MEM_BATCH_FUSED>(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
+  octree_block<kMemU>(a, blockIdx.x, blockIdx.y, oct_lds, wtot, sort_stack);
 }
 
 // Test hook (vsg_debug_device_sort): the octree's std::sort replay -- wave-parallel partition phase + stable rank --
@@ -1894,6 +1896,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 // (VSG_OB_WAVES, vsg_kernels.h: 4 waves per SIMD = 128 registers.  With the round-5 blur arithmetic the blur's waves are
 // bound by memory latency more than by issue slots, and 12 rows of loads in flight at 4 waves beat 7 rows at 5 waves and the
 // octree's 59 spilled registers: + 1.0-1.2 % on the 512-frame step, 3 waves - 2.5 %: profiles/r05_p_*)
+template <int kMemU>
 __device__ __forceinline__ void octree_blur_body(const OctArgs &a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
                                                  const Src0 &s0, int nlevels, int nframes, int lead, uint8_t *oct_lds, int *wtot,
                                                  int *sort_stack) {
@@ -1909,16 +1912,17 @@ __device__ __forceinline__ void octree_blur_body(const OctArgs &a, const uint8_t
     if (blk.y < 0 || blk.y >= nframes) return;
   }
   if (blk.x < nlevels)
-    octree_block<VSG_OCT_MEM_BATCH_FUSED>(a, blk.x, blk.y, oct_lds, wtot, sort_stack);
+    octree_block<kMemU>(a, blk.x, blk.y, oct_lds, wtot, sort_stack);
   else
     blur_block<VSG_BLUR_AHEAD>(pyr, blur, a.fg, s0, BlockXY{blk.x - nlevels, blk.y});
 }
+template <int kMemU>
 __global__ __launch_bounds__(kOctThreads) __attribute__((amdgpu_waves_per_eu(VSG_OB_WAVES, VSG_OB_WAVES))) void k_octree_blur(
     OctArgs a, const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Src0 s0, int nlevels, int nframes, int lead) {
   extern __shared__ __attribute__((aligned(16))) uint8_t oct_lds[];
   __shared__ int wtot[2 * kMaxWaves];
   __shared__ int sort_stack[kSortStackInts];
-  octree_blur_body(a, pyr, blur, s0, nlevels, nframes, lead, oct_lds, wtot, sort_stack);
+  octree_blur_body<kMemU>(a, pyr, blur, s0, nlevels, nframes, lead, oct_lds, wtot, sort_stack);
 }
 // (Rounds 3-5 had a second instantiation of this launch for calls of a few frames, compiled for 4 waves per SIMD; since round 5
 // k_octree_blur itself is compiled for VSG_OB_WAVES = 4 waves -- 125 registers, nothing in scratch -- the two were the same code
@@ -2662,14 +2666,27 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   hipGetDevice(&dev);
   const OctArgs a = {d_fg, cand, cand_count, d_cells, cell_count, cand2, node_of, sel, sel_count, cap, prefix_off,
                      (int)lab_off, (int)(lab_bytes / 2), hist_big ? 1 : 0};
+  const bool few = nframes <= kOctFewFrames;  // a call waits for ONE workgroup per level
   if (blur_out) {  // the blur of the same frames as extra workgroups of this launch (latency path)
-    lds_limit_ensure(2, dev, (const void *)k_octree_blur, lds);
     // octree workgroups `lead` frames ahead of the blur's (see the kernel); only for launches long enough to have a tail
     // (64 rows, a multiple of 8 = whole XCD rounds: 317.5 -> 320.5 k frames/s at 512 C2 frames; 32 and 128 measured the same +-0.3 %)
     constexpr int kLead = 64;
     const int lead = nframes >= 4 * kLead ? kLead : 0;
-    hipLaunchKernelGGL(k_octree_blur, dim3(fg.nlevels + fg.total_blur_blocks, nframes + lead), dim3(kOctThreads), lds, s, a,
-                       blur_pyr, blur_out, *blur_s0, fg.nlevels, nframes, lead);
+    // Few-frame calls of the geometries whose levels are memory-resident as a rule (1280x720 / 2000: the workspace size that also
+    // keeps their BATCHES out of this launch) take the instantiation with batched memory-form sweeps: one 1280x720 frame per
+    // call 0.180 -> 0.173 ms, the building photograph 0.362 -> 0.302.  Everything else keeps the other one: with batched sweeps
+    // the one-frame call of a 640x480 photograph gets 2 % shorter and the register-form calls -- every 640x480 / 752x480
+    // frame of the default content -- 1-2 % LONGER, the same register-allocation effect as in the batch launch (profiles/r06_u_*)
+    const dim3 grid(fg.nlevels + fg.total_blur_blocks, nframes + lead);
+    if (few && 5 * work_lds > 160 * 1024) {
+      lds_limit_ensure(5, dev, (const void *)k_octree_blur<VSG_OCT_MEM_BATCH>, lds);
+      hipLaunchKernelGGL(k_octree_blur<VSG_OCT_MEM_BATCH>, grid, dim3(kOctThreads), lds, s, a, blur_pyr, blur_out, *blur_s0,
+                         fg.nlevels, nframes, lead);
+    } else {
+      lds_limit_ensure(2, dev, (const void *)k_octree_blur<VSG_OCT_MEM_BATCH_FUSED>, lds);
+      hipLaunchKernelGGL(k_octree_blur<VSG_OCT_MEM_BATCH_FUSED>, grid, dim3(kOctThreads), lds, s, a, blur_pyr, blur_out, *blur_s0,
+                         fg.nlevels, nframes, lead);
+    }
     return;
   }
   dim3 grid(fg.nlevels, nframes), block(kOctThreads);
@@ -2678,9 +2695,14 @@ void launch_octree(hipStream_t s, const FrameGeom *d_fg, const uint32_t *cand, c
   // 5-waves one with its 59 spilled registers -- its launch time was bimodal from run to run, the only scratch user of the
   // chain); where the workspace caps a CU at four workgroups anyway (1280x720 / 2000: 33 KB) the 5-waves form measures 0.8 %
   // more frames/s (115.3-116.8 against 115.1-115.6 k, profiles/r05_p_*) and stays.
-  if (nframes <= kOctFewFrames || 5 * work_lds <= 160 * 1024) {
-    lds_limit_ensure(4, dev, (const void *)k_octree_few, lds);
-    hipLaunchKernelGGL(k_octree_few, grid, block, lds, s, a);
+  if (few) {
+    lds_limit_ensure(6, dev, (const void *)k_octree_few<VSG_OCT_MEM_BATCH>, lds);
+    hipLaunchKernelGGL(k_octree_few<VSG_OCT_MEM_BATCH>, grid, block, lds, s, a);
+    return;
+  }
+  if (5 * work_lds <= 160 * 1024) {
+    lds_limit_ensure(4, dev, (const void *)k_octree_few<VSG_OCT_MEM_BATCH_FUSED>, lds);
+    hipLaunchKernelGGL(k_octree_few<VSG_OCT_MEM_BATCH_FUSED>, grid, block, lds, s, a);
     return;
   }
   lds_limit_ensure(1, dev, (const void *)k_octree, lds);
