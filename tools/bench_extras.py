@@ -247,7 +247,17 @@ def add_extras(out, W, H, nfeat, B, local_rank, cpu_seconds):
                           "counters": "profiles/r05_*_c3_chain_pmc.txt (k_stereo, k_bow_descend, k_search_by_bow per call)"}
     other.append(c3)
     try:
-        other.append(device_rate("C4", 256, 10, local_rank))
+        r4 = device_rate("C4", 256, 10, local_rank)
+        try:  # the same configuration on a real photograph (~20 k level-0 candidates per frame: the octree's memory-resident form)
+            from visual_sgraphs_amd import synth as _s
+            W4, H4, _ = WORKLOADS["C4"]
+            uniq = np.stack([_s.content_frame("photo_china", W4, H4, 5000, t) for t in range(16)])
+            rp = device_rate("C4", 256, 10, local_rank, cpu_seconds=1.0, uniq=uniq, label="photo_china")
+            r4["photo_china"] = {k: rp[k] for k in ("frames_per_s", "fast_ms", "keypoints_per_frame", "parity")}
+            r4["photo_china"]["frames_checked"] = rp["parity_gate"]["frames_checked"]
+        except Exception as e:  # noqa: BLE001
+            r4["photo_china"] = {"error": str(e)}
+        other.append(r4)
     except Exception as e:  # noqa: BLE001
         other.append({"workload": "C4", "error": str(e)})
     other.append(chain.get("C5", {"workload": "C5", **chain}))
